@@ -1,0 +1,14 @@
+"""cornac_amd — MI355X (gfx950) backend for the embedding-SGD + scoring hot path of PreferredAI/cornac.
+
+Public surface mirrors the reference for this path: `BPR`, `WBPR`, `MF` (models with the
+reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface) and `Dataset`.
+All compute runs in libcornac_hip.so (hand-written HIP for gfx950, C ABI in include/cornac_hip.h);
+there is no CPU fallback.
+"""
+from .data import Dataset
+from .recommender import Recommender, ScoreException
+from .bpr import BPR, WBPR
+from .mf import MF
+
+__all__ = ["Dataset", "Recommender", "ScoreException", "BPR", "WBPR", "MF"]
+__version__ = "0.1.0"

@@ -1,0 +1,314 @@
+"""ctypes binding of libcornac_hip.so (the C ABI declared in include/cornac_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no
+gfx950 device is visible when a kernel is requested, the product path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcornac_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MODE_DETERMINISTIC = 0
+MODE_HOGWILD = 1
+NEG_UNIFORM = 0
+NEG_POPULARITY = 1
+
+# every symbol include/cornac_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "cornac_hip_last_error", "cornac_hip_version", "cornac_hip_device_count", "cornac_hip_device_info",
+    "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
+    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
+    "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
+    "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
+    "cornac_hip_bpr_last_timing",
+    "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
+    "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
+    "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
+    "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device",
+]
+
+
+class HipError(RuntimeError):
+    """A libcornac_hip call returned a non-zero status."""
+
+    def __init__(self, code, msg):
+        super().__init__("libcornac_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False, verbose=False):
+    """Compile libcornac_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", "4"] + (["-B"] if force else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise RuntimeError("building libcornac_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+_f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64 = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+
+def lib():
+    """Load the shared library (raises if it has not been built — no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libcornac_hip.so not found at %s. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cornac_amd/csrc`. cornac_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.cornac_hip_last_error.restype = C.c_char_p
+        L.cornac_hip_version.restype = C.c_char_p
+        L.cornac_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.cornac_hip_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                            C.c_int, _i32, _i32, C.c_int64]
+        L.cornac_hip_bpr_destroy.argtypes = [_vp]
+        L.cornac_hip_bpr_set_factors.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_get_factors.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_bind_device.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_device_ptrs.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
+        L.cornac_hip_bpr_set_stream.argtypes = [_vp, _vp]
+        L.cornac_hip_bpr_seed_mt19937.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_int]
+        L.cornac_hip_bpr_seed_hogwild.argtypes = [_vp, C.c_uint64]
+        L.cornac_hip_bpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_hogwild_enqueue.argtypes = [_vp, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.cornac_hip_bpr_sync.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_debug_draw.argtypes = [_vp, C.c_int, C.c_uint64, C.c_int64, _i64]
+        L.cornac_hip_bpr_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_mf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i64, _f32,
+                                           C.c_int64]
+        L.cornac_hip_mf_destroy.argtypes = [_vp]
+        L.cornac_hip_mf_set_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        L.cornac_hip_mf_get_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        L.cornac_hip_mf_fit.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp,
+                                        C.POINTER(C.c_int)]
+        L.cornac_hip_mf_fit_sgd.argtypes = [C.c_int, _i64, _i64, _f32, C.c_int64, _f32, _f32, _f32, _f32, C.c_int64,
+                                            C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]
+        L.cornac_hip_mf_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_scorer_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int]
+        L.cornac_hip_scorer_destroy.argtypes = [_vp]
+        L.cornac_hip_scorer_set.argtypes = [_vp, _f32, _f32, _vp, _vp]
+        L.cornac_hip_score_user.argtypes = [_vp, C.c_int64, _f32]
+        L.cornac_hip_score_block.argtypes = [_vp, _i32, C.c_int64, _f32]
+        L.cornac_hip_rank_topk.argtypes = [_vp, _i32, C.c_int64, C.c_int, _vp, _vp, _i32, _f32]
+        L.cornac_hip_rank_topk_device.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError(rc, lib().cornac_hip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().cornac_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cus = C.c_int()
+    mem = C.c_int64()
+    check(lib().cornac_hip_device_info(device, name, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f32c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class BprTrainer:
+    """Thin owner of a cornac_hip_bpr_t handle."""
+
+    def __init__(self, indptr, indices, n_users, n_items, total_users, total_items, k, device=0):
+        self.indptr = np.ascontiguousarray(indptr, np.int32)
+        self.indices = np.ascontiguousarray(indices, np.int32)
+        self.shape = (int(total_users), int(total_items), int(k))
+        self.nnz = len(self.indices)
+        self.h = _vp()
+        check(lib().cornac_hip_bpr_create(C.byref(self.h), device, n_users, n_items, total_users, total_items, k,
+                                          self.indptr, self.indices, self.nnz))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().cornac_hip_bpr_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_factors(self, U=None, V=None, B=None):
+        U, V, B = _f32c(U), _f32c(V), _f32c(B)
+        tu, ti, k = self.shape
+        assert U is None or U.shape == (tu, k)
+        assert V is None or V.shape == (ti, k)
+        assert B is None or B.shape == (ti,)
+        check(lib().cornac_hip_bpr_set_factors(self.h, _ptr(U), _ptr(V), _ptr(B)))
+
+    def get_factors(self):
+        tu, ti, k = self.shape
+        U, V, B = np.empty((tu, k), np.float32), np.empty((ti, k), np.float32), np.empty(ti, np.float32)
+        check(lib().cornac_hip_bpr_get_factors(self.h, U.ctypes.data, V.ctypes.data, B.ctypes.data))
+        return U, V, B
+
+    def seed_mt19937(self, seed_pos, seed_neg, shared_stream=False):
+        check(lib().cornac_hip_bpr_seed_mt19937(self.h, seed_pos, seed_neg, int(shared_stream)))
+
+    def seed_hogwild(self, seed):
+        check(lib().cornac_hip_bpr_seed_hogwild(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def fit_epochs(self, n_epochs, lr, reg, use_bias=True, neg_population=NEG_UNIFORM, mode=MODE_HOGWILD, flags=0):
+        c, s = C.c_int64(), C.c_int64()
+        check(lib().cornac_hip_bpr_fit_epochs(self.h, n_epochs, lr, reg, int(use_bias), neg_population, mode, flags,
+                                              C.byref(c), C.byref(s)))
+        return c.value, s.value
+
+    def hogwild_enqueue(self, n_samples, lr, reg, use_bias=True, neg_population=NEG_UNIFORM, flags=0):
+        check(lib().cornac_hip_bpr_hogwild_enqueue(self.h, n_samples, lr, reg, int(use_bias), neg_population, flags))
+
+    def sync(self):
+        c, s = C.c_int64(), C.c_int64()
+        check(lib().cornac_hip_bpr_sync(self.h, C.byref(c), C.byref(s)))
+        return c.value, s.value
+
+    def bind_device(self, dU=None, dV=None, dB=None):
+        check(lib().cornac_hip_bpr_bind_device(self.h, dU, dV, dB))
+
+    def device_ptrs(self):
+        u, v, b = _vp(), _vp(), _vp()
+        check(lib().cornac_hip_bpr_device_ptrs(self.h, C.byref(u), C.byref(v), C.byref(b)))
+        return u.value, v.value, b.value
+
+    def set_stream(self, stream_ptr):
+        check(lib().cornac_hip_bpr_set_stream(self.h, stream_ptr))
+
+    def debug_draw(self, stream, hi, n):
+        out = np.empty(n, np.int64)
+        check(lib().cornac_hip_bpr_debug_draw(self.h, stream, hi, n, out))
+        return out
+
+    def last_timing(self):
+        t = (C.c_double * 4)()
+        check(lib().cornac_hip_bpr_last_timing(self.h, t))
+        return {"sampler_ms": t[0], "schedule_ms": t[1], "sgd_ms": t[2], "total_ms": t[3]}
+
+
+class MfTrainer:
+    def __init__(self, rid, cid, val, n_users, n_items, k, device=0):
+        self.rid = np.ascontiguousarray(rid, np.int64)
+        self.cid = np.ascontiguousarray(cid, np.int64)
+        self.val = np.ascontiguousarray(val, np.float32)
+        self.shape = (int(n_users), int(n_items), int(k))
+        self.h = _vp()
+        check(lib().cornac_hip_mf_create(C.byref(self.h), device, n_users, n_items, k, self.rid, self.cid, self.val,
+                                         len(self.val)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().cornac_hip_mf_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_factors(self, U=None, V=None, Bu=None, Bi=None):
+        U, V, Bu, Bi = _f32c(U), _f32c(V), _f32c(Bu), _f32c(Bi)
+        check(lib().cornac_hip_mf_set_factors(self.h, _ptr(U), _ptr(V), _ptr(Bu), _ptr(Bi)))
+
+    def get_factors(self):
+        nu, ni, k = self.shape
+        U, V = np.empty((nu, k), np.float32), np.empty((ni, k), np.float32)
+        Bu, Bi = np.empty(nu, np.float32), np.empty(ni, np.float32)
+        check(lib().cornac_hip_mf_get_factors(self.h, U.ctypes.data, V.ctypes.data, Bu.ctypes.data, Bi.ctypes.data))
+        return U, V, Bu, Bi
+
+    def fit(self, max_iter, lr, reg, mu, use_bias=True, early_stop=False, mode=MODE_HOGWILD):
+        loss = np.zeros(max(max_iter, 1), np.float32)
+        n = C.c_int()
+        check(lib().cornac_hip_mf_fit(self.h, max_iter, lr, reg, mu, int(use_bias), int(early_stop), mode,
+                                      loss.ctypes.data, C.byref(n)))
+        return loss[:n.value], n.value
+
+    def last_timing(self):
+        t = (C.c_double * 4)()
+        check(lib().cornac_hip_mf_last_timing(self.h, t))
+        return {"schedule_ms": t[1], "sgd_ms": t[2], "total_ms": t[3]}
+
+
+def mf_fit_sgd(rid, cid, val, U, V, Bu, Bi, lr, reg, mu, max_iter, use_bias, early_stop, mode, device=0):
+    """One-shot in-place call with the reference's argument list (backend_cpu.pyx:35-40)."""
+    loss = np.zeros(max(max_iter, 1), np.float32)
+    n = C.c_int()
+    check(lib().cornac_hip_mf_fit_sgd(device, np.ascontiguousarray(rid, np.int64), np.ascontiguousarray(cid, np.int64),
+                                      np.ascontiguousarray(val, np.float32), len(val), U, V, Bu, Bi, U.shape[0],
+                                      V.shape[0], U.shape[1], lr, reg, mu, max_iter, int(use_bias), int(early_stop),
+                                      mode, loss.ctypes.data, C.byref(n)))
+    return loss[:n.value]
+
+
+class Scorer:
+    def __init__(self, U, V, item_base=None, user_base=None, device=0):
+        U, V = _f32c(U), _f32c(V)
+        self.n_users, self.k = U.shape
+        self.n_items = V.shape[0]
+        self.h = _vp()
+        check(lib().cornac_hip_scorer_create(C.byref(self.h), device, self.n_users, self.n_items, self.k))
+        self.set(U, V, item_base, user_base)
+
+    def set(self, U, V, item_base=None, user_base=None):
+        ib, ub = _f32c(item_base), _f32c(user_base)
+        check(lib().cornac_hip_scorer_set(self.h, _f32c(U), _f32c(V), _ptr(ib), _ptr(ub)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().cornac_hip_scorer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def score_user(self, user):
+        out = np.empty(self.n_items, np.float32)
+        check(lib().cornac_hip_score_user(self.h, int(user), out))
+        return out
+
+    def score_block(self, users):
+        users = np.ascontiguousarray(users, np.int32)
+        out = np.empty((len(users), self.n_items), np.float32)
+        check(lib().cornac_hip_score_block(self.h, users, len(users), out))
+        return out
+
+    def rank_topk(self, users, topk, exclude=None):
+        """exclude: optional (indptr int64[n+1], indices int32) CSR of items to drop per listed user."""
+        users = np.ascontiguousarray(users, np.int32)
+        items = np.empty((len(users), topk), np.int32)
+        scores = np.empty((len(users), topk), np.float32)
+        ip = ix = None
+        if exclude is not None:
+            ip = np.ascontiguousarray(exclude[0], np.int64)
+            ix = np.ascontiguousarray(exclude[1], np.int32)
+        check(lib().cornac_hip_rank_topk(self.h, users, len(users), topk, _ptr(ip), _ptr(ix), items, scores))
+        return items, scores
+
+    def rank_topk_device_ms(self, u0, n, topk, repeats=1):
+        ms = C.c_double()
+        check(lib().cornac_hip_rank_topk_device(self.h, u0, n, topk, repeats, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,179 @@
+"""BPR and WBPR on MI355X — same constructor, `fit/score/rank` surface and learned attributes
+(`u_factors`, `i_factors`, `i_biases`) as the reference models
+(cornac/models/bpr/recom_bpr.pyx:65-333, cornac/models/bpr/recom_wbpr.pyx:30-144); the per-epoch
+`_fit_sgd` call is replaced by libcornac_hip (include/cornac_hip.h).
+
+Mode selection follows the reference's threading rule (recom_bpr.pyx:132-137): a `seed` forces
+the sequential, reproducible path -> `deterministic` mode (bit-faithful mt19937 sample streams,
+order-preserving level schedule); no seed -> `hogwild` mode, the counterpart of the reference's
+racy multi-thread path.  `mode=` overrides the rule explicitly.
+"""
+import numpy as np
+
+from . import _lib
+from .recommender import Recommender
+
+DTYPE = np.float32
+
+
+def _uniform(shape, rng):
+    # cornac/utils/init_utils.py:33-57 `uniform(shape, low=0, high=1, dtype=float32)`
+    return rng.uniform(0.0, 1.0, shape).astype(DTYPE)
+
+
+def rngvector_mt_seed(seed):
+    """RNGVector(1, rows, seed): the single engine is mt19937(get_rng(seed).randint(2**31))
+    (recom_bpr.pyx:55-59)."""
+    return int(np.random.RandomState(seed).randint(2 ** 31))
+
+
+class BPR(Recommender):
+    """Bayesian Personalized Ranking (Rendle et al., UAI 2009).
+
+    Parameters are those of the reference (recom_bpr.pyx:68-143) plus:
+
+    mode: None | "deterministic" | "hogwild"
+        None: deterministic if `seed` is given, else hogwild (the reference's num_threads rule).
+    device: int, HIP device ordinal.
+    """
+
+    _neg_population = _lib.NEG_UNIFORM
+    _shared_stream = False
+
+    def __init__(self, name="BPR", k=10, max_iter=100, learning_rate=0.001, lambda_reg=0.01, use_bias=True,
+                 num_threads=0, trainable=True, verbose=False, init_params=None, seed=None, mode=None, device=0):
+        super().__init__(name=name, trainable=trainable, verbose=verbose)
+        self.k = int(k)
+        self.max_iter = max_iter
+        self.learning_rate = learning_rate
+        self.lambda_reg = lambda_reg
+        self.use_bias = use_bias
+        self.seed = seed
+        self.rng = np.random.RandomState(seed)
+        self.num_threads = num_threads  # kept for clone()/API compatibility; the device decides its own width
+        if mode not in (None, "deterministic", "hogwild"):
+            raise ValueError(f"mode={mode} is not supported")
+        self.mode = mode
+        self.device = device
+        self.init_params = {} if init_params is None else init_params
+        self.u_factors = self.init_params.get("U", None)
+        self.i_factors = self.init_params.get("V", None)
+        self.i_biases = self.init_params.get("Bi", None)
+
+    @property
+    def effective_mode(self):
+        if self.mode is not None:
+            return self.mode
+        return "deterministic" if self.seed is not None else "hogwild"
+
+    def _init(self):
+        # recom_bpr.pyx:145-152 — sizes use total_users/total_items
+        n_users, n_items = self.total_users, self.total_items
+        if self.u_factors is None:
+            self.u_factors = (_uniform((n_users, self.k), self.rng) - 0.5) / self.k
+        if self.i_factors is None:
+            self.i_factors = (_uniform((n_items, self.k), self.rng) - 0.5) / self.k
+        if self.i_biases is None or self.use_bias is False:
+            self.i_biases = np.zeros(n_items, dtype=DTYPE)
+        if self.u_factors.dtype != DTYPE or self.i_factors.dtype != DTYPE or self.i_biases.dtype != DTYPE:
+            raise ValueError("the HIP backend trains float32 factors (the reference's DTYPE, recom_bpr.pyx:40)")
+
+    def _seed_trainer(self, trainer):
+        if self.effective_mode == "deterministic":
+            # recom_bpr.pyx:190-191: two draws from self.rng, in this order, AFTER _init
+            seed_pos = rngvector_mt_seed(self.rng.randint(2 ** 31))
+            seed_neg = rngvector_mt_seed(self.rng.randint(2 ** 31))
+            trainer.seed_mt19937(seed_pos, seed_neg, shared_stream=False)
+        else:
+            lo, hi = int(self.rng.randint(2 ** 31)), int(self.rng.randint(2 ** 31))
+            trainer.seed_hogwild((hi << 32) | lo)
+
+    def fit(self, train_set, val_set=None):
+        Recommender.fit(self, train_set, val_set)
+        self._init()
+        if not self.trainable:
+            return self
+        X = train_set.matrix
+        if not X.has_sorted_indices:
+            X.sort_indices()
+        trainer = _lib.BprTrainer(X.indptr, X.indices, train_set.num_users, train_set.num_items, self.total_users,
+                                  self.total_items, self.k, device=self.device)
+        try:
+            trainer.set_factors(self.u_factors, self.i_factors, self.i_biases)
+            self._seed_trainer(trainer)
+            mode = _lib.MODE_DETERMINISTIC if self.effective_mode == "deterministic" else _lib.MODE_HOGWILD
+            nnz = X.nnz
+            self.fit_stats = []
+            if self.verbose:
+                from tqdm.auto import trange
+
+                with trange(self.max_iter) as progress:
+                    for _ in progress:
+                        correct, skipped = trainer.fit_epochs(1, self.learning_rate, self.lambda_reg, self.use_bias,
+                                                              self._neg_population, mode)
+                        self.fit_stats.append((correct, skipped))
+                        progress.set_postfix({
+                            "correct": "%.2f%%" % (100.0 * correct / (nnz - skipped + 1e-8)),
+                            "skipped": "%.2f%%" % (100.0 * skipped / nnz),
+                        })
+                print("Optimization finished!")
+            else:
+                correct, skipped = trainer.fit_epochs(self.max_iter, self.learning_rate, self.lambda_reg,
+                                                      self.use_bias, self._neg_population, mode)
+                self.fit_stats.append((correct, skipped))
+            self.last_timing = trainer.last_timing()
+            U, V, B = trainer.get_factors()
+            # the reference mutates the arrays in place (also user-provided init_params)
+            self.u_factors[...] = U
+            self.i_factors[...] = V
+            self.i_biases[...] = B
+        finally:
+            trainer.close()
+        self._drop_scorer()
+        return self
+
+    # ---- prediction -------------------------------------------------------------------------------
+    def _scoring_tables(self):
+        return self.u_factors, self.i_factors, self.i_biases, None
+
+    def _scorer_row(self, user_idx):
+        return int(user_idx) if user_idx is not None and 0 <= user_idx < len(self.u_factors) else None
+
+    def score(self, user_idx, item_idx=None):
+        """recom_bpr.pyx:272-297: scores over len(i_biases) items, or one scalar."""
+        if item_idx is None:
+            return self._get_scorer().score_user(user_idx)
+        return self.i_biases[item_idx] + np.dot(self.u_factors[user_idx], self.i_factors[item_idx])
+
+    # ANN mixin surface (recom_bpr.pyx:299-333)
+    def get_vector_measure(self):
+        return "dot"
+
+    def get_user_vectors(self):
+        return np.concatenate((self.u_factors, np.ones([self.u_factors.shape[0], 1])), axis=1)
+
+    def get_item_vectors(self):
+        return np.concatenate((self.i_factors, self.i_biases.reshape((-1, 1))), axis=1)
+
+
+class WBPR(BPR):
+    """Weighted BPR: negatives sampled proportionally to item popularity
+    (cornac/models/bpr/recom_wbpr.pyx:30-144).  Same kernel; the negative population is
+    `X.indices` and — as in the reference — ONE generator supplies both draws of a sample."""
+
+    _neg_population = _lib.NEG_POPULARITY
+    _shared_stream = True
+
+    def __init__(self, name="WBPR", k=10, max_iter=100, learning_rate=0.001, lambda_reg=0.01, use_bias=True,
+                 num_threads=0, trainable=True, verbose=False, init_params=None, seed=None, mode=None, device=0):
+        super().__init__(name=name, k=k, max_iter=max_iter, learning_rate=learning_rate, lambda_reg=lambda_reg,
+                         use_bias=use_bias, num_threads=num_threads, trainable=trainable, verbose=verbose,
+                         init_params=init_params, seed=seed, mode=mode, device=device)
+
+    def _seed_trainer(self, trainer):
+        if self.effective_mode == "deterministic":
+            s = rngvector_mt_seed(self.rng.randint(2 ** 31))  # recom_wbpr.pyx:131
+            trainer.seed_mt19937(s, s, shared_stream=True)
+        else:
+            lo, hi = int(self.rng.randint(2 ** 31)), int(self.rng.randint(2 ** 31))
+            trainer.seed_hogwild((hi << 32) | lo)

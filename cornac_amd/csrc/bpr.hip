@@ -1,0 +1,751 @@
+// BPR / WBPR training on MI355X (gfx950): triplet sampler + pairwise-loss SGD.
+//
+// Replaces the reference's BPR._fit_sgd hot loop (cornac/models/bpr/recom_bpr.pyx:208-269), its
+// sampler RNGVector (:54-62) and the CSR membership test has_non_zero (:46-51).
+//
+// Two execution modes:
+//   deterministic — reproduces the seeded (single-thread) reference: bit-faithful mt19937/boost
+//                   draw streams on the device, then the nnz sequential updates are executed as a
+//                   level schedule of the row-conflict DAG (levels = kernels, samples of a level
+//                   touch disjoint rows), with the reference's float expression order.
+//   hogwild       — throughput mode (the reference's num_threads > 1 path): counter-based
+//                   sampling, one 64-sample tile per wave staged through LDS, G lanes per
+//                   triplet with 16-byte row gathers, wave-shuffle dot products and fp32 atomic
+//                   scatter-updates.  HBM/fabric-bandwidth bound; no MFMA (nothing is GEMM-shaped).
+#include <algorithm>
+
+#include "common.h"
+#include "rng.h"
+#include "sgd_device.h"
+
+namespace chip {
+
+// ------------------------------------------------------------------------------------------------
+// deterministic mode: sampler -> (u, i, j) per sample
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bpr_det_sample_kernel(
+    const uint32_t *__restrict__ pos_draw, int pos_stride, const uint32_t *__restrict__ neg_draw, int neg_stride,
+    int64_t n, const int32_t *__restrict__ user_ids, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ indptr, int neg_population, int32_t *__restrict__ su, int32_t *__restrict__ si,
+    int32_t *__restrict__ sj, unsigned long long *__restrict__ counters) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool skip = false;
+    if (s < n) {
+        const uint32_t ii = pos_draw[s * pos_stride];
+        const uint32_t jj = neg_draw[s * neg_stride];
+        const int32_t u = user_ids[ii];
+        const int32_t i = indices[ii];
+        const int32_t j = neg_population == CORNAC_HIP_NEG_POPULARITY ? indices[jj] : (int32_t)jj;
+        skip = csr_row_contains(indices, indptr[u], indptr[u + 1], j);
+        su[s] = skip ? -1 : u;
+        si[s] = i;
+        sj[s] = j;
+    }
+    const unsigned long long m = __ballot(skip);
+    if (lane_id() == 0 && m) atomicAdd(&counters[1], (unsigned long long)__popcll(m));
+}
+
+// One level of the conflict-free schedule: samples [off, off+cnt) touch pairwise-disjoint rows.
+// G lanes per triplet.  The dot product is accumulated in index order (score = B_i - B_j, then
+// += u_f * (vi_f - vj_f) for f = 0..k-1) so the result is bit-identical to the sequential oracle.
+template <int G>
+__global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__restrict__ su,
+                                                               const int32_t *__restrict__ si,
+                                                               const int32_t *__restrict__ sj, int64_t off, int cnt,
+                                                               float *U, float *V, float *B, int k, float lr,
+                                                               float reg, int use_bias,
+                                                               unsigned long long *__restrict__ counters) {
+    const int gid = (blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lg = threadIdx.x & (G - 1);
+    const bool active = gid < cnt;
+    const int64_t t = off + (active ? gid : cnt - 1);
+    const int32_t u = su[t], i = si[t], j = sj[t];
+    float *pu = U + (size_t)u * k, *pi = V + (size_t)i * k, *pj = V + (size_t)j * k;
+    float score = B[i] - B[j];
+    for (int base = 0; base < k; base += G) {
+        const int f = base + lg;
+        float p = 0.f;
+        if (f < k) p = pu[f] * (pi[f] - pj[f]);
+        const int lim = min(G, k - base);
+        for (int l = 0; l < lim; ++l) score = score + __shfl(p, l, G);
+    }
+    const float z = sigmoid_neg_exact(score);
+    if (active) {
+        for (int f = lg; f < k; f += G) {
+            const float uf = pu[f], vi = pi[f], vj = pj[f];
+            pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
+            pi[f] = vi + lr * (z * uf - reg * vi);
+            pj[f] = vj + lr * (-z * uf - reg * vj);
+        }
+        if (lg == 0 && use_bias) {
+            const float bi = B[i], bj = B[j];
+            B[i] = bi + lr * (z - reg * bi);
+            B[j] = bj + lr * (-z - reg * bj);
+        }
+    }
+    const unsigned long long m = __ballot(active && lg == 0 && z < .5f);
+    if (lane_id() == 0 && m) atomicAdd(&counters[0], (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// hogwild mode
+// ------------------------------------------------------------------------------------------------
+struct HogArgs {
+    const int32_t *user_ids, *indices, *indptr;
+    float *U, *V, *B;
+    unsigned long long *counters;
+    int64_t n;        // samples in this launch
+    uint64_t s_begin; // sample counter of the first one
+    uint64_t seed;
+    uint32_t epoch;
+    uint32_t n_pos, n_neg, th_pos, th_neg;
+    int k, neg_population, use_bias;
+    float lr, reg;
+};
+
+// per-lane: draw one (u, i, j) and test membership; returns validity
+__device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int32_t &u, int32_t &i, int32_t &j,
+                                           bool &in_range) {
+    in_range = local < a.n;
+    const uint64_t s = a.s_begin + (uint64_t)(in_range ? local : 0);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), a.epoch, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
+    const uint32_t ii = lemire_bounded2(w[0], w[1], a.n_pos, a.th_pos);
+    const uint32_t jj = lemire_bounded2(w[2], w[3], a.n_neg, a.th_neg);
+    u = a.user_ids[ii];
+    i = a.indices[ii];
+    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
+    const bool skip = csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
+    return in_range && !skip;
+}
+
+// k % 4 == 0 and k <= 4*G: each lane owns one 16-byte slice of the three rows (registers only).
+template <int G, bool ATOMIC>
+__global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs a) {
+    __shared__ int32_t stage[kWavesPerBlock][3][kWave];
+    constexpr int TPW = kWave / G;  // triplets processed concurrently by one wave
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int grp = lane / G, lg = lane & (G - 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    const int f0 = 4 * lg;
+    const bool inb = f0 < a.k;
+    unsigned int n_correct = 0, n_skipped = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
+        int32_t u, i, j;
+        bool in_range;
+        const bool valid = hog_sample(a, tile * kWave + lane, u, i, j, in_range);
+        const unsigned long long mask = __ballot(valid);
+        n_skipped += (in_range && !valid) ? 1u : 0u;
+        if (valid) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            stage[wave][0][pos] = u;
+            stage[wave][1][pos] = i;
+            stage[wave][2][pos] = j;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nvalid = __popcll(mask);
+        for (int b = 0; b < nvalid; b += TPW) {
+            const int slot = b + grp;
+            const bool act = slot < nvalid;
+            const int sl = act ? slot : b;
+            const int32_t tu = stage[wave][0][sl], ti = stage[wave][1][sl], tj = stage[wave][2][sl];
+            float *pu = a.U + (size_t)tu * a.k + f0;
+            float *pi = a.V + (size_t)ti * a.k + f0;
+            float *pj = a.V + (size_t)tj * a.k + f0;
+            v4f u4 = {0.f, 0.f, 0.f, 0.f}, vi4 = u4, vj4 = u4;
+            if (inb) {
+                u4 = load_row4_fresh(pu);
+                vi4 = load_row4_fresh(pi);
+                vj4 = load_row4_fresh(pj);
+            }
+            const float bi = a.B[ti], bj = a.B[tj];
+            const v4f d = vi4 - vj4;
+            const float part = u4.x * d.x + u4.y * d.y + u4.z * d.z + u4.w * d.w;
+            const float score = (bi - bj) + group_sum<G>(part);
+            const float z = sigmoid_neg_fast(score);
+            if (act && inb) {
+                const v4f du = a.lr * (z * d - a.reg * u4);
+                const v4f dvi = a.lr * (z * u4 - a.reg * vi4);
+                const v4f dvj = a.lr * (-z * u4 - a.reg * vj4);
+                if (ATOMIC) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        atomic_add_f32(pu + c, du[c]);
+                        atomic_add_f32(pi + c, dvi[c]);
+                        atomic_add_f32(pj + c, dvj[c]);
+                    }
+                } else {
+                    *reinterpret_cast<v4f *>(pu) = u4 + du;
+                    *reinterpret_cast<v4f *>(pi) = vi4 + dvi;
+                    *reinterpret_cast<v4f *>(pj) = vj4 + dvj;
+                }
+            }
+            if (act && lg == 0) {
+                if (a.use_bias) {
+                    const float dbi = a.lr * (z - a.reg * bi), dbj = a.lr * (-z - a.reg * bj);
+                    if (ATOMIC) {
+                        atomic_add_f32(a.B + ti, dbi);
+                        atomic_add_f32(a.B + tj, dbj);
+                    } else {
+                        a.B[ti] = bi + dbi;
+                        a.B[tj] = bj + dbj;
+                    }
+                }
+                n_correct += z < .5f ? 1u : 0u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // wave-level reduction of the counters, one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_correct += __shfl_xor(n_correct, o, kWave);
+        n_skipped += __shfl_xor(n_skipped, o, kWave);
+    }
+    if (lane == 0) {
+        if (n_correct) atomicAdd(&a.counters[0], (unsigned long long)n_correct);
+        if (n_skipped) atomicAdd(&a.counters[1], (unsigned long long)n_skipped);
+    }
+}
+
+// any k: G lanes per triplet stride over the factors (two passes over the rows).
+template <int G, bool ATOMIC>
+__global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogArgs a) {
+    __shared__ int32_t stage[kWavesPerBlock][3][kWave];
+    constexpr int TPW = kWave / G;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int grp = lane / G, lg = lane & (G - 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    unsigned int n_correct = 0, n_skipped = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
+        int32_t u, i, j;
+        bool in_range;
+        const bool valid = hog_sample(a, tile * kWave + lane, u, i, j, in_range);
+        const unsigned long long mask = __ballot(valid);
+        n_skipped += (in_range && !valid) ? 1u : 0u;
+        if (valid) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            stage[wave][0][pos] = u;
+            stage[wave][1][pos] = i;
+            stage[wave][2][pos] = j;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nvalid = __popcll(mask);
+        for (int b = 0; b < nvalid; b += TPW) {
+            const int slot = b + grp;
+            const bool act = slot < nvalid;
+            const int sl = act ? slot : b;
+            const int32_t tu = stage[wave][0][sl], ti = stage[wave][1][sl], tj = stage[wave][2][sl];
+            float *pu = a.U + (size_t)tu * a.k, *pi = a.V + (size_t)ti * a.k, *pj = a.V + (size_t)tj * a.k;
+            float part = 0.f;
+            for (int f = lg; f < a.k; f += G)
+                part += load_f32_fresh(pu + f) * (load_f32_fresh(pi + f) - load_f32_fresh(pj + f));
+            const float bi = a.B[ti], bj = a.B[tj];
+            const float score = (bi - bj) + group_sum<G>(part);
+            const float z = sigmoid_neg_fast(score);
+            if (act) {
+                for (int f = lg; f < a.k; f += G) {
+                    const float uf = load_f32_fresh(pu + f), vi = load_f32_fresh(pi + f),
+                                vj = load_f32_fresh(pj + f);
+                    const float du = a.lr * (z * (vi - vj) - a.reg * uf);
+                    const float dvi = a.lr * (z * uf - a.reg * vi);
+                    const float dvj = a.lr * (-z * uf - a.reg * vj);
+                    if (ATOMIC) {
+                        atomic_add_f32(pu + f, du);
+                        atomic_add_f32(pi + f, dvi);
+                        atomic_add_f32(pj + f, dvj);
+                    } else {
+                        pu[f] = uf + du;
+                        pi[f] = vi + dvi;
+                        pj[f] = vj + dvj;
+                    }
+                }
+                if (lg == 0) {
+                    if (a.use_bias) {
+                        const float dbi = a.lr * (z - a.reg * bi), dbj = a.lr * (-z - a.reg * bj);
+                        if (ATOMIC) {
+                            atomic_add_f32(a.B + ti, dbi);
+                            atomic_add_f32(a.B + tj, dbj);
+                        } else {
+                            a.B[ti] = bi + dbi;
+                            a.B[tj] = bj + dbj;
+                        }
+                    }
+                    n_correct += z < .5f ? 1u : 0u;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_correct += __shfl_xor(n_correct, o, kWave);
+        n_skipped += __shfl_xor(n_skipped, o, kWave);
+    }
+    if (lane == 0) {
+        if (n_correct) atomicAdd(&a.counters[0], (unsigned long long)n_correct);
+        if (n_skipped) atomicAdd(&a.counters[1], (unsigned long long)n_skipped);
+    }
+}
+
+static int pow2_group(int k) {  // lanes per triplet for scalar-per-lane kernels
+    int g = 4;
+    while (g < k && g < 64) g <<= 1;
+    return g;
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+// ================================================================================================
+// handle
+// ================================================================================================
+struct cornac_hip_bpr {
+    int device = 0;
+    int64_t n_users = 0, n_items = 0, total_users = 0, total_items = 0, nnz = 0;
+    int k = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DevBuf<int32_t> indptr, indices, user_ids;
+    DevBuf<float> U, V, B;
+    DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped
+    // deterministic sampler state
+    DevBuf<uint32_t> mt_state;  // 2 x 624
+    DevBuf<int32_t> mt_idx;     // 2
+    DevBuf<MtStreamParams> mt_params;
+    bool mt_seeded = false, shared_stream = false;
+    DevBuf<uint32_t> draws;  // 2 x chunk
+    DevBuf<int32_t> trip;    // 6 x chunk : su si sj | ou oi oj
+    PinnedBuf<int32_t> h_trip;
+    std::vector<int32_t> lvl_u, lvl_i, level;
+    LevelSchedule sched;
+    // hogwild sampler state
+    bool hog_seeded = false;
+    uint64_t hog_seed = 0;
+    uint32_t hog_epoch = 0;
+    int64_t hog_offset = 0;  // samples already consumed in the current epoch
+    double timing[4] = {0, 0, 0, 0};
+};
+
+static constexpr int64_t kDetChunk = int64_t(1) << 24;
+
+static void bpr_check(cornac_hip_bpr_t h) {
+    REQUIRE(h != nullptr, "BPR handle is NULL");
+    HIP_CHECK(hipSetDevice(h->device));
+}
+
+extern "C" {
+
+int cornac_hip_bpr_create(cornac_hip_bpr_t *out, int device, int64_t n_users, int64_t n_items, int64_t total_users,
+                          int64_t total_items, int k, const int32_t *indptr, const int32_t *indices, int64_t nnz) {
+    return guarded([&] {
+        REQUIRE(out != nullptr, "out handle pointer is NULL");
+        *out = nullptr;
+        REQUIRE(n_users > 0 && n_items > 0, "n_users and n_items must be positive");
+        REQUIRE(total_users >= n_users && total_items >= n_items, "total_* must cover the train counts");
+        REQUIRE(k > 0, "k must be positive");
+        REQUIRE(indptr && indices, "CSR pointers are NULL");
+        REQUIRE(nnz > 0, "empty interaction matrix (nnz == 0)");
+        REQUIRE(nnz < (int64_t(1) << 31), "nnz >= 2^31 is beyond the reference (int32 CSR, recom_bpr.pyx:186)");
+        REQUIRE(n_items < (int64_t(1) << 31) && total_users < (int64_t(1) << 31), "index range exceeds int32");
+        REQUIRE(indptr[0] == 0 && (int64_t)indptr[n_users] == nnz, "indptr does not match nnz");
+        use_device(device);
+        std::unique_ptr<cornac_hip_bpr> h(new cornac_hip_bpr());
+        h->device = device;
+        h->n_users = n_users; h->n_items = n_items; h->total_users = total_users; h->total_items = total_items;
+        h->nnz = nnz; h->k = k;
+        HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->stream = h->own_stream;
+        std::vector<int32_t> uid((size_t)nnz);
+        for (int64_t u = 0; u < n_users; ++u) {
+            REQUIRE(indptr[u + 1] >= indptr[u], "indptr is not monotone at row %lld", (long long)u);
+            for (int32_t p = indptr[u]; p < indptr[u + 1]; ++p) {
+                uid[(size_t)p] = (int32_t)u;
+                REQUIRE(indices[p] >= 0 && indices[p] < n_items, "column index out of range at %d", p);
+                REQUIRE(p == indptr[u] || indices[p] > indices[p - 1], "CSR row %lld is not strictly sorted",
+                        (long long)u);
+            }
+        }
+        h->indptr.alloc((size_t)n_users + 1);
+        h->indices.alloc((size_t)nnz);
+        h->user_ids.alloc((size_t)nnz);
+        h->indptr.upload(indptr, (size_t)n_users + 1, h->stream);
+        h->indices.upload(indices, (size_t)nnz, h->stream);
+        h->user_ids.upload(uid.data(), (size_t)nnz, h->stream);
+        h->U.alloc((size_t)total_users * k);
+        h->V.alloc((size_t)total_items * k);
+        h->B.alloc((size_t)total_items);
+        HIP_CHECK(hipMemsetAsync(h->U.p, 0, h->U.n * sizeof(float), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->V.p, 0, h->V.n * sizeof(float), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->B.p, 0, h->B.n * sizeof(float), h->stream));
+        h->counters.alloc(2);
+        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        *out = h.release();
+    });
+}
+
+int cornac_hip_bpr_destroy(cornac_hip_bpr_t h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipSetDevice(h->device);
+        if (h->own_stream) {
+            (void)hipStreamSynchronize(h->own_stream);
+            (void)hipStreamDestroy(h->own_stream);
+        }
+        delete h;
+    });
+}
+
+int cornac_hip_bpr_set_factors(cornac_hip_bpr_t h, const float *U, const float *V, const float *B) {
+    return guarded([&] {
+        bpr_check(h);
+        if (U) h->U.upload(U, (size_t)h->total_users * h->k, h->stream);
+        if (V) h->V.upload(V, (size_t)h->total_items * h->k, h->stream);
+        if (B) h->B.upload(B, (size_t)h->total_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B) {
+    return guarded([&] {
+        bpr_check(h);
+        if (U) h->U.download(U, (size_t)h->total_users * h->k, h->stream);
+        if (V) h->V.download(V, (size_t)h->total_items * h->k, h->stream);
+        if (B) h->B.download(B, (size_t)h->total_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB) {
+    return guarded([&] {
+        bpr_check(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (dU) h->U.bind(dU, (size_t)h->total_users * h->k);
+        if (dV) h->V.bind(dV, (size_t)h->total_items * h->k);
+        if (dB) h->B.bind(dB, (size_t)h->total_items);
+    });
+}
+
+int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB) {
+    return guarded([&] {
+        bpr_check(h);
+        if (dU) *dU = h->U.p;
+        if (dV) *dV = h->V.p;
+        if (dB) *dB = h->B.p;
+    });
+}
+
+int cornac_hip_bpr_set_stream(cornac_hip_bpr_t h, void *hip_stream) {
+    return guarded([&] {
+        bpr_check(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    });
+}
+
+static void mt_init_genrand(uint32_t seed, uint32_t *mt) {
+    mt[0] = seed;
+    for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+int cornac_hip_bpr_seed_mt19937(cornac_hip_bpr_t h, uint32_t mt_seed_pos, uint32_t mt_seed_neg, int shared_stream) {
+    return guarded([&] {
+        bpr_check(h);
+        std::vector<uint32_t> st(2 * MT_N);
+        mt_init_genrand(mt_seed_pos, st.data());
+        mt_init_genrand(mt_seed_neg, st.data() + MT_N);
+        const int32_t idx[2] = {MT_N, MT_N};
+        h->mt_state.ensure(2 * MT_N);
+        h->mt_idx.ensure(2);
+        h->mt_params.ensure(2);
+        h->mt_state.upload(st.data(), 2 * MT_N, h->stream);
+        h->mt_idx.upload(idx, 2, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->mt_seeded = true;
+        h->shared_stream = shared_stream != 0;
+    });
+}
+
+int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed) {
+    return guarded([&] {
+        bpr_check(h);
+        h->hog_seed = seed;
+        h->hog_epoch = 0;
+        h->hog_offset = 0;
+        h->hog_seeded = true;
+    });
+}
+}  // extern "C"
+
+// ---- deterministic draws -------------------------------------------------------------------------
+static MtStreamParams make_mt_params(cornac_hip_bpr_t h, int stream, uint64_t hi, int64_t need, uint32_t *out) {
+    REQUIRE(hi <= 0xFFFFFFFFull, "sampling range >= 2^32 is not reachable in the reference (boost multi-draw branch)");
+    MtStreamParams p;
+    p.state = h->mt_state.p + (size_t)stream * MT_N;
+    p.idx = h->mt_idx.p + stream;
+    p.out = out;
+    p.need = need;
+    p.range = (uint32_t)hi;
+    if (hi == 0xFFFFFFFFull) {
+        p.bucket = 1;
+    } else {
+        const uint32_t r1 = (uint32_t)hi + 1u;
+        p.bucket = 0xFFFFFFFFu / r1;
+        if (0xFFFFFFFFu % r1 == (uint32_t)hi) ++p.bucket;
+    }
+    p.out_stride = 1;
+    p.out_offset = 0;
+    return p;
+}
+
+// launches the generator for up to two streams; hi == 0 streams draw nothing (boost returns min
+// without touching the engine, uniform_int_distribution.hpp:64-65)
+static void mt_draw(cornac_hip_bpr_t h, int n_streams, const int *streams, const uint64_t *his, const int64_t *needs,
+                    uint32_t *const *outs) {
+    MtStreamParams ps[2];
+    int n = 0;
+    for (int s = 0; s < n_streams; ++s) {
+        if (his[s] == 0) {
+            HIP_CHECK(hipMemsetAsync(outs[s], 0, (size_t)needs[s] * sizeof(uint32_t), h->stream));
+        } else if (needs[s] > 0) {
+            ps[n++] = make_mt_params(h, streams[s], his[s], needs[s], outs[s]);
+        }
+    }
+    if (n == 0) return;
+    HIP_CHECK(hipMemcpyAsync(h->mt_params.p, ps, sizeof(MtStreamParams) * n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(mt19937_draw_kernel, dim3(n), dim3(MT_THREADS), 0, h->stream, h->mt_params.p);
+    HIP_CHECK(hipGetLastError());
+    // params live in pageable host memory: make sure the copy has been consumed before ps dies
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+template <int G>
+static void launch_det_level(cornac_hip_bpr_t h, const int32_t *ou, const int32_t *oi, const int32_t *oj, int64_t off,
+                             int cnt, float lr, float reg, int use_bias) {
+    const int groups_per_block = kBlock / G;
+    const int grid = (cnt + groups_per_block - 1) / groups_per_block;
+    hipLaunchKernelGGL(bpr_det_level_kernel<G>, dim3(grid), dim3(kBlock), 0, h->stream, ou, oi, oj, off, cnt, h->U.p,
+                       h->V.p, h->B.p, h->k, lr, reg, use_bias, h->counters.p);
+}
+
+static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int use_bias, int neg_population) {
+    REQUIRE(h->mt_seeded, "deterministic mode needs cornac_hip_bpr_seed_mt19937 first");
+    const int64_t nnz = h->nnz;
+    const uint64_t pos_hi = (uint64_t)nnz - 1;
+    const uint64_t neg_hi = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint64_t)nnz - 1 : (uint64_t)h->n_items - 1;
+    const int64_t chunk = std::min(nnz, kDetChunk);
+    h->draws.ensure((size_t)2 * chunk);
+    h->trip.ensure((size_t)6 * chunk);
+    h->h_trip.ensure((size_t)6 * chunk);
+    const int G = pow2_group(h->k);
+    for (int64_t c0 = 0; c0 < nnz; c0 += chunk) {
+        const int64_t n = std::min(chunk, nnz - c0);
+        Timer t_s;
+        uint32_t *d_pos = h->draws.p, *d_neg = h->draws.p + chunk;
+        int pos_stride = 1, neg_stride = 1;
+        if (h->shared_stream) {
+            // WBPR: one engine, draws alternate pos, neg, pos, ... with the same range (recom_wbpr.pyx:131-139)
+            REQUIRE(pos_hi == neg_hi, "shared-stream sampling needs equal ranges (WBPR uses X.indices for both)");
+            const int st = 0;
+            const int64_t need = 2 * n;
+            uint32_t *o = h->draws.p;
+            mt_draw(h, 1, &st, &pos_hi, &need, &o);
+            d_pos = h->draws.p;
+            d_neg = h->draws.p + 1;
+            pos_stride = neg_stride = 2;
+        } else {
+            const int st[2] = {0, 1};
+            const uint64_t his[2] = {pos_hi, neg_hi};
+            const int64_t needs[2] = {n, n};
+            uint32_t *outs[2] = {d_pos, d_neg};
+            mt_draw(h, 2, st, his, needs, outs);
+        }
+        int32_t *su = h->trip.p, *si = su + chunk, *sj = si + chunk;
+        int32_t *ou = sj + chunk, *oi = ou + chunk, *oj = oi + chunk;
+        hipLaunchKernelGGL(bpr_det_sample_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           h->stream, d_pos, pos_stride, d_neg, neg_stride, n, h->user_ids.p, h->indices.p,
+                           h->indptr.p, neg_population, su, si, sj, h->counters.p);
+        HIP_CHECK(hipGetLastError());
+        int32_t *hsu = h->h_trip.p, *hsi = hsu + chunk, *hsj = hsi + chunk;
+        int32_t *hou = hsj + chunk, *hoi = hou + chunk, *hoj = hoi + chunk;
+        HIP_CHECK(hipMemcpyAsync(hsu, su, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(hsi, si, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(hsj, sj, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->timing[0] += t_s.ms();
+        Timer t_l;
+        build_level_schedule(hsu, hsi, hsj, n, h->total_users, h->total_items, hou, hoi, hoj, h->sched, h->lvl_u,
+                             h->lvl_i, h->level);
+        h->timing[1] += t_l.ms();
+        Timer t_k;
+        const int64_t na = h->sched.n_active;
+        if (na > 0) {
+            HIP_CHECK(hipMemcpyAsync(ou, hou, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(oi, hoi, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(oj, hoj, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        const std::vector<int64_t> &lp = h->sched.level_ptr;
+        for (size_t l = 1; l + 1 < lp.size(); ++l) {
+            const int64_t off = lp[l];
+            const int cnt = (int)(lp[l + 1] - lp[l]);
+            if (cnt <= 0) continue;
+            switch (G) {
+                case 4: launch_det_level<4>(h, ou, oi, oj, off, cnt, lr, reg, use_bias); break;
+                case 8: launch_det_level<8>(h, ou, oi, oj, off, cnt, lr, reg, use_bias); break;
+                case 16: launch_det_level<16>(h, ou, oi, oj, off, cnt, lr, reg, use_bias); break;
+                case 32: launch_det_level<32>(h, ou, oi, oj, off, cnt, lr, reg, use_bias); break;
+                default: launch_det_level<64>(h, ou, oi, oj, off, cnt, lr, reg, use_bias); break;
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->timing[2] += t_k.ms();
+    }
+}
+
+// ---- hogwild launch -------------------------------------------------------------------------------
+template <bool ATOMIC>
+static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a) {
+    const DeviceInfo &di = device_info(h->device);
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * 8));
+    const int k = h->k;
+    dim3 g(grid), b(kBlock);
+    if (k % 4 == 0 && k <= 256) {
+        const int q = k / 4;
+        if (q <= 4) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<4, ATOMIC>), g, b, 0, h->stream, a);
+        else if (q <= 8) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<8, ATOMIC>), g, b, 0, h->stream, a);
+        else if (q <= 16) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<16, ATOMIC>), g, b, 0, h->stream, a);
+        else if (q <= 32) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<32, ATOMIC>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<64, ATOMIC>), g, b, 0, h->stream, a);
+    } else {
+        switch (pow2_group(k)) {
+            case 4: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<4, ATOMIC>), g, b, 0, h->stream, a); break;
+            case 8: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<8, ATOMIC>), g, b, 0, h->stream, a); break;
+            case 16: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<16, ATOMIC>), g, b, 0, h->stream, a); break;
+            case 32: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<32, ATOMIC>), g, b, 0, h->stream, a); break;
+            default: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<64, ATOMIC>), g, b, 0, h->stream, a); break;
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
+                            int neg_population, int flags) {
+    REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+    int64_t left = n_samples;
+    while (left > 0) {
+        const int64_t n = std::min(left, h->nnz - h->hog_offset);
+        HogArgs a;
+        a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
+        a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
+        a.counters = h->counters.p;
+        a.n = n;
+        a.s_begin = (uint64_t)h->hog_offset;
+        a.seed = h->hog_seed;
+        a.epoch = h->hog_epoch;
+        a.n_pos = (uint32_t)h->nnz;
+        a.n_neg = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint32_t)h->nnz : (uint32_t)h->n_items;
+        a.th_pos = lemire_thresh(a.n_pos);
+        a.th_neg = lemire_thresh(a.n_neg);
+        a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
+        a.lr = lr; a.reg = reg;
+        if (flags & 1) launch_hogwild<false>(h, a); else launch_hogwild<true>(h, a);
+        h->hog_offset += n;
+        left -= n;
+        if (h->hog_offset >= h->nnz) {
+            h->hog_offset = 0;
+            ++h->hog_epoch;
+        }
+    }
+}
+
+static void fetch_counters(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped) {
+    unsigned long long c[2];
+    HIP_CHECK(hipMemcpyAsync(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->counters.p, 0, sizeof c, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (correct) *correct += (int64_t)c[0];
+    if (skipped) *skipped += (int64_t)c[1];
+}
+
+extern "C" {
+
+int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, int use_bias, int neg_population,
+                              int mode, int hogwild_flags, int64_t *correct, int64_t *skipped) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
+        REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
+                "unknown neg_population %d", neg_population);
+        REQUIRE(mode == CORNAC_HIP_MODE_DETERMINISTIC || mode == CORNAC_HIP_MODE_HOGWILD, "unknown mode %d", mode);
+        if (correct) *correct = 0;
+        if (skipped) *skipped = 0;
+        for (double &t : h->timing) t = 0;
+        Timer total;
+        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        for (int e = 0; e < n_epochs; ++e) {
+            if (mode == CORNAC_HIP_MODE_DETERMINISTIC) {
+                bpr_epoch_deterministic(h, lr, reg, use_bias, neg_population);
+            } else {
+                Timer t_k;
+                hogwild_enqueue(h, h->nnz, lr, reg, use_bias, neg_population, hogwild_flags);
+                h->timing[2] += t_k.ms();
+            }
+        }
+        Timer t_sync;
+        fetch_counters(h, correct, skipped);
+        if (mode == CORNAC_HIP_MODE_HOGWILD) h->timing[2] += t_sync.ms();
+        h->timing[3] = total.ms();
+    });
+}
+
+int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
+                                   int neg_population, int hogwild_flags) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(n_samples >= 0, "n_samples must be >= 0");
+        hogwild_enqueue(h, n_samples, lr, reg, use_bias, neg_population, hogwild_flags);
+    });
+}
+
+int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped) {
+    return guarded([&] {
+        bpr_check(h);
+        if (correct) *correct = 0;
+        if (skipped) *skipped = 0;
+        fetch_counters(h, correct, skipped);
+    });
+}
+
+int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64_t n, int64_t *out) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->mt_seeded, "seed the mt19937 streams first");
+        REQUIRE(stream == 0 || stream == 1, "stream must be 0 or 1");
+        REQUIRE(n >= 0 && out != nullptr, "bad output");
+        if (n == 0) return;
+        DevBuf<uint32_t> d;
+        d.alloc((size_t)n);
+        uint32_t *o = d.p;
+        mt_draw(h, 1, &stream, &hi, &n, &o);
+        std::vector<uint32_t> tmp((size_t)n);
+        d.download(tmp.data(), (size_t)n, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (int64_t t = 0; t < n; ++t) out[t] = (int64_t)tmp[(size_t)t];
+    });
+}
+
+int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4) {
+    return guarded([&] {
+        REQUIRE(h && ms4, "NULL argument");
+        for (int t = 0; t < 4; ++t) ms4[t] = h->timing[t];
+    });
+}
+}

@@ -1,0 +1,415 @@
+// Biased matrix factorisation SGD on MI355X (gfx950).
+//
+// Replaces backend_cpu.fit_sgd (cornac/models/mf/backend_cpu.pyx:35-97): per epoch, for every
+// rating in stored COO order: pred = mu + Bu[u] + Bi[i] + <U[u], V[i]>, err = r - pred, in-place
+// SGD on the two rows and two biases, loss = 0.5 * sum(err^2).
+//
+//   deterministic — the seeded (1-thread) reference order, executed as a level schedule of the
+//                   row-conflict DAG (built once: the COO order never changes between epochs);
+//                   float expression order identical to the reference => bit-identical factors.
+//   hogwild       — the reference's `prange(..., schedule='static')` racy path: a wave takes 64
+//                   consecutive ratings (coalesced int64/float reads), G lanes per rating gather the
+//                   two rows with 16-byte loads and scatter fp32 atomic updates.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "sgd_device.h"
+
+namespace chip {
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void mf_det_level_kernel(const int32_t *__restrict__ ou,
+                                                              const int32_t *__restrict__ oi,
+                                                              const float *__restrict__ orat, int64_t off, int cnt,
+                                                              float *U, float *V, float *Bu, float *Bi, int k, float lr,
+                                                              float reg, float mu, int use_bias,
+                                                              double *__restrict__ loss_acc) {
+    const int gid = (blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lg = threadIdx.x & (G - 1);
+    const bool active = gid < cnt;
+    const int64_t t = off + (active ? gid : cnt - 1);
+    const int32_t u = ou[t], i = oi[t];
+    const float r = orat[t];
+    float *pu = U + (size_t)u * k, *pi = V + (size_t)i * k;
+    float pred = mu + Bu[u] + Bi[i];
+    for (int base = 0; base < k; base += G) {
+        const int f = base + lg;
+        float p = 0.f;
+        if (f < k) p = pu[f] * pi[f];
+        const int lim = min(G, k - base);
+        for (int l = 0; l < lim; ++l) pred = pred + __shfl(p, l, G);
+    }
+    const float err = r - pred;
+    if (active) {
+        for (int f = lg; f < k; f += G) {
+            const float uf = pu[f], vf = pi[f];
+            pu[f] = uf + lr * (err * vf - reg * uf);
+            pi[f] = vf + lr * (err * uf - reg * vf);
+        }
+        if (lg == 0 && use_bias) {
+            const float bu = Bu[u], bi = Bi[i];
+            Bu[u] = bu + lr * (err - reg * bu);
+            Bi[i] = bi + lr * (err - reg * bi);
+        }
+    }
+    // loss: fp64 partial sums (the reference sums err^2 into a float sequentially)
+    double e2 = (active && lg == 0) ? (double)err * (double)err : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, kWave);
+    if (lane_id() == 0 && e2 != 0.0) atomicAdd(loss_acc, e2);
+}
+
+struct MfHogArgs {
+    const int64_t *rid, *cid;
+    const float *val;
+    float *U, *V, *Bu, *Bi;
+    double *loss_acc;
+    int64_t n;
+    int k, use_bias;
+    float lr, reg, mu;
+};
+
+template <int G, bool VEC4>
+__global__ __launch_bounds__(kBlock) void mf_hogwild_kernel(const MfHogArgs a) {
+    constexpr int TPW = kWave / G;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int grp = lane / G, lg = lane & (G - 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    double loss = 0.0;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
+        const int64_t s = tile * kWave + lane;
+        const bool in_range = s < a.n;
+        int32_t mu_ = 0, mi_ = 0;
+        float mr = 0.f;
+        if (in_range) {
+            mu_ = (int32_t)a.rid[s];
+            mi_ = (int32_t)a.cid[s];
+            mr = a.val[s];
+        }
+        const int nvalid = (int)min((int64_t)kWave, a.n - tile * kWave);
+        for (int b = 0; b < nvalid; b += TPW) {
+            const int slot = b + grp;
+            const bool act = slot < nvalid;
+            const int sl = act ? slot : b;
+            const int32_t tu = __shfl(mu_, sl, kWave), ti = __shfl(mi_, sl, kWave);
+            const float tr = __shfl(mr, sl, kWave);
+            float *pu = a.U + (size_t)tu * a.k, *pi = a.V + (size_t)ti * a.k;
+            const float bu = a.Bu[tu], bi = a.Bi[ti];
+            float err;
+            if (VEC4) {
+                const int f0 = 4 * lg;
+                const bool inb = f0 < a.k;
+                v4f u4 = {0.f, 0.f, 0.f, 0.f}, v4 = u4;
+                if (inb) {
+                    u4 = load_row4_fresh(pu + f0);
+                    v4 = load_row4_fresh(pi + f0);
+                }
+                const float part = u4.x * v4.x + u4.y * v4.y + u4.z * v4.z + u4.w * v4.w;
+                err = tr - ((a.mu + bu + bi) + group_sum<G>(part));
+                if (act && inb) {
+                    const v4f du = a.lr * (err * v4 - a.reg * u4);
+                    const v4f dv = a.lr * (err * u4 - a.reg * v4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        atomic_add_f32(pu + f0 + c, du[c]);
+                        atomic_add_f32(pi + f0 + c, dv[c]);
+                    }
+                }
+            } else {
+                float part = 0.f;
+                for (int f = lg; f < a.k; f += G) part += load_f32_fresh(pu + f) * load_f32_fresh(pi + f);
+                err = tr - ((a.mu + bu + bi) + group_sum<G>(part));
+                if (act) {
+                    for (int f = lg; f < a.k; f += G) {
+                        const float uf = load_f32_fresh(pu + f), vf = load_f32_fresh(pi + f);
+                        atomic_add_f32(pu + f, a.lr * (err * vf - a.reg * uf));
+                        atomic_add_f32(pi + f, a.lr * (err * uf - a.reg * vf));
+                    }
+                }
+            }
+            if (act && lg == 0) {
+                if (a.use_bias) {
+                    atomic_add_f32(a.Bu + tu, a.lr * (err - a.reg * bu));
+                    atomic_add_f32(a.Bi + ti, a.lr * (err - a.reg * bi));
+                }
+                loss += (double)err * (double)err;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, kWave);
+    if (lane == 0 && loss != 0.0) atomicAdd(a.loss_acc, loss);
+}
+
+static int mf_pow2_group(int k) {
+    int g = 4;
+    while (g < k && g < 64) g <<= 1;
+    return g;
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+struct cornac_hip_mf {
+    int device = 0;
+    int64_t n_users = 0, n_items = 0, nnz = 0;
+    int k = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<int64_t> rid, cid;
+    DevBuf<float> val;
+    DevBuf<float> U, V, Bu, Bi;
+    DevBuf<double> loss;  // one slot per epoch
+    // deterministic schedule (built lazily, reused by every epoch)
+    bool sched_built = false;
+    DevBuf<int32_t> ou, oi;
+    DevBuf<float> orat;
+    LevelSchedule sched;
+    std::vector<int64_t> host_rid, host_cid;
+    std::vector<float> host_val;
+    double timing[4] = {0, 0, 0, 0};
+};
+
+static void mf_check(cornac_hip_mf_t h) {
+    REQUIRE(h != nullptr, "MF handle is NULL");
+    HIP_CHECK(hipSetDevice(h->device));
+}
+
+static void mf_build_schedule(cornac_hip_mf_t h) {
+    if (h->sched_built) return;
+    Timer t;
+    const int64_t n = h->nnz;
+    std::vector<int32_t> su((size_t)n), si((size_t)n), outu((size_t)n), outi((size_t)n);
+    for (int64_t s = 0; s < n; ++s) {
+        su[(size_t)s] = (int32_t)h->host_rid[(size_t)s];
+        si[(size_t)s] = (int32_t)h->host_cid[(size_t)s];
+    }
+    // level[s] = 1 + max(level of the previous rating of the same user / same item); the rating
+    // values ride along through the counting sort.
+    std::vector<int32_t> lvl_u((size_t)h->n_users, 0), lvl_i((size_t)h->n_items, 0), level((size_t)n);
+    int32_t max_level = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        int32_t l = std::max(lvl_u[(size_t)su[(size_t)s]], lvl_i[(size_t)si[(size_t)s]]) + 1;
+        lvl_u[(size_t)su[(size_t)s]] = l;
+        lvl_i[(size_t)si[(size_t)s]] = l;
+        level[(size_t)s] = l;
+        max_level = std::max(max_level, l);
+    }
+    h->sched.level_ptr.assign((size_t)max_level + 2, 0);
+    for (int64_t s = 0; s < n; ++s) ++h->sched.level_ptr[(size_t)level[(size_t)s] + 1];
+    for (size_t l = 1; l < h->sched.level_ptr.size(); ++l) h->sched.level_ptr[l] += h->sched.level_ptr[l - 1];
+    std::vector<int64_t> cursor(h->sched.level_ptr.begin(), h->sched.level_ptr.end());
+    std::vector<float> outr((size_t)n);
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t pos = cursor[(size_t)level[(size_t)s]]++;
+        outu[(size_t)pos] = su[(size_t)s];
+        outi[(size_t)pos] = si[(size_t)s];
+        outr[(size_t)pos] = h->host_val[(size_t)s];
+    }
+    h->sched.n_active = n;
+    h->ou.alloc((size_t)n);
+    h->oi.alloc((size_t)n);
+    h->orat.alloc((size_t)n);
+    h->ou.upload(outu.data(), (size_t)n, h->stream);
+    h->oi.upload(outi.data(), (size_t)n, h->stream);
+    h->orat.upload(outr.data(), (size_t)n, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->sched_built = true;
+    h->timing[1] += t.ms();
+}
+
+template <int G>
+static void launch_mf_level(cornac_hip_mf_t h, int64_t off, int cnt, float lr, float reg, float mu, int use_bias,
+                            double *loss_slot) {
+    const int groups_per_block = kBlock / G;
+    const int grid = (cnt + groups_per_block - 1) / groups_per_block;
+    hipLaunchKernelGGL(mf_det_level_kernel<G>, dim3(grid), dim3(kBlock), 0, h->stream, h->ou.p, h->oi.p, h->orat.p,
+                       off, cnt, h->U.p, h->V.p, h->Bu.p, h->Bi.p, h->k, lr, reg, mu, use_bias, loss_slot);
+}
+
+static void mf_epoch_deterministic(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    mf_build_schedule(h);
+    const int G = mf_pow2_group(h->k);
+    const std::vector<int64_t> &lp = h->sched.level_ptr;
+    for (size_t l = 1; l + 1 < lp.size(); ++l) {
+        const int64_t off = lp[l];
+        const int cnt = (int)(lp[l + 1] - lp[l]);
+        if (cnt <= 0) continue;
+        switch (G) {
+            case 4: launch_mf_level<4>(h, off, cnt, lr, reg, mu, use_bias, loss_slot); break;
+            case 8: launch_mf_level<8>(h, off, cnt, lr, reg, mu, use_bias, loss_slot); break;
+            case 16: launch_mf_level<16>(h, off, cnt, lr, reg, mu, use_bias, loss_slot); break;
+            case 32: launch_mf_level<32>(h, off, cnt, lr, reg, mu, use_bias, loss_slot); break;
+            default: launch_mf_level<64>(h, off, cnt, lr, reg, mu, use_bias, loss_slot); break;
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    const DeviceInfo &di = device_info(h->device);
+    MfHogArgs a;
+    a.rid = h->rid.p; a.cid = h->cid.p; a.val = h->val.p;
+    a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p; a.Bi = h->Bi.p;
+    a.loss_acc = loss_slot;
+    a.n = h->nnz; a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * 8));
+    dim3 g(grid), b(kBlock);
+    const int k = h->k;
+    if (k % 4 == 0 && k <= 256) {
+        const int q = k / 4;
+        if (q <= 4) hipLaunchKernelGGL((mf_hogwild_kernel<4, true>), g, b, 0, h->stream, a);
+        else if (q <= 8) hipLaunchKernelGGL((mf_hogwild_kernel<8, true>), g, b, 0, h->stream, a);
+        else if (q <= 16) hipLaunchKernelGGL((mf_hogwild_kernel<16, true>), g, b, 0, h->stream, a);
+        else if (q <= 32) hipLaunchKernelGGL((mf_hogwild_kernel<32, true>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((mf_hogwild_kernel<64, true>), g, b, 0, h->stream, a);
+    } else {
+        switch (mf_pow2_group(k)) {
+            case 4: hipLaunchKernelGGL((mf_hogwild_kernel<4, false>), g, b, 0, h->stream, a); break;
+            case 8: hipLaunchKernelGGL((mf_hogwild_kernel<8, false>), g, b, 0, h->stream, a); break;
+            case 16: hipLaunchKernelGGL((mf_hogwild_kernel<16, false>), g, b, 0, h->stream, a); break;
+            case 32: hipLaunchKernelGGL((mf_hogwild_kernel<32, false>), g, b, 0, h->stream, a); break;
+            default: hipLaunchKernelGGL((mf_hogwild_kernel<64, false>), g, b, 0, h->stream, a); break;
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" {
+
+int cornac_hip_mf_create(cornac_hip_mf_t *out, int device, int64_t n_users, int64_t n_items, int k,
+                         const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz) {
+    return guarded([&] {
+        REQUIRE(out != nullptr, "out handle pointer is NULL");
+        *out = nullptr;
+        REQUIRE(n_users > 0 && n_items > 0 && k > 0, "n_users, n_items and k must be positive");
+        REQUIRE(n_users < (int64_t(1) << 31) && n_items < (int64_t(1) << 31), "index range exceeds int32");
+        REQUIRE(nnz > 0 && rid && cid && val, "empty or NULL rating arrays");
+        for (int64_t s = 0; s < nnz; ++s)
+            REQUIRE(rid[s] >= 0 && rid[s] < n_users && cid[s] >= 0 && cid[s] < n_items,
+                    "rating %lld has an out-of-range index", (long long)s);
+        use_device(device);
+        std::unique_ptr<cornac_hip_mf> h(new cornac_hip_mf());
+        h->device = device; h->n_users = n_users; h->n_items = n_items; h->k = k; h->nnz = nnz;
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->rid.alloc((size_t)nnz); h->cid.alloc((size_t)nnz); h->val.alloc((size_t)nnz);
+        h->rid.upload(rid, (size_t)nnz, h->stream);
+        h->cid.upload(cid, (size_t)nnz, h->stream);
+        h->val.upload(val, (size_t)nnz, h->stream);
+        h->host_rid.assign(rid, rid + nnz);
+        h->host_cid.assign(cid, cid + nnz);
+        h->host_val.assign(val, val + nnz);
+        h->U.alloc((size_t)n_users * k); h->V.alloc((size_t)n_items * k);
+        h->Bu.alloc((size_t)n_users); h->Bi.alloc((size_t)n_items);
+        HIP_CHECK(hipMemsetAsync(h->U.p, 0, h->U.n * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(h->V.p, 0, h->V.n * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(h->Bu.p, 0, h->Bu.n * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(h->Bi.p, 0, h->Bi.n * 4, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        *out = h.release();
+    });
+}
+
+int cornac_hip_mf_destroy(cornac_hip_mf_t h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipSetDevice(h->device);
+        if (h->stream) {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamDestroy(h->stream);
+        }
+        delete h;
+    });
+}
+
+int cornac_hip_mf_set_factors(cornac_hip_mf_t h, const float *U, const float *V, const float *Bu, const float *Bi) {
+    return guarded([&] {
+        mf_check(h);
+        if (U) h->U.upload(U, (size_t)h->n_users * h->k, h->stream);
+        if (V) h->V.upload(V, (size_t)h->n_items * h->k, h->stream);
+        if (Bu) h->Bu.upload(Bu, (size_t)h->n_users, h->stream);
+        if (Bi) h->Bi.upload(Bi, (size_t)h->n_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_mf_get_factors(cornac_hip_mf_t h, float *U, float *V, float *Bu, float *Bi) {
+    return guarded([&] {
+        mf_check(h);
+        if (U) h->U.download(U, (size_t)h->n_users * h->k, h->stream);
+        if (V) h->V.download(V, (size_t)h->n_items * h->k, h->stream);
+        if (Bu) h->Bu.download(Bu, (size_t)h->n_users, h->stream);
+        if (Bi) h->Bi.download(Bi, (size_t)h->n_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, float mu, int use_bias, int early_stop,
+                      int mode, float *loss_per_epoch, int *epochs_run) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(max_iter >= 0, "max_iter must be >= 0");
+        REQUIRE(mode == CORNAC_HIP_MODE_DETERMINISTIC || mode == CORNAC_HIP_MODE_HOGWILD, "unknown mode %d", mode);
+        for (double &t : h->timing) t = 0;
+        Timer total;
+        h->loss.ensure((size_t)std::max(max_iter, 1));
+        HIP_CHECK(hipMemsetAsync(h->loss.p, 0, h->loss.n * sizeof(double), h->stream));
+        if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_build_schedule(h);
+        Timer t_k;
+        float loss = 0.f, last_loss = 0.f;
+        int e = 0;
+        for (; e < max_iter; ++e) {
+            if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
+            else mf_epoch_hogwild(h, lr, reg, mu, use_bias, h->loss.p + e);
+            if (early_stop) {  // needs this epoch's loss on the host (backend_cpu.pyx:89-93)
+                double l;
+                HIP_CHECK(hipMemcpyAsync(&l, h->loss.p + e, sizeof l, hipMemcpyDeviceToHost, h->stream));
+                HIP_CHECK(hipStreamSynchronize(h->stream));
+                last_loss = loss;
+                loss = (float)(0.5 * l);
+                if (fabsf(loss - last_loss) < 1e-5f) {
+                    ++e;
+                    break;
+                }
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->timing[2] = t_k.ms();
+        if (loss_per_epoch && e > 0) {
+            std::vector<double> l((size_t)e);
+            HIP_CHECK(hipMemcpy(l.data(), h->loss.p, sizeof(double) * (size_t)e, hipMemcpyDeviceToHost));
+            for (int t = 0; t < e; ++t) loss_per_epoch[t] = (float)(0.5 * l[(size_t)t]);
+        }
+        if (epochs_run) *epochs_run = e;
+        h->timing[3] = total.ms();
+    });
+}
+
+int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz, float *U,
+                          float *V, float *Bu, float *Bi, int64_t n_users, int64_t n_items, int k, float lr, float reg,
+                          float mu, int max_iter, int use_bias, int early_stop, int mode, float *loss_per_epoch,
+                          int *epochs_run) {
+    cornac_hip_mf_t h = nullptr;
+    int rc = cornac_hip_mf_create(&h, device, n_users, n_items, k, rid, cid, val, nnz);
+    if (rc != CORNAC_HIP_OK) return rc;
+    rc = cornac_hip_mf_set_factors(h, U, V, Bu, Bi);
+    if (rc == CORNAC_HIP_OK)
+        rc = cornac_hip_mf_fit(h, max_iter, lr, reg, mu, use_bias, early_stop, mode, loss_per_epoch, epochs_run);
+    if (rc == CORNAC_HIP_OK) rc = cornac_hip_mf_get_factors(h, U, V, Bu, Bi);
+    std::string keep = cornac_hip_last_error();
+    cornac_hip_mf_destroy(h);
+    if (rc != CORNAC_HIP_OK) chip::set_last_error(keep);
+    return rc;
+}
+
+int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4) {
+    return guarded([&] {
+        REQUIRE(h && ms4, "NULL argument");
+        for (int t = 0; t < 4; ++t) ms4[t] = h->timing[t];
+    });
+}
+}

@@ -1,0 +1,66 @@
+// Device building blocks shared by the BPR and MF SGD kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// The SGD arithmetic mirrors the reference's unfused float expressions; never let the compiler
+// contract a*b+c into an fma in these kernels (explicit fmaf is used where a fused op is wanted).
+#pragma clang fp contract(off)
+
+namespace chip {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// butterfly sum over the G lanes of a lane group (G = power of two <= 64); every lane gets the sum
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// sigmoid(-score) exactly as the reference evaluates it (cornac/models/bpr/recom_bpr.pyx:250):
+// exp on a float, then 1.0/(1.0+e) in double, rounded to float on assignment.
+__device__ __forceinline__ float sigmoid_neg_exact(float score) {
+    const float e = (float)exp((double)score);
+    return (float)(1.0 / (1.0 + (double)e));
+}
+__device__ __forceinline__ float sigmoid_neg_fast(float score) {
+    return __frcp_rn(1.0f + __expf(score));
+}
+
+// device-scope fp32 atomic add without return (global_atomic_add_f32)
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// write-through (sc1) store: visible to the other XCDs' L2s without a release fence
+__device__ __forceinline__ void store_f32_agent(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// L1-bypassing loads of rows that other CUs update concurrently (hogwild)
+__device__ __forceinline__ v4f load_row4_fresh(const float *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+}
+__device__ __forceinline__ float load_f32_fresh(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// is `col` present in the sorted CSR row [lo, hi)?  (has_non_zero, recom_bpr.pyx:46-51)
+__device__ __forceinline__ bool csr_row_contains(const int32_t *__restrict__ indices, int32_t lo, int32_t hi,
+                                                 int32_t col) {
+    const int32_t end = hi;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if (indices[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo < end && indices[lo] == col;
+}
+
+}  // namespace chip

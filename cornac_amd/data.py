@@ -1,0 +1,127 @@
+"""Interaction dataset handed to the trainers — the host-side mirror of the reference's
+`cornac.data.Dataset` (cornac/data/dataset.py:31-358), restricted to what the hot path reads:
+
+  * `uir_tuple`  (int64 users, int64 items, float64 ratings, in insertion order — dataset.py:340-344),
+  * `matrix` / `csr_matrix`  (scipy CSR, int32 indptr/indices sorted per row — dataset.py:226-235),
+  * `num_users`, `num_items`, `uid_map`, `iid_map`, `min_rating`, `max_rating`, `global_mean`,
+  * `reset()` (re-seeds the dataset RNG, dataset.py:401-404).
+
+A real `cornac.data.Dataset` exposes the same attributes, so the models in this package accept
+either (duck typing); nothing here imports the reference.
+"""
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+
+class Dataset:
+    def __init__(self, num_users, num_items, uid_map, iid_map, uir_tuple, timestamps=None, seed=None):
+        self.num_users = int(num_users)
+        self.num_items = int(num_items)
+        self.uid_map = uid_map
+        self.iid_map = iid_map
+        self.uir_tuple = uir_tuple
+        self.timestamps = timestamps
+        self.seed = seed
+        self.rng = np.random.RandomState(seed)
+        r = uir_tuple[2]
+        self.num_ratings = len(r)
+        self.max_rating = np.max(r)
+        self.min_rating = np.min(r)
+        self.global_mean = np.mean(r)
+        self._csr = None
+
+    @classmethod
+    def build(cls, data, global_uid_map=None, global_iid_map=None, seed=None, exclude_unknowns=False):
+        """(user, item, rating) triplets -> Dataset; first occurrence of a (user, item) pair wins,
+        ids are numbered in order of first appearance (dataset.py:257-358)."""
+        gu = OrderedDict() if global_uid_map is None else global_uid_map
+        gi = OrderedDict() if global_iid_map is None else global_iid_map
+        seen = set()
+        us, its, rs = [], [], []
+        dups = 0
+        for rec in data:
+            uid, iid, rating = rec[0], rec[1], rec[2]
+            if exclude_unknowns and (uid not in gu or iid not in gi):
+                continue
+            if (uid, iid) in seen:
+                dups += 1
+                continue
+            seen.add((uid, iid))
+            us.append(gu.setdefault(uid, len(gu)))
+            its.append(gi.setdefault(iid, len(gi)))
+            rs.append(float(rating))
+        if dups:
+            warnings.warn("%d duplicated observations are removed!" % dups)
+        if not seen:
+            raise ValueError("data is empty after being filtered!")
+        uir = (np.asarray(us, dtype="int"), np.asarray(its, dtype="int"), np.asarray(rs, dtype="float"))
+        return cls(len(gu), len(gi), gu, gi, uir, seed=seed)
+
+    @classmethod
+    def from_uir(cls, data, seed=None):
+        return cls.build(data, seed=seed)
+
+    @classmethod
+    def from_arrays(cls, users, items, ratings, num_users=None, num_items=None, seed=None):
+        """Index arrays -> Dataset without the Python-level id mapping loop (identity id maps);
+        used for large synthetic interaction sets.  (user, item) pairs must be unique."""
+        users = np.asarray(users, dtype="int")
+        items = np.asarray(items, dtype="int")
+        ratings = np.asarray(ratings, dtype="float")
+        nu = int(users.max()) + 1 if num_users is None else int(num_users)
+        ni = int(items.max()) + 1 if num_items is None else int(num_items)
+        return cls(nu, ni, _RangeMap(nu), _RangeMap(ni), (users, items, ratings), seed=seed)
+
+    def reset(self):
+        self.rng = np.random.RandomState(self.seed)
+        return self
+
+    @property
+    def matrix(self):
+        return self.csr_matrix
+
+    @property
+    def csr_matrix(self):
+        if self._csr is None:
+            u, i, r = self.uir_tuple
+            self._csr = csr_matrix((r, (u, i)), shape=(self.num_users, self.num_items))
+        return self._csr
+
+    @property
+    def user_ids(self):
+        return list(self.uid_map.keys())
+
+    @property
+    def item_ids(self):
+        return list(self.iid_map.keys())
+
+
+class _RangeMap:
+    """Identity raw-id -> index map over range(n) that behaves like the OrderedDict id maps
+    (len, get, keys, items, in) without materialising n Python objects."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __contains__(self, key):
+        return isinstance(key, (int, np.integer)) and 0 <= key < self.n
+
+    def get(self, key, default=None):
+        return int(key) if key in self else default
+
+    def __getitem__(self, key):
+        if key not in self:
+            raise KeyError(key)
+        return int(key)
+
+    def keys(self):
+        return range(self.n)
+
+    def items(self):
+        return ((i, i) for i in range(self.n))

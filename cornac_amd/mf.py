@@ -1,0 +1,128 @@
+"""Biased matrix factorisation on MI355X — constructor, `fit/score/rank` surface and learned
+attributes (`u_factors, i_factors, u_biases, i_biases, global_mean`) of the reference's
+`cornac.models.MF` (cornac/models/mf/recom_mf.py:29-302); the `backend_cpu.fit_sgd` call
+(recom_mf.py:189-209) is replaced by `cornac_hip_mf_fit` through a new `backend="hip"` next to the
+reference's `"cpu"` / `"pytorch"` switch (recom_mf.py:177-183).
+"""
+import numpy as np
+
+from . import _lib
+from .recommender import Recommender, ScoreException
+
+DTYPE = np.float32
+
+
+def _normal(shape, rng, std):
+    # cornac/utils/init_utils.py:60-82 `normal(shape, mean=0, std, dtype=float32)`
+    return rng.normal(0.0, std, shape).astype(DTYPE)
+
+
+class MF(Recommender):
+    """Parameters are those of the reference (recom_mf.py:32-131); `backend` accepts "hip" only
+    (the reference raises ValueError for an unknown backend, recom_mf.py:183 — so does this).
+    `mode` as in BPR: None -> deterministic when seeded, hogwild otherwise."""
+
+    def __init__(self, name="MF", k=10, backend="hip", optimizer="sgd", max_iter=20, learning_rate=0.01,
+                 batch_size=256, lambda_reg=0.02, dropout=0.0, use_bias=True, early_stop=False, num_threads=0,
+                 trainable=True, verbose=False, init_params=None, seed=None, mode=None, device=0):
+        super().__init__(name=name, trainable=trainable, verbose=verbose)
+        self.k = k
+        self.backend = backend
+        self.optimizer = optimizer
+        self.max_iter = max_iter
+        self.learning_rate = learning_rate
+        self.batch_size = batch_size
+        self.lambda_reg = lambda_reg
+        self.dropout = dropout
+        self.use_bias = use_bias
+        self.early_stop = early_stop
+        self.seed = seed
+        self.num_threads = num_threads
+        if mode not in (None, "deterministic", "hogwild"):
+            raise ValueError(f"mode={mode} is not supported")
+        self.mode = mode
+        self.device = device
+        self.init_params = {} if init_params is None else init_params
+        self.u_factors = self.init_params.get("U", None)
+        self.i_factors = self.init_params.get("V", None)
+        self.u_biases = self.init_params.get("Bu", None)
+        self.i_biases = self.init_params.get("Bi", None)
+
+    @property
+    def effective_mode(self):
+        if self.mode is not None:
+            return self.mode
+        return "deterministic" if self.seed is not None else "hogwild"
+
+    def _init(self):
+        # recom_mf.py:138-156 — a FRESH RandomState(seed) per fit; sizes use num_users/num_items
+        rng = np.random.RandomState(self.seed)
+        if self.u_factors is None:
+            self.u_factors = _normal([self.num_users, self.k], rng, 0.01)
+        if self.i_factors is None:
+            self.i_factors = _normal([self.num_items, self.k], rng, 0.01)
+        self.u_biases = np.zeros(self.num_users, dtype=DTYPE) if self.u_biases is None else self.u_biases
+        self.i_biases = np.zeros(self.num_items, dtype=DTYPE) if self.i_biases is None else self.i_biases
+        self.global_mean = np.dtype(DTYPE).type(self.global_mean if self.use_bias else 0.0)
+
+    def fit(self, train_set, val_set=None):
+        Recommender.fit(self, train_set, val_set)
+        self._init()
+        if self.trainable:
+            if self.backend == "hip":
+                self._fit_hip(train_set, val_set)
+            else:
+                raise ValueError(f"{self.backend} is not supported")
+        self._drop_scorer()
+        return self
+
+    def _fit_hip(self, train_set, val_set):
+        rid, cid, val = train_set.uir_tuple
+        mode = _lib.MODE_DETERMINISTIC if self.effective_mode == "deterministic" else _lib.MODE_HOGWILD
+        trainer = _lib.MfTrainer(rid, cid, val.astype(DTYPE), self.num_users, self.num_items, self.k,
+                                 device=self.device)
+        try:
+            trainer.set_factors(self.u_factors, self.i_factors, self.u_biases, self.i_biases)
+            self.loss_history, self.epochs_run = trainer.fit(self.max_iter, self.learning_rate, self.lambda_reg,
+                                                             float(self.global_mean), self.use_bias, self.early_stop,
+                                                             mode)
+            self.last_timing = trainer.last_timing()
+            U, V, Bu, Bi = trainer.get_factors()
+            self.u_factors[...] = U
+            self.i_factors[...] = V
+            self.u_biases[...] = Bu
+            self.i_biases[...] = Bi
+        finally:
+            trainer.close()
+        if self.verbose:
+            print("Optimization finished!")
+
+    # ---- prediction -------------------------------------------------------------------------------
+    def _scoring_tables(self):
+        if self.__dict__.get("_item_base") is None or self._item_base_src is not self.i_biases:
+            self._item_base = (self.global_mean + self.i_biases).astype(DTYPE)
+            self._item_base_src = self.i_biases
+        return self.u_factors, self.i_factors, self._item_base, self.u_biases
+
+    def score(self, user_idx, item_idx=None):
+        """recom_mf.py:254-286"""
+        if item_idx is not None and self.is_unknown_item(item_idx):
+            raise ScoreException("Can't make score prediction for item %d" % item_idx)
+        if item_idx is None:
+            if self.knows_user(user_idx):
+                return self._get_scorer().score_user(user_idx)
+            return self.global_mean + self.i_biases
+        item_score = self.global_mean + self.i_biases[item_idx]
+        if self.knows_user(user_idx):
+            item_score += self.u_biases[user_idx]
+            item_score += self.u_factors[user_idx].dot(self.i_factors[item_idx])
+        return item_score
+
+    def get_vector_measure(self):
+        return "dot"
+
+    def get_user_vectors(self):
+        return np.concatenate((self.u_factors, np.ones([self.u_factors.shape[0], 1])), axis=1)
+
+    def get_item_vectors(self):
+        return np.concatenate((self.i_factors, self.i_biases.reshape((-1, 1))), axis=1)

@@ -1,0 +1,296 @@
+"""Model base class of the MI355X backend — host-side mirror of the reference's plug-in API
+`cornac.models.Recommender` (cornac/models/recommender.py:84-653): `fit / score / rate / rank /
+recommend / save / load / clone`, same names, argument meaning and error behaviour, so a model of
+this package is used exactly like a reference model (and its parity tests read the same).
+
+What differs by design: `rank()` and `rank_batch()` run on the device (batched users x items
+scoring + top-k kernels in libcornac_hip) instead of `score()` + NumPy argsort per user
+(recommender.py:503-530).  Learned parameters stay plain NumPy attributes (`u_factors`,
+`i_factors`, ...), so pickling, `clone()` and ANN wrappers keep working; device handles live in
+attributes listed in `ignored_attrs` (mechanism at recommender.py:137, :182-190).
+"""
+import copy
+import inspect
+import json
+import os
+import pickle
+import warnings
+from datetime import datetime
+from glob import glob
+
+import numpy as np
+
+
+class CornacException(Exception):
+    """cornac/exception.py:16-20"""
+
+
+class ScoreException(CornacException):
+    """Raised by score() for unknown users/items (cornac/exception.py:22-26)."""
+
+
+def clip(values, lower_bound, upper_bound):
+    """cornac/utils/common.py `clip`: clamp into [lower_bound, upper_bound]."""
+    values = np.where(values > upper_bound, upper_bound, values)
+    values = np.where(values < lower_bound, lower_bound, values)
+    return values
+
+
+class Recommender:
+    def __init__(self, name, trainable=True, verbose=False):
+        self.name = name
+        self.trainable = trainable
+        self.verbose = verbose
+        self.is_fitted = False
+        # not pickled / deep-copied: datasets and device-side state
+        self.ignored_attrs = ["train_set", "val_set", "test_set", "_scorer", "_scorer_key", "_trainer"]
+        self.num_users = None
+        self.num_items = None
+        self.uid_map = None
+        self.iid_map = None
+        self.max_rating = None
+        self.min_rating = None
+        self.global_mean = None
+        self._item_ids = None
+
+    # ---- bookkeeping -------------------------------------------------------------------------
+    @property
+    def total_users(self):
+        return len(self.uid_map) if self.uid_map is not None else self.num_users
+
+    @property
+    def total_items(self):
+        return len(self.iid_map) if self.iid_map is not None else self.num_items
+
+    @property
+    def user_ids(self):
+        return list(self.uid_map.keys())
+
+    @property
+    def item_ids(self):
+        if self._item_ids is None:
+            self._item_ids = list(self.iid_map.keys())
+        return self._item_ids
+
+    def reset_info(self):
+        self.best_value = float("-inf")
+        self.best_epoch = 0
+        self.current_epoch = 0
+        self.stopped_epoch = 0
+        self.wait = 0
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        result = cls.__new__(cls)
+        ignored = set(self.ignored_attrs)
+        for k, v in self.__dict__.items():
+            if k in ignored:
+                continue
+            setattr(result, k, copy.deepcopy(v))
+        return result
+
+    def __getstate__(self):
+        ignored = set(self.ignored_attrs)
+        return {k: v for k, v in self.__dict__.items() if k not in ignored}
+
+    @classmethod
+    def _get_init_params(cls):
+        sig = inspect.signature(cls.__init__)
+        return sorted(p.name for p in sig.parameters.values() if p.name != "self")
+
+    def clone(self, new_params=None):
+        """Fresh, unfitted instance with the same constructor arguments (recommender.py:204-221)."""
+        new_params = {} if new_params is None else new_params
+        init_params = {}
+        for name in self._get_init_params():
+            init_params[name] = new_params.get(name, copy.deepcopy(getattr(self, name)))
+        return self.__class__(**init_params)
+
+    def save(self, save_dir=None, save_trainset=False, metadata=None):
+        """Pickle the model (+ .meta json, optional .trainset) under save_dir/<name>/ (recommender.py:223-276)."""
+        if save_dir is None:
+            return None
+        model_dir = os.path.join(save_dir, self.name)
+        os.makedirs(model_dir, exist_ok=True)
+        stamp = datetime.now().strftime("%Y-%m-%d_%H-%M-%S-%f")
+        model_file = os.path.join(model_dir, "{}.pkl".format(stamp))
+        saved = copy.deepcopy(self)
+        with open(model_file, "wb") as f:
+            pickle.dump(saved, f, protocol=pickle.HIGHEST_PROTOCOL)
+        if self.verbose:
+            print("{} model is saved to {}".format(self.name, model_file))
+        metadata = {} if metadata is None else metadata
+        metadata["model_classname"] = type(saved).__name__
+        metadata["model_file"] = os.path.basename(model_file)
+        if save_trainset:
+            trainset_file = model_file + ".trainset"
+            with open(trainset_file, "wb") as f:
+                pickle.dump(self.train_set, f, protocol=pickle.HIGHEST_PROTOCOL)
+            metadata["trainset_file"] = os.path.basename(trainset_file)
+        with open(model_file + ".meta", "w", encoding="utf-8") as f:
+            json.dump(metadata, f, ensure_ascii=False, indent=4)
+        return model_file
+
+    @staticmethod
+    def load(model_path, trainable=False):
+        """recommender.py:278-304 (a directory loads its newest .pkl)."""
+        if os.path.isdir(model_path):
+            model_file = sorted(glob("{}/*.pkl".format(model_path)))[-1]
+        else:
+            model_file = model_path
+        with open(model_file, "rb") as f:
+            model = pickle.load(f)
+        model.trainable = trainable
+        model.load_from = model_file
+        return model
+
+    def fit(self, train_set, val_set=None):
+        """Record the dataset facts prediction needs (recommender.py:306-346)."""
+        if self.is_fitted:
+            warnings.warn("Model is already fitted. Re-fitting will overwrite the previous model.")
+        self.reset_info()
+        train_set.reset()
+        if val_set is not None:
+            val_set.reset()
+        self.num_users = train_set.num_users
+        self.num_items = train_set.num_items
+        self.uid_map = train_set.uid_map
+        self.iid_map = train_set.iid_map
+        self.min_rating = train_set.min_rating
+        self.max_rating = train_set.max_rating
+        self.global_mean = train_set.global_mean
+        self.train_set = train_set
+        self.val_set = val_set
+        self.is_fitted = True
+        self._item_ids = None
+        self._drop_scorer()
+        return self
+
+    def knows_user(self, user_idx):
+        return user_idx is not None and 0 <= user_idx < self.num_users
+
+    def knows_item(self, item_idx):
+        return item_idx is not None and 0 <= item_idx < self.num_items
+
+    def is_unknown_user(self, user_idx):
+        return not self.knows_user(user_idx)
+
+    def is_unknown_item(self, item_idx):
+        return not self.knows_item(item_idx)
+
+    # ---- prediction --------------------------------------------------------------------------
+    def score(self, user_idx, item_idx=None):
+        raise NotImplementedError("The algorithm is not able to make score prediction!")
+
+    def default_score(self):
+        return self.global_mean
+
+    def rate(self, user_idx, item_idx, clipping=True):
+        """recommender.py:447-474"""
+        try:
+            rating_pred = self.score(user_idx, item_idx)
+        except ScoreException:
+            rating_pred = self.default_score()
+        if clipping:
+            rating_pred = clip(rating_pred, self.min_rating, self.max_rating)
+        return rating_pred
+
+    # device scorer -------------------------------------------------------------------------------
+    def _scoring_tables(self):
+        """(U, V, item_base, user_base) such that score(u, i) = item_base[i] + user_base[u] + <U[u], V[i]>."""
+        raise NotImplementedError
+
+    def _drop_scorer(self):
+        sc = self.__dict__.pop("_scorer", None)
+        self.__dict__.pop("_scorer_key", None)
+        if sc is not None:
+            sc.close()
+
+    def _get_scorer(self):
+        from . import _lib
+
+        U, V, ib, ub = self._scoring_tables()
+        key = tuple(id(x) for x in (U, V, ib, ub))
+        if self.__dict__.get("_scorer") is None or self.__dict__.get("_scorer_key") != key:
+            self._drop_scorer()
+            self._scorer = _lib.Scorer(U, V, ib, ub, device=getattr(self, "device", 0))
+            self._scorer_key = key
+        return self._scorer
+
+    def rank(self, user_idx, item_indices=None, k=-1, **kwargs):
+        """Rank items for one user: `(ranked_items, item_scores)` with the reference's meaning
+        (recommender.py:476-530): `item_scores[t]` is the score of `item_indices[t]`,
+        `ranked_items` are the candidates by descending score.
+
+        Scores (score_user kernel) and the ordering (top-k / sort kernels) run on the device.
+        Ties are ordered by descending item index (the reference leaves tie order unspecified,
+        tests/cornac/models/test_recommender.py:89-93).  With k != -1 the result holds exactly the
+        ranked top-k; the reference appends the remaining candidates in unspecified argpartition
+        order, which no caller may rely on."""
+        try:
+            known_item_scores = self.score(user_idx, **kwargs)
+        except ScoreException:
+            known_item_scores = np.ones(self.total_items) * self.default_score()
+        n_known = len(known_item_scores)
+        if n_known == self.total_items:
+            all_item_scores = known_item_scores
+        else:
+            all_item_scores = np.ones(self.total_items) * np.min(known_item_scores)
+            all_item_scores[: self.num_items] = known_item_scores
+        item_indices = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
+        item_scores = all_item_scores[item_indices]
+        n_cand = len(item_indices)
+        topk = n_cand if k == -1 else min(int(k), n_cand)
+        row = self._scorer_row(user_idx)
+        if row is not None and n_cand > 0 and int(item_indices.max()) < self._get_scorer().n_items:
+            sc = self._get_scorer()
+            mask = np.ones(sc.n_items, dtype=bool)
+            mask[item_indices] = False
+            excl = np.flatnonzero(mask).astype(np.int32)
+            items, _ = sc.rank_topk(np.array([row], np.int32), topk,
+                                    exclude=(np.array([0, len(excl)], np.int64), excl) if len(excl) else None)
+            ranked_items = items[0].astype(item_indices.dtype)
+        else:
+            # user unknown to the device tables (constant scores) or candidates beyond the scored
+            # items (all tied at the row minimum): only the pinned tie rule is left to apply.
+            order = np.argsort(item_scores, kind="stable")[::-1]
+            ranked_items = item_indices[order][:topk]
+        return ranked_items, item_scores
+
+    def rank_batch(self, user_indices, k=10, exclude=None):
+        """Batched top-k for many users in one scoring-GEMM + top-k pass (what the evaluation loop
+        cornac/eval_methods/base_method.py:176-220 does one user at a time).
+
+        exclude: optional CSR `(indptr int64[n+1], indices int32)` of items to drop per listed user
+        (e.g. training positives).  Returns `(items [n, k] int32, scores [n, k] float32)`, padded
+        with (-1, -inf) when a user has fewer than k candidates."""
+        rows = np.asarray([self._scorer_row(int(u)) for u in user_indices])
+        if (rows == None).any():  # noqa: E711
+            raise ScoreException("rank_batch needs users known to the model")
+        sc = self._get_scorer()
+        topk = sc.n_items if k == -1 else min(int(k), sc.n_items)
+        return sc.rank_topk(rows.astype(np.int32), topk, exclude=exclude)
+
+    def _scorer_row(self, user_idx):
+        """Row of the device user table for user_idx, or None if its score is not table-driven."""
+        return int(user_idx) if self.knows_user(user_idx) else None
+
+    def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
+        """Top-k raw item ids for a raw user id (recommender.py:532-580)."""
+        user_idx = self.uid_map.get(user_id, -1)
+        if user_idx == -1:
+            raise ValueError(f"{user_id} is unknown to the model.")
+        if k < -1 or k > self.total_items:
+            raise ValueError(f"k={k} is invalid, there are {self.total_users} users in total.")
+        item_indices = np.arange(self.total_items)
+        if remove_seen:
+            if train_set is None:
+                raise ValueError("train_set must be provided to remove seen items.")
+            seen = np.zeros(len(item_indices), dtype=bool)
+            if user_idx < train_set.csr_matrix.shape[0]:
+                seen[train_set.csr_matrix.getrow(user_idx).indices] = True
+                item_indices = item_indices[~seen]
+        item_rank, _ = self.rank(user_idx, item_indices)
+        if k != -1:
+            item_rank = item_rank[:k]
+        return [self.item_ids[i] for i in item_rank]

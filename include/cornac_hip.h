@@ -1,0 +1,181 @@
+/*
+ * cornac_hip.h — C ABI of libcornac_hip.so, the MI355X (gfx950) backend for the
+ * embedding-SGD + scoring hot path of PreferredAI/cornac.
+ *
+ * The reference has no FFI: its plug-in boundary is four Cython call sites.
+ * Every entry point below names the reference interface it replaces (paths are
+ * relative to the reference repository root).  The reference-side bindings a
+ * maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++ exceptions cross the boundary; every function returns an
+ *     int status (0 = CORNAC_HIP_OK) and cornac_hip_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - host buffers are caller-owned; device buffers are library-owned unless a
+ *     *_bind_device call hands in caller-owned device pointers (used by the
+ *     multi-GPU driver so torch.distributed/RCCL can all-reduce them in place);
+ *   - calls on one handle are not re-entrant (one HIP stream per handle);
+ *     different handles may be driven from different threads / devices;
+ *   - all calls block until the device work is complete unless stated otherwise.
+ */
+#ifndef CORNAC_HIP_H_
+#define CORNAC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORNAC_HIP_OK 0
+#define CORNAC_HIP_ERR_INVALID 1   /* bad argument (message says which)            */
+#define CORNAC_HIP_ERR_HIP 2       /* a HIP runtime call failed                    */
+#define CORNAC_HIP_ERR_NO_DEVICE 3 /* no gfx950 device visible                     */
+#define CORNAC_HIP_ERR_UNSUPPORTED 4
+
+/* Execution mode.
+ * DETERMINISTIC reproduces the reference's seeded run (seed != None forces
+ * num_threads = 1, cornac/models/bpr/recom_bpr.pyx:132-133, recom_mf.py:124-125):
+ * every update observes all earlier ones, in the reference's sample order.
+ * HOGWILD is the throughput mode, the counterpart of the reference's racy
+ * multi-thread path (num_threads > 1, recom_bpr.pyx:228-267, backend_cpu.pyx:62). */
+#define CORNAC_HIP_MODE_DETERMINISTIC 0
+#define CORNAC_HIP_MODE_HOGWILD 1
+
+/* Negative-item population of the triplet sampler. */
+#define CORNAC_HIP_NEG_UNIFORM 0    /* BPR : neg_item_ids = arange(num_items)  (recom_bpr.pyx:186)  */
+#define CORNAC_HIP_NEG_POPULARITY 1 /* WBPR: neg_item_ids = X.indices          (recom_wbpr.pyx:135) */
+
+const char *cornac_hip_last_error(void);
+const char *cornac_hip_version(void);
+int cornac_hip_device_count(int *count);
+/* name (<=255 chars), CU count and HBM bytes of a device */
+int cornac_hip_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------- *
+ * BPR / WBPR trainer.
+ * Replaces: BPR._fit_sgd(rng_pos, rng_neg, num_threads, user_ids, item_ids,
+ *           neg_item_ids, indptr, U, V, B) -> (correct, skipped)
+ *           cornac/models/bpr/recom_bpr.pyx:208-269, its caller loop
+ *           BPR.fit :188-201 and WBPR.fit cornac/models/bpr/recom_wbpr.pyx:127-142,
+ *           the sampler RNGVector recom_bpr.pyx:54-62 and has_non_zero :46-51.
+ * ------------------------------------------------------------------------- */
+typedef struct cornac_hip_bpr *cornac_hip_bpr_t;
+
+/* CSR interaction matrix = train_set.matrix (int32 indptr[n_users+1], int32
+ * indices[nnz], sorted per row — cornac/data/dataset.py:226-235).  U is
+ * [total_users, k], V is [total_items, k], B is [total_items] like BPR._init
+ * (recom_bpr.pyx:145-152); n_users/n_items are the TRAIN counts used by the
+ * sampler. */
+int cornac_hip_bpr_create(cornac_hip_bpr_t *out, int device, int64_t n_users, int64_t n_items,
+                          int64_t total_users, int64_t total_items, int k, const int32_t *indptr,
+                          const int32_t *indices, int64_t nnz);
+int cornac_hip_bpr_destroy(cornac_hip_bpr_t h);
+
+/* host -> device / device -> host copies of the factor tables (fp32, C order).
+ * Any pointer may be NULL to skip that table. */
+int cornac_hip_bpr_set_factors(cornac_hip_bpr_t h, const float *U, const float *V, const float *B);
+int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B);
+
+/* Use caller-owned device buffers (same shapes) instead of the library's. */
+int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB);
+int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB);
+/* run the handle's work on a caller-provided hipStream_t (NULL = the handle's own) */
+int cornac_hip_bpr_set_stream(cornac_hip_bpr_t h, void *hip_stream);
+
+/* Deterministic-mode sampler state = the two boost::random::mt19937 engines of
+ * RNGVector(1, ...) (recom_bpr.pyx:188-191): pass the ALREADY-DERIVED 32-bit
+ * mt19937 seeds (RandomState(seed_a).randint(2**31)).  shared_stream != 0 is
+ * WBPR's single generator used for both draws (recom_wbpr.pyx:131).  The
+ * streams persist across fit_epochs calls exactly like the reference's
+ * RNGVector objects persist across epochs. */
+int cornac_hip_bpr_seed_mt19937(cornac_hip_bpr_t h, uint32_t mt_seed_pos, uint32_t mt_seed_neg, int shared_stream);
+/* Hogwild-mode sampler state: counter-based Philox4x32-10 keyed by `seed`;
+ * the epoch counter persists across calls. */
+int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
+
+/* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
+ * reference's per-epoch counters over the epochs run (either may be NULL).
+ * hogwild_flags: bit0 = use plain (racy, non-atomic) row stores instead of
+ * fp32 atomics; 0 = default. */
+int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, int use_bias, int neg_population,
+                              int mode, int hogwild_flags, int64_t *correct, int64_t *skipped);
+/* Same, but only enqueues `n_samples` hogwild samples (sample counter and
+ * epoch continue) on the handle's stream and returns without synchronising;
+ * counters are added into device memory and fetched by ..._sync.  Used by the
+ * multi-GPU driver to interleave training chunks with RCCL reductions. */
+int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
+                                   int neg_population, int hogwild_flags);
+int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped);
+
+/* Test hooks of the deterministic sampler: draw `n` values from stream 0/1
+ * (boost uniform_int_distribution<long>(0, hi), uniform_int_distribution.hpp:188-227). */
+int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64_t n, int64_t *out);
+/* time spent (ms) in the last fit_epochs call: [0] sampler, [1] host level
+ * scheduling, [2] SGD kernels, [3] total */
+int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4);
+
+/* ------------------------------------------------------------------------- *
+ * Matrix factorisation trainer.
+ * Replaces: backend_cpu.fit_sgd(rid, cid, val, U, V, Bu, Bi, lr, reg, mu,
+ *           max_iter, num_threads, use_bias, early_stop, verbose)
+ *           cornac/models/mf/backend_cpu.pyx:35-97 (called from
+ *           MF._fit_cpu, cornac/models/mf/recom_mf.py:189-209).
+ * ------------------------------------------------------------------------- */
+typedef struct cornac_hip_mf *cornac_hip_mf_t;
+
+/* rid/cid are the int64 COO arrays of train_set.uir_tuple in stored order, val fp32. */
+int cornac_hip_mf_create(cornac_hip_mf_t *out, int device, int64_t n_users, int64_t n_items, int k,
+                         const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz);
+int cornac_hip_mf_destroy(cornac_hip_mf_t h);
+int cornac_hip_mf_set_factors(cornac_hip_mf_t h, const float *U, const float *V, const float *Bu, const float *Bi);
+int cornac_hip_mf_get_factors(cornac_hip_mf_t h, float *U, float *V, float *Bu, float *Bi);
+/* Runs up to max_iter epochs; loss_per_epoch[e] = 0.5 * sum(err^2) (may be NULL);
+ * early_stop: stop when |loss - last_loss| < 1e-5 (backend_cpu.pyx:89-93).
+ * epochs_run receives the number of epochs executed. */
+int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, float mu, int use_bias, int early_stop,
+                      int mode, float *loss_per_epoch, int *epochs_run);
+/* One-shot form with the reference's exact argument list (host buffers, in place). */
+int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz, float *U,
+                          float *V, float *Bu, float *Bi, int64_t n_users, int64_t n_items, int k, float lr, float reg,
+                          float mu, int max_iter, int use_bias, int early_stop, int mode, float *loss_per_epoch,
+                          int *epochs_run);
+int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
+
+/* ------------------------------------------------------------------------- *
+ * Scoring / ranking.
+ * Replaces: fast_dot(vec, mat, output)  cornac/utils/fast_dot.pyx:40-43 as used by
+ *           BPR.score (recom_bpr.pyx:288-291) and MF.score (recom_mf.py:273-278),
+ *           and the per-user argsort/argpartition of Recommender.rank
+ *           (cornac/models/recommender.py:503-530), batched over users.
+ * score(u, i) = item_base[i] + user_base[u] + sum_f U[u,f]*V[i,f], accumulated
+ * as an index-ordered fp32 fma chain (what the gfx950 fp32 MFMA computes).
+ * ------------------------------------------------------------------------- */
+typedef struct cornac_hip_scorer *cornac_hip_scorer_t;
+
+int cornac_hip_scorer_create(cornac_hip_scorer_t *out, int device, int64_t n_users, int64_t n_items, int k);
+int cornac_hip_scorer_destroy(cornac_hip_scorer_t h);
+/* item_base: BPR -> i_biases; MF -> global_mean + i_biases.  user_base: MF -> u_biases; NULL = 0. */
+int cornac_hip_scorer_set(cornac_hip_scorer_t h, const float *U, const float *V, const float *item_base,
+                          const float *user_base);
+/* out[n_items] for one user  (= model.score(user_idx)) */
+int cornac_hip_score_user(cornac_hip_scorer_t h, int64_t user, float *out);
+/* out[n * n_items] for a block of users */
+int cornac_hip_score_block(cornac_hip_scorer_t h, const int32_t *users, int64_t n, float *out);
+/* Batched rank(): for each of the n users, the topk best items in descending
+ * score order (ties: higher item index first — the oracle's pinned tie rule),
+ * excluding the items listed in the optional CSR (excl_indptr[n+1],
+ * excl_indices) row of that user.  topk == n_items gives the full ranking.
+ * items_out / scores_out are [n, topk]; slots beyond the number of candidates
+ * are filled with -1 / -inf. */
+int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n, int topk, const int64_t *excl_indptr,
+                         const int32_t *excl_indices, int32_t *items_out, float *scores_out);
+/* Device-resident throughput probe used by bench.py: ranks users
+ * [u0, u0 + n) with fused top-k, keeps results on device; returns elapsed ms of
+ * the kernels (hipEvent) in *ms. */
+int cornac_hip_rank_topk_device(cornac_hip_scorer_t h, int64_t u0, int64_t n, int topk, int repeats, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORNAC_HIP_H_ */

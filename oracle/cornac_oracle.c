@@ -1,0 +1,389 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — CPU restatement ("oracle") of the cornac hot path.
+ *
+ * This file is the checker for the HIP kernels in cornac_amd/csrc/.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load
+ * it.  Nothing under cornac_amd/ links, imports or calls it; the product path
+ * fails loudly when libcornac_hip.so is missing.
+ *
+ * Parity status: PINNED.  Every function below is validated against the real
+ * compiled reference (oracle/_ref, built from /root/reference by
+ * oracle/build_ref.py) in tests/test_oracle_vs_reference.py, and against the
+ * golden vectors that the real reference produced (tests/golden/*.npz, made by
+ * tests/golden/make_golden.py).  The reference's own test-suite holds exactly
+ * one known-answer test on this path (tests/cornac/utils/test_fastdot.py:26-37)
+ * which is replayed in tests/test_oracle_golden.py.
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference).  Written from the algorithm's description; no reference
+ * source text is reproduced.
+ *
+ * Build: oracle/Makefile  (gcc -O2 -fopenmp, NO -ffast-math: the oracle's
+ * floating point is strict IEEE in index order, so it is a well-defined
+ * function of its inputs; the reference's -ffast-math build differs from it by
+ * a few ulp per dot product, far inside the 1e-4 parity tolerance).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- *
+ * MT19937 — boost::random::mt19937 (cornac/utils/external/boost/random/
+ * mersenne_twister.hpp:624 typedef; seeding = the standard init_genrand,
+ * which is also NumPy's RandomState legacy seeding).  Used by RNGVector
+ * (cornac/models/bpr/recom_bpr.pyx:54-62).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t mt[624];
+    int32_t idx; /* next unread word; 624 => regenerate first */
+} oracle_mt19937;
+
+void oracle_mt_seed(oracle_mt19937 *g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+
+static void mt_twist(oracle_mt19937 *g) {
+    uint32_t *mt = g->mt;
+    for (int i = 0; i < 624; ++i) {
+        uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        uint32_t v = mt[(i + 397) % 624] ^ (y >> 1);
+        if (y & 1u) v ^= 0x9908b0dfu;
+        mt[i] = v;
+    }
+    g->idx = 0;
+}
+
+uint32_t oracle_mt_next(oracle_mt19937 *g) {
+    if (g->idx >= 624) mt_twist(g);
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* ------------------------------------------------------------------------- *
+ * boost 1.72 uniform_int_distribution<long>(0, hi)(mt19937)
+ * (cornac/utils/external/boost/random/uniform_int_distribution.hpp:49-228,
+ * the `brange > range` branch :188-227 and the trivial branches :64-70).
+ * hi >= 2^32 would take the multi-draw branch (:71-187); the reference BPR
+ * cannot reach it (int32 indices, recom_bpr.pyx:186) so it is an error here.
+ * Returns -1 for that unsupported case.
+ * ------------------------------------------------------------------------- */
+int64_t oracle_boost_uniform(oracle_mt19937 *g, uint64_t hi) {
+    if (hi == 0) return 0; /* no engine call */
+    if (hi == 0xFFFFFFFFull) return (int64_t)oracle_mt_next(g);
+    if (hi > 0xFFFFFFFFull) return -1;
+    uint32_t range = (uint32_t)hi;
+    uint32_t bucket = 0xFFFFFFFFu / (range + 1u);
+    if (0xFFFFFFFFu % (range + 1u) == range) ++bucket;
+    for (;;) {
+        uint32_t r = oracle_mt_next(g) / bucket;
+        if (r <= range) return (int64_t)r;
+    }
+}
+
+/* Bulk draws (used by tests of the device sampler). */
+int oracle_boost_uniform_fill(oracle_mt19937 *g, uint64_t hi, int64_t n, int64_t *out) {
+    for (int64_t s = 0; s < n; ++s) {
+        int64_t v = oracle_boost_uniform(g, hi);
+        if (v < 0) return -1;
+        out[s] = v;
+    }
+    return 0;
+}
+
+/* raw tempered outputs (tests of the device MT19937 block generator) */
+void oracle_mt_fill_raw(oracle_mt19937 *g, int64_t n, uint32_t *out) {
+    for (int64_t s = 0; s < n; ++s) out[s] = oracle_mt_next(g);
+}
+
+/* ------------------------------------------------------------------------- *
+ * has_non_zero (cornac/models/bpr/recom_bpr.pyx:46-51): std::binary_search of
+ * colid in the sorted CSR row.
+ * ------------------------------------------------------------------------- */
+static int has_non_zero(const int32_t *indptr, const int32_t *indices, int32_t row, int32_t col) {
+    int32_t lo = indptr[row], hi = indptr[row + 1];
+    while (lo < hi) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (indices[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo < indptr[row + 1] && indices[lo] == col;
+}
+
+/* one BPR SGD step (cornac/models/bpr/recom_bpr.pyx:246-267).
+ * exp: Cython's libc.math exp on a C++ float resolves to the float overload
+ * (expf); 1.0/(1.0+...) is evaluated in double and rounded to float on
+ * assignment.  The oracle defines e = (float)exp((double)score), i.e. the
+ * correctly rounded float exponential: glibc's expf equals it except in the
+ * ~0.4% of arguments where its 0.502-ulp bound matters, and the device's
+ * double-precision exp rounds to the same float, which is what lets the HIP
+ * deterministic kernels be compared bit-for-bit against this file. */
+static inline int bpr_step(float *user, float *item_i, float *item_j, float *B, int32_t i_id, int32_t j_id,
+                           int k, float lr, float reg, int use_bias) {
+    float score = B[i_id] - B[j_id];
+    for (int f = 0; f < k; ++f) score = score + user[f] * (item_i[f] - item_j[f]);
+    float e = (float)exp((double)score);
+    float z = (float)(1.0 / (1.0 + (double)e));
+    for (int f = 0; f < k; ++f) {
+        float temp = user[f];
+        user[f] += lr * (z * (item_i[f] - item_j[f]) - reg * user[f]);
+        item_i[f] += lr * (z * temp - reg * item_i[f]);
+        item_j[f] += lr * (-z * temp - reg * item_j[f]);
+    }
+    if (use_bias) {
+        B[i_id] += lr * (z - reg * B[i_id]);
+        B[j_id] += lr * (-z - reg * B[j_id]);
+    }
+    return z < .5f;
+}
+
+/* ------------------------------------------------------------------------- *
+ * BPR._fit_sgd, seeded (num_threads == 1) — one epoch = num_samples draws
+ * (cornac/models/bpr/recom_bpr.pyx:208-269).  rng_pos / rng_neg persist across
+ * epochs (RNGVector objects are created once per fit, :188-191).  WBPR passes
+ * the SAME generator for both and neg_item_ids = X.indices
+ * (cornac/models/bpr/recom_wbpr.pyx:131-139): pass rng_neg == rng_pos.
+ * Optionally records the sampled (i_index, j_index) pairs and skip flags.
+ * ------------------------------------------------------------------------- */
+int oracle_bpr_epoch_seq(oracle_mt19937 *rng_pos, oracle_mt19937 *rng_neg, uint64_t pos_hi, uint64_t neg_hi,
+                         int64_t num_samples, const int32_t *user_ids, const int32_t *item_ids,
+                         const int32_t *neg_item_ids, const int32_t *indptr, float *U, float *V, float *B, int k,
+                         float lr, float reg, int use_bias, int64_t *correct_out, int64_t *skipped_out,
+                         int64_t *rec_ii, int64_t *rec_jj, uint8_t *rec_skip) {
+    int64_t correct = 0, skipped = 0;
+    for (int64_t s = 0; s < num_samples; ++s) {
+        int64_t i_index = oracle_boost_uniform(rng_pos, pos_hi);
+        int64_t j_index = oracle_boost_uniform(rng_neg, neg_hi);
+        if (i_index < 0 || j_index < 0) return -1;
+        int32_t i_id = item_ids[i_index];
+        int32_t j_id = neg_item_ids[j_index];
+        int32_t u_id = user_ids[i_index];
+        if (rec_ii) { rec_ii[s] = i_index; rec_jj[s] = j_index; }
+        if (has_non_zero(indptr, item_ids, u_id, j_id)) {
+            ++skipped;
+            if (rec_skip) rec_skip[s] = 1;
+            continue;
+        }
+        if (rec_skip) rec_skip[s] = 0;
+        correct += bpr_step(U + (int64_t)u_id * k, V + (int64_t)i_id * k, V + (int64_t)j_id * k, B, i_id, j_id, k,
+                            lr, reg, use_bias);
+    }
+    *correct_out = correct;
+    *skipped_out = skipped;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * BPR._fit_sgd, unseeded (num_threads = T > 1): racy Hogwild, one generator
+ * pair per thread (recom_bpr.pyx:228-267, `prange(..., schedule='guided')`).
+ * This is the CPU throughput baseline ("port" of the OpenMP path); results
+ * are not reproducible, exactly like the reference's.  rngs_pos/rngs_neg are
+ * arrays of T generators.
+ * ------------------------------------------------------------------------- */
+int oracle_bpr_epoch_omp(oracle_mt19937 *rngs_pos, oracle_mt19937 *rngs_neg, int num_threads, uint64_t pos_hi,
+                         uint64_t neg_hi, int64_t num_samples, const int32_t *user_ids, const int32_t *item_ids,
+                         const int32_t *neg_item_ids, const int32_t *indptr, float *U, float *V, float *B, int k,
+                         float lr, float reg, int use_bias, int64_t *correct_out, int64_t *skipped_out) {
+    int64_t correct = 0, skipped = 0;
+#pragma omp parallel num_threads(num_threads) reduction(+ : correct, skipped)
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        oracle_mt19937 *gp = &rngs_pos[t], *gn = &rngs_neg[t];
+#pragma omp for schedule(guided)
+        for (int64_t s = 0; s < num_samples; ++s) {
+            int64_t i_index = oracle_boost_uniform(gp, pos_hi);
+            int64_t j_index = oracle_boost_uniform(gn, neg_hi);
+            int32_t i_id = item_ids[i_index];
+            int32_t j_id = neg_item_ids[j_index];
+            int32_t u_id = user_ids[i_index];
+            if (has_non_zero(indptr, item_ids, u_id, j_id)) { ++skipped; continue; }
+            correct += bpr_step(U + (int64_t)u_id * k, V + (int64_t)i_id * k, V + (int64_t)j_id * k, B, i_id, j_id,
+                                k, lr, reg, use_bias);
+        }
+    }
+    *correct_out = correct;
+    *skipped_out = skipped;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * backend_cpu.fit_sgd (cornac/models/mf/backend_cpu.pyx:35-97): all epochs in
+ * one call, COO order, in-place SGD; loss_per_epoch[e] = 0.5*sum(err^2) with
+ * the float accumulator the reference uses; early stop on |dloss| < 1e-5.
+ * Returns the number of epochs run.  num_threads > 1 = racy static-chunk
+ * Hogwild (`prange(..., schedule='static')`, :62).
+ * ------------------------------------------------------------------------- */
+int oracle_mf_fit(const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz, float *U, float *V,
+                  float *Bu, float *Bi, int k, float lr, float reg, float mu, int max_iter, int num_threads,
+                  int use_bias, int early_stop, float *loss_per_epoch) {
+    float loss = 0.f, last_loss = 0.f;
+    int epoch = 0;
+    for (; epoch < max_iter; ++epoch) {
+        last_loss = loss;
+        loss = 0.f;
+        if (num_threads <= 1) {
+            for (int64_t j = 0; j < nnz; ++j) {
+                int64_t u = rid[j], i = cid[j];
+                float r = val[j];
+                float *user = U + u * k, *item = V + i * k;
+                float r_pred = mu + Bu[u] + Bi[i];
+                for (int f = 0; f < k; ++f) r_pred = r_pred + user[f] * item[f];
+                float error = r - r_pred;
+                loss += error * error;
+                for (int f = 0; f < k; ++f) {
+                    float u_f = user[f], i_f = item[f];
+                    user[f] += lr * (error * i_f - reg * u_f);
+                    item[f] += lr * (error * u_f - reg * i_f);
+                }
+                if (use_bias) {
+                    Bu[u] += lr * (error - reg * Bu[u]);
+                    Bi[i] += lr * (error - reg * Bi[i]);
+                }
+            }
+        } else {
+            float lsum = 0.f;
+#pragma omp parallel for schedule(static) num_threads(num_threads) reduction(+ : lsum)
+            for (int64_t j = 0; j < nnz; ++j) {
+                int64_t u = rid[j], i = cid[j];
+                float r = val[j];
+                float *user = U + u * k, *item = V + i * k;
+                float r_pred = mu + Bu[u] + Bi[i];
+                for (int f = 0; f < k; ++f) r_pred = r_pred + user[f] * item[f];
+                float error = r - r_pred;
+                lsum += error * error;
+                for (int f = 0; f < k; ++f) {
+                    float u_f = user[f], i_f = item[f];
+                    user[f] += lr * (error * i_f - reg * u_f);
+                    item[f] += lr * (error * u_f - reg * i_f);
+                }
+                if (use_bias) {
+                    Bu[u] += lr * (error - reg * Bu[u]);
+                    Bi[i] += lr * (error - reg * Bi[i]);
+                }
+            }
+            loss = lsum;
+        }
+        loss = 0.5f * loss;
+        if (loss_per_epoch) loss_per_epoch[epoch] = loss;
+        float delta = loss - last_loss;
+        if (early_stop && fabsf(delta) < 1e-5f) { ++epoch; break; }
+    }
+    return epoch;
+}
+
+/* ------------------------------------------------------------------------- *
+ * fast_dot (cornac/utils/fast_dot.pyx:25-43): output[i] += dot(vec, mat[i]).
+ * The reference calls BLAS sdot, whose summation order is implementation
+ * defined; the oracle fixes it: mode 0 = index-order mul+add, mode 1 =
+ * index-order fmaf chain (bit-identical to the gfx950 fp32 MFMA / v_fmac
+ * accumulation used by the HIP scoring kernels), mode 2 = fp64 accumulate.
+ * ------------------------------------------------------------------------- */
+void oracle_fast_dot(const float *vec, const float *mat, float *output, int64_t n_rows, int k, int mode) {
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const float *row = mat + i * k;
+        if (mode == 0) {
+            float acc = 0.f;
+            for (int f = 0; f < k; ++f) acc = acc + vec[f] * row[f];
+            output[i] += acc;
+        } else if (mode == 1) {
+            float acc = 0.f;
+            for (int f = 0; f < k; ++f) acc = fmaf(vec[f], row[f], acc);
+            output[i] += acc;
+        } else {
+            double acc = 0.0;
+            for (int f = 0; f < k; ++f) acc += (double)vec[f] * (double)row[f];
+            output[i] = (float)((double)output[i] + acc);
+        }
+    }
+}
+
+/* scores for a block of users: out[b, i] = base[i] + ubase[b] + dot_fma(U[users[b]], V[i])
+ * = BPR.score (recom_bpr.pyx:288-291: copy(B) then fast_dot) and MF.score
+ * (recom_mf.py:273-278: mu + Bi (+ Bu[u] + fast_dot)), accumulation mode 1
+ * with the bias added AFTER the dot product like fast_dot's `output[i] +=`. */
+void oracle_score_block(const float *U, const float *V, const float *item_base, const float *user_base,
+                        const int32_t *users, int64_t n_block, int64_t n_items, int k, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < n_block; ++b) {
+        const float *u = U + (int64_t)users[b] * k;
+        float ub = user_base ? user_base[users[b]] : 0.f;
+        for (int64_t i = 0; i < n_items; ++i) {
+            const float *row = V + i * k;
+            float acc = 0.f;
+            for (int f = 0; f < k; ++f) acc = fmaf(u[f], row[f], acc);
+            float base = item_base ? item_base[i] : 0.f;
+            out[b * n_items + i] = (base + ub) + acc;
+        }
+    }
+}
+
+/* Hogwild-mode pair sampler of the HIP throughput kernel, restated on the CPU
+ * so tests can check the device sampler bit-exactly (this one has no
+ * reference counterpart: the reference's multi-thread streams are not
+ * reproducible; see DESIGN.md "hogwild sampler").  Philox4x32-10, key =
+ * (seed_lo, seed_hi), counter = (sample_lo, sample_hi, epoch, stream).
+ * Bounded draw = Lemire multiply-shift, words (0,1) for the positive index and
+ * (2,3) for the negative index. */
+static inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+void oracle_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                       uint32_t out[4]) {
+    uint32_t c[4] = {c0, c1, c2, c3};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    memcpy(out, c, sizeof(uint32_t) * 4);
+}
+
+static inline uint32_t lemire_bounded2(uint32_t wa, uint32_t wb, uint32_t n) {
+    /* uniform in [0, n): multiply-shift; if the low word of the first product falls
+     * in the biased zone (< 2^32 mod n) the second word is used unconditionally
+     * (residual bias < (n/2^32)^2). */
+    uint32_t thresh = (uint32_t)(-n) % n;
+    uint64_t m = (uint64_t)wa * n;
+    if ((uint32_t)m < thresh) m = (uint64_t)wb * n;
+    return (uint32_t)(m >> 32);
+}
+
+void oracle_hogwild_sample(uint64_t seed, uint32_t epoch, int64_t s0, int64_t n, uint32_t n_pos, uint32_t n_neg,
+                           int64_t *ii_out, int64_t *jj_out) {
+    for (int64_t t = 0; t < n; ++t) {
+        uint64_t s = (uint64_t)(s0 + t);
+        uint32_t w[4];
+        oracle_philox4x32((uint32_t)s, (uint32_t)(s >> 32), epoch, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        ii_out[t] = lemire_bounded2(w[0], w[1], n_pos);
+        jj_out[t] = lemire_bounded2(w[2], w[3], n_neg);
+    }
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int oracle_sizeof_mt(void) { return (int)sizeof(oracle_mt19937); }

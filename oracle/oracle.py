@@ -1,0 +1,308 @@
+"""TEST INFRASTRUCTURE ONLY — Python face of the CPU oracle (oracle/cornac_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+It restates, on the CPU, what the reference's seeded (num_threads == 1) path
+computes, end to end:
+
+  * BPROracle / WBPROracle  -> cornac/models/bpr/recom_bpr.pyx:145-206, recom_wbpr.pyx:103-144
+  * MFOracle               -> cornac/models/mf/recom_mf.py:138-209 + backend_cpu.pyx:35-97
+  * fast_dot / score / rank -> cornac/utils/fast_dot.pyx:40-43, recom_bpr.pyx:272-297,
+                               recom_mf.py:254-286, cornac/models/recommender.py:476-530
+
+The initialisers use NumPy's RandomState exactly like the reference
+(cornac/utils/init_utils.py:33-57 `uniform`, :60-82 `normal`) so seeded runs
+start from bit-identical factors.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libcornac_oracle.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cornac_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.oracle_mt_seed.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_mt_next.argtypes = [C.c_void_p]
+        L.oracle_mt_next.restype = C.c_uint32
+        L.oracle_boost_uniform.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_boost_uniform.restype = C.c_int64
+        L.oracle_boost_uniform_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, i64p]
+        L.oracle_mt_fill_raw.argtypes = [C.c_void_p, C.c_int64, u32p]
+        L.oracle_bpr_epoch_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, i32p, i32p,
+                                           i32p, i32p, f32p, f32p, f32p, C.c_int, C.c_float, C.c_float, C.c_int,
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+        L.oracle_bpr_epoch_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, i32p,
+                                           i32p, i32p, i32p, f32p, f32p, f32p, C.c_int, C.c_float, C.c_float,
+                                           C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.oracle_mf_fit.argtypes = [i64p, i64p, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
+                                    C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_fast_dot.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int, C.c_int]
+        L.oracle_score_block.argtypes = [f32p, f32p, C.c_void_p, C.c_void_p, i32p, C.c_int64, C.c_int64, C.c_int,
+                                         f32p]
+        L.oracle_philox4x32.argtypes = [C.c_uint32] * 6 + [u32p]
+        L.oracle_hogwild_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32,
+                                            i64p, i64p]
+        L.oracle_num_threads.restype = C.c_int
+        L.oracle_sizeof_mt.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class MT19937:
+    """boost::random::mt19937 (recom_bpr.pxd:26-32)."""
+
+    def __init__(self, seed):
+        self.buf = C.create_string_buffer(lib().oracle_sizeof_mt())
+        lib().oracle_mt_seed(self.buf, int(seed) & 0xFFFFFFFF)
+
+    @property
+    def ptr(self):
+        return C.cast(self.buf, C.c_void_p)
+
+    def raw(self, n):
+        out = np.empty(n, np.uint32)
+        lib().oracle_mt_fill_raw(self.ptr, n, out)
+        return out
+
+    def uniform_int(self, hi, n):
+        out = np.empty(n, np.int64)
+        if lib().oracle_boost_uniform_fill(self.ptr, int(hi), n, out) != 0:
+            raise ValueError("range >= 2**32 is not reachable in the reference")
+        return out
+
+
+def rngvector_seed(seed):
+    """RNGVector(1, rows, seed): thread 0's mt19937 seed = RandomState(seed).randint(2**31)
+    (recom_bpr.pyx:55-59)."""
+    return int(np.random.RandomState(seed).randint(2 ** 31))
+
+
+def rngvector_seeds(seed, num_threads):
+    rng = np.random.RandomState(seed)
+    return [int(rng.randint(2 ** 31)) for _ in range(num_threads)]
+
+
+def _uniform(shape, rng, dtype=np.float32):
+    # cornac/utils/init_utils.py:33-57  uniform(shape, low=0, high=1).astype(dtype)
+    return rng.uniform(0.0, 1.0, shape).astype(dtype)
+
+
+def _normal(shape, rng, std, dtype=np.float32):
+    # cornac/utils/init_utils.py:60-82
+    return rng.normal(0.0, std, shape).astype(dtype)
+
+
+def csr_arrays(train_set):
+    X = train_set.matrix
+    indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+    user_ids = np.repeat(np.arange(train_set.num_users), np.ediff1d(indptr)).astype(np.int32)
+    return indptr, indices, user_ids
+
+
+class BPROracle:
+    """Seeded BPR exactly as the reference runs it with `seed is not None`."""
+
+    weighted = False  # WBPR: one shared stream, negatives drawn from X.indices
+
+    def __init__(self, k=10, max_iter=100, learning_rate=0.001, lambda_reg=0.01, use_bias=True, seed=None,
+                 init_params=None):
+        self.k, self.max_iter, self.lr, self.reg, self.use_bias = int(k), max_iter, learning_rate, lambda_reg, use_bias
+        self.seed = seed
+        self.rng = np.random.RandomState(seed)  # created in __init__ (recom_bpr.pyx:130)
+        ip = init_params or {}
+        self.u_factors, self.i_factors, self.i_biases = ip.get("U"), ip.get("V"), ip.get("Bi")
+        self.record = None
+
+    def _init(self, train_set):
+        # Recommender.total_users/total_items = len(uid_map)/len(iid_map) (recommender.py:150-158)
+        nu, ni = len(train_set.uid_map), len(train_set.iid_map)
+        if self.u_factors is None:
+            self.u_factors = (_uniform((nu, self.k), self.rng) - 0.5) / self.k
+        if self.i_factors is None:
+            self.i_factors = (_uniform((ni, self.k), self.rng) - 0.5) / self.k
+        if self.i_biases is None or not self.use_bias:
+            self.i_biases = np.zeros(ni, np.float32)
+        for n in ("u_factors", "i_factors", "i_biases"):
+            setattr(self, n, np.ascontiguousarray(getattr(self, n), dtype=np.float32))
+
+    def fit(self, train_set, record=False):
+        L = lib()
+        self._init(train_set)
+        indptr, indices, user_ids = csr_arrays(train_set)
+        nnz = len(user_ids)
+        if self.weighted:
+            g = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+            gp = gn = g
+            neg_ids, neg_hi = indices, nnz - 1
+        else:
+            neg_ids = np.arange(train_set.num_items, dtype=np.int32)
+            gp = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+            gn = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+            neg_hi = train_set.num_items - 1
+        self.correct, self.skipped = [], []
+        if record:
+            self.record = []
+        for _ in range(self.max_iter):
+            c, s = C.c_int64(), C.c_int64()
+            rec = [None, None, None]
+            if record:
+                rec = [np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.uint8)]
+            rc = L.oracle_bpr_epoch_seq(gp.ptr, gn.ptr, nnz - 1, neg_hi, nnz, user_ids, indices, neg_ids, indptr,
+                                        self.u_factors, self.i_factors, self.i_biases, self.k, self.lr, self.reg,
+                                        int(self.use_bias), C.byref(c), C.byref(s),
+                                        *[r.ctypes.data if r is not None else None for r in rec])
+            if rc != 0:
+                raise ValueError("oracle_bpr_epoch_seq failed")
+            self.correct.append(c.value)
+            self.skipped.append(s.value)
+            if record:
+                self.record.append(rec)
+        return self
+
+    def score(self, user_idx, mode=1):
+        out = np.copy(self.i_biases)
+        lib().oracle_fast_dot(self.u_factors[user_idx], self.i_factors, out, len(out), self.k, mode)
+        return out
+
+
+class WBPROracle(BPROracle):
+    weighted = True
+
+
+def bpr_hogwild_epochs(indptr, indices, user_ids, n_items, U, V, B, k, lr, reg, use_bias, seed, num_threads,
+                       epochs):
+    """The reference's unseeded multi-thread path (racy), for the CPU throughput baseline."""
+    L = lib()
+    nnz = len(user_ids)
+    T = num_threads
+    sz = L.oracle_sizeof_mt()
+    rng = np.random.RandomState(seed)
+    bufs = []
+    for _ in range(2):
+        buf = C.create_string_buffer(sz * T)
+        for t, s in enumerate(rngvector_seeds(rng.randint(2 ** 31), T)):
+            L.oracle_mt_seed(C.cast(C.addressof(buf) + t * sz, C.c_void_p), s)
+        bufs.append(buf)
+    neg_ids = np.arange(n_items, dtype=np.int32)
+    tot_c = tot_s = 0
+    for _ in range(epochs):
+        c, s = C.c_int64(), C.c_int64()
+        L.oracle_bpr_epoch_omp(bufs[0], bufs[1], T, nnz - 1, n_items - 1, nnz, user_ids, indices, neg_ids, indptr,
+                               U, V, B, k, lr, reg, int(use_bias), C.byref(c), C.byref(s))
+        tot_c += c.value
+        tot_s += s.value
+    return tot_c, tot_s
+
+
+class MFOracle:
+    """MF(backend='cpu') seeded (recom_mf.py:138-209)."""
+
+    def __init__(self, k=10, max_iter=20, learning_rate=0.01, lambda_reg=0.02, use_bias=True, early_stop=False,
+                 seed=None, init_params=None, num_threads=1):
+        self.k, self.max_iter, self.lr, self.reg = int(k), max_iter, learning_rate, lambda_reg
+        self.use_bias, self.early_stop, self.seed, self.num_threads = use_bias, early_stop, seed, num_threads
+        ip = init_params or {}
+        self.u_factors, self.i_factors = ip.get("U"), ip.get("V")
+        self.u_biases, self.i_biases = ip.get("Bu"), ip.get("Bi")
+
+    def fit(self, train_set):
+        rng = np.random.RandomState(self.seed)
+        nu, ni = train_set.num_users, train_set.num_items
+        if self.u_factors is None:
+            self.u_factors = _normal((nu, self.k), rng, 0.01)
+        if self.i_factors is None:
+            self.i_factors = _normal((ni, self.k), rng, 0.01)
+        if self.u_biases is None:
+            self.u_biases = np.zeros(nu, np.float32)
+        if self.i_biases is None:
+            self.i_biases = np.zeros(ni, np.float32)
+        for n in ("u_factors", "i_factors", "u_biases", "i_biases"):
+            setattr(self, n, np.ascontiguousarray(getattr(self, n), dtype=np.float32))
+        self.global_mean = np.float32(train_set.global_mean if self.use_bias else 0.0)
+        rid, cid, val = train_set.uir_tuple
+        rid = np.ascontiguousarray(rid, np.int64)
+        cid = np.ascontiguousarray(cid, np.int64)
+        val = np.ascontiguousarray(val, np.float32)
+        self.loss = np.zeros(max(self.max_iter, 1), np.float32)
+        self.epochs_run = lib().oracle_mf_fit(rid, cid, val, len(val), self.u_factors, self.i_factors, self.u_biases,
+                                              self.i_biases, self.k, self.lr, self.reg, float(self.global_mean),
+                                              self.max_iter, self.num_threads, int(self.use_bias),
+                                              int(self.early_stop), self.loss.ctypes.data)
+        return self
+
+    def score(self, user_idx, mode=1):
+        out = (self.global_mean + self.i_biases).astype(np.float32)
+        out += self.u_biases[user_idx]
+        lib().oracle_fast_dot(self.u_factors[user_idx], self.i_factors, out, len(out), self.k, mode)
+        return out
+
+
+def fast_dot(vec, mat, output, mode=0):
+    """output += mat @ vec in place (cornac/utils/fast_dot.pyx:40-43)."""
+    vec = np.ascontiguousarray(vec, np.float32)
+    mat = np.ascontiguousarray(mat, np.float32)
+    assert output.dtype == np.float32 and output.flags.c_contiguous
+    lib().oracle_fast_dot(vec, mat, output, mat.shape[0], mat.shape[1], mode)
+
+
+def score_block(U, V, item_base, user_base, users):
+    users = np.ascontiguousarray(users, np.int32)
+    out = np.empty((len(users), V.shape[0]), np.float32)
+    ib = None if item_base is None else np.ascontiguousarray(item_base, np.float32).ctypes.data
+    ub = None if user_base is None else np.ascontiguousarray(user_base, np.float32).ctypes.data
+    lib().oracle_score_block(np.ascontiguousarray(U, np.float32), np.ascontiguousarray(V, np.float32), ib, ub, users,
+                             len(users), V.shape[0], V.shape[1], out)
+    return out
+
+
+def rank(all_item_scores, num_items, total_items, item_indices=None, k=-1):
+    """Recommender.rank after score() (cornac/models/recommender.py:503-530).
+
+    The reference's tie order is unspecified (np.argsort default / argpartition;
+    acknowledged in tests/cornac/models/test_recommender.py:89-93).  The oracle pins
+    it: descending score, ties by descending position in `item_indices` (= a
+    stable ascending argsort read backwards).  With k != -1 only the first k
+    entries are defined (the reference leaves the tail in argpartition order).
+    """
+    known = np.asarray(all_item_scores)
+    if len(known) != total_items:
+        full = np.ones(total_items) * np.min(known)
+        full[:num_items] = known
+        known = full
+    item_indices = np.arange(num_items) if item_indices is None else np.asarray(item_indices)
+    item_scores = known[item_indices]
+    order = np.argsort(item_scores, kind="stable")[::-1]
+    ranked = item_indices[order]
+    if k != -1:
+        ranked = ranked[:k]
+    return ranked, item_scores
+
+
+def hogwild_sample(seed, epoch, s0, n, n_pos, n_neg):
+    ii = np.empty(n, np.int64)
+    jj = np.empty(n, np.int64)
+    lib().oracle_hogwild_sample(int(seed), int(epoch), int(s0), int(n), int(n_pos), int(n_neg), ii, jj)
+    return ii, jj

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING THE REAL REFERENCE (only possible in the build
+container, where /root/reference exists and oracle/build_ref.py has compiled its hot-path
+extensions into oracle/_ref/).  The fixtures travel to the GPU box; this script does not.
+
+Each fixture stores the exact inputs (interaction triplets in insertion order) and what the
+compiled reference (Cython BPR/WBPR/MF, seed => num_threads = 1) learned from them, plus
+`score()` / `rank()` outputs of the fitted reference model for a few users.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle import build_ref, ref_loader  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def synth_pairs(n_users, n_items, nnz, a, seed):
+    rs = np.random.RandomState(seed)
+    p = 1.0 / np.arange(1, n_items + 1) ** a
+    p /= p.sum()
+    pairs = set()
+    while len(pairs) < nnz:
+        pairs.add((int(rs.randint(n_users)), int(rs.choice(n_items, p=p))))
+    pairs = sorted(pairs)
+    ratings = rs.randint(1, 6, size=len(pairs)).astype(np.float64)
+    # shuffle the insertion order so COO order != CSR order (exercises MF's order dependence)
+    order = rs.permutation(len(pairs))
+    u = np.array([pairs[t][0] for t in order], np.int64)
+    i = np.array([pairs[t][1] for t in order], np.int64)
+    return u, i, ratings[order]
+
+
+def dataset(ns, u, i, r):
+    return ns.Dataset.from_uir([(int(a), int(b), float(c)) for a, b, c in zip(u, i, r)], seed=123)
+
+
+def rank_samples(model, users, k):
+    out = {}
+    for t, uu in enumerate(users):
+        ranked, scores = model.rank(int(uu), k=-1)
+        out["rank_full_%d" % t] = ranked.astype(np.int64)
+        out["rank_scores_%d" % t] = scores.astype(np.float32)
+        out["score_%d" % t] = model.score(int(uu)).astype(np.float32)
+        topk, _ = model.rank(int(uu), k=k)
+        out["rank_top_%d" % t] = topk[:k].astype(np.int64)
+    out["rank_users"] = np.asarray(users, np.int64)
+    out["rank_k"] = np.int64(k)
+    return out
+
+
+def main():
+    build_ref.build()
+    ns = ref_loader.load()
+    cases = {
+        # name: (n_users, n_items, nnz, zipf, data_seed, k, epochs, lr, reg, model_seed)
+        "tiny": (12, 9, 40, 0.5, 3, 4, 30, 0.05, 0.01, 123),
+        "small": (60, 40, 600, 0.8, 5, 8, 10, 0.05, 0.01, 42),
+        "odd_k": (70, 50, 900, 0.8, 7, 10, 5, 0.01, 0.02, 7),
+        "ml100k_shape": (943, 1682, 20000, 0.8, 1, 10, 3, 0.001, 0.01, 123),
+    }
+    for name, (nu, ni, nnz, a, dseed, k, epochs, lr, reg, mseed) in cases.items():
+        u, i, r = synth_pairs(nu, ni, nnz, a, dseed)
+        ds = dataset(ns, u, i, r)
+        fx = {"users": u, "items": i, "ratings": r, "k": np.int64(k), "epochs": np.int64(epochs),
+              "lr": np.float64(lr), "reg": np.float64(reg), "seed": np.int64(mseed)}
+        rank_users = [0, nu // 2, nu - 1]
+        for tag, cls in (("bpr", ns.BPR), ("wbpr", ns.WBPR)):
+            for use_bias in (True, False):
+                if tag == "wbpr" and not use_bias:
+                    continue
+                m = cls(k=k, max_iter=epochs, learning_rate=lr, lambda_reg=reg, use_bias=use_bias, seed=mseed).fit(ds)
+                sfx = "" if use_bias else "_nobias"
+                fx[tag + sfx + "_U"] = m.u_factors.copy()
+                fx[tag + sfx + "_V"] = m.i_factors.copy()
+                fx[tag + sfx + "_B"] = m.i_biases.copy()
+                if tag == "bpr" and use_bias:
+                    for kk, vv in rank_samples(m, rank_users, 5).items():
+                        fx["bpr_" + kk] = vv
+        m = ns.MF(k=k, max_iter=epochs, learning_rate=lr, lambda_reg=reg * 2, use_bias=True, seed=mseed).fit(ds)
+        fx["mf_U"], fx["mf_V"] = m.u_factors.copy(), m.i_factors.copy()
+        fx["mf_Bu"], fx["mf_Bi"] = m.u_biases.copy(), m.i_biases.copy()
+        fx["mf_mu"] = np.float32(m.global_mean)
+        for kk, vv in rank_samples(m, rank_users, 5).items():
+            fx["mf_" + kk] = vv
+        m = ns.MF(k=k, max_iter=epochs, learning_rate=lr, lambda_reg=reg * 2, use_bias=False, seed=mseed).fit(ds)
+        fx["mf_nobias_U"], fx["mf_nobias_V"] = m.u_factors.copy(), m.i_factors.copy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+        print("wrote", name, {kk: getattr(vv, "shape", None) for kk, vv in list(fx.items())[:6]})
+
+    # the reference's own known-answer test for this path: tests/cornac/utils/test_fastdot.py:26-37
+    vec = np.array([1, 2], np.float32)
+    mat = np.array([[1, 2], [3, 4]], np.float32)
+    out = np.array([0, 0], np.float32)
+    ns.fast_dot(vec, mat, out)
+    rs = np.random.RandomState(0)
+    v2 = rs.normal(size=64).astype(np.float32)
+    m2 = rs.normal(size=(257, 64)).astype(np.float32)
+    o2 = rs.normal(size=257).astype(np.float32)
+    o2_in = o2.copy()
+    ns.fast_dot(v2, m2, o2)
+    np.savez_compressed(os.path.join(OUT, "fast_dot.npz"), kat_vec=vec, kat_mat=mat, kat_out=out, vec=v2, mat=m2,
+                        out_in=o2_in, out=o2)
+    print("wrote fast_dot", out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+"""GPU parity tests of the BPR/WBPR path — everything goes through the C ABI (cornac_amd._lib)."""
+import numpy as np
+import pytest
+
+from conftest import golden_dataset, load_golden, synth_dataset
+from cornac_amd import BPR, WBPR, _lib
+
+pytestmark = pytest.mark.gpu
+CASES = ["tiny", "small", "odd_k", "ml100k_shape"]
+
+
+def _kw(fx):
+    return dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+                lambda_reg=float(fx["reg"]), seed=int(fx["seed"]))
+
+
+def _trainer(ds, k):
+    X = ds.matrix
+    return _lib.BprTrainer(X.indptr, X.indices, ds.num_users, ds.num_items, len(ds.uid_map), len(ds.iid_map), k)
+
+
+@pytest.mark.parametrize("hi", [1, 2, 9, 999, 26743, 20000262, 2 ** 31 - 1, 2 ** 31, 3 * 2 ** 30, 2 ** 32 - 2, 2 ** 32 - 1])
+def test_device_mt19937_boost_draws_bit_exact(oracle, hi):
+    """device sampler == boost::mt19937 + uniform_int_distribution<long>(0, hi), across several
+    calls (stream state persists, partial 624-word blocks, heavy-rejection ranges)."""
+    ds = synth_dataset(20, 15, 100, seed=1)
+    tr = _trainer(ds, 4)
+    tr.seed_mt19937(12345, 777)
+    g0, g1 = oracle.MT19937(12345), oracle.MT19937(777)
+    for n in (1, 623, 624, 625, 5000, 3):
+        assert np.array_equal(tr.debug_draw(0, hi, n), g0.uniform_int(hi, n))
+    assert np.array_equal(tr.debug_draw(1, hi, 2000), g1.uniform_int(hi, 2000))
+    tr.close()
+
+
+def test_device_draws_degenerate_range(oracle):
+    ds = synth_dataset(20, 15, 100, seed=1)
+    tr = _trainer(ds, 4)
+    tr.seed_mt19937(5, 6)
+    assert (tr.debug_draw(0, 0, 50) == 0).all()  # hi == 0: returns min without touching the engine
+    assert np.array_equal(tr.debug_draw(0, 10, 20), oracle.MT19937(5).uniform_int(10, 20))
+    with pytest.raises(_lib.HipError):
+        tr.debug_draw(0, 2 ** 32, 4)
+    tr.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("cls_name", ["BPR", "WBPR"])
+def test_deterministic_matches_oracle_and_reference_golden(oracle, name, cls_name):
+    """seeded fit == sequential oracle (bit-exact up to the last ulp of exp) and within 1e-4 of
+    what the real reference learned (golden)."""
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    cls, ocls, tag = (BPR, oracle.BPROracle, "bpr") if cls_name == "BPR" else (WBPR, oracle.WBPROracle, "wbpr")
+    m = cls(**_kw(fx)).fit(ds)
+    o = ocls(**_kw(fx)).fit(ds)
+    assert m.effective_mode == "deterministic"
+    for a, b, g in ((m.u_factors, o.u_factors, "_U"), (m.i_factors, o.i_factors, "_V"), (m.i_biases, o.i_biases, "_B")):
+        assert np.abs(a - b).max() <= 1e-6, "HIP deterministic vs oracle"
+        assert np.abs(a - fx[tag + g]).max() <= 1e-4, "HIP deterministic vs reference golden (north_star tolerance)"
+    assert m.fit_stats[0] == (sum(o.correct), sum(o.skipped))
+
+
+def test_deterministic_no_bias_and_bit_exact_fraction(oracle):
+    fx = load_golden("small")
+    ds = golden_dataset(fx)
+    m = BPR(use_bias=False, **_kw(fx)).fit(ds)
+    o = oracle.BPROracle(use_bias=False, **_kw(fx)).fit(ds)
+    assert not m.i_biases.any()
+    assert np.abs(m.u_factors - fx["bpr_nobias_U"]).max() <= 1e-4
+    same = np.mean(m.u_factors == o.u_factors)
+    assert same > 0.999, "expected bit-identical factors, got fraction %.4f" % same
+
+
+@pytest.mark.parametrize("k", [1, 3, 64, 100, 128])
+def test_deterministic_various_k_and_epoch_continuation(oracle, k):
+    """all lane-group widths; running 2+3 epochs through the handle == 5 epochs (streams persist)."""
+    ds = synth_dataset(120, 90, 2500, seed=k)
+    o = oracle.BPROracle(k=k, max_iter=5, learning_rate=0.05, lambda_reg=0.01, seed=11).fit(ds)
+    rng = np.random.RandomState(11)
+    U = ((rng.uniform(0, 1, (len(ds.uid_map), k)).astype(np.float32) - 0.5) / k)
+    V = ((rng.uniform(0, 1, (len(ds.iid_map), k)).astype(np.float32) - 0.5) / k)
+    tr = _trainer(ds, k)
+    tr.set_factors(U, V, np.zeros(len(ds.iid_map), np.float32))
+    from cornac_amd.bpr import rngvector_mt_seed
+
+    tr.seed_mt19937(rngvector_mt_seed(rng.randint(2 ** 31)), rngvector_mt_seed(rng.randint(2 ** 31)))
+    c1, s1 = tr.fit_epochs(2, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_DETERMINISTIC)
+    c2, s2 = tr.fit_epochs(3, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_DETERMINISTIC)
+    U2, V2, B2 = tr.get_factors()
+    tr.close()
+    assert (c1 + c2, s1 + s2) == (sum(o.correct), sum(o.skipped))
+    assert np.abs(U2 - o.u_factors).max() <= 1e-6 and np.abs(V2 - o.i_factors).max() <= 1e-6
+    assert np.abs(B2 - o.i_biases).max() <= 1e-6
+
+
+def test_refit_warm_starts_like_the_reference(oracle):
+    """fit() twice on one object continues from the trained factors AND the model RNG stream
+    (recom_bpr.pyx:130,148-152) — mirror that."""
+    ds = synth_dataset(60, 40, 800, seed=4)
+    m = BPR(k=8, max_iter=3, learning_rate=0.05, seed=5)
+    o = oracle.BPROracle(k=8, max_iter=3, learning_rate=0.05, seed=5)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(ds).fit(ds)
+    o.fit(ds).fit(ds)
+    assert np.abs(m.u_factors - o.u_factors).max() <= 1e-6
+    assert np.abs(m.i_factors - o.i_factors).max() <= 1e-6
+
+
+def _bpr_loss(U, V, B, ds, n=20000, seed=0):
+    """mean -log sigmoid(x_uij) over a fixed sample of (u, i, j) with j not a positive of u."""
+    rs = np.random.RandomState(seed)
+    X = ds.matrix
+    u_all = np.repeat(np.arange(X.shape[0]), np.diff(X.indptr))
+    pick = rs.randint(len(u_all), size=n)
+    u, i = u_all[pick], X.indices[pick]
+    j = rs.randint(X.shape[1], size=n)
+    keep = np.asarray(X[u, j]).ravel() == 0
+    u, i, j = u[keep], i[keep], j[keep]
+    x = B[i] - B[j] + np.einsum("nk,nk->n", U[u], V[i] - V[j])
+    return float(np.mean(np.log1p(np.exp(-x)))), float(np.mean(x > 0))
+
+
+@pytest.mark.parametrize("k", [10, 16, 64])
+def test_hogwild_statistical_parity_with_reference_threads(oracle, k):
+    """hogwild mode is not reproducible (neither is the reference's num_threads > 1 path); gate it
+    statistically: same data, same hyper-parameters, same epochs -> pairwise loss / accuracy within
+    noise of the multi-thread CPU oracle and of the sequential oracle."""
+    ds = synth_dataset(2000, 1500, 120000, zipf=0.9, seed=21)
+    kw = dict(k=k, max_iter=15, learning_rate=0.05, lambda_reg=0.002)
+    seq = oracle.BPROracle(seed=3, **kw).fit(ds)
+    l_seq, a_seq = _bpr_loss(seq.u_factors, seq.i_factors, seq.i_biases, ds)
+    m = BPR(seed=3, mode="hogwild", **kw).fit(ds)
+    assert m.effective_mode == "hogwild"
+    l_hip, a_hip = _bpr_loss(m.u_factors, m.i_factors, m.i_biases, ds)
+    # multi-thread CPU port of the reference, same init
+    rng = np.random.RandomState(3)
+    U = ((rng.uniform(0, 1, (len(ds.uid_map), k)).astype(np.float32) - 0.5) / k)
+    V = ((rng.uniform(0, 1, (len(ds.iid_map), k)).astype(np.float32) - 0.5) / k)
+    B = np.zeros(len(ds.iid_map), np.float32)
+    indptr, indices, user_ids = oracle.csr_arrays(ds)
+    oracle.bpr_hogwild_epochs(indptr, indices, user_ids, ds.num_items, U, V, B, k, 0.05, 0.002, True, 99, 4, 15)
+    l_omp, a_omp = _bpr_loss(U, V, B, ds)
+    l0, _ = _bpr_loss(*(lambda r: (((r.uniform(0, 1, (len(ds.uid_map), k)).astype(np.float32) - 0.5) / k),
+                                   ((r.uniform(0, 1, (len(ds.iid_map), k)).astype(np.float32) - 0.5) / k),
+                                   np.zeros(len(ds.iid_map), np.float32)))(np.random.RandomState(3)), ds)
+    assert l_seq < 0.8 * l0, "the task must be learnable for the gate to mean anything"
+    assert abs(l_hip - l_seq) < 0.05 * l0 and abs(l_hip - l_omp) < 0.05 * l0, (l0, l_seq, l_omp, l_hip)
+    assert abs(a_hip - a_seq) < 0.02 and abs(a_hip - a_omp) < 0.02, (a_seq, a_omp, a_hip)
+    c, s = m.fit_stats[0]
+    assert abs(s - sum(seq.skipped)) < 0.05 * sum(seq.skipped) + 50, "skip rate of the device sampler"
+
+
+def test_hogwild_sampler_matches_its_cpu_restatement(oracle):
+    """one-sample-at-a-time check of the Philox/Lemire pair sampler: lr = 0 leaves the factors
+    untouched, and the skip counter must equal the CPU restatement's count."""
+    ds = synth_dataset(300, 50, 6000, zipf=0.5, seed=8)
+    X = ds.matrix
+    tr = _trainer(ds, 8)
+    tr.seed_hogwild(0xDEADBEEF12345)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    tr.close()
+    indptr, indices, user_ids = oracle.csr_arrays(ds)
+    skipped = 0
+    for epoch in range(2):
+        ii, jj = oracle.hogwild_sample(0xDEADBEEF12345, epoch, 0, X.nnz, X.nnz, ds.num_items)
+        assert ii.max() < X.nnz and jj.max() < ds.num_items
+        u = user_ids[ii]
+        skipped += int(np.sum(np.asarray(X[u, jj]).ravel() != 0))
+    assert s == skipped
+
+
+def test_atomic_updates_do_not_lose_writes():
+    """all triplets of a tiny dataset hit the same few rows: with reg = 0 the sum of all fp32
+    atomic deltas is conserved: sum_i V[i] is invariant (dV_i = -dV_j per triplet)."""
+    ds = synth_dataset(4, 6, 12, zipf=0.1, seed=2)
+    k = 16
+    rng = np.random.RandomState(0)
+    U = rng.normal(0, 0.1, (len(ds.uid_map), k)).astype(np.float32)
+    V = rng.normal(0, 0.1, (len(ds.iid_map), k)).astype(np.float32)
+    B = np.zeros(len(ds.iid_map), np.float32)
+    tr = _trainer(ds, k)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(1)
+    for _ in range(20):
+        tr.hogwild_enqueue(5000, 0.01, 0.0, True)
+    tr.sync()
+    U2, V2, B2 = tr.get_factors()
+    tr.close()
+    assert np.abs(V2 - V).max() > 1e-3
+    assert np.abs(V2.sum(0) - V.sum(0)).max() < 1e-3
+    assert abs(float(B2.sum())) < 1e-3
+
+
+def test_api_errors():
+    ds = synth_dataset(20, 15, 100, seed=1)
+    tr = _trainer(ds, 4)
+    with pytest.raises(_lib.HipError, match="seed"):
+        tr.fit_epochs(1, 0.1, 0.1, True, _lib.NEG_UNIFORM, _lib.MODE_DETERMINISTIC)
+    with pytest.raises(_lib.HipError, match="seed"):
+        tr.fit_epochs(1, 0.1, 0.1, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    with pytest.raises(_lib.HipError, match="mode"):
+        tr.fit_epochs(1, 0.1, 0.1, True, _lib.NEG_UNIFORM, 7)
+    tr.close()
+    X = ds.matrix
+    row = int(np.argmax(np.diff(X.indptr)))
+    bad = X.indices.copy()
+    a = X.indptr[row]
+    bad[a], bad[a + 1] = bad[a + 1], bad[a]
+    with pytest.raises(_lib.HipError, match="sorted"):
+        _lib.BprTrainer(X.indptr, bad, ds.num_users, ds.num_items, ds.num_users, ds.num_items, 4)
+    with pytest.raises(ValueError):
+        BPR(mode="fast")

@@ -1,0 +1,94 @@
+"""GPU parity tests of the MF path (cornac_hip_mf_*), through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import golden_dataset, load_golden, synth_dataset
+from cornac_amd import MF, _lib
+
+pytestmark = pytest.mark.gpu
+CASES = ["tiny", "small", "odd_k", "ml100k_shape"]
+
+
+def _kw(fx):
+    return dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+                lambda_reg=2 * float(fx["reg"]), seed=int(fx["seed"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_deterministic_matches_oracle_and_reference_golden(oracle, name):
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    m = MF(**_kw(fx)).fit(ds)
+    o = oracle.MFOracle(**_kw(fx)).fit(ds)
+    assert m.effective_mode == "deterministic"
+    for a, b, g in ((m.u_factors, o.u_factors, "mf_U"), (m.i_factors, o.i_factors, "mf_V"),
+                    (m.u_biases, o.u_biases, "mf_Bu"), (m.i_biases, o.i_biases, "mf_Bi")):
+        assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max()), "HIP deterministic vs oracle"
+        assert np.abs(a - fx[g]).max() <= 1e-4 * max(1.0, np.abs(fx[g]).max()), "vs reference golden"
+    assert m.global_mean == o.global_mean
+    # loss: device sums err^2 in fp64 tree order, the reference sequentially in fp32
+    assert np.allclose(m.loss_history, o.loss[: len(m.loss_history)], rtol=2e-4)
+    assert np.mean(m.u_factors == o.u_factors) > 0.999
+
+
+def test_no_bias_and_one_shot_reference_signature(oracle):
+    fx = load_golden("small")
+    ds = golden_dataset(fx)
+    kw = _kw(fx)
+    m = MF(use_bias=False, **kw).fit(ds)
+    assert np.abs(m.u_factors - fx["mf_nobias_U"]).max() <= 1e-4 * max(1.0, np.abs(fx["mf_nobias_U"]).max())
+    assert not m.u_biases.any() and not m.i_biases.any() and m.global_mean == 0
+    # backend_cpu.fit_sgd's exact argument list, in place
+    o = oracle.MFOracle(use_bias=True, **kw).fit(ds)
+    rng = np.random.RandomState(kw["seed"])
+    U = rng.normal(0, 0.01, (ds.num_users, kw["k"])).astype(np.float32)
+    V = rng.normal(0, 0.01, (ds.num_items, kw["k"])).astype(np.float32)
+    Bu, Bi = np.zeros(ds.num_users, np.float32), np.zeros(ds.num_items, np.float32)
+    rid, cid, val = ds.uir_tuple
+    loss = _lib.mf_fit_sgd(rid, cid, val.astype(np.float32), U, V, Bu, Bi, kw["learning_rate"], kw["lambda_reg"],
+                           float(np.float32(ds.global_mean)), kw["max_iter"], True, False, _lib.MODE_DETERMINISTIC)
+    assert np.abs(U - o.u_factors).max() <= 1e-6 and np.abs(Bi - o.i_biases).max() <= 1e-6
+    assert len(loss) == kw["max_iter"]
+
+
+@pytest.mark.parametrize("k", [1, 7, 32, 128, 200])
+def test_various_k(oracle, k):
+    ds = synth_dataset(150, 100, 3000, seed=k)
+    kw = dict(k=k, max_iter=4, learning_rate=0.01, lambda_reg=0.02, seed=3)
+    m, o = MF(**kw).fit(ds), oracle.MFOracle(**kw).fit(ds)
+    assert np.abs(m.u_factors - o.u_factors).max() <= 1e-6
+    assert np.abs(m.i_factors - o.i_factors).max() <= 1e-6
+
+
+def test_early_stop_semantics(oracle):
+    """|loss - last_loss| < 1e-5 stops (backend_cpu.pyx:89-93): lr = 0 makes the loss constant, so
+    the second epoch triggers the stop in both implementations."""
+    ds = synth_dataset(40, 30, 300, seed=1)
+    kw = dict(k=4, max_iter=10, learning_rate=0.0, lambda_reg=0.0, seed=1, early_stop=True)
+    m, o = MF(**kw).fit(ds), oracle.MFOracle(**kw).fit(ds)
+    assert m.epochs_run == o.epochs_run == 2
+
+
+@pytest.mark.parametrize("k", [10, 64])
+def test_hogwild_statistical_parity(oracle, k):
+    """throughput mode vs the sequential oracle and the reference's static-chunk multi-thread
+    path: training loss per epoch within a few percent."""
+    ds = synth_dataset(3000, 2000, 200000, zipf=0.9, seed=5)
+    kw = dict(k=k, max_iter=12, learning_rate=0.01, lambda_reg=0.02)
+    seq = oracle.MFOracle(seed=2, **kw).fit(ds)
+    omp = oracle.MFOracle(seed=2, num_threads=4, **kw).fit(ds)
+    m = MF(seed=2, mode="hogwild", **kw).fit(ds)
+    assert m.effective_mode == "hogwild"
+    assert seq.loss[-1] < 0.9 * seq.loss[0]
+    assert np.allclose(m.loss_history, seq.loss, rtol=0.03), (m.loss_history, seq.loss)
+    assert np.allclose(m.loss_history, omp.loss, rtol=0.03)
+    assert np.abs(m.i_biases - seq.i_biases).mean() < 0.02
+
+
+def test_errors():
+    ds = synth_dataset(20, 15, 100, seed=1)
+    with pytest.raises(ValueError, match="not supported"):
+        MF(backend="cpu").fit(ds)
+    rid, cid, val = ds.uir_tuple
+    with pytest.raises(_lib.HipError, match="out-of-range"):
+        _lib.MfTrainer(rid + 1000, cid, val, ds.num_users, ds.num_items, 4)

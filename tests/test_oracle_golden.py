@@ -1,0 +1,124 @@
+"""Pins the CPU oracle (oracle/cornac_oracle.c) against golden vectors produced by the REAL
+compiled reference (tests/golden/make_golden.py) and against the reference's own known-answer
+test for this path (tests/cornac/utils/test_fastdot.py:26-37).  Runs everywhere (no GPU, no
+/root/reference)."""
+import numpy as np
+import pytest
+
+
+def assert_close(a, b, atol=2e-6, rtol=5e-6):
+    """oracle (strict IEEE) vs reference (-ffast-math): a few ulp of the value magnitude"""
+    err = np.abs(np.asarray(a) - np.asarray(b)).max()
+    assert err <= atol + rtol * np.abs(b).max(), err
+
+from conftest import golden_dataset, load_golden
+
+CASES = ["tiny", "small", "odd_k", "ml100k_shape"]
+TOL = 2e-6  # reference is built with -ffast-math; the oracle is strict IEEE in index order
+
+
+def _kw(fx):
+    return dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+                lambda_reg=float(fx["reg"]), seed=int(fx["seed"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bpr_oracle_matches_reference_golden(oracle, name):
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    for use_bias, sfx in ((True, ""), (False, "_nobias")):
+        o = oracle.BPROracle(use_bias=use_bias, **_kw(fx)).fit(ds)
+        assert_close(o.u_factors, fx["bpr" + sfx + "_U"])
+        assert_close(o.i_factors, fx["bpr" + sfx + "_V"])
+        assert_close(o.i_biases, fx["bpr" + sfx + "_B"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_wbpr_oracle_matches_reference_golden(oracle, name):
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    o = oracle.WBPROracle(**_kw(fx)).fit(ds)
+    assert_close(o.u_factors, fx["wbpr_U"])
+    assert_close(o.i_factors, fx["wbpr_V"])
+    assert_close(o.i_biases, fx["wbpr_B"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_mf_oracle_matches_reference_golden(oracle, name):
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    kw = _kw(fx)
+    kw["lambda_reg"] *= 2
+    o = oracle.MFOracle(use_bias=True, **kw).fit(ds)
+    for a, b in ((o.u_factors, "mf_U"), (o.i_factors, "mf_V"), (o.u_biases, "mf_Bu"), (o.i_biases, "mf_Bi")):
+        assert_close(a, fx[b])
+    assert abs(float(o.global_mean) - float(fx["mf_mu"])) < 1e-7
+    o = oracle.MFOracle(use_bias=False, **kw).fit(ds)
+    assert_close(o.u_factors, fx["mf_nobias_U"])
+    assert_close(o.i_factors, fx["mf_nobias_V"])
+
+
+def test_fast_dot_known_answer_and_golden(oracle):
+    fx = load_golden("fast_dot")
+    # the reference's KAT: [[1,2],[3,4]] @ [1,2] -> [5, 11], exact
+    for mode in (0, 1, 2):
+        out = np.zeros(2, np.float32)
+        oracle.fast_dot(fx["kat_vec"], fx["kat_mat"], out, mode=mode)
+        assert np.array_equal(out, np.array([5, 11], np.float32))
+        assert np.array_equal(out, fx["kat_out"])
+    for mode in (0, 1, 2):
+        out = fx["out_in"].copy()
+        oracle.fast_dot(fx["vec"], fx["mat"], out, mode=mode)
+        # BLAS sdot sums in SIMD order: agreement to a few ulp of the accumulated magnitude
+        assert np.abs(out - fx["out"]).max() < 8e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_scores_and_ranking_match_reference(oracle, name):
+    """score() within BLAS-order tolerance; rank() identical wherever the reference's own adjacent
+    score gaps exceed that tolerance (ties/near-ties are unspecified in the reference)."""
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    o = oracle.BPROracle(**_kw(fx)).fit(ds)
+    k = int(fx["bpr_rank_k"])
+    for t, u in enumerate(fx["bpr_rank_users"]):
+        s = o.score(int(u), mode=1)
+        ref_s = fx["bpr_score_%d" % t]
+        assert np.abs(s - ref_s).max() < 5e-6
+        ranked, scores = oracle.rank(s, ds.num_items, len(ds.iid_map), k=-1)
+        ref_rank = fx["bpr_rank_full_%d" % t]
+        assert sorted(ranked.tolist()) == sorted(ref_rank.tolist())
+        gap_ok = np.abs(np.diff(ref_s[ref_rank])) > 1e-5  # positions whose order is well defined
+        safe = np.concatenate([[True], gap_ok]) & np.concatenate([gap_ok, [True]])
+        assert np.array_equal(ranked[safe], ref_rank[safe])
+        top, _ = oracle.rank(s, ds.num_items, len(ds.iid_map), k=k)
+        if safe[: k + 1].all():
+            assert np.array_equal(top, fx["bpr_rank_top_%d" % t])
+
+
+def test_boost_uniform_int_properties(oracle):
+    """bucket/rejection algorithm (uniform_int_distribution.hpp:188-227): range, determinism, the
+    hi == 0 branch draws nothing, hi == 2^32-1 passes raw words through."""
+    g1, g2 = oracle.MT19937(5489), oracle.MT19937(5489)
+    raw = g1.raw(4)
+    # mt19937 known answers for the default seed 5489 (first outputs of the standard generator)
+    assert raw.tolist() == [3499211612, 581869302, 3890346734, 3586334585]
+    assert np.array_equal(g2.uniform_int(0xFFFFFFFF, 4), raw.astype(np.int64))
+    g = oracle.MT19937(1)
+    before = g.raw(0)
+    z = g.uniform_int(0, 10)
+    assert (z == 0).all() and len(before) == 0
+    a = oracle.MT19937(7).uniform_int(999, 100000)
+    assert a.min() == 0 and a.max() == 999
+    counts = np.bincount(a, minlength=1000)
+    assert counts.min() > 50 and counts.max() < 160
+    with pytest.raises(ValueError):
+        oracle.MT19937(1).uniform_int(1 << 32, 1)
+
+
+def test_numpy_seeding_equals_mt19937_init_genrand(oracle):
+    """RNGVector seeds boost::mt19937(seed) — same init_genrand as NumPy's legacy seeding."""
+    for seed in (0, 1, 123, 2 ** 31 - 1):
+        raw = oracle.MT19937(seed).raw(8)
+        rs = np.random.RandomState(seed)
+        assert np.array_equal(raw, rs.randint(0, 2 ** 32, size=8, dtype=np.uint64).astype(np.uint32))

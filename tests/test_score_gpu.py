@@ -1,0 +1,140 @@
+"""GPU parity tests of scoring / ranking (cornac_hip_score_*, cornac_hip_rank_topk)."""
+import numpy as np
+import pytest
+
+from conftest import golden_dataset, load_golden, synth_dataset
+from cornac_amd import BPR, MF, ScoreException, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(n_users, n_items, k, seed, ties=False):
+    rs = np.random.RandomState(seed)
+    U = rs.normal(0, 0.3, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (n_items, k)).astype(np.float32)
+    if ties:
+        V[n_items // 2:] = V[: n_items - n_items // 2]  # exact score ties between item pairs
+    ib = rs.normal(0, 0.1, n_items).astype(np.float32)
+    if ties:
+        ib[n_items // 2:] = ib[: n_items - n_items // 2]
+    ub = rs.normal(0, 0.1, n_users).astype(np.float32)
+    return U, V, ib, ub
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 10, 64, 100, 128, 200])
+@pytest.mark.parametrize("with_user_base", [False, True])
+def test_scores_bit_exact_vs_oracle_fma_chain(oracle, k, with_user_base):
+    """score_user (VALU) and score_block (fp32 MFMA for k <= 128) == index-ordered fmaf chain."""
+    U, V, ib, ub = _tables(77, 333, k, k)
+    sc = _lib.Scorer(U, V, ib, ub if with_user_base else None)
+    users = np.array([0, 5, 76, 33, 5], np.int32)
+    want = oracle.score_block(U, V, ib, ub if with_user_base else None, users)
+    got = sc.score_block(users)
+    assert np.array_equal(got, want)
+    assert np.array_equal(sc.score_user(33), want[3])
+    many = np.arange(77, dtype=np.int32)
+    assert np.array_equal(sc.score_block(many), oracle.score_block(U, V, ib, ub if with_user_base else None, many))
+    sc.close()
+
+
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("topk", [1, 5, 10, 100, 333])
+def test_rank_topk_exact_order(oracle, topk, ties):
+    U, V, ib, ub = _tables(50, 333, 16, 3, ties=ties)
+    sc = _lib.Scorer(U, V, ib, None)
+    users = np.arange(50, dtype=np.int32)
+    items, scores = sc.rank_topk(users, topk)
+    full = oracle.score_block(U, V, ib, None, users)
+    for b in range(50):
+        want, _ = oracle.rank(full[b], 333, 333, k=topk)
+        assert np.array_equal(items[b], want[:topk])
+        assert np.array_equal(scores[b], full[b][want[:topk]])
+    sc.close()
+
+
+def test_rank_topk_with_exclusions_and_short_rows(oracle):
+    U, V, ib, ub = _tables(20, 64, 8, 4)
+    sc = _lib.Scorer(U, V, ib, None)
+    users = np.array([3, 7, 11], np.int32)
+    excl_lists = [np.arange(0, 64, 2), np.array([], np.int64), np.arange(60)]  # last user keeps 4 candidates
+    indptr = np.cumsum([0] + [len(x) for x in excl_lists]).astype(np.int64)
+    indices = np.concatenate(excl_lists).astype(np.int32)
+    items, scores = sc.rank_topk(users, 10, exclude=(indptr, indices))
+    full = oracle.score_block(U, V, ib, None, users)
+    for b in range(3):
+        cand = np.setdiff1d(np.arange(64), excl_lists[b])
+        want, _ = oracle.rank(full[b], 64, 64, item_indices=cand, k=10)
+        n = min(10, len(cand))
+        assert np.array_equal(items[b][:n], want[:n])
+        assert (items[b][n:] == -1).all() and np.isneginf(scores[b][n:]).all()
+    sc.close()
+
+
+def test_full_ranking_large_item_count(oracle):
+    """topk == n_items > 2048 goes through the full-sort kernel."""
+    U, V, ib, ub = _tables(6, 5000, 12, 9)
+    sc = _lib.Scorer(U, V, ib, None)
+    users = np.arange(6, dtype=np.int32)
+    items, scores = sc.rank_topk(users, 5000)
+    full = oracle.score_block(U, V, ib, None, users)
+    for b in range(6):
+        want, _ = oracle.rank(full[b], 5000, 5000, k=-1)
+        assert np.array_equal(items[b], want)
+    sc.close()
+
+
+@pytest.mark.parametrize("name", ["small", "ml100k_shape"])
+def test_model_score_and_rank_vs_reference_golden(oracle, name):
+    """BPR.score / rank after a seeded fit vs what the real reference returned (golden): scores
+    within BLAS-order tolerance, ranked order identical wherever the reference's adjacent score
+    gaps exceed that tolerance, top-k identical when its boundary is not a near-tie."""
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    kw = dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+              lambda_reg=float(fx["reg"]), seed=int(fx["seed"]))
+    for tag, m in (("bpr", BPR(**kw).fit(ds)), ("mf", MF(**dict(kw, lambda_reg=2 * kw["lambda_reg"])).fit(ds))):
+        kk = int(fx[tag + "_rank_k"])
+        for t, u in enumerate(fx[tag + "_rank_users"]):
+            ref_s, ref_rank = fx[tag + "_score_%d" % t], fx[tag + "_rank_full_%d" % t]
+            s = m.score(int(u))
+            assert s.dtype == np.float32 and np.abs(s - ref_s).max() < 2e-5
+            ranked, scores = m.rank(int(u))
+            assert np.abs(scores - fx[tag + "_rank_scores_%d" % t]).max() < 2e-5
+            assert sorted(ranked.tolist()) == sorted(ref_rank.tolist())
+            gap_ok = np.abs(np.diff(ref_s[ref_rank])) > 1e-4
+            safe = np.concatenate([[True], gap_ok]) & np.concatenate([gap_ok, [True]])
+            assert np.array_equal(ranked[safe], ref_rank[safe])
+            top, _ = m.rank(int(u), k=kk)
+            if safe[: kk + 1].all():
+                assert np.array_equal(top, fx[tag + "_rank_top_%d" % t])
+
+
+def test_recommender_surface(tmp_path, oracle):
+    """rank with candidates, recommend(remove_seen), save/load, clone, exceptions — the reference's
+    tests/cornac/models/test_recommender.py scenarios."""
+    ds = synth_dataset(30, 25, 300, seed=6)
+    m = MF(k=4, max_iter=3, seed=123).fit(ds)
+    assert m.knows_user(0) and not m.knows_user(ds.num_users) and m.knows_item(3)
+    cand = np.array([3, 1, 20, 7, 11])
+    ranked, scores = m.rank(2, item_indices=cand)
+    s = m.score(2)
+    assert np.array_equal(scores, s[cand])
+    assert np.array_equal(ranked, cand[np.argsort(s[cand], kind="stable")[::-1]])
+    uid = ds.user_ids[2]
+    rec_all = m.recommend(uid, k=5)
+    rec_unseen = m.recommend(uid, k=5, remove_seen=True, train_set=ds)
+    seen = {ds.item_ids[i] for i in ds.matrix.getrow(2).indices}
+    assert len(rec_all) == 5 and not (set(rec_unseen) & seen)
+    with pytest.raises(ValueError):
+        m.recommend("nobody")
+    with pytest.raises(ScoreException):
+        m.score(0, ds.num_items + 5)
+    assert m.rate(0, ds.num_items + 5) == pytest.approx(np.clip(m.global_mean, ds.min_rating, ds.max_rating))
+    path = m.save(str(tmp_path))
+    m2 = MF.load(path)
+    assert np.array_equal(m2.u_factors, m.u_factors) and np.array_equal(m2.score(2), s)
+    c = m.clone({"k": 7})
+    assert c.k == 7 and c.max_iter == 3 and c.u_factors is None and not c.is_fitted
+    items, sc = m.rank_batch(np.arange(10), k=3, exclude=(ds.matrix.indptr[:11].astype(np.int64), ds.matrix.indices[: ds.matrix.indptr[10]]))
+    for b in range(10):
+        assert not (set(items[b].tolist()) & set(ds.matrix.getrow(b).indices.tolist()))
