@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BPR training throughput (triplets/s) + batched rank() throughput (items
+scored/s) on an ML-20M-shaped synthetic interaction set, k = 64, fp32 tables (BASELINE.json
+configs[1]), hogwild (throughput) mode — the counterpart of the reference's OpenMP path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one BPR epoch (nnz = 20 000 263 sampled triplets) over the resident interaction
+matrix.  For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU;
+every rank owns a disjoint ML-20M-shaped user population (weak scaling) and the replicated item
+table is reconciled by RCCL all-reduce of its deltas (cornac_amd/dist.py).
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def algorithmic_bytes_per_triplet(k, mean_degree):
+    """3 rows + 2 biases read and written (24k + 16), user_ids/item_ids (8),
+    indptr pair (8), ceil(log2(d+1)) 4-byte membership probes."""
+    probes = int(np.ceil(np.log2(mean_degree + 1)))
+    return 24 * k + 16 + 8 + 8 + 4 * probes, 8 + 8 + 4 * probes  # (processed triplet, skipped draw)
+
+
+def load_dataset(name, seed_shift, cache_dir):
+    from cornac_amd import synth
+
+    n_users, n_items, nnz, a, seed = synth.CONFIGS[name]
+    tag = "%s_s%d" % (name, seed + seed_shift)
+    path = os.path.join(cache_dir, "cornac_amd_%s.npz" % tag)
+    if os.path.exists(path):
+        z = np.load(path)
+        return n_users, n_items, z["indptr"], z["indices"]
+    users, items = synth.zipf_interactions(n_users, n_items, nnz, a, seed + seed_shift)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    try:
+        np.savez(path, indptr=indptr, indices=indices)
+    except OSError:
+        pass
+    return n_users, n_items, indptr, indices
+
+
+def init_factors(n_users, n_items, k, seed):
+    rng = np.random.RandomState(seed)
+    U = ((rng.uniform(0, 1, (n_users, k)).astype(np.float32) - 0.5) / k)
+    V = ((rng.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k)
+    return U, V, np.zeros(n_items, np.float32)
+
+
+def cpu_baseline(indptr, indices, n_items, k, lr, reg, budget_s):
+    """The reference's OpenMP Hogwild path (restated in oracle/cornac_oracle.c, same loop, same
+    boost sampler, compiled with the reference's flags) timed on this host's cores over a bounded
+    sample of the same workload."""
+    from oracle import oracle as orc
+
+    L = orc.lib()
+    threads = max(1, min(os.cpu_count() or 1, L.oracle_num_threads()))
+    n_users = len(indptr) - 1
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+    U, V, B = init_factors(n_users, n_items, k, 1)
+    nnz = len(indices)
+    probe = min(nnz, 2_000_000)
+    t0 = time.time()
+    orc.bpr_hogwild_epochs(indptr, indices, user_ids, n_items, U, V, B, k, lr, reg, True, 5, threads, 1,
+                           num_samples=probe)
+    rate = probe / (time.time() - t0)
+    n = int(min(nnz * 4, max(probe, rate * budget_s)))
+    t0 = time.time()
+    orc.bpr_hogwild_epochs(indptr, indices, user_ids, n_items, U, V, B, k, lr, reg, True, 6, threads, 1,
+                           num_samples=n)
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "triplets/s", "cores": threads, "kind": "port",
+            "sample": "%d BPR triplets (%.2f epoch) of the same ML-20M-shaped matrix, k=%d, OpenMP hogwild, "
+                      "%d threads, %.1f s" % (n, n / nnz, k, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="ml20m")
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--reg", type=float, default=0.01)
+    ap.add_argument("--flags", type=int, default=0, help="hogwild_flags of cornac_hip_bpr_fit_epochs")
+    ap.add_argument("--sync-per-epoch", type=int, default=8, help="item-table all-reduces per epoch (N > 1)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-rank", action="store_true")
+    ap.add_argument("--rank-users", type=int, default=0, help="users ranked in the scoring leg (0 = all)")
+    ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
+    args = ap.parse_args()
+
+    import torch
+
+    from cornac_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libcornac_hip has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_users, n_items, indptr, indices = load_dataset(args.config, rank, args.cache_dir)
+    nnz = len(indices)
+    k = args.k
+    trainer = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k, device=local_rank)
+    U, V, B = init_factors(n_users, n_items, k, 100 + rank)
+    if distributed:
+        V, B = init_factors(n_users, n_items, k, 100)[1:]  # identical item table on every rank
+    trainer.set_factors(U, V, B)
+    trainer.seed_hogwild(0xC0FFEE + 7919 * rank)
+
+    sharded = None
+    if distributed:
+        from cornac_amd.dist import ShardedBprTrainer
+
+        sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
+                                    // args.sync_per_epoch)
+        sharded.load_items(V, B)
+
+    def step():
+        if sharded is None:
+            return trainer.fit_epochs(1, args.lr, args.reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, args.flags)
+        sharded.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags)
+        return (0, 0)
+
+    for _ in range(args.warmup):
+        step()
+    if sharded is not None:
+        sharded.finish()
+    trainer.kernel_timing(enable=True)  # start recording HIP events around the SGD kernel launches
+    barrier()
+    t0 = time.perf_counter()
+    correct = skipped = 0
+    for _ in range(args.steps):
+        c, s = step()
+        correct += c
+        skipped += s
+    if sharded is not None:
+        correct, skipped = sharded.finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = trainer.kernel_timing(enable=False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_triplets = float(nnz) * args.steps * world
+    value = total_triplets / elapsed
+    out = {
+        "metric": "bpr_triplets_per_sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
+                               "GPU), hogwild mode, fp32 tables resident in HBM" % (k, n_users, n_items, nnz),
+                   "k": k, "lr": args.lr, "reg": args.reg, "hogwild_flags": args.flags,
+                   "parallelism": "1 gpu" if world == 1 else "user-partitioned dp%d, item table all-reduce x%d/epoch"
+                                  % (world, args.sync_per_epoch)},
+    }
+    if rank == 0:
+        mean_deg = nnz / n_users
+        b_full, b_skip = algorithmic_bytes_per_triplet(k, mean_deg)
+        n_draws = float(nnz) * args.steps
+        skip_frac = skipped / n_draws if n_draws else 0.0
+        bytes_per_launch = (nnz * (1.0 - skip_frac)) * b_full + (nnz * skip_frac) * b_skip
+        avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bpr_hogwild_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                           "kernel": "bpr_hogwild_vec4_kernel", "launches": launches,
+                           "avg_launch_ms": 1e3 * avg_launch_s, "algorithmic_bytes_per_triplet": b_full,
+                           "skip_fraction": skip_frac}
+        out["train_stats"] = {"correct_frac": correct / max(n_draws - skipped, 1.0), "skipped_frac": skip_frac}
+
+    # ---- scoring leg: batched rank() over users with fused top-10 --------------------------------------------
+    if not args.no_rank and rank == 0:
+        U2, V2, B2 = trainer.get_factors()
+        sc = _lib.Scorer(U2, V2, B2, None, device=local_rank)
+        n_rank = n_users if args.rank_users <= 0 else min(args.rank_users, n_users)
+        sc.rank_topk_device_ms(0, min(n_rank, 4096), 10, 1)  # warm-up
+        ms = sc.rank_topk_device_ms(0, n_rank, 10, 1)
+        pairs = float(n_rank) * n_items
+        out["rank"] = {"metric": "rank_items_scored_per_sec", "value": pairs / (ms / 1e3), "unit": "items/s",
+                       "users": n_rank, "items": n_items, "topk": 10, "ms": ms,
+                       "roofline": {"bound": "mfma", "achieved": 2.0 * k * pairs / (ms / 1e3) / 1e12,
+                                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": 2.0 * k * pairs / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF}}
+        sc.close()
+    trainer.close()
+
+    # ---- CPU baseline leg (rank 0, N = 1 only) ------------------------------------------------------------------
+    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(indptr, indices, n_items, k, args.lr, args.reg, args.cpu_baseline_seconds)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ SYMBOLS = [
     "cornac_hip_bpr_bind_device", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
-    "cornac_hip_bpr_last_timing",
+    "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -89,6 +89,8 @@ def lib():
         L.cornac_hip_bpr_sync.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_draw.argtypes = [_vp, C.c_int, C.c_uint64, C.c_int64, _i64]
         L.cornac_hip_bpr_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i64, _f32,
                                            C.c_int64]
         L.cornac_hip_mf_destroy.argtypes = [_vp]
@@ -207,6 +209,12 @@ class BprTrainer:
         check(lib().cornac_hip_bpr_debug_draw(self.h, stream, hi, n, out))
         return out
 
+    def kernel_timing(self, enable=True):
+        """(total_ms, launches) of the hogwild kernel launches recorded since the last call (HIP events)."""
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().cornac_hip_bpr_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def last_timing(self):
         t = (C.c_double * 4)()
         check(lib().cornac_hip_bpr_last_timing(self.h, t))
@@ -247,6 +255,11 @@ class MfTrainer:
         check(lib().cornac_hip_mf_fit(self.h, max_iter, lr, reg, mu, int(use_bias), int(early_stop), mode,
                                       loss.ctypes.data, C.byref(n)))
         return loss[:n.value], n.value
+
+    def kernel_timing(self, enable=True):
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().cornac_hip_mf_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def last_timing(self):
         t = (C.c_double * 4)()

@@ -329,6 +329,7 @@ struct cornac_hip_bpr {
     uint32_t hog_epoch = 0;
     int64_t hog_offset = 0;  // samples already consumed in the current epoch
     double timing[4] = {0, 0, 0, 0};
+    EventTimer ktimer;  // hogwild SGD kernel launches
 };
 
 static constexpr int64_t kDetChunk = int64_t(1) << 24;
@@ -656,7 +657,9 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         a.th_neg = lemire_thresh(a.n_neg);
         a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
         a.lr = lr; a.reg = reg;
+        h->ktimer.before(h->stream);
         if (flags & 1) launch_hogwild<false>(h, a); else launch_hogwild<true>(h, a);
+        h->ktimer.after(h->stream);
         h->hog_offset += n;
         left -= n;
         if (h->hog_offset >= h->nnz) {
@@ -739,6 +742,15 @@ int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64
         d.download(tmp.data(), (size_t)n, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
         for (int64_t t = 0; t < n; ++t) out[t] = (int64_t)tmp[(size_t)t];
+    });
+}
+
+int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_ms, int64_t *launches) {
+    return guarded([&] {
+        bpr_check(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->ktimer.collect(total_ms, launches);
+        h->ktimer.enabled = enable != 0;
     });
 }
 

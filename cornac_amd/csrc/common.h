@@ -126,6 +126,45 @@ struct Timer {
     }
 };
 
+// ---- HIP-event timing of the dominant kernel's launches (on the stream they are launched on) ------
+struct EventTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;  // pairs: [2i] before, [2i+1] after
+    size_t used = 0;
+    ~EventTimer() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+    void before(hipStream_t s) {
+        if (!enabled) return;
+        if (used + 2 > ev.size()) {
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+            ev.push_back(a);
+            ev.push_back(b);
+        }
+        HIP_CHECK(hipEventRecord(ev[used], s));
+    }
+    void after(hipStream_t s) {
+        if (!enabled) return;
+        HIP_CHECK(hipEventRecord(ev[used + 1], s));
+        used += 2;
+    }
+    // sums the elapsed time of all recorded launches (stream must be idle) and resets
+    void collect(double *total_ms, int64_t *launches) {
+        double t = 0;
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            HIP_CHECK(hipEventSynchronize(ev[i + 1]));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            t += ms;
+        }
+        if (total_ms) *total_ms = t;
+        if (launches) *launches = (int64_t)(used / 2);
+        used = 0;
+    }
+};
+
 // ---- conflict-free level scheduling of an ordered update stream (host, sched.cpp) ---------------
 // sample s touches user row su[s] and item rows si[s], sj[s] (sj < 0: none; su < 0: sample skipped).
 // level[s] = 1 + max(level of the previous sample touching any of its rows).  Samples of one level

@@ -170,6 +170,7 @@ struct cornac_hip_mf {
     std::vector<int64_t> host_rid, host_cid;
     std::vector<float> host_val;
     double timing[4] = {0, 0, 0, 0};
+    EventTimer ktimer;  // hogwild SGD kernel launches
 };
 
 static void mf_check(cornac_hip_mf_t h) {
@@ -260,6 +261,7 @@ static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, i
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * 8));
     dim3 g(grid), b(kBlock);
     const int k = h->k;
+    h->ktimer.before(h->stream);
     if (k % 4 == 0 && k <= 256) {
         const int q = k / 4;
         if (q <= 4) hipLaunchKernelGGL((mf_hogwild_kernel<4, true>), g, b, 0, h->stream, a);
@@ -276,6 +278,7 @@ static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, i
             default: hipLaunchKernelGGL((mf_hogwild_kernel<64, false>), g, b, 0, h->stream, a); break;
         }
     }
+    h->ktimer.after(h->stream);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -404,6 +407,15 @@ int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, co
     cornac_hip_mf_destroy(h);
     if (rc != CORNAC_HIP_OK) chip::set_last_error(keep);
     return rc;
+}
+
+int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms, int64_t *launches) {
+    return guarded([&] {
+        mf_check(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->ktimer.collect(total_ms, launches);
+        h->ktimer.enabled = enable != 0;
+    });
 }
 
 int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4) {

@@ -111,6 +111,10 @@ int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped);
 /* Test hooks of the deterministic sampler: draw `n` values from stream 0/1
  * (boost uniform_int_distribution<long>(0, hi), uniform_int_distribution.hpp:188-227). */
 int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64_t n, int64_t *out);
+/* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
+ * stream: returns the summed duration and count of the launches recorded since
+ * the previous call, then enables/disables recording for the following ones. */
+int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_ms, int64_t *launches);
 /* time spent (ms) in the last fit_epochs call: [0] sampler, [1] host level
  * scheduling, [2] SGD kernels, [3] total */
 int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4);
@@ -140,6 +144,7 @@ int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, co
                           float *V, float *Bu, float *Bi, int64_t n_users, int64_t n_items, int k, float lr, float reg,
                           float mu, int max_iter, int use_bias, int early_stop, int mode, float *loss_per_epoch,
                           int *epochs_run);
+int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms, int64_t *launches);
 int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 
 /* ------------------------------------------------------------------------- *

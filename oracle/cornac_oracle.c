@@ -9,7 +9,7 @@
  * Parity status: PINNED.  Every function below is validated against the real
  * compiled reference (oracle/_ref, built from /root/reference by
  * oracle/build_ref.py) in tests/test_oracle_vs_reference.py, and against the
- * golden vectors that the real reference produced (tests/golden/*.npz, made by
+ * golden vectors that the real reference produced (tests/golden/ npz files, made by
  * tests/golden/make_golden.py).  The reference's own test-suite holds exactly
  * one known-answer test on this path (tests/cornac/utils/test_fastdot.py:26-37)
  * which is replayed in tests/test_oracle_golden.py.
@@ -40,6 +40,7 @@
 typedef struct {
     uint32_t mt[624];
     int32_t idx; /* next unread word; 624 => regenerate first */
+    int32_t pad[15]; /* sizeof == 2560 = 40 cache lines: per-thread engines never share a line */
 } oracle_mt19937;
 
 void oracle_mt_seed(oracle_mt19937 *g, uint32_t seed) {

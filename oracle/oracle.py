@@ -32,16 +32,34 @@ u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 def build(force=False):
     src = os.path.join(_HERE, "cornac_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    fast = _SO.replace("libcornac_oracle.so", "libcornac_oracle_fast.so")
+    if force or not os.path.exists(_SO) or not os.path.exists(fast) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
+
+
+_fast = None
+
+
+def fast_lib():
+    """same source compiled with the reference's flags (-O3 -ffast-math): CPU-baseline timing only"""
+    global _fast
+    if _fast is None:
+        build()
+        _fast = _bind(C.CDLL(_SO.replace("libcornac_oracle.so", "libcornac_oracle_fast.so")))
+    return _fast
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_SO)
+        _lib = _bind(C.CDLL(_SO))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.oracle_mt_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.oracle_mt_next.argtypes = [C.c_void_p]
         L.oracle_mt_next.restype = C.c_uint32
@@ -66,8 +84,7 @@ def lib():
                                             i64p, i64p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
-        _lib = L
-    return _lib
+    return L
 
 
 class MT19937:
@@ -193,24 +210,28 @@ class WBPROracle(BPROracle):
 
 
 def bpr_hogwild_epochs(indptr, indices, user_ids, n_items, U, V, B, k, lr, reg, use_bias, seed, num_threads,
-                       epochs):
-    """The reference's unseeded multi-thread path (racy), for the CPU throughput baseline."""
-    L = lib()
+                       epochs, num_samples=None, fast=True):
+    """The reference's unseeded multi-thread path (racy), for the CPU throughput baseline.
+    num_samples: draws per epoch (default nnz, like the reference)."""
+    L = fast_lib() if fast else lib()
     nnz = len(user_ids)
+    n_draw = nnz if num_samples is None else int(num_samples)
     T = num_threads
     sz = L.oracle_sizeof_mt()
     rng = np.random.RandomState(seed)
-    bufs = []
+    bufs, keep = [], []
     for _ in range(2):
-        buf = C.create_string_buffer(sz * T)
+        raw = C.create_string_buffer(sz * T + 64)
+        base = (C.addressof(raw) + 63) & ~63  # cache-line aligned array of T engines
         for t, s in enumerate(rngvector_seeds(rng.randint(2 ** 31), T)):
-            L.oracle_mt_seed(C.cast(C.addressof(buf) + t * sz, C.c_void_p), s)
-        bufs.append(buf)
+            L.oracle_mt_seed(C.c_void_p(base + t * sz), s)
+        keep.append(raw)
+        bufs.append(C.c_void_p(base))
     neg_ids = np.arange(n_items, dtype=np.int32)
     tot_c = tot_s = 0
     for _ in range(epochs):
         c, s = C.c_int64(), C.c_int64()
-        L.oracle_bpr_epoch_omp(bufs[0], bufs[1], T, nnz - 1, n_items - 1, nnz, user_ids, indices, neg_ids, indptr,
+        L.oracle_bpr_epoch_omp(bufs[0], bufs[1], T, nnz - 1, n_items - 1, n_draw, user_ids, indices, neg_ids, indptr,
                                U, V, B, k, lr, reg, int(use_bias), C.byref(c), C.byref(s))
         tot_c += c.value
         tot_s += s.value

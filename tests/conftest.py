@@ -56,7 +56,9 @@ def synth_dataset(n_users, n_items, nnz, zipf=0.8, seed=0, shuffle=True):
     keys = np.unique(rs.randint(n_users, size=nnz * 2).astype(np.int64) * n_items + rs.choice(n_items, nnz * 2, p=p))
     keys = rs.permutation(keys)[:nnz] if shuffle else keys[:nnz]
     u, i = keys // n_items, keys % n_items
-    r = rs.randint(1, 6, size=len(u)).astype(float)
+    # ratings with user/item structure so that MF has something to learn
+    bu, bi = rs.normal(0, 0.8, n_users), rs.normal(0, 0.8, n_items)
+    r = np.clip(np.rint(3.0 + bu[u] + bi[i] + rs.normal(0, 0.5, len(u))), 1, 5).astype(float)
     return Dataset.from_uir(list(zip(u.tolist(), i.tolist(), r.tolist())), seed=123)
 
 

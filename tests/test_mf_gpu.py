@@ -80,8 +80,11 @@ def test_hogwild_statistical_parity(oracle, k):
     m = MF(seed=2, mode="hogwild", **kw).fit(ds)
     assert m.effective_mode == "hogwild"
     assert seq.loss[-1] < 0.9 * seq.loss[0]
-    assert np.allclose(m.loss_history, seq.loss, rtol=0.03), (m.loss_history, seq.loss)
-    assert np.allclose(m.loss_history, omp.loss, rtol=0.03)
+    # epoch 1 pays for update staleness (thousands of ratings in flight vs 1..4 on the CPU);
+    # from epoch 2 on the trajectories coincide
+    assert np.allclose(m.loss_history[:1], seq.loss[:1], rtol=0.06), (m.loss_history, seq.loss)
+    assert np.allclose(m.loss_history[1:], seq.loss[1:], rtol=0.01), (m.loss_history, seq.loss)
+    assert np.allclose(m.loss_history[1:], omp.loss[1:], rtol=0.01)
     assert np.abs(m.i_biases - seq.i_biases).mean() < 0.02
 
 
