@@ -210,6 +210,118 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
     }
 }
 
+// Row-wise layout (the production shape): the G lanes of a group own consecutive floats of a row,
+// so every gather and every fp32-atomic scatter instruction covers whole 128-byte lines
+// (tools/atomic_probe.hip: device-scope atomics cost one slot per touched line and instruction,
+// ~10 G line-requests/s chip-wide, regardless of how many dwords of the line are active — the
+// float4-per-lane layout above needs 4x the requests).  k <= G * R; UNR batches of TPW triplets
+// are kept in flight per wave to cover the HBM/fabric latency.
+template <int G, int R, int UNR, bool ATOMIC>
+__global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
+    __shared__ int32_t stage[kWavesPerBlock][3][kWave];
+    constexpr int TPW = kWave / G;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int grp = lane / G, lg = lane & (G - 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    unsigned int n_correct = 0, n_skipped = 0;
+    bool inb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) inb[r] = lg + G * r < a.k;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
+        int32_t su, si, sj;
+        bool in_range;
+        const bool valid = hog_sample(a, tile * kWave + lane, su, si, sj, in_range);
+        const unsigned long long mask = __ballot(valid);
+        n_skipped += (in_range && !valid) ? 1u : 0u;
+        if (valid) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            stage[wave][0][pos] = su;
+            stage[wave][1][pos] = si;
+            stage[wave][2][pos] = sj;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nvalid = __popcll(mask);
+        for (int b = 0; b < nvalid; b += TPW * UNR) {
+            float u[UNR][R], vi[UNR][R], vj[UNR][R], bi[UNR], bj[UNR];
+            float *pu[UNR], *pi[UNR], *pj[UNR];
+            int32_t ti[UNR], tj[UNR];
+            bool act[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int slot = b + q * TPW + grp;
+                act[q] = slot < nvalid;
+                const int sl = act[q] ? slot : b;
+                const int32_t tu = stage[wave][0][sl];
+                ti[q] = stage[wave][1][sl];
+                tj[q] = stage[wave][2][sl];
+                pu[q] = a.U + (size_t)tu * a.k + lg;
+                pi[q] = a.V + (size_t)ti[q] * a.k + lg;
+                pj[q] = a.V + (size_t)tj[q] * a.k + lg;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    u[q][r] = inb[r] ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
+                    vi[q][r] = inb[r] ? __builtin_nontemporal_load(pi[q] + G * r) : 0.f;
+                    vj[q][r] = inb[r] ? __builtin_nontemporal_load(pj[q] + G * r) : 0.f;
+                }
+                bi[q] = __builtin_nontemporal_load(a.B + ti[q]);
+                bj[q] = __builtin_nontemporal_load(a.B + tj[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) part += u[q][r] * (vi[q][r] - vj[q][r]);
+                const float score = (bi[q] - bj[q]) + group_sum<G>(part);
+                const float z = sigmoid_neg_fast(score);
+                if (act[q]) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (inb[r]) {
+                            const float du = a.lr * (z * (vi[q][r] - vj[q][r]) - a.reg * u[q][r]);
+                            const float dvi = a.lr * (z * u[q][r] - a.reg * vi[q][r]);
+                            const float dvj = a.lr * (-z * u[q][r] - a.reg * vj[q][r]);
+                            if (ATOMIC) {
+                                atomic_add_f32(pu[q] + G * r, du);
+                                atomic_add_f32(pi[q] + G * r, dvi);
+                                atomic_add_f32(pj[q] + G * r, dvj);
+                            } else {
+                                pu[q][G * r] = u[q][r] + du;
+                                pi[q][G * r] = vi[q][r] + dvi;
+                                pj[q][G * r] = vj[q][r] + dvj;
+                            }
+                        }
+                    }
+                    if (lg == 0) {
+                        if (a.use_bias) {
+                            const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
+                            if (ATOMIC) {
+                                atomic_add_f32(a.B + ti[q], dbi);
+                                atomic_add_f32(a.B + tj[q], dbj);
+                            } else {
+                                a.B[ti[q]] = bi[q] + dbi;
+                                a.B[tj[q]] = bj[q] + dbj;
+                            }
+                        }
+                        n_correct += z < .5f ? 1u : 0u;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_correct += __shfl_xor(n_correct, o, kWave);
+        n_skipped += __shfl_xor(n_skipped, o, kWave);
+    }
+    if (lane == 0) {
+        if (n_correct) atomicAdd(&a.counters[0], (unsigned long long)n_correct);
+        if (n_skipped) atomicAdd(&a.counters[1], (unsigned long long)n_skipped);
+    }
+}
+
 // any k: G lanes per triplet stride over the factors (two passes over the rows).
 template <int G, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogArgs a) {
@@ -330,6 +442,8 @@ struct cornac_hip_bpr {
     int64_t hog_offset = 0;  // samples already consumed in the current epoch
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
+    void (*hog_kernel)(const chip::HogArgs) = nullptr;
+    int hog_blocks_per_cu = 8;
 };
 
 static constexpr int64_t kDetChunk = int64_t(1) << 24;
@@ -610,30 +724,53 @@ static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int
 }
 
 // ---- hogwild launch -------------------------------------------------------------------------------
+typedef void (*HogKernel)(const HogArgs);
+
 template <bool ATOMIC>
-static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a) {
-    const DeviceInfo &di = device_info(h->device);
-    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
-    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * 8));
-    const int k = h->k;
-    dim3 g(grid), b(kBlock);
+static HogKernel pick_hogwild_kernel(int k, int flags) {
+    const bool vec4_layout = (flags & 2) != 0;  // experiment switch: the float4-per-lane layout
+    if (!vec4_layout && k <= 256) {
+        if (k <= 4) return bpr_hogwild_rowwise_kernel<4, 1, 2, ATOMIC>;
+        if (k <= 8) return bpr_hogwild_rowwise_kernel<8, 1, 2, ATOMIC>;
+        if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC>;
+        if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC>;
+        if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, ATOMIC>;
+        if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, ATOMIC>;
+        if (k <= 192) return bpr_hogwild_rowwise_kernel<64, 3, 2, ATOMIC>;
+        return bpr_hogwild_rowwise_kernel<64, 4, 1, ATOMIC>;
+    }
     if (k % 4 == 0 && k <= 256) {
         const int q = k / 4;
-        if (q <= 4) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<4, ATOMIC>), g, b, 0, h->stream, a);
-        else if (q <= 8) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<8, ATOMIC>), g, b, 0, h->stream, a);
-        else if (q <= 16) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<16, ATOMIC>), g, b, 0, h->stream, a);
-        else if (q <= 32) hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<32, ATOMIC>), g, b, 0, h->stream, a);
-        else hipLaunchKernelGGL((bpr_hogwild_vec4_kernel<64, ATOMIC>), g, b, 0, h->stream, a);
-    } else {
-        switch (pow2_group(k)) {
-            case 4: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<4, ATOMIC>), g, b, 0, h->stream, a); break;
-            case 8: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<8, ATOMIC>), g, b, 0, h->stream, a); break;
-            case 16: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<16, ATOMIC>), g, b, 0, h->stream, a); break;
-            case 32: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<32, ATOMIC>), g, b, 0, h->stream, a); break;
-            default: hipLaunchKernelGGL((bpr_hogwild_generic_kernel<64, ATOMIC>), g, b, 0, h->stream, a); break;
-        }
+        if (q <= 4) return bpr_hogwild_vec4_kernel<4, ATOMIC>;
+        if (q <= 8) return bpr_hogwild_vec4_kernel<8, ATOMIC>;
+        if (q <= 16) return bpr_hogwild_vec4_kernel<16, ATOMIC>;
+        if (q <= 32) return bpr_hogwild_vec4_kernel<32, ATOMIC>;
+        return bpr_hogwild_vec4_kernel<64, ATOMIC>;
     }
+    switch (pow2_group(k)) {
+        case 4: return bpr_hogwild_generic_kernel<4, ATOMIC>;
+        case 8: return bpr_hogwild_generic_kernel<8, ATOMIC>;
+        case 16: return bpr_hogwild_generic_kernel<16, ATOMIC>;
+        case 32: return bpr_hogwild_generic_kernel<32, ATOMIC>;
+        default: return bpr_hogwild_generic_kernel<64, ATOMIC>;
+    }
+}
+
+static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a, int flags) {
+    const DeviceInfo &di = device_info(h->device);
+    HogKernel kern = (flags & 1) ? pick_hogwild_kernel<false>(h->k, flags) : pick_hogwild_kernel<true>(h->k, flags);
+    // persistent grid: exactly the number of workgroups that are co-resident, so the tile loop of
+    // every wave starts at once (no second dispatch round with a ragged tail)
+    if (h->hog_kernel != kern) {
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+        h->hog_kernel = kern;
+        h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
+    }
+    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * h->hog_blocks_per_cu));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, h->stream, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -658,7 +795,7 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
         a.lr = lr; a.reg = reg;
         h->ktimer.before(h->stream);
-        if (flags & 1) launch_hogwild<false>(h, a); else launch_hogwild<true>(h, a);
+        launch_hogwild(h, a, flags);
         h->ktimer.after(h->stream);
         h->hog_offset += n;
         left -= n;

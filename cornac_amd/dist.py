@@ -59,7 +59,7 @@ class ShardedBprTrainer:
         self.table = ItemTableReplica(total_items, k, device, group)
         self.sync_every = int(sync_every)
         self.device = device
-        if device.type == "cuda":
+        if device.type == "cuda" and trainer is not None:
             trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
             trainer.set_stream(torch.cuda.current_stream(device).cuda_stream)
 

@@ -1,0 +1,95 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path's host logic (cornac_amd/dist.py): user
+partitioning and the item-table delta all-reduce.  The HIP trainer is replaced by a host stand-in
+that applies known per-rank updates, so the reduction algebra is checked exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cornac_amd.dist import ItemTableReplica, ShardedBprTrainer, partition_users_by_nnz, slice_csr
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _FakeTrainer:
+    """stands in for _lib.BprTrainer on a CPU host: every enqueue adds rank-dependent deltas to V/B"""
+
+    def __init__(self, table, rank):
+        self.table, self.rank, self.calls = table, rank, []
+
+    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
+        self.calls.append(n)
+        self.table.V[self.rank::2] += lr * n  # each rank touches its own stripe of rows ...
+        self.table.V[0] += 1.0                # ... and both touch row 0
+        self.table.B.add_((self.rank + 1) * 0.5)
+
+    def sync(self):
+        return (sum(self.calls), 0)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        sh = ShardedBprTrainer(None, total_items=6, k=4, device=dev, sync_every=100)
+        sh.trainer = _FakeTrainer(sh.table, rank)
+        V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
+        sh.load_items(V0, np.zeros(6, np.float32))
+        sh.run(250, lr=0.01, reg=0.0)  # chunks of 100, 100, 50 -> 3 syncs
+        correct, _ = sh.finish()
+        out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), sh.trainer.calls, correct)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_item_table_allreduce_of_deltas_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    (V_a, B_a, calls_a, c_a), (V_b, B_b, calls_b, c_b) = out[0], out[1]
+    assert calls_a == calls_b == [100, 100, 50] and c_a == 250
+    assert np.array_equal(V_a, V_b) and np.array_equal(B_a, B_b), "replicas must agree after every sync"
+    V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
+    want = V0.copy()
+    want[0::2] += 0.01 * 250  # rank 0's stripe
+    want[1::2] += 0.01 * 250  # rank 1's stripe
+    want[0] += 2.0 * 3        # both ranks, three chunks
+    assert np.allclose(V_a, want, atol=1e-5)
+    assert np.allclose(B_a, 3 * (0.5 + 1.0))
+
+
+def test_single_process_sync_is_a_rebase():
+    t = ItemTableReplica(5, 3, torch.device("cpu"))
+    t.load(np.ones((5, 3), np.float32), np.zeros(5, np.float32))
+    t.V[2] += 4
+    t.sync()
+    assert torch.equal(t.base, t.flat) and float(t.V[2, 0]) == 5.0
+
+
+def test_partition_users_by_nnz_and_slice():
+    rs = np.random.RandomState(0)
+    deg = rs.poisson(20, size=1000)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    indices = rs.randint(0, 50, size=indptr[-1]).astype(np.int32)
+    for world in (1, 2, 4, 8):
+        cuts = partition_users_by_nnz(indptr, world)
+        assert cuts[0] == 0 and cuts[-1] == 1000 and (np.diff(cuts) > 0).all()
+        loads = [indptr[cuts[r + 1]] - indptr[cuts[r]] for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * deg.max()
+        total = 0
+        for r in range(world):
+            ip, ix = slice_csr(indptr, indices, cuts[r], cuts[r + 1])
+            assert ip[0] == 0 and ip[-1] == len(ix) and ip.dtype == np.int32
+            assert np.array_equal(ix, indices[indptr[cuts[r]]:indptr[cuts[r + 1]]])
+            total += len(ix)
+        assert total == indptr[-1]

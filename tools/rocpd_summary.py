@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 (ROCm 7.2, rocpd sqlite output) results into small text summaries for profiles/.
+
+    python tools/rocpd_summary.py stats  gpurun_out/prof/stats/r01_results.db      > profiles/r01_kernel_stats.csv
+    python tools/rocpd_summary.py pmc    gpurun_out/prof/pmc_fetch/r01_results.db  > profiles/r01_pmc_fetch.csv
+"""
+import sqlite3
+import sys
+
+
+def stats(path):
+    cur = sqlite3.connect(path).cursor()
+    print("kernel,calls,total_us,avg_us,percent")
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print('"%s",%d,%.1f,%.1f,%.2f' % (name, calls, total, avg, pct))
+
+
+def pmc(path):
+    cur = sqlite3.connect(path).cursor()
+    q = ("select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration) "
+         "from counters_collection group by kernel_name, counter_name order by avg(duration)*count(*) desc")
+    print("kernel,counter,dispatches,avg_value,min_value,max_value,avg_duration_ns")
+    for r in cur.execute(q):
+        print('"%s",%s,%d,%.1f,%.1f,%.1f,%.0f' % r)
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
