@@ -26,6 +26,7 @@ SYMBOLS = [
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
+    "cornac_hip_bpr_debug_ownership",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -89,6 +90,7 @@ def lib():
         L.cornac_hip_bpr_sync.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_draw.argtypes = [_vp, C.c_int, C.c_uint64, C.c_int64, _i64]
         L.cornac_hip_bpr_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i64, _f32,
@@ -208,6 +210,18 @@ class BprTrainer:
         out = np.empty(n, np.int64)
         check(lib().cornac_hip_bpr_debug_draw(self.h, stream, hi, n, out))
         return out
+
+    def debug_ownership(self):
+        """(wave_ptr, own_u, own_i) of the hogwild sampler's user-row ownership, or None if unused"""
+        w = C.c_int64()
+        check(lib().cornac_hip_bpr_debug_ownership(self.h, C.byref(w), None, None, None))
+        if w.value == 0:
+            return None
+        wp = np.empty(w.value + 1, np.int64)
+        ou, oi = np.empty(self.nnz, np.int32), np.empty(self.nnz, np.int32)
+        check(lib().cornac_hip_bpr_debug_ownership(self.h, C.byref(w), wp.ctypes.data, ou.ctypes.data,
+                                                   oi.ctypes.data))
+        return wp, ou, oi
 
     def kernel_timing(self, enable=True):
         """(total_ms, launches) of the hogwild kernel launches recorded since the last call (HIP events)."""

@@ -13,6 +13,8 @@
 //                   triplet with 16-byte row gathers, wave-shuffle dot products and fp32 atomic
 //                   scatter-updates.  HBM/fabric-bandwidth bound; no MFMA (nothing is GEMM-shaped).
 #include <algorithm>
+#include <numeric>
+#include <queue>
 
 #include "common.h"
 #include "rng.h"
@@ -101,6 +103,13 @@ struct HogArgs {
     uint32_t n_pos, n_neg, th_pos, th_neg;
     int k, neg_population, use_bias;
     float lr, reg;
+    // user-row ownership (see build_ownership): wave w samples positives only from
+    // own_u/own_i[wave_ptr[w] .. wave_ptr[w+1]); own_u < 0 encodes a shared (heavy) user as ~u
+    const int32_t *own_u, *own_i;
+    const int64_t *wave_ptr;
+    int64_t nnz;
+    int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
+    int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
 };
 
 // per-lane: draw one (u, i, j) and test membership; returns validity
@@ -115,7 +124,25 @@ __device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int3
     u = a.user_ids[ii];
     i = a.indices[ii];
     j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
-    const bool skip = csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
+    const bool skip = (a.ablate & 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
+    return in_range && !skip;
+}
+
+// ownership variant: the positive is drawn from the calling wave's own slice [base, base+len);
+// `local` indexes the wave's samples of this epoch.  u is returned encoded (negative = shared user).
+__device__ __forceinline__ bool hog_sample_owned(const HogArgs &a, uint32_t wave_id, int64_t base, uint32_t len,
+                                                 uint32_t th_len, int64_t local, bool in_range, int32_t &u_enc,
+                                                 int32_t &i, int32_t &j) {
+    const uint64_t s = (uint64_t)(in_range ? local : 0);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)s, wave_id, a.epoch, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
+    const uint32_t r = lemire_bounded2(w[0], w[1], len, th_len);
+    const uint32_t jj = lemire_bounded2(w[2], w[3], a.n_neg, a.th_neg);
+    u_enc = a.own_u[base + r];
+    i = a.own_i[base + r];
+    const int32_t u = u_enc < 0 ? ~u_enc : u_enc;
+    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
+    const bool skip = (a.ablate & 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
 }
 
@@ -160,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
                 vi4 = load_row4_fresh(pi);
                 vj4 = load_row4_fresh(pj);
             }
-            const float bi = a.B[ti], bj = a.B[tj];
+            const float bi = a.B[(size_t)ti * a.bstride], bj = a.B[(size_t)tj * a.bstride];
             const v4f d = vi4 - vj4;
             const float part = u4.x * d.x + u4.y * d.y + u4.z * d.z + u4.w * d.w;
             const float score = (bi - bj) + group_sum<G>(part);
@@ -186,11 +213,11 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
                 if (a.use_bias) {
                     const float dbi = a.lr * (z - a.reg * bi), dbj = a.lr * (-z - a.reg * bj);
                     if (ATOMIC) {
-                        atomic_add_f32(a.B + ti, dbi);
-                        atomic_add_f32(a.B + tj, dbj);
+                        atomic_add_f32(a.B + (size_t)ti * a.bstride, dbi);
+                        atomic_add_f32(a.B + (size_t)tj * a.bstride, dbj);
                     } else {
-                        a.B[ti] = bi + dbi;
-                        a.B[tj] = bj + dbj;
+                        a.B[(size_t)ti * a.bstride] = bi + dbi;
+                        a.B[(size_t)tj * a.bstride] = bj + dbj;
                     }
                 }
                 n_correct += z < .5f ? 1u : 0u;
@@ -216,22 +243,49 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
 // ~10 G line-requests/s chip-wide, regardless of how many dwords of the line are active — the
 // float4-per-lane layout above needs 4x the requests).  k <= G * R; UNR batches of TPW triplets
 // are kept in flight per wave to cover the HBM/fabric latency.
-template <int G, int R, int UNR, bool ATOMIC>
+//
+// OWNED (G == 64 only): every wave owns a fixed set of users for the whole launch and draws its
+// positives only from their interactions, so a user row is read and written by exactly one wave:
+// plain load/store instead of 2 atomic line-requests per triplet, and no lost or stale U update.
+// Heavy users (more interactions than half a wave's share) are split over all waves and keep atomics.
+template <int G, int R, int UNR, bool ATOMIC, bool OWNED>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
+    static_assert(!OWNED || G == kWave, "ownership needs one triplet per wave step");
     __shared__ int32_t stage[kWavesPerBlock][3][kWave];
     constexpr int TPW = kWave / G;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int grp = lane / G, lg = lane & (G - 1);
     const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+    const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int64_t n_tiles = (a.n + kWave - 1) / kWave, tile0 = wave_id, tile_step = total_waves;
+    int64_t own_base = 0, own_lo = 0, own_hi = 0;
+    uint32_t own_len = 1, own_th = 0;
+    if (OWNED) {
+        own_base = a.wave_ptr[wave_id];
+        own_len = (uint32_t)(a.wave_ptr[wave_id + 1] - own_base);
+        // this launch covers the epoch fraction [s_begin, s_begin + n) / nnz of every wave's samples
+        own_lo = (int64_t)(((unsigned __int128)own_len * a.s_begin) / (uint64_t)a.nnz);
+        own_hi = (int64_t)(((unsigned __int128)own_len * (a.s_begin + (uint64_t)a.n)) / (uint64_t)a.nnz);
+        n_tiles = own_len ? (own_hi - own_lo + kWave - 1) / kWave : 0;
+        tile0 = 0;
+        tile_step = 1;
+        own_th = own_len ? lemire_thresh(own_len) : 0;
+    }
     unsigned int n_correct = 0, n_skipped = 0;
     bool inb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) inb[r] = lg + G * r < a.k;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
+    for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
         int32_t su, si, sj;
         bool in_range;
-        const bool valid = hog_sample(a, tile * kWave + lane, su, si, sj, in_range);
+        bool valid;
+        if (OWNED) {
+            const int64_t local = own_lo + tile * kWave + lane;
+            in_range = local < own_hi;
+            valid = hog_sample_owned(a, (uint32_t)wave_id, own_base, own_len, own_th, local, in_range, su, si, sj);
+        } else {
+            valid = hog_sample(a, tile * kWave + lane, su, si, sj, in_range);
+        }
         const unsigned long long mask = __ballot(valid);
         n_skipped += (in_range && !valid) ? 1u : 0u;
         if (valid) {
@@ -246,14 +300,17 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         for (int b = 0; b < nvalid; b += TPW * UNR) {
             float u[UNR][R], vi[UNR][R], vj[UNR][R], bi[UNR], bj[UNR];
             float *pu[UNR], *pi[UNR], *pj[UNR];
-            int32_t ti[UNR], tj[UNR];
+            int32_t ti[UNR], tj[UNR], tue[UNR];
             bool act[UNR];
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 const int slot = b + q * TPW + grp;
                 act[q] = slot < nvalid;
                 const int sl = act[q] ? slot : b;
-                const int32_t tu = stage[wave][0][sl];
+                int32_t tu = stage[wave][0][sl];
+                if (OWNED) tu = __builtin_amdgcn_readfirstlane(tu);  // one triplet per wave step: wave-uniform
+                tue[q] = tu;
+                if (OWNED && tu < 0) tu = ~tu;
                 ti[q] = stage[wave][1][sl];
                 tj[q] = stage[wave][2][sl];
                 pu[q] = a.U + (size_t)tu * a.k + lg;
@@ -261,13 +318,15 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 pj[q] = a.V + (size_t)tj[q] * a.k + lg;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    u[q][r] = inb[r] ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
-                    vi[q][r] = inb[r] ? __builtin_nontemporal_load(pi[q] + G * r) : 0.f;
-                    vj[q][r] = inb[r] ? __builtin_nontemporal_load(pj[q] + G * r) : 0.f;
+                    const bool ld = inb[r] && !(a.ablate & 4);
+                    u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : 0.01f;
+                    vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : 0.02f;
+                    vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : 0.03f;
                 }
-                bi[q] = __builtin_nontemporal_load(a.B + ti[q]);
-                bj[q] = __builtin_nontemporal_load(a.B + tj[q]);
+                bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(a.B + (size_t)ti[q] * a.bstride);
+                bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(a.B + (size_t)tj[q] * a.bstride);
             }
+            float du_all[UNR][R];
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 float part = 0.f;
@@ -275,14 +334,20 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 for (int r = 0; r < R; ++r) part += u[q][r] * (vi[q][r] - vj[q][r]);
                 const float score = (bi[q] - bj[q]) + group_sum<G>(part);
                 const float z = sigmoid_neg_fast(score);
+#pragma unroll
+                for (int r = 0; r < R; ++r) du_all[q][r] = a.lr * (z * (vi[q][r] - vj[q][r]) - a.reg * u[q][r]);
                 if (act[q]) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        if (inb[r]) {
-                            const float du = a.lr * (z * (vi[q][r] - vj[q][r]) - a.reg * u[q][r]);
+                        if (inb[r] && !(a.ablate & 2)) {
+                            const float du = du_all[q][r];
                             const float dvi = a.lr * (z * u[q][r] - a.reg * vi[q][r]);
                             const float dvj = a.lr * (-z * u[q][r] - a.reg * vj[q][r]);
-                            if (ATOMIC) {
+                            if (OWNED) {
+                                if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
+                                atomic_add_f32(pi[q] + G * r, dvi);
+                                atomic_add_f32(pj[q] + G * r, dvj);
+                            } else if (ATOMIC) {
                                 atomic_add_f32(pu[q] + G * r, du);
                                 atomic_add_f32(pi[q] + G * r, dvi);
                                 atomic_add_f32(pj[q] + G * r, dvj);
@@ -294,17 +359,39 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                         }
                     }
                     if (lg == 0) {
-                        if (a.use_bias) {
+                        if (a.use_bias && !(a.ablate & 8)) {
                             const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
-                            if (ATOMIC) {
-                                atomic_add_f32(a.B + ti[q], dbi);
-                                atomic_add_f32(a.B + tj[q], dbj);
+                            if (ATOMIC || OWNED) {
+                                atomic_add_f32(a.B + (size_t)ti[q] * a.bstride, dbi);
+                                atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, dbj);
                             } else {
-                                a.B[ti[q]] = bi[q] + dbi;
-                                a.B[tj[q]] = bj[q] + dbj;
+                                a.B[(size_t)ti[q] * a.bstride] = bi[q] + dbi;
+                                a.B[(size_t)tj[q] * a.bstride] = bj[q] + dbj;
                             }
                         }
                         n_correct += z < .5f ? 1u : 0u;
+                    }
+                }
+            }
+            if (OWNED) {
+                // exclusive users: plain store of u_old + (sum of the deltas of every triplet of this
+                // batch that has the same user) — all four loads saw the same u_old
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    if (act[q] && tue[q] >= 0 && !(a.ablate & 2)) {
+                        float tot[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) tot[r] = du_all[q][r];
+#pragma unroll
+                        for (int q2 = 0; q2 < UNR; ++q2) {
+                            if (q2 != q && act[q2] && tue[q2] == tue[q]) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r) tot[r] += du_all[q2][r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (inb[r]) pu[q][G * r] = u[q][r] + tot[r];
                     }
                 }
             }
@@ -356,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
             float part = 0.f;
             for (int f = lg; f < a.k; f += G)
                 part += load_f32_fresh(pu + f) * (load_f32_fresh(pi + f) - load_f32_fresh(pj + f));
-            const float bi = a.B[ti], bj = a.B[tj];
+            const float bi = a.B[(size_t)ti * a.bstride], bj = a.B[(size_t)tj * a.bstride];
             const float score = (bi - bj) + group_sum<G>(part);
             const float z = sigmoid_neg_fast(score);
             if (act) {
@@ -380,11 +467,11 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
                     if (a.use_bias) {
                         const float dbi = a.lr * (z - a.reg * bi), dbj = a.lr * (-z - a.reg * bj);
                         if (ATOMIC) {
-                            atomic_add_f32(a.B + ti, dbi);
-                            atomic_add_f32(a.B + tj, dbj);
+                            atomic_add_f32(a.B + (size_t)ti * a.bstride, dbi);
+                            atomic_add_f32(a.B + (size_t)tj * a.bstride, dbj);
                         } else {
-                            a.B[ti] = bi + dbi;
-                            a.B[tj] = bj + dbj;
+                            a.B[(size_t)ti * a.bstride] = bi + dbi;
+                            a.B[(size_t)tj * a.bstride] = bj + dbj;
                         }
                     }
                     n_correct += z < .5f ? 1u : 0u;
@@ -402,6 +489,21 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
         if (n_correct) atomicAdd(&a.counters[0], (unsigned long long)n_correct);
         if (n_skipped) atomicAdd(&a.counters[1], (unsigned long long)n_skipped);
     }
+}
+
+// The hogwild kernels address the item biases through a padded table (one bias per 128-byte line):
+// a dense 4-byte-per-item table concentrates all bias atomics on a handful of memory channels and
+// serialises unrelated items that share a line (measured: half of the epoch time at ML-20M shape).
+constexpr int kBiasStride = 32;
+__global__ __launch_bounds__(kBlock) void bias_pad_kernel(const float *__restrict__ dense, float *__restrict__ padded,
+                                                          int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) padded[i * kBiasStride] = dense[i];
+}
+__global__ __launch_bounds__(kBlock) void bias_unpad_kernel(const float *__restrict__ padded, float *__restrict__ dense,
+                                                            int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dense[i] = padded[i * kBiasStride];
 }
 
 static int pow2_group(int k) {  // lanes per triplet for scalar-per-lane kernels
@@ -424,6 +526,7 @@ struct cornac_hip_bpr {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
+    DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped
     // deterministic sampler state
     DevBuf<uint32_t> mt_state;  // 2 x 624
@@ -444,6 +547,13 @@ struct cornac_hip_bpr {
     EventTimer ktimer;  // hogwild SGD kernel launches
     void (*hog_kernel)(const chip::HogArgs) = nullptr;
     int hog_blocks_per_cu = 8;
+    // user-row ownership tables of the hogwild kernel (built lazily for the persistent grid width)
+    std::vector<int32_t> h_indptr, h_indices;
+    int64_t own_waves = 0;
+    DevBuf<int32_t> own_u, own_i;
+    DevBuf<int64_t> wave_ptr;
+    std::vector<int32_t> h_own_u, h_own_i;
+    std::vector<int64_t> h_wave_ptr;
 };
 
 static constexpr int64_t kDetChunk = int64_t(1) << 24;
@@ -485,6 +595,8 @@ int cornac_hip_bpr_create(cornac_hip_bpr_t *out, int device, int64_t n_users, in
                         (long long)u);
             }
         }
+        h->h_indptr.assign(indptr, indptr + n_users + 1);
+        h->h_indices.assign(indices, indices + nnz);
         h->indptr.alloc((size_t)n_users + 1);
         h->indices.alloc((size_t)nnz);
         h->user_ids.alloc((size_t)nnz);
@@ -730,14 +842,21 @@ template <bool ATOMIC>
 static HogKernel pick_hogwild_kernel(int k, int flags) {
     const bool vec4_layout = (flags & 2) != 0;  // experiment switch: the float4-per-lane layout
     if (!vec4_layout && k <= 256) {
-        if (k <= 4) return bpr_hogwild_rowwise_kernel<4, 1, 2, ATOMIC>;
-        if (k <= 8) return bpr_hogwild_rowwise_kernel<8, 1, 2, ATOMIC>;
-        if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC>;
-        if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC>;
-        if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, ATOMIC>;
-        if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, ATOMIC>;
-        if (k <= 192) return bpr_hogwild_rowwise_kernel<64, 3, 2, ATOMIC>;
-        return bpr_hogwild_rowwise_kernel<64, 4, 1, ATOMIC>;
+        const bool owned = ATOMIC && (flags & 4) == 0 && k > 32;  // bit2 disables user-row ownership
+        if (k <= 4) return bpr_hogwild_rowwise_kernel<4, 1, 2, ATOMIC, false>;
+        if (k <= 8) return bpr_hogwild_rowwise_kernel<8, 1, 2, ATOMIC, false>;
+        if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC, false>;
+        if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC, false>;
+        if (owned) {
+            if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true>;
+            if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true>;
+            if (k <= 192) return bpr_hogwild_rowwise_kernel<64, 3, 2, true, true>;
+            return bpr_hogwild_rowwise_kernel<64, 4, 1, true, true>;
+        }
+        if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, ATOMIC, false>;
+        if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, ATOMIC, false>;
+        if (k <= 192) return bpr_hogwild_rowwise_kernel<64, 3, 2, ATOMIC, false>;
+        return bpr_hogwild_rowwise_kernel<64, 4, 1, ATOMIC, false>;
     }
     if (k % 4 == 0 && k <= 256) {
         const int q = k / 4;
@@ -756,8 +875,92 @@ static HogKernel pick_hogwild_kernel(int k, int flags) {
     }
 }
 
-static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a, int flags) {
+// Assign every user to one wave of the persistent grid, balanced by interaction count (LPT greedy).
+// Users heavier than half a wave's share are "shared": their interactions are dealt out evenly
+// to all waves and their rows keep atomic updates (encoded as ~u in own_u).
+static void build_ownership(cornac_hip_bpr_t h, int64_t W) {
+    if (h->own_waves == W) return;
+    const int64_t nnz = h->nnz, nu = h->n_users;
+    const int32_t *indptr = h->h_indptr.data(), *indices = h->h_indices.data();
+    const int64_t cap = std::max<int64_t>(1, nnz / W / 2);
+    std::vector<int64_t> load((size_t)W, 0);
+    std::vector<int32_t> owner((size_t)nu, -1);
+    // shared users first: their positions are dealt in equal contiguous blocks
+    int64_t n_shared_pos = 0;
+    for (int64_t u = 0; u < nu; ++u)
+        if (indptr[u + 1] - indptr[u] > cap) n_shared_pos += indptr[u + 1] - indptr[u];
+    const int64_t blk = (n_shared_pos + W - 1) / W;
+    for (int64_t w = 0; w < W && blk > 0; ++w) load[(size_t)w] = std::max<int64_t>(0, std::min(blk, n_shared_pos - w * blk));
+    // exclusive users: heaviest first onto the least loaded wave
+    std::vector<int32_t> order;
+    order.reserve((size_t)nu);
+    for (int64_t u = 0; u < nu; ++u) {
+        const int64_t d = indptr[u + 1] - indptr[u];
+        if (d > 0 && d <= cap) order.push_back((int32_t)u);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y];
+    });
+    typedef std::pair<int64_t, int64_t> LW;  // (load, wave)
+    std::priority_queue<LW, std::vector<LW>, std::greater<LW>> heap;
+    for (int64_t w = 0; w < W; ++w) heap.push(LW(load[(size_t)w], w));
+    for (int32_t u : order) {
+        LW t = heap.top();
+        heap.pop();
+        owner[(size_t)u] = (int32_t)t.second;
+        t.first += indptr[u + 1] - indptr[u];
+        load[(size_t)t.second] = t.first;
+        heap.push(t);
+    }
+    h->h_wave_ptr.assign((size_t)W + 1, 0);
+    for (int64_t w = 0; w < W; ++w) h->h_wave_ptr[(size_t)w + 1] = h->h_wave_ptr[(size_t)w] + load[(size_t)w];
+    REQUIRE(h->h_wave_ptr[(size_t)W] == nnz, "ownership tables do not cover the interaction matrix");
+    h->h_own_u.resize((size_t)nnz);
+    h->h_own_i.resize((size_t)nnz);
+    std::vector<int64_t> cursor(h->h_wave_ptr.begin(), h->h_wave_ptr.end() - 1);
+    int64_t sp = 0;  // running index over shared positions
+    for (int64_t u = 0; u < nu; ++u) {
+        const int64_t d = indptr[u + 1] - indptr[u];
+        if (d == 0) continue;
+        if (d > cap) {
+            for (int32_t p = indptr[u]; p < indptr[u + 1]; ++p, ++sp) {
+                const int64_t w = sp / blk;
+                const int64_t pos = cursor[(size_t)w]++;
+                h->h_own_u[(size_t)pos] = ~(int32_t)u;
+                h->h_own_i[(size_t)pos] = indices[p];
+            }
+        } else {
+            const int64_t w = owner[(size_t)u];
+            for (int32_t p = indptr[u]; p < indptr[u + 1]; ++p) {
+                const int64_t pos = cursor[(size_t)w]++;
+                h->h_own_u[(size_t)pos] = (int32_t)u;
+                h->h_own_i[(size_t)pos] = indices[p];
+            }
+        }
+    }
+    h->own_u.ensure((size_t)nnz);
+    h->own_i.ensure((size_t)nnz);
+    h->wave_ptr.ensure((size_t)W + 1);
+    h->own_u.upload(h->h_own_u.data(), (size_t)nnz, h->stream);
+    h->own_i.upload(h->h_own_i.data(), (size_t)nnz, h->stream);
+    h->wave_ptr.upload(h->h_wave_ptr.data(), (size_t)W + 1, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->own_waves = W;
+}
+
+static bool hogwild_uses_ownership(cornac_hip_bpr_t h, int flags) {
+    // bit0 plain stores, bit1 float4 layout, bit2 explicit opt-out; needs one triplet per wave step
+    // (k > 32) and at least one 64-sample tile per wave and epoch
+    flags &= ~8;  // bit3 (dense bias) is independent of ownership
+    if ((flags & 7) != 0 || h->k <= 32 || h->k > 256) return false;  // bits >= 8 are profiling ablations
+    const int64_t W = (int64_t)device_info(h->device).cus * 8 * kWavesPerBlock;
+    return h->nnz >= W * kWave;
+}
+
+static void launch_hogwild(cornac_hip_bpr_t h, HogArgs a, int flags) {
     const DeviceInfo &di = device_info(h->device);
+    const bool owned = hogwild_uses_ownership(h, flags);
+    if (!owned) flags |= 4;
     HogKernel kern = (flags & 1) ? pick_hogwild_kernel<false>(h->k, flags) : pick_hogwild_kernel<true>(h->k, flags);
     // persistent grid: exactly the number of workgroups that are co-resident, so the tile loop of
     // every wave starts at once (no second dispatch round with a ragged tail)
@@ -767,9 +970,18 @@ static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a, int flags) {
         h->hog_kernel = kern;
         h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
     }
-    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
-    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * h->hog_blocks_per_cu));
+    int grid;
+    if (owned) {
+        grid = di.cus * h->hog_blocks_per_cu;
+        build_ownership(h, (int64_t)grid * kWavesPerBlock);
+        a.own_u = h->own_u.p;
+        a.own_i = h->own_i.p;
+        a.wave_ptr = h->wave_ptr.p;
+    } else {
+        const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+        const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * h->hog_blocks_per_cu));
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, h->stream, a);
     HIP_CHECK(hipGetLastError());
 }
@@ -777,12 +989,16 @@ static void launch_hogwild(cornac_hip_bpr_t h, const HogArgs &a, int flags) {
 static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+    if ((flags & 8) == 0) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
     int64_t left = n_samples;
     while (left > 0) {
         const int64_t n = std::min(left, h->nnz - h->hog_offset);
         HogArgs a;
         a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
-        a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
+        const bool pad_bias = (flags & 8) == 0;  // bit3: experiment switch, dense bias table
+        a.U = h->U.p; a.V = h->V.p;
+        a.B = pad_bias ? h->Bpad.p : h->B.p;
+        a.bstride = pad_bias ? kBiasStride : 1;
         a.counters = h->counters.p;
         a.n = n;
         a.s_begin = (uint64_t)h->hog_offset;
@@ -794,9 +1010,19 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         a.th_neg = lemire_thresh(a.n_neg);
         a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
         a.lr = lr; a.reg = reg;
+        a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr;
+        a.nnz = h->nnz;
+        a.ablate = (flags >> 8) & 0xff;
+        const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
+        if (pad_bias)
+            hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p,
+                               h->total_items);
         h->ktimer.before(h->stream);
         launch_hogwild(h, a, flags);
         h->ktimer.after(h->stream);
+        if (pad_bias)
+            hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p,
+                               h->total_items);
         h->hog_offset += n;
         left -= n;
         if (h->hog_offset >= h->nnz) {
@@ -879,6 +1105,26 @@ int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64
         d.download(tmp.data(), (size_t)n, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
         for (int64_t t = 0; t < n; ++t) out[t] = (int64_t)tmp[(size_t)t];
+    });
+}
+
+int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t *wave_ptr, int32_t *own_u,
+                                   int32_t *own_i) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(n_waves != nullptr, "n_waves is NULL");
+        *n_waves = 0;
+        if (!hogwild_uses_ownership(h, 0)) return;
+        // same kernel/grid choice as launch_hogwild with flags == 0
+        HogKernel kern = pick_hogwild_kernel<true>(h->k, 0);
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+        const int64_t W = (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 8)) * kWavesPerBlock;
+        build_ownership(h, W);
+        *n_waves = W;
+        if (wave_ptr) std::copy(h->h_wave_ptr.begin(), h->h_wave_ptr.end(), wave_ptr);
+        if (own_u) std::copy(h->h_own_u.begin(), h->h_own_u.end(), own_u);
+        if (own_i) std::copy(h->h_own_i.begin(), h->h_own_i.end(), own_i);
     });
 }
 

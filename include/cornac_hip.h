@@ -96,8 +96,9 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
 
 /* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
  * reference's per-epoch counters over the epochs run (either may be NULL).
- * hogwild_flags: bit0 = use plain (racy, non-atomic) row stores instead of
- * fp32 atomics; 0 = default. */
+ * hogwild_flags (experiment switches, 0 = default): bit0 = plain (racy,
+ * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
+ * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic). */
 int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, int use_bias, int neg_population,
                               int mode, int hogwild_flags, int64_t *correct, int64_t *skipped);
 /* Same, but only enqueues `n_samples` hogwild samples (sample counter and
@@ -111,6 +112,12 @@ int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped);
 /* Test hooks of the deterministic sampler: draw `n` values from stream 0/1
  * (boost uniform_int_distribution<long>(0, hi), uniform_int_distribution.hpp:188-227). */
 int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64_t n, int64_t *out);
+/* Test hook of the hogwild sampler's user-row ownership: *n_waves receives the
+ * width W of the persistent grid (0 when ownership is not used for this
+ * handle); wave_ptr[W+1], own_u[nnz] (negative = shared heavy user, stored as
+ * ~u), own_i[nnz] receive the tables when non-NULL. */
+int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t *wave_ptr, int32_t *own_u,
+                                   int32_t *own_i);
 /* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
  * stream: returns the summed duration and count of the launches recorded since
  * the previous call, then enables/disables recording for the following ones. */

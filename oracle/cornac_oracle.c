@@ -379,6 +379,19 @@ void oracle_hogwild_sample(uint64_t seed, uint32_t epoch, int64_t s0, int64_t n,
     }
 }
 
+/* ownership variant of the device sampler (bpr.hip: hog_sample_owned): wave `wave_id` draws its
+ * local samples [lo, hi) of an epoch from its own slice of length `len`; counter =
+ * (local, wave_id, epoch, 1). */
+void oracle_hogwild_sample_owned(uint64_t seed, uint32_t epoch, uint32_t wave_id, uint32_t len, uint32_t n_neg,
+                                 int64_t lo, int64_t hi, int64_t *r_out, int64_t *jj_out) {
+    for (int64_t t = lo; t < hi; ++t) {
+        uint32_t w[4];
+        oracle_philox4x32((uint32_t)t, wave_id, epoch, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        r_out[t - lo] = lemire_bounded2(w[0], w[1], len);
+        jj_out[t - lo] = lemire_bounded2(w[2], w[3], n_neg);
+    }
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

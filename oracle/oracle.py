@@ -82,6 +82,8 @@ def _bind(L):
         L.oracle_philox4x32.argtypes = [C.c_uint32] * 6 + [u32p]
         L.oracle_hogwild_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32,
                                             i64p, i64p]
+        L.oracle_hogwild_sample_owned.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.c_int64, C.c_int64, i64p, i64p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
     return L
@@ -327,3 +329,11 @@ def hogwild_sample(seed, epoch, s0, n, n_pos, n_neg):
     jj = np.empty(n, np.int64)
     lib().oracle_hogwild_sample(int(seed), int(epoch), int(s0), int(n), int(n_pos), int(n_neg), ii, jj)
     return ii, jj
+
+
+def hogwild_sample_owned(seed, epoch, wave_id, length, n_neg, lo, hi):
+    r = np.empty(hi - lo, np.int64)
+    jj = np.empty(hi - lo, np.int64)
+    lib().oracle_hogwild_sample_owned(int(seed), int(epoch), int(wave_id), int(length), int(n_neg), int(lo), int(hi),
+                                      r, jj)
+    return r, jj
