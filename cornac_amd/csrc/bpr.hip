@@ -491,21 +491,6 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
     }
 }
 
-// The hogwild kernels address the item biases through a padded table (one bias per 128-byte line):
-// a dense 4-byte-per-item table concentrates all bias atomics on a handful of memory channels and
-// serialises unrelated items that share a line (measured: half of the epoch time at ML-20M shape).
-constexpr int kBiasStride = 32;
-__global__ __launch_bounds__(kBlock) void bias_pad_kernel(const float *__restrict__ dense, float *__restrict__ padded,
-                                                          int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) padded[i * kBiasStride] = dense[i];
-}
-__global__ __launch_bounds__(kBlock) void bias_unpad_kernel(const float *__restrict__ padded, float *__restrict__ dense,
-                                                            int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dense[i] = padded[i * kBiasStride];
-}
-
 static int pow2_group(int k) {  // lanes per triplet for scalar-per-lane kernels
     int g = 4;
     while (g < k && g < 64) g <<= 1;

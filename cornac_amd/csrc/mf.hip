@@ -12,6 +12,7 @@
 //                   two rows with 16-byte loads and scatter fp32 atomic updates.
 #include <algorithm>
 #include <cmath>
+#include <queue>
 
 #include "common.h"
 #include "sgd_device.h"
@@ -61,17 +62,148 @@ __global__ __launch_bounds__(kBlock) void mf_det_level_kernel(const int32_t *__r
 }
 
 struct MfHogArgs {
-    const int64_t *rid, *cid;
+    const int64_t *rid, *cid;  // COO order (no ownership)
     const float *val;
+    // ownership tables: wave w processes own_*[wave_ptr[w] .. wave_ptr[w+1]) every epoch;
+    // own_u < 0 encodes a shared (heavy) user as ~u
+    const int32_t *own_u, *own_i;
+    const float *own_r;
+    const int64_t *wave_ptr;
     float *U, *V, *Bu, *Bi;
     double *loss_acc;
     int64_t n;
-    int k, use_bias;
+    int k, use_bias, bstride;
     float lr, reg, mu;
 };
 
-template <int G, bool VEC4>
-__global__ __launch_bounds__(kBlock) void mf_hogwild_kernel(const MfHogArgs a) {
+// Row-wise layout as in bpr.hip: the G lanes of a group own consecutive floats of a row, so every
+// gather / fp32-atomic scatter instruction covers whole 128-byte lines.  OWNED (G == 64): every
+// wave owns a fixed set of users and all of their ratings, so U rows and user biases are updated
+// with plain stores by exactly one wave (no atomics, nothing lost); item rows and item biases use
+// device-scope atomics.  Ratings of a wave are interleaved round-robin over its users so that the
+// UNR ratings in flight rarely share a user; when they do, their deltas are summed.
+template <int G, int R, int UNR, bool OWNED>
+__global__ __launch_bounds__(kBlock) void mf_hogwild_rowwise_kernel(const MfHogArgs a) {
+    static_assert(!OWNED || G == kWave, "ownership needs one rating per wave step");
+    constexpr int TPW = kWave / G;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int grp = lane / G, lg = lane & (G - 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int64_t begin = 0, end = a.n, tile0 = wave_id, tile_step = total_waves;
+    if (OWNED) {
+        begin = a.wave_ptr[wave_id];
+        end = a.wave_ptr[wave_id + 1];
+        tile0 = 0;
+        tile_step = 1;
+    }
+    const int64_t n_tiles = (end - begin + kWave - 1) / kWave;
+    bool inb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) inb[r] = lg + G * r < a.k;
+    double loss = 0.0;
+    for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+        const int64_t s = begin + tile * kWave + lane;
+        int32_t mu_ = 0, mi_ = 0;
+        float mr = 0.f;
+        if (s < end) {
+            if (OWNED) {
+                mu_ = a.own_u[s];
+                mi_ = a.own_i[s];
+                mr = a.own_r[s];
+            } else {
+                mu_ = (int32_t)a.rid[s];
+                mi_ = (int32_t)a.cid[s];
+                mr = a.val[s];
+            }
+        }
+        const int nvalid = (int)min((int64_t)kWave, end - (begin + tile * kWave));
+        for (int b = 0; b < nvalid; b += TPW * UNR) {
+            float u[UNR][R], v[UNR][R], bu[UNR], bi[UNR], rt[UNR], du_all[UNR][R], dbu_all[UNR];
+            float *pu[UNR], *pi[UNR];
+            int32_t tue[UNR], tu[UNR], ti[UNR];
+            bool act[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int slot = b + q * TPW + grp;
+                act[q] = slot < nvalid;
+                const int sl = act[q] ? slot : b;
+                int32_t x = __shfl(mu_, sl, kWave);
+                if (OWNED) x = __builtin_amdgcn_readfirstlane(x);
+                tue[q] = x;
+                tu[q] = (OWNED && x < 0) ? ~x : x;
+                ti[q] = __shfl(mi_, sl, kWave);
+                rt[q] = __shfl(mr, sl, kWave);
+                pu[q] = a.U + (size_t)tu[q] * a.k + lg;
+                pi[q] = a.V + (size_t)ti[q] * a.k + lg;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    u[q][r] = inb[r] ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
+                    v[q][r] = inb[r] ? __builtin_nontemporal_load(pi[q] + G * r) : 0.f;
+                }
+                bu[q] = __builtin_nontemporal_load(a.Bu + tu[q]);
+                bi[q] = __builtin_nontemporal_load(a.Bi + (size_t)ti[q] * a.bstride);
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) part += u[q][r] * v[q][r];
+                const float err = rt[q] - ((a.mu + bu[q] + bi[q]) + group_sum<G>(part));
+#pragma unroll
+                for (int r = 0; r < R; ++r) du_all[q][r] = a.lr * (err * v[q][r] - a.reg * u[q][r]);
+                dbu_all[q] = a.lr * (err - a.reg * bu[q]);
+                if (act[q]) {
+                    const bool excl = OWNED && tue[q] >= 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (inb[r]) {
+                            atomic_add_f32(pi[q] + G * r, a.lr * (err * u[q][r] - a.reg * v[q][r]));
+                            if (!excl) atomic_add_f32(pu[q] + G * r, du_all[q][r]);
+                        }
+                    }
+                    if (lg == 0) {
+                        if (a.use_bias) {
+                            atomic_add_f32(a.Bi + (size_t)ti[q] * a.bstride, a.lr * (err - a.reg * bi[q]));
+                            if (!excl) atomic_add_f32(a.Bu + tu[q], dbu_all[q]);
+                        }
+                        loss += (double)err * (double)err;
+                    }
+                }
+            }
+            if (OWNED) {
+                // exclusive users: u_old + the summed deltas of every rating of this batch with the same user
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    if (act[q] && tue[q] >= 0) {
+                        float tot[R], totb = dbu_all[q];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) tot[r] = du_all[q][r];
+#pragma unroll
+                        for (int q2 = 0; q2 < UNR; ++q2) {
+                            if (q2 != q && act[q2] && tue[q2] == tue[q]) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r) tot[r] += du_all[q2][r];
+                                totb += dbu_all[q2];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (inb[r]) pu[q][G * r] = u[q][r] + tot[r];
+                        if (lg == 0 && a.use_bias) a.Bu[tu[q]] = bu[q] + totb;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, kWave);
+    if (lane == 0 && loss != 0.0) atomicAdd(a.loss_acc, loss);
+}
+
+// any k (> 256): G lanes per rating stride over the factors, two passes
+template <int G>
+__global__ __launch_bounds__(kBlock) void mf_hogwild_generic_kernel(const MfHogArgs a) {
     constexpr int TPW = kWave / G;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int grp = lane / G, lg = lane & (G - 1);
@@ -80,10 +212,9 @@ __global__ __launch_bounds__(kBlock) void mf_hogwild_kernel(const MfHogArgs a) {
     double loss = 0.0;
     for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += total_waves) {
         const int64_t s = tile * kWave + lane;
-        const bool in_range = s < a.n;
         int32_t mu_ = 0, mi_ = 0;
         float mr = 0.f;
-        if (in_range) {
+        if (s < a.n) {
             mu_ = (int32_t)a.rid[s];
             mi_ = (int32_t)a.cid[s];
             mr = a.val[s];
@@ -96,45 +227,23 @@ __global__ __launch_bounds__(kBlock) void mf_hogwild_kernel(const MfHogArgs a) {
             const int32_t tu = __shfl(mu_, sl, kWave), ti = __shfl(mi_, sl, kWave);
             const float tr = __shfl(mr, sl, kWave);
             float *pu = a.U + (size_t)tu * a.k, *pi = a.V + (size_t)ti * a.k;
-            const float bu = a.Bu[tu], bi = a.Bi[ti];
-            float err;
-            if (VEC4) {
-                const int f0 = 4 * lg;
-                const bool inb = f0 < a.k;
-                v4f u4 = {0.f, 0.f, 0.f, 0.f}, v4 = u4;
-                if (inb) {
-                    u4 = load_row4_fresh(pu + f0);
-                    v4 = load_row4_fresh(pi + f0);
+            const float bu = load_f32_fresh(a.Bu + tu), bi = load_f32_fresh(a.Bi + (size_t)ti * a.bstride);
+            float part = 0.f;
+            for (int f = lg; f < a.k; f += G) part += load_f32_fresh(pu + f) * load_f32_fresh(pi + f);
+            const float err = tr - ((a.mu + bu + bi) + group_sum<G>(part));
+            if (act) {
+                for (int f = lg; f < a.k; f += G) {
+                    const float uf = load_f32_fresh(pu + f), vf = load_f32_fresh(pi + f);
+                    atomic_add_f32(pu + f, a.lr * (err * vf - a.reg * uf));
+                    atomic_add_f32(pi + f, a.lr * (err * uf - a.reg * vf));
                 }
-                const float part = u4.x * v4.x + u4.y * v4.y + u4.z * v4.z + u4.w * v4.w;
-                err = tr - ((a.mu + bu + bi) + group_sum<G>(part));
-                if (act && inb) {
-                    const v4f du = a.lr * (err * v4 - a.reg * u4);
-                    const v4f dv = a.lr * (err * u4 - a.reg * v4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        atomic_add_f32(pu + f0 + c, du[c]);
-                        atomic_add_f32(pi + f0 + c, dv[c]);
+                if (lg == 0) {
+                    if (a.use_bias) {
+                        atomic_add_f32(a.Bu + tu, a.lr * (err - a.reg * bu));
+                        atomic_add_f32(a.Bi + (size_t)ti * a.bstride, a.lr * (err - a.reg * bi));
                     }
+                    loss += (double)err * (double)err;
                 }
-            } else {
-                float part = 0.f;
-                for (int f = lg; f < a.k; f += G) part += load_f32_fresh(pu + f) * load_f32_fresh(pi + f);
-                err = tr - ((a.mu + bu + bi) + group_sum<G>(part));
-                if (act) {
-                    for (int f = lg; f < a.k; f += G) {
-                        const float uf = load_f32_fresh(pu + f), vf = load_f32_fresh(pi + f);
-                        atomic_add_f32(pu + f, a.lr * (err * vf - a.reg * uf));
-                        atomic_add_f32(pi + f, a.lr * (err * uf - a.reg * vf));
-                    }
-                }
-            }
-            if (act && lg == 0) {
-                if (a.use_bias) {
-                    atomic_add_f32(a.Bu + tu, a.lr * (err - a.reg * bu));
-                    atomic_add_f32(a.Bi + ti, a.lr * (err - a.reg * bi));
-                }
-                loss += (double)err * (double)err;
             }
         }
     }
@@ -171,6 +280,13 @@ struct cornac_hip_mf {
     std::vector<float> host_val;
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
+    DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
+    void (*hog_kernel)(const chip::MfHogArgs) = nullptr;
+    int hog_blocks_per_cu = 8;
+    int64_t own_waves = 0;
+    DevBuf<int32_t> own_u, own_i;
+    DevBuf<float> own_r;
+    DevBuf<int64_t> wave_ptr;
 };
 
 static void mf_check(cornac_hip_mf_t h) {
@@ -249,36 +365,179 @@ static void mf_epoch_deterministic(cornac_hip_mf_t h, float lr, float reg, float
     HIP_CHECK(hipGetLastError());
 }
 
-static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
-    const DeviceInfo &di = device_info(h->device);
-    MfHogArgs a;
-    a.rid = h->rid.p; a.cid = h->cid.p; a.val = h->val.p;
-    a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p; a.Bi = h->Bi.p;
-    a.loss_acc = loss_slot;
-    a.n = h->nnz; a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
-    const int64_t n_tiles = (a.n + kWave - 1) / kWave;
-    const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * 8));
-    dim3 g(grid), b(kBlock);
-    const int k = h->k;
-    h->ktimer.before(h->stream);
-    if (k % 4 == 0 && k <= 256) {
-        const int q = k / 4;
-        if (q <= 4) hipLaunchKernelGGL((mf_hogwild_kernel<4, true>), g, b, 0, h->stream, a);
-        else if (q <= 8) hipLaunchKernelGGL((mf_hogwild_kernel<8, true>), g, b, 0, h->stream, a);
-        else if (q <= 16) hipLaunchKernelGGL((mf_hogwild_kernel<16, true>), g, b, 0, h->stream, a);
-        else if (q <= 32) hipLaunchKernelGGL((mf_hogwild_kernel<32, true>), g, b, 0, h->stream, a);
-        else hipLaunchKernelGGL((mf_hogwild_kernel<64, true>), g, b, 0, h->stream, a);
-    } else {
-        switch (mf_pow2_group(k)) {
-            case 4: hipLaunchKernelGGL((mf_hogwild_kernel<4, false>), g, b, 0, h->stream, a); break;
-            case 8: hipLaunchKernelGGL((mf_hogwild_kernel<8, false>), g, b, 0, h->stream, a); break;
-            case 16: hipLaunchKernelGGL((mf_hogwild_kernel<16, false>), g, b, 0, h->stream, a); break;
-            case 32: hipLaunchKernelGGL((mf_hogwild_kernel<32, false>), g, b, 0, h->stream, a); break;
-            default: hipLaunchKernelGGL((mf_hogwild_kernel<64, false>), g, b, 0, h->stream, a); break;
+typedef void (*MfHogKernel)(const MfHogArgs);
+
+static float hash_key(uint32_t x) {  // position -> pseudo-random key in [0, 1)
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+static MfHogKernel pick_mf_kernel(int k, bool owned) {
+    if (k <= 4) return mf_hogwild_rowwise_kernel<4, 1, 2, false>;
+    if (k <= 8) return mf_hogwild_rowwise_kernel<8, 1, 2, false>;
+    if (k <= 16) return mf_hogwild_rowwise_kernel<16, 1, 2, false>;
+    if (k <= 32) return mf_hogwild_rowwise_kernel<32, 1, 4, false>;
+    if (owned) {
+        if (k <= 64) return mf_hogwild_rowwise_kernel<64, 1, 4, true>;
+        if (k <= 128) return mf_hogwild_rowwise_kernel<64, 2, 2, true>;
+        if (k <= 192) return mf_hogwild_rowwise_kernel<64, 3, 2, true>;
+        return mf_hogwild_rowwise_kernel<64, 4, 1, true>;
+    }
+    if (k <= 64) return mf_hogwild_rowwise_kernel<64, 1, 4, false>;
+    if (k <= 128) return mf_hogwild_rowwise_kernel<64, 2, 2, false>;
+    if (k <= 192) return mf_hogwild_rowwise_kernel<64, 3, 2, false>;
+    if (k <= 256) return mf_hogwild_rowwise_kernel<64, 4, 1, false>;
+    return mf_hogwild_generic_kernel<64>;
+}
+
+// Users -> waves of the persistent grid, balanced by rating count (LPT); users heavier than half a
+// wave's share are shared (their ratings are dealt evenly to all waves, atomics).  Inside a wave the
+// ratings of its users are interleaved round-robin.
+static void mf_build_ownership(cornac_hip_mf_t h, int64_t W) {
+    if (h->own_waves == W) return;
+    const int64_t nnz = h->nnz, nu = h->n_users;
+    std::vector<int64_t> uptr((size_t)nu + 1, 0);
+    for (int64_t s = 0; s < nnz; ++s) ++uptr[(size_t)h->host_rid[(size_t)s] + 1];
+    for (int64_t u = 0; u < nu; ++u) uptr[(size_t)u + 1] += uptr[(size_t)u];
+    std::vector<int32_t> pos((size_t)nnz);  // COO positions grouped by user, stable
+    {
+        std::vector<int64_t> cur(uptr.begin(), uptr.end() - 1);
+        for (int64_t s = 0; s < nnz; ++s) pos[(size_t)cur[(size_t)h->host_rid[(size_t)s]]++] = (int32_t)s;
+    }
+    const int64_t cap = std::max<int64_t>(1, nnz / W / 2);
+    std::vector<int64_t> load((size_t)W, 0);
+    int64_t n_shared = 0;
+    for (int64_t u = 0; u < nu; ++u)
+        if (uptr[(size_t)u + 1] - uptr[(size_t)u] > cap) n_shared += uptr[(size_t)u + 1] - uptr[(size_t)u];
+    const int64_t blk = (n_shared + W - 1) / W;
+    for (int64_t w = 0; w < W && blk > 0; ++w) load[(size_t)w] = std::max<int64_t>(0, std::min(blk, n_shared - w * blk));
+    std::vector<int32_t> order;
+    for (int64_t u = 0; u < nu; ++u) {
+        const int64_t d = uptr[(size_t)u + 1] - uptr[(size_t)u];
+        if (d > 0 && d <= cap) order.push_back((int32_t)u);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return uptr[(size_t)x + 1] - uptr[(size_t)x] > uptr[(size_t)y + 1] - uptr[(size_t)y];
+    });
+    typedef std::pair<int64_t, int64_t> LW;
+    std::priority_queue<LW, std::vector<LW>, std::greater<LW>> heap;
+    for (int64_t w = 0; w < W; ++w) heap.push(LW(load[(size_t)w], w));
+    std::vector<std::vector<int32_t>> wave_users((size_t)W);
+    for (int32_t u : order) {
+        LW t = heap.top();
+        heap.pop();
+        wave_users[(size_t)t.second].push_back(u);
+        t.first += uptr[(size_t)u + 1] - uptr[(size_t)u];
+        load[(size_t)t.second] = t.first;
+        heap.push(t);
+    }
+    std::vector<int64_t> wptr((size_t)W + 1, 0);
+    for (int64_t w = 0; w < W; ++w) wptr[(size_t)w + 1] = wptr[(size_t)w] + load[(size_t)w];
+    REQUIRE(wptr[(size_t)W] == nnz, "MF ownership tables do not cover the ratings");
+    std::vector<int32_t> ou((size_t)nnz), oi((size_t)nnz);
+    std::vector<float> orr((size_t)nnz);
+    auto emit = [&](int64_t dst, int32_t s, bool shared) {
+        const int32_t u = (int32_t)h->host_rid[(size_t)s];
+        ou[(size_t)dst] = shared ? ~u : u;
+        oi[(size_t)dst] = (int32_t)h->host_cid[(size_t)s];
+        orr[(size_t)dst] = h->host_val[(size_t)s];
+    };
+    // Shared ratings are dealt round-robin (rating p of the shared sequence -> wave p % W) so that a
+    // heavy user's ratings are spread over all waves; inside a wave the ratings are put in a
+    // (deterministic, hash-keyed) random order.  Any order that is correlated across waves is
+    // poison: with COO input sorted by (user, item), "r-th rating of every user" would make all
+    // ~80 k in-flight ratings hit the same narrow band of item rows — hundreds of stale concurrent
+    // updates per row, which both serialises the atomics and makes SGD diverge.
+    std::vector<std::vector<int32_t>> wave_shared((size_t)W);
+    {
+        int64_t sp = 0;
+        for (int64_t u = 0; u < nu; ++u) {
+            if (uptr[(size_t)u + 1] - uptr[(size_t)u] <= cap) continue;
+            for (int64_t p = uptr[(size_t)u]; p < uptr[(size_t)u + 1]; ++p, ++sp)
+                wave_shared[(size_t)(sp % W)].push_back(pos[(size_t)p]);
         }
     }
+    // loads were computed with contiguous blocks of `blk`; recompute them for the round-robin deal
+    for (int64_t w = 0; w < W; ++w) {
+        int64_t l = (int64_t)wave_shared[(size_t)w].size();
+        for (int32_t u : wave_users[(size_t)w]) l += uptr[(size_t)u + 1] - uptr[(size_t)u];
+        wptr[(size_t)w + 1] = wptr[(size_t)w] + l;
+    }
+    REQUIRE(wptr[(size_t)W] == nnz, "MF ownership tables do not cover the ratings");
+    std::vector<std::pair<float, int32_t>> keyed;  // (key, COO position | shared flag in the sign of a side array)
+    std::vector<char> is_shared;
+    for (int64_t w = 0; w < W; ++w) {
+        keyed.clear();
+        is_shared.clear();
+        const std::vector<int32_t> &sh = wave_shared[(size_t)w];
+        for (size_t r = 0; r < sh.size(); ++r) {
+            keyed.emplace_back(hash_key((uint32_t)sh[r]), (int32_t)is_shared.size());
+            is_shared.push_back(1);
+        }
+        std::vector<int32_t> src;
+        src.reserve((size_t)(wptr[(size_t)w + 1] - wptr[(size_t)w]));
+        for (int32_t s0 : sh) src.push_back(s0);
+        for (int32_t u : wave_users[(size_t)w]) {
+            const int64_t d = uptr[(size_t)u + 1] - uptr[(size_t)u];
+            for (int64_t r = 0; r < d; ++r) {
+                keyed.emplace_back(hash_key((uint32_t)pos[(size_t)(uptr[(size_t)u] + r)]), (int32_t)src.size());
+                src.push_back(pos[(size_t)(uptr[(size_t)u] + r)]);
+                is_shared.push_back(0);
+            }
+        }
+        std::stable_sort(keyed.begin(), keyed.end(),
+                         [](const std::pair<float, int32_t> &x, const std::pair<float, int32_t> &y) { return x.first < y.first; });
+        int64_t dst = wptr[(size_t)w];
+        for (const auto &kv : keyed) emit(dst++, src[(size_t)kv.second], is_shared[(size_t)kv.second] != 0);
+    }
+    h->own_u.ensure((size_t)nnz);
+    h->own_i.ensure((size_t)nnz);
+    h->own_r.ensure((size_t)nnz);
+    h->wave_ptr.ensure((size_t)W + 1);
+    h->own_u.upload(ou.data(), (size_t)nnz, h->stream);
+    h->own_i.upload(oi.data(), (size_t)nnz, h->stream);
+    h->own_r.upload(orr.data(), (size_t)nnz, h->stream);
+    h->wave_ptr.upload(wptr.data(), (size_t)W + 1, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->own_waves = W;
+}
+
+static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    const DeviceInfo &di = device_info(h->device);
+    const int k = h->k;
+    const bool owned = k > 32 && k <= 256 && h->nnz >= (int64_t)di.cus * 8 * kWavesPerBlock * kWave;
+    MfHogKernel kern = pick_mf_kernel(k, owned);
+    if (h->hog_kernel != kern) {
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+        h->hog_kernel = kern;
+        h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
+    }
+    MfHogArgs a;
+    a.rid = h->rid.p; a.cid = h->cid.p; a.val = h->val.p;
+    a.own_u = nullptr; a.own_i = nullptr; a.own_r = nullptr; a.wave_ptr = nullptr;
+    a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p;
+    h->Bipad.ensure((size_t)h->n_items * kBiasStride);
+    a.Bi = h->Bipad.p;
+    a.bstride = kBiasStride;
+    a.loss_acc = loss_slot;
+    a.n = h->nnz; a.k = k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    int grid;
+    if (owned) {
+        grid = di.cus * h->hog_blocks_per_cu;
+        mf_build_ownership(h, (int64_t)grid * kWavesPerBlock);
+        a.own_u = h->own_u.p; a.own_i = h->own_i.p; a.own_r = h->own_r.p; a.wave_ptr = h->wave_ptr.p;
+    } else {
+        const int64_t n_tiles = (a.n + kWave - 1) / kWave;
+        const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * h->hog_blocks_per_cu));
+    }
+    const unsigned bgrid = (unsigned)((h->n_items + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bi.p, h->Bipad.p, h->n_items);
+    h->ktimer.before(h->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, h->stream, a);
     h->ktimer.after(h->stream);
+    hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bipad.p, h->Bi.p, h->n_items);
     HIP_CHECK(hipGetLastError());
 }
 

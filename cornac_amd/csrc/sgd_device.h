@@ -52,6 +52,21 @@ __device__ __forceinline__ float load_f32_fresh(const float *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The hogwild kernels address item biases through a padded table (one bias per 128-byte line): a
+// dense 4-byte-per-item table concentrates all bias atomics on a handful of memory channels and
+// serialises unrelated items that share a line (measured: half of a BPR epoch at ML-20M shape).
+constexpr int kBiasStride = 32;
+static __global__ __launch_bounds__(kBlock) void bias_pad_kernel(const float *__restrict__ dense,
+                                                                 float *__restrict__ padded, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) padded[i * kBiasStride] = dense[i];
+}
+static __global__ __launch_bounds__(kBlock) void bias_unpad_kernel(const float *__restrict__ padded,
+                                                                   float *__restrict__ dense, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dense[i] = padded[i * kBiasStride];
+}
+
 // is `col` present in the sorted CSR row [lo, hi)?  (has_non_zero, recom_bpr.pyx:46-51)
 __device__ __forceinline__ bool csr_row_contains(const int32_t *__restrict__ indices, int32_t lo, int32_t hi,
                                                  int32_t col) {
