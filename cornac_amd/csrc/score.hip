@@ -15,6 +15,7 @@
 //                               tie rule) is a plain descending sort of integers.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -22,6 +23,7 @@ namespace chip {
 
 constexpr int kBlk = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t order_key(float s) {
     const uint32_t b = __float_as_uint(s);
@@ -38,15 +40,15 @@ __global__ __launch_bounds__(kBlk) void score_valu_kernel(const float *__restric
                                                           const float *__restrict__ item_base,
                                                           const float *__restrict__ user_base,
                                                           const int32_t *__restrict__ users, int64_t u0,
-                                                          int64_t n_items, int k, float *__restrict__ out) {
+                                                          int64_t n_items, int k, int ld, float *__restrict__ out) {
     extern __shared__ float urow[];
     const int64_t b = blockIdx.y;
     const int64_t u = users ? (int64_t)users[b] : u0 + b;
-    for (int f = threadIdx.x; f < k; f += kBlk) urow[f] = U[u * k + f];
+    for (int f = threadIdx.x; f < k; f += kBlk) urow[f] = U[u * ld + f];
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= n_items) return;
-    const float *row = V + i * k;
+    const float *row = V + i * ld;
     float acc = 0.f;
     for (int f = 0; f < k; ++f) acc = fmaf(urow[f], row[f], acc);
     const float ub = user_base ? user_base[u] : 0.f;
@@ -80,12 +82,9 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
         const bool ok = r < n_rows;
         const int64_t u = ok ? (users ? (int64_t)users[r] : u0 + r) : 0;
         urow[m] = u;
-        const float *p = U + u * k;
+        const float *p = U + u * (2 * KT) + half;  // tables are zero-padded to 2*KT columns
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const int f = 2 * t + half;
-            a[m][t] = (ok && f < k) ? p[f] : 0.f;
-        }
+        for (int t = 0; t < KT; ++t) a[m][t] = p[2 * t];
         ubias[m] = 0.f;
     }
     const int64_t n_item_tiles = (n_items + 31) / 32;
@@ -94,13 +93,10 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
     for (int64_t it = t_begin; it < t_end; ++it) {
         const int64_t item = it * 32 + col;
         const bool iok = item < n_items;
-        const float *q = V + (iok ? item : 0) * k;
+        const float *q = V + (iok ? item : 0) * (2 * KT) + half;
         float bfrag[KT];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const int f = 2 * t + half;
-            bfrag[t] = (iok && f < k) ? q[f] : 0.f;
-        }
+        for (int t = 0; t < KT; ++t) bfrag[t] = q[2 * t];
         const float ib = (iok && item_base) ? item_base[item] : 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -122,6 +118,261 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
     }
     (void)ubias;
     (void)urow;
+}
+
+// ---- fused scoring GEMM + top-k: the users x items score tile never leaves the registers ------------------
+// One wave owns a 32-user tile (A fragments in registers) and walks a strip of 32-item tiles with
+// v_mfma_f32_32x32x2_f32.
+// Every accumulator value is compared with its row's running threshold (the score of the row's
+// current topk-th candidate); the rare survivors are appended to a per-row candidate buffer in LDS
+// (CAP slots, LDS atomic cursor).  When a buffer could overflow on the next tile the wave compacts
+// its rows: 64-lane bitonic sort of the 64-bit (score, item) keys, keep the topk best, raise the
+// threshold.  Expected survivors per row over N items is ~topk*ln(N/topk), so the epilogue is a few
+// percent of the MFMA time.  Optional exclusion lists (sorted CSR per row) are consulted only for
+// survivors.  Each strip emits topk keys per row; rank_merge_kernel merges the strips.
+template <int KT, int CAP>
+__global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                          const float *__restrict__ item_base,
+                                                          const float *__restrict__ user_base,
+                                                          const int32_t *__restrict__ users, int64_t u0,
+                                                          int64_t n_rows, int64_t n_items, int k, int tiles_per_strip,
+                                                          int topk, const int64_t *__restrict__ excl_indptr,
+                                                          const int32_t *__restrict__ excl_indices, int64_t excl_row0,
+                                                          unsigned long long *__restrict__ part, int ablate) {
+    constexpr int KP = 2 * KT;  // padded row length of the device tables
+    __shared__ unsigned long long keys[kBlk / 64][32][CAP];
+    __shared__ int cnt[kBlk / 64][32];
+    __shared__ float tau[kBlk / 64][32];
+    // the 4 waves of a workgroup walk the same item tiles: the B tile is staged once per workgroup
+    // (coalesced 16-byte global loads, double-buffered) instead of gathered 4x through the TA
+    __shared__ float btile[2][32][KP + 1];
+    __shared__ float ibase[2][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t row_tile = (int64_t)blockIdx.y * (kBlk / 64) + wave;
+    if (lane < 32) {
+        cnt[wave][lane] = 0;
+        tau[wave][lane] = -INFINITY;
+    }
+    // A fragments + this lane's user bias
+    float a[KT];
+    {
+        const int64_t r = row_tile * 32 + col;
+        const bool ok = r < n_rows;
+        const int64_t u = ok ? (users ? (int64_t)users[r] : u0 + r) : 0;
+        const float *p = U + u * (2 * KT) + half;  // tables are zero-padded to 2*KT columns
+#pragma unroll
+        for (int t = 0; t < KT; ++t) a[t] = p[2 * t];
+    }
+    // per accumulator register: the row it belongs to, that row's user bias and threshold
+    float ubias[16], thr[16];
+    bool row_ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int64_t row = row_tile * 32 + rl;
+        row_ok[r] = row < n_rows;
+        ubias[r] = 0.f;
+        if (user_base && row_ok[r]) ubias[r] = user_base[users ? (int64_t)users[row] : u0 + row];
+        thr[r] = -INFINITY;
+    }
+    const int64_t n_item_tiles = (n_items + 31) / 32;
+    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_strip;
+    const int64_t t_end = min(n_item_tiles, t_begin + tiles_per_strip);
+    float bcur[KT];
+    // staging: 32 items x KP floats = 8*KP float4; thread i moves float4 #i, #i+256, ...
+    constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
+    v4f32 stg[STG];
+    float stg_ib = 0.f;
+    auto stage_load = [&](int64_t it) {
+#pragma unroll
+        for (int q = 0; q < STG; ++q) {
+            const int idx = threadIdx.x + q * kBlk;
+            const int64_t item = min(it * 32 + idx / (KP / 4), n_items - 1);
+            stg[q] = *reinterpret_cast<const v4f32 *>(V + item * KP + 4 * (idx % (KP / 4)));
+        }
+        if (threadIdx.x < 32) {
+            const int64_t item = it * 32 + threadIdx.x;
+            stg_ib = (item < n_items && item_base) ? item_base[item] : 0.f;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < STG; ++q) {
+            const int idx = threadIdx.x + q * kBlk;
+            if (idx < 32 * KP / 4) {
+                float *dst = &btile[buf][idx / (KP / 4)][4 * (idx % (KP / 4))];
+                dst[0] = stg[q].x; dst[1] = stg[q].y; dst[2] = stg[q].z; dst[3] = stg[q].w;
+            }
+        }
+        if (threadIdx.x < 32) ibase[buf][threadIdx.x] = stg_ib;
+    };
+    // wave-wide compaction of the rows whose buffer could overflow on the next tile (all rows if force)
+    auto compact = [&](bool force) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int rl = 0; rl < 32; ++rl) {
+            const int c = cnt[wave][rl];
+            if (c <= CAP - 32 && !force) continue;  // only rows that could overflow on the next tile
+            unsigned long long key = lane < c ? keys[wave][rl][lane] : 0ull;
+            if (excl_indptr && key != 0ull) {  // drop excluded items before they can raise the threshold
+                const int32_t item = (int32_t)(uint32_t)key;
+                const int64_t grow = excl_row0 + row_tile * 32 + rl;
+                int64_t lo = excl_indptr[grow], hi = excl_indptr[grow + 1];
+                const int64_t end = hi;
+                while (lo < hi) {
+                    const int64_t mid = lo + ((hi - lo) >> 1);
+                    if (excl_indices[mid] < item) lo = mid + 1; else hi = mid;
+                }
+                if (lo < end && excl_indices[lo] == item) key = 0ull;
+            }
+            // 64-lane bitonic sort, descending
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)key, j, 64);
+                    const unsigned hi = __shfl_xor((unsigned)(key >> 32), j, 64);
+                    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                    const bool up = (lane & j) == 0;          // lower lane of the pair
+                    const bool desc = (lane & kk) == 0;       // direction of this bitonic block
+                    const bool take_max = up == desc;
+                    key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+                }
+            }
+            const int n_live = __popcll(__ballot(key != 0ull));  // excluded entries sorted to the tail
+            const int keep = min(n_live, topk);
+            if (lane < CAP) keys[wave][rl][lane] = lane < keep ? key : 0ull;
+            const unsigned long long kth = __shfl(key, topk - 1, 64);  // 0 when fewer than topk candidates
+            if (lane == 0) {
+                cnt[wave][rl] = keep;
+                tau[wave][rl] = kth != 0ull ? key_to_float((unsigned)(kth >> 32)) : -INFINITY;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) thr[r] = tau[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
+    };
+    // Software pipeline: iteration `it` issues the MFMA chain of tile it+1 and, interleaved between
+    // those MFMAs in program order, evaluates the finished accumulators of tile it (a wave issues in
+    // order, so VALU work only overlaps its own MFMAs when it sits between them).  The two
+    // workgroups of a CU run in phase, so without this the matrix pipe idles during every epilogue.
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc_cur = zero16;
+    float ib_cur2 = 0.f;
+    if (t_begin < t_end) {
+        stage_load(t_begin);
+        stage_store(0);
+    }
+    __syncthreads();
+    if (t_begin + 1 < t_end) stage_load(t_begin + 1);
+    {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) bcur[t] = btile[0][col][2 * t + half];
+        ib_cur2 = ibase[0][col];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_cur, 0, 0, 0);
+    }
+    if (t_begin + 1 < t_end) stage_store(1);
+    __syncthreads();
+    for (int64_t it = t_begin; it < t_end; ++it) {
+        const int buf_next = (int)((it + 1 - t_begin) & 1);
+        if (it + 2 < t_end) stage_load(it + 2);
+        // ---- one basic block: B fragments + MFMA chain of tile it+1, compare of tile it ----------------
+#pragma unroll
+        for (int t = 0; t < KT; ++t) bcur[t] = btile[buf_next][col][2 * t + half];
+        const float ib_next = ibase[buf_next][col];
+        f32x16 acc_nxt = zero16;
+        const int64_t item = it * 32 + col;
+        const bool iok = item < n_items && !(ablate & 1);
+        unsigned hitbits = 0;
+        float sc[16];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            acc_nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_nxt, 0, 0, 0);
+            if (t < 16) {
+                const int r = t;
+                sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
+                hitbits |= (iok && row_ok[r] && sc[r] >= thr[r]) ? (1u << r) : 0u;
+            }
+        }
+        if (KT < 16) {
+#pragma unroll
+            for (int r = KT; r < 16; ++r) {
+                sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
+                hitbits |= (iok && row_ok[r] && sc[r] >= thr[r]) ? (1u << r) : 0u;
+            }
+        }
+        // ---- rare path: append the survivors of tile it ---------------------------------------------------
+        if (__any(hitbits != 0u)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (hitbits & (1u << r)) {
+                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int pos = atomicAdd(&cnt[wave][rl], 1);
+                    keys[wave][rl][pos] =
+                        ((unsigned long long)order_key(sc[r]) << 32) | (unsigned long long)(uint32_t)item;
+                }
+            }
+            // a tile adds at most 32 entries per row: compact before any buffer can exceed CAP
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int mx = cnt[wave][lane & 31];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if (__builtin_amdgcn_readfirstlane(mx) > CAP - 32) compact(false);  // wave-uniform decision
+        }
+        if (it + 2 < t_end) stage_store((int)((it + 2 - t_begin) & 1));
+        __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
+        acc_cur = acc_nxt;
+        ib_cur2 = ib_next;
+    }
+    compact(true);
+    // emit this strip's candidates: part[strip][row][topk]
+    for (int rl = 0; rl < 32; ++rl) {
+        const int64_t row = row_tile * 32 + rl;
+        if (row >= n_rows) break;  // also covers waves whose whole row tile is out of range
+        if (lane < topk) part[((int64_t)blockIdx.x * n_rows + row) * topk + lane] = keys[wave][rl][lane];
+    }
+}
+
+// merge the strips' candidates of one row: bitonic sort of n_strips*topk keys in LDS, emit the topk best
+__global__ __launch_bounds__(64) void rank_merge_kernel(const unsigned long long *__restrict__ part, int n_strips,
+                                                        int64_t n_rows, int topk, int pad,
+                                                        int32_t *__restrict__ items_out,
+                                                        float *__restrict__ scores_out) {
+    extern __shared__ unsigned long long mlist[];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = n_strips * topk;
+    for (int i = tid; i < pad; i += 64) {
+        unsigned long long key = 0ull;
+        if (i < n) key = part[((int64_t)(i / topk) * n_rows + row) * topk + (i % topk)];
+        mlist[i] = key;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= pad; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < pad; i += 64) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = mlist[i], y = mlist[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        mlist[i] = y;
+                        mlist[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < topk; i += 64) {
+        const unsigned long long key = mlist[i];
+        items_out[row * topk + i] = key ? (int32_t)(uint32_t)key : -1;
+        scores_out[row * topk + i] = key ? key_to_float((uint32_t)(key >> 32)) : -INFINITY;
+    }
 }
 
 // ---- exclusion: out[row, item] = NaN-tagged "excluded" marker (handled as key 0) ----------------------
@@ -267,6 +518,7 @@ struct cornac_hip_scorer {
     int device = 0;
     int64_t n_users = 0, n_items = 0;
     int k = 0;
+    int ld = 0;  // row stride of the device tables: k zero-padded to 16/32/64/128 for the MFMA kernels
     hipStream_t stream = nullptr;
     DevBuf<float> U, V, item_base, user_base;
     bool has_user_base = false, is_set = false;
@@ -275,7 +527,7 @@ struct cornac_hip_scorer {
     DevBuf<int32_t> d_users, d_items_out, d_excl_indices;
     DevBuf<int64_t> d_excl_indptr;
     DevBuf<float> d_scores_out;
-    DevBuf<unsigned long long> sort_scratch;
+    DevBuf<unsigned long long> sort_scratch, part;
 };
 
 static void sc_check(cornac_hip_scorer_t h, bool need_set = true) {
@@ -295,7 +547,6 @@ static void launch_scores(cornac_hip_scorer_t h, const int32_t *d_users, int64_t
     const float *ub = h->has_user_base ? h->user_base.p : nullptr;
     const int k = h->k;
     if (use_mfma && k <= 128) {
-        const int KT = (k + 1) / 2;
         const int64_t n_item_tiles = (h->n_items + 31) / 32;
         const DeviceInfo &di = device_info(h->device);
         auto go = [&](auto kernel, int MT) {
@@ -308,14 +559,14 @@ static void launch_scores(cornac_hip_scorer_t h, const int32_t *d_users, int64_t
             hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)wg_rows), dim3(kBlk), 0, h->stream, h->U.p, h->V.p,
                                h->item_base.p, ub, d_users, u0, n, h->n_items, k, tiles_per_strip, h->scores.p);
         };
-        if (KT <= 8) go(score_gemm_mfma_kernel<8, 2>, 2);
-        else if (KT <= 16) go(score_gemm_mfma_kernel<16, 2>, 2);
-        else if (KT <= 32) go(score_gemm_mfma_kernel<32, 2>, 2);
+        if (h->ld == 16) go(score_gemm_mfma_kernel<8, 2>, 2);
+        else if (h->ld == 32) go(score_gemm_mfma_kernel<16, 2>, 2);
+        else if (h->ld == 64) go(score_gemm_mfma_kernel<32, 2>, 2);
         else go(score_gemm_mfma_kernel<64, 1>, 1);
     } else {
         dim3 grid((unsigned)((h->n_items + kBlk - 1) / kBlk), (unsigned)n);
         hipLaunchKernelGGL(score_valu_kernel, grid, dim3(kBlk), (size_t)k * sizeof(float), h->stream, h->U.p, h->V.p,
-                           h->item_base.p, ub, d_users, u0, h->n_items, k, h->scores.p);
+                           h->item_base.p, ub, d_users, u0, h->n_items, k, h->ld, h->scores.p);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -338,6 +589,55 @@ static void launch_rank(cornac_hip_scorer_t h, int64_t n, int topk, bool have_ex
     HIP_CHECK(hipGetLastError());
 }
 
+constexpr int kFusedMaxTopk = 32;
+
+static bool can_fuse(cornac_hip_scorer_t h, int topk) { return topk <= kFusedMaxTopk && h->k <= 128; }
+
+// fused GEMM + top-k for rows [0, n): users from d_users (or u0 + row); optional exclusion CSR on the device
+static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int64_t u0, int64_t n, int topk,
+                              const int64_t *d_excl_indptr, const int32_t *d_excl_indices, int64_t excl_row0,
+                              int32_t *items_out, float *scores_out) {
+    const float *ub = h->has_user_base ? h->user_base.p : nullptr;
+    const DeviceInfo &di = device_info(h->device);
+    const int k = h->k;
+    static const int ablate = getenv("CORNAC_HIP_RANK_ABLATE") ? atoi(getenv("CORNAC_HIP_RANK_ABLATE")) : 0;  // profiling only
+    const int64_t n_item_tiles = (h->n_items + 31) / 32;
+    const int64_t wg_rows = (n + 127) / 128;  // 4 waves x 32 rows per workgroup
+    int64_t strips = std::max<int64_t>(1, ((int64_t)di.cus * 8 + wg_rows - 1) / wg_rows);
+    strips = std::min<int64_t>(strips, std::max<int64_t>(1, n_item_tiles / 16));
+    strips = std::min<int64_t>(strips, 16);
+    const int tiles_per_strip = (int)((n_item_tiles + strips - 1) / strips);
+    const int64_t gx = (n_item_tiles + tiles_per_strip - 1) / tiles_per_strip;
+    h->part.ensure((size_t)(gx * n * topk));
+    dim3 grid((unsigned)gx, (unsigned)wg_rows), block(kBlk);
+#define FUSED(KT_, CAP_) do {                                                                                    \
+    if (getenv("CORNAC_HIP_RANK_ABLATE")) {                                                                       \
+        int occ = 0;                                                                                              \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rank_fused_kernel<KT_, CAP_>, kBlk, 0);           \
+        fprintf(stderr, "[rank_fused<%d,%d>] grid %ux%u, %d workgroups/CU\n", KT_, CAP_, grid.x, grid.y, occ);     \
+    }                                                                                                             \
+    hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_>), grid, block, 0, h->stream, h->U.p, h->V.p, h->item_base.p, \
+                       ub, d_users, u0, n, h->n_items, k, tiles_per_strip, topk, d_excl_indptr, d_excl_indices,   \
+                       excl_row0, h->part.p, ablate); } while (0)
+    if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
+        if (h->ld == 16) FUSED(8, 56);
+        else if (h->ld == 32) FUSED(16, 56);
+        else if (h->ld == 64) FUSED(32, 56);
+        else FUSED(64, 56);
+    } else {
+        if (h->ld == 16) FUSED(8, 64);
+        else if (h->ld == 32) FUSED(16, 64);
+        else if (h->ld == 64) FUSED(32, 64);
+        else FUSED(64, 64);
+    }
+#undef FUSED
+    int pad = 1;
+    while (pad < (int)gx * topk) pad <<= 1;
+    hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)n), dim3(64), (size_t)pad * 8, h->stream, h->part.p, (int)gx,
+                       n, topk, pad, items_out, scores_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 extern "C" {
 
 int cornac_hip_scorer_create(cornac_hip_scorer_t *out, int device, int64_t n_users, int64_t n_items, int k) {
@@ -349,9 +649,13 @@ int cornac_hip_scorer_create(cornac_hip_scorer_t *out, int device, int64_t n_use
         use_device(device);
         std::unique_ptr<cornac_hip_scorer> h(new cornac_hip_scorer());
         h->device = device; h->n_users = n_users; h->n_items = n_items; h->k = k;
+        h->ld = k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : k;
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        h->U.alloc((size_t)n_users * k);
-        h->V.alloc((size_t)n_items * k);
+        h->U.alloc((size_t)n_users * h->ld);
+        h->V.alloc((size_t)n_items * h->ld);
+        HIP_CHECK(hipMemsetAsync(h->U.p, 0, h->U.n * sizeof(float), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->V.p, 0, h->V.n * sizeof(float), h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
         h->item_base.alloc((size_t)n_items);
         h->user_base.alloc((size_t)n_users);
         *out = h.release();
@@ -375,8 +679,10 @@ int cornac_hip_scorer_set(cornac_hip_scorer_t h, const float *U, const float *V,
     return guarded([&] {
         sc_check(h, false);
         REQUIRE(U && V, "U and V are required");
-        h->U.upload(U, (size_t)h->n_users * h->k, h->stream);
-        h->V.upload(V, (size_t)h->n_items * h->k, h->stream);
+        HIP_CHECK(hipMemcpy2DAsync(h->U.p, (size_t)h->ld * 4, U, (size_t)h->k * 4, (size_t)h->k * 4, (size_t)h->n_users,
+                                   hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpy2DAsync(h->V.p, (size_t)h->ld * 4, V, (size_t)h->k * 4, (size_t)h->k * 4, (size_t)h->n_items,
+                                   hipMemcpyHostToDevice, h->stream));
         if (item_base) h->item_base.upload(item_base, (size_t)h->n_items, h->stream);
         else HIP_CHECK(hipMemsetAsync(h->item_base.p, 0, (size_t)h->n_items * 4, h->stream));
         h->has_user_base = user_base != nullptr;
@@ -426,6 +732,32 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
         for (int64_t b = 0; b < n; ++b)
             REQUIRE(users[b] >= 0 && users[b] < h->n_users, "user %d out of range", users[b]);
         const bool have_excl = excl_indptr != nullptr && excl_indices != nullptr;
+        if (have_excl) {
+            REQUIRE(excl_indptr[0] == 0, "excl_indptr must start at 0");
+            h->d_excl_indptr.ensure((size_t)n + 1);
+            h->d_excl_indptr.upload(excl_indptr, (size_t)n + 1, h->stream);
+            const int64_t ne = excl_indptr[n];
+            h->d_excl_indices.ensure((size_t)std::max<int64_t>(ne, 1));
+            if (ne > 0) h->d_excl_indices.upload(excl_indices, (size_t)ne, h->stream);
+        }
+        if (can_fuse(h, topk)) {
+            // fused path: no score workspace, all users in one launch; the exclusion rows must be sorted
+            if (have_excl)
+                for (int64_t b = 0; b < n; ++b)
+                    for (int64_t p = excl_indptr[b] + 1; p < excl_indptr[b + 1]; ++p)
+                        REQUIRE(excl_indices[p] > excl_indices[p - 1], "exclusion row %lld is not strictly sorted",
+                                (long long)b);
+            h->d_users.ensure((size_t)n);
+            h->d_items_out.ensure((size_t)(n * topk));
+            h->d_scores_out.ensure((size_t)(n * topk));
+            h->d_users.upload(users, (size_t)n, h->stream);
+            launch_rank_fused(h, h->d_users.p, 0, n, topk, have_excl ? h->d_excl_indptr.p : nullptr,
+                              have_excl ? h->d_excl_indices.p : nullptr, 0, h->d_items_out.p, h->d_scores_out.p);
+            h->d_items_out.download(items_out, (size_t)(n * topk), h->stream);
+            h->d_scores_out.download(scores_out, (size_t)(n * topk), h->stream);
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            return;
+        }
         int64_t cap = rows_per_batch(h);
         if (topk > TOPK_MAX) cap = std::min<int64_t>(cap, 1024);
         const int64_t nb_max = std::min(cap, n);
@@ -433,14 +765,7 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
         h->d_users.ensure((size_t)nb_max);
         h->d_items_out.ensure((size_t)(nb_max * topk));
         h->d_scores_out.ensure((size_t)(nb_max * topk));
-        if (have_excl) {
-            h->excl.ensure((size_t)(nb_max * h->n_items));
-            h->d_excl_indptr.ensure((size_t)n + 1);
-            h->d_excl_indptr.upload(excl_indptr, (size_t)n + 1, h->stream);
-            const int64_t ne = excl_indptr[n];
-            h->d_excl_indices.ensure((size_t)std::max<int64_t>(ne, 1));
-            if (ne > 0) h->d_excl_indices.upload(excl_indices, (size_t)ne, h->stream);
-        }
+        if (have_excl) h->excl.ensure((size_t)(nb_max * h->n_items));
         for (int64_t b0 = 0; b0 < n; b0 += cap) {
             const int64_t nb = std::min(cap, n - b0);
             h->d_users.upload(users + b0, (size_t)nb, h->stream);
@@ -464,9 +789,10 @@ int cornac_hip_rank_topk_device(cornac_hip_scorer_t h, int64_t u0, int64_t n, in
         REQUIRE(u0 >= 0 && n > 0 && u0 + n <= h->n_users, "user range out of bounds");
         REQUIRE(topk >= 1 && topk <= h->n_items && topk <= TOPK_MAX, "topk out of range for the device probe");
         REQUIRE(repeats >= 1 && ms, "bad arguments");
-        const int64_t cap = rows_per_batch(h);
+        const bool fused = can_fuse(h, topk);
+        const int64_t cap = fused ? n : rows_per_batch(h);
         const int64_t nb_max = std::min(cap, n);
-        h->scores.ensure((size_t)(nb_max * h->n_items));
+        if (!fused) h->scores.ensure((size_t)(nb_max * h->n_items));
         h->d_items_out.ensure((size_t)(nb_max * topk));
         h->d_scores_out.ensure((size_t)(nb_max * topk));
         hipEvent_t e0, e1;
@@ -476,8 +802,13 @@ int cornac_hip_rank_topk_device(cornac_hip_scorer_t h, int64_t u0, int64_t n, in
         for (int r = 0; r < repeats; ++r) {
             for (int64_t b0 = 0; b0 < n; b0 += cap) {
                 const int64_t nb = std::min(cap, n - b0);
-                launch_scores(h, nullptr, u0 + b0, nb, true);
-                launch_rank(h, nb, topk, false, h->d_items_out.p, h->d_scores_out.p);
+                if (fused) {
+                    launch_rank_fused(h, nullptr, u0 + b0, nb, topk, nullptr, nullptr, 0, h->d_items_out.p,
+                                      h->d_scores_out.p);
+                } else {
+                    launch_scores(h, nullptr, u0 + b0, nb, true);
+                    launch_rank(h, nb, topk, false, h->d_items_out.p, h->d_scores_out.p);
+                }
             }
         }
         HIP_CHECK(hipEventRecord(e1, h->stream));

@@ -42,7 +42,7 @@ class ItemTableReplica:
 
     def sync(self):
         """flat <- base + sum_over_ranks(flat - base); base <- flat"""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             self.base.copy_(self.flat)
             return
         delta = self.flat - self.base
