@@ -9,6 +9,7 @@ from .data import Dataset
 from .recommender import Recommender, ScoreException
 from .bpr import BPR, WBPR
 from .mf import MF
+from . import eval, metrics  # noqa: A004,F401
 
 __all__ = ["Dataset", "Recommender", "ScoreException", "BPR", "WBPR", "MF"]
 __version__ = "0.1.0"

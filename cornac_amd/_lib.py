@@ -30,7 +30,7 @@ SYMBOLS = [
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
-    "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device",
+    "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
         L.cornac_hip_scorer_set.argtypes = [_vp, _f32, _f32, _vp, _vp]
         L.cornac_hip_score_user.argtypes = [_vp, C.c_int64, _f32]
         L.cornac_hip_score_block.argtypes = [_vp, _i32, C.c_int64, _f32]
+        L.cornac_hip_score_pairs.argtypes = [_vp, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float, _f32]
         L.cornac_hip_rank_topk.argtypes = [_vp, _i32, C.c_int64, C.c_int, _vp, _vp, _i32, _f32]
         L.cornac_hip_rank_topk_device.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
@@ -321,6 +322,14 @@ class Scorer:
         users = np.ascontiguousarray(users, np.int32)
         out = np.empty((len(users), self.n_items), np.float32)
         check(lib().cornac_hip_score_block(self.h, users, len(users), out))
+        return out
+
+    def score_pairs(self, users, items, clip=None):
+        users = np.ascontiguousarray(users, np.int32)
+        items = np.ascontiguousarray(items, np.int32)
+        out = np.empty(len(users), np.float32)
+        lo, hi = (0.0, 0.0) if clip is None else (float(clip[0]), float(clip[1]))
+        check(lib().cornac_hip_score_pairs(self.h, users, items, len(users), int(clip is not None), lo, hi, out))
         return out
 
     def rank_topk(self, users, topk, exclude=None):

@@ -56,6 +56,26 @@ __global__ __launch_bounds__(kBlk) void score_valu_kernel(const float *__restric
     out[b * n_items + i] = (ib + ub) + acc;
 }
 
+// ---- (user, item) pair scoring: the batched form of Recommender.rate()'s score(u, i) calls ----------------
+// (cornac/eval_methods/base_method.py:35-105 calls rate() once per test rating).  One lane per pair,
+// fmaf chain in index order; optional clipping to [lo, hi] (cornac/utils/common.py clip).
+__global__ __launch_bounds__(kBlk) void score_pairs_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                           const float *__restrict__ item_base,
+                                                           const float *__restrict__ user_base,
+                                                           const int32_t *__restrict__ users,
+                                                           const int32_t *__restrict__ items, int64_t n, int k, int ld,
+                                                           int do_clip, float lo, float hi, float *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (p >= n) return;
+    const int64_t u = users[p], i = items[p];
+    const float *pu = U + u * ld, *pv = V + i * ld;
+    float acc = 0.f;
+    for (int f = 0; f < k; ++f) acc = fmaf(pu[f], pv[f], acc);
+    float s = ((item_base ? item_base[i] : 0.f) + (user_base ? user_base[u] : 0.f)) + acc;
+    if (do_clip) s = fminf(fmaxf(s, lo), hi);
+    out[p] = s;
+}
+
 // ---- MFMA scoring GEMM ---------------------------------------------------------------------------
 // One wave owns MT stacked 32-user tiles and walks a strip of 32-item tiles.  Operand layout of
 // v_mfma_f32_32x32x2_f32: lane l supplies A[row = l & 31][kk = l >> 5] and B[kk = l >> 5][col = l & 31];
@@ -174,8 +194,11 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         row_ok[r] = row < n_rows;
         ubias[r] = 0.f;
         if (user_base && row_ok[r]) ubias[r] = user_base[users ? (int64_t)users[row] : u0 + row];
-        thr[r] = -INFINITY;
+        thr[r] = row_ok[r] ? -INFINITY : INFINITY;
     }
+    // rows beyond n_rows: tau = +inf (nothing ever passes); items beyond n_items get a NaN item base
+    // (NaN >= thr is false), so the hot compare needs no validity masks
+    if (lane < 32 && row_tile * 32 + lane >= n_rows) tau[wave][lane] = INFINITY;
     const int64_t n_item_tiles = (n_items + 31) / 32;
     const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_strip;
     const int64_t t_end = min(n_item_tiles, t_begin + tiles_per_strip);
@@ -193,7 +216,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         }
         if (threadIdx.x < 32) {
             const int64_t item = it * 32 + threadIdx.x;
-            stg_ib = (item < n_items && item_base) ? item_base[item] : 0.f;
+            stg_ib = item < n_items ? (item_base ? item_base[item] : 0.f) : __builtin_nanf("");
         }
     };
     auto stage_store = [&](int buf) {
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
             const int keep = min(n_live, topk);
             if (lane < CAP) keys[wave][rl][lane] = lane < keep ? key : 0ull;
             const unsigned long long kth = __shfl(key, topk - 1, 64);  // 0 when fewer than topk candidates
-            if (lane == 0) {
+            if (lane == 0 && row_tile * 32 + rl < n_rows) {
                 cnt[wave][rl] = keep;
                 tau[wave][rl] = kth != 0ull ? key_to_float((unsigned)(kth >> 32)) : -INFINITY;
             }
@@ -285,7 +308,6 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         const float ib_next = ibase[buf_next][col];
         f32x16 acc_nxt = zero16;
         const int64_t item = it * 32 + col;
-        const bool iok = item < n_items && !(ablate & 1);
         unsigned hitbits = 0;
         float sc[16];
 #pragma unroll
@@ -294,16 +316,17 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
             if (t < 16) {
                 const int r = t;
                 sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
-                hitbits |= (iok && row_ok[r] && sc[r] >= thr[r]) ? (1u << r) : 0u;
+                hitbits |= (sc[r] >= thr[r]) ? (1u << r) : 0u;
             }
         }
         if (KT < 16) {
 #pragma unroll
             for (int r = KT; r < 16; ++r) {
                 sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
-                hitbits |= (iok && row_ok[r] && sc[r] >= thr[r]) ? (1u << r) : 0u;
+                hitbits |= (sc[r] >= thr[r]) ? (1u << r) : 0u;
             }
         }
+        if (ablate & 1) hitbits = 0;
         // ---- rare path: append the survivors of tile it ---------------------------------------------------
         if (__any(hitbits != 0u)) {
 #pragma unroll
@@ -780,6 +803,30 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
             h->d_scores_out.download(scores_out + b0 * topk, (size_t)(nb * topk), h->stream);
             HIP_CHECK(hipStreamSynchronize(h->stream));
         }
+    });
+}
+
+int cornac_hip_score_pairs(cornac_hip_scorer_t h, const int32_t *users, const int32_t *items, int64_t n, int clip,
+                           float lo, float hi, float *out) {
+    return guarded([&] {
+        sc_check(h);
+        REQUIRE(users && items && out && n > 0, "bad arguments");
+        for (int64_t p = 0; p < n; ++p)
+            REQUIRE(users[p] >= 0 && users[p] < h->n_users && items[p] >= 0 && items[p] < h->n_items,
+                    "pair %lld is out of range", (long long)p);
+        DevBuf<int32_t> du, di;
+        DevBuf<float> dout;
+        du.alloc((size_t)n);
+        di.alloc((size_t)n);
+        dout.alloc((size_t)n);
+        du.upload(users, (size_t)n, h->stream);
+        di.upload(items, (size_t)n, h->stream);
+        hipLaunchKernelGGL(score_pairs_kernel, dim3((unsigned)((n + kBlk - 1) / kBlk)), dim3(kBlk), 0, h->stream,
+                           h->U.p, h->V.p, h->item_base.p, h->has_user_base ? h->user_base.p : nullptr, du.p, di.p, n,
+                           h->k, h->ld, clip, lo, hi, dout.p);
+        HIP_CHECK(hipGetLastError());
+        dout.download(out, (size_t)n, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
     });
 }
 

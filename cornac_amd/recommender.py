@@ -195,6 +195,23 @@ class Recommender:
             rating_pred = clip(rating_pred, self.min_rating, self.max_rating)
         return rating_pred
 
+    def rate_batch(self, user_indices, item_indices, clipping=True):
+        """Batched rate(): predictions for many (user, item) pairs in one kernel — what
+        `rating_eval` (cornac/eval_methods/base_method.py:35-105) computes one Python call at a
+        time.  Unknown users/items get `default_score()` like rate() does after a ScoreException."""
+        u = np.asarray(user_indices, dtype=np.int64)
+        i = np.asarray(item_indices, dtype=np.int64)
+        sc = self._get_scorer()
+        rows = np.array([-1 if (r := self._scorer_row(int(x))) is None else r for x in u], dtype=np.int64)
+        known = (rows >= 0) & (i >= 0) & (i < sc.n_items) & (i < self.num_items)
+        out = np.full(len(u), float(self.default_score()), dtype=np.float64)
+        if clipping:
+            out = np.clip(out, self.min_rating, self.max_rating)
+        if known.any():
+            clip_rng = (self.min_rating, self.max_rating) if clipping else None
+            out[known] = sc.score_pairs(rows[known], i[known], clip=clip_rng)
+        return out
+
     # device scorer -------------------------------------------------------------------------------
     def _scoring_tables(self):
         """(U, V, item_base, user_base) such that score(u, i) = item_base[i] + user_base[u] + <U[u], V[i]>."""

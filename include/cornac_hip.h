@@ -174,6 +174,11 @@ int cornac_hip_scorer_set(cornac_hip_scorer_t h, const float *U, const float *V,
 int cornac_hip_score_user(cornac_hip_scorer_t h, int64_t user, float *out);
 /* out[n * n_items] for a block of users */
 int cornac_hip_score_block(cornac_hip_scorer_t h, const int32_t *users, int64_t n, float *out);
+/* out[p] = score(users[p], items[p]) for n pairs, optionally clipped to [lo, hi]:
+ * the batched form of Recommender.rate() (cornac/models/recommender.py:447-474) as
+ * called once per test rating by rating_eval (cornac/eval_methods/base_method.py:35-105). */
+int cornac_hip_score_pairs(cornac_hip_scorer_t h, const int32_t *users, const int32_t *items, int64_t n, int clip,
+                           float lo, float hi, float *out);
 /* Batched rank(): for each of the n users, the topk best items in descending
  * score order (ties: higher item index first — the oracle's pinned tie rule),
  * excluding the items listed in the optional CSR (excl_indptr[n+1],

@@ -61,3 +61,59 @@ def test_host_mirror_matches_reference_dataset_and_rank(oracle):
         assert np.array_equal(scores, ref_scores)
         n = len(cand) if k == -1 else k
         assert np.array_equal(ranked[:n], ref_rank[:n])
+
+
+def test_metric_mirrors_and_batched_eval_logic_match_reference():
+    """cornac_amd.metrics == cornac.metrics on random rankings; cornac_amd.eval.ranking_eval (driven by
+    a host stand-in model with rank()/rank_batch()) == the reference's ranking_eval."""
+    import cornac_amd.eval as ev
+    import cornac_amd.metrics as mm
+
+    ns = ref_loader.load()
+    rm = ns.metrics
+    rs = np.random.RandomState(0)
+    for _ in range(20):
+        pd_rank = rs.permutation(50)
+        gt_pos = rs.choice(50, rs.randint(1, 8), replace=False)
+        for k in (1, 5, 10, -1):
+            for mine, ref in ((mm.Precision, rm.Precision), (mm.Recall, rm.Recall), (mm.NDCG, rm.NDCG),
+                              (mm.HitRatio, rm.HitRatio)):
+                assert mine(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank) == pytest.approx(
+                    ref(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank))
+
+    class HostModel:  # scores from a fixed matrix; same tie rule as the device kernels
+        def __init__(self, S, n_items):
+            self.S, self.num_items, self.total_items = S, n_items, n_items
+
+        def rank(self, user_idx, item_indices=None, k=-1, **kw):
+            s = self.S[user_idx]
+            item_indices = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
+            sc = s[item_indices]
+            order = np.argsort(sc, kind="stable")[::-1]
+            r = item_indices[order]
+            return (r if k == -1 else r[:k]), sc
+
+        def rank_batch(self, users, k=10, exclude=None):
+            out = np.full((len(users), k), -1, np.int32)
+            for r, u in enumerate(users):
+                ex = exclude[1][exclude[0][r]:exclude[0][r + 1]]
+                cand = np.setdiff1d(np.arange(self.num_items), ex)
+                rr, _ = self.rank(u, cand, k)
+                out[r, :len(rr)] = rr
+            return out, None
+
+    data = _pairs(60, 45, 1200, 4)
+    rs.shuffle(data)
+    train = ns.Dataset.build(data[:900])
+    test = ns.Dataset.build(data[900:], global_uid_map=train.uid_map, global_iid_map=train.iid_map,
+                            exclude_unknowns=True)
+    S = rs.normal(size=(train.num_users, train.num_items)).astype(np.float32)
+    model = HostModel(S, train.num_items)
+    ref_metrics = [rm.Recall(k=10), rm.NDCG(k=10), rm.Precision(k=5)]
+    my_metrics = [mm.Recall(k=10), mm.NDCG(k=10), mm.Precision(k=5)]
+    ref_avg, ref_user = ns.eval_methods.base_method.ranking_eval(model, ref_metrics, train, test)
+    avg, user = ev.ranking_eval(model, my_metrics, train, test)
+    assert np.allclose(avg, ref_avg) and user[0].keys() == ref_user[0].keys()
+    avg2, _ = ev.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)  # k = -1 -> per-user full-rank flow
+    ref_avg2, _ = ns.eval_methods.base_method.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)
+    assert np.allclose(avg2, ref_avg2)
