@@ -5,11 +5,11 @@ reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface) an
 All compute runs in libcornac_hip.so (hand-written HIP for gfx950, C ABI in include/cornac_hip.h);
 there is no CPU fallback.
 """
-from .data import Dataset
+from .data import Dataset, PurchaseViewDataset
 from .recommender import Recommender, ScoreException
-from .bpr import BPR, WBPR
+from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "Recommender", "ScoreException", "BPR", "WBPR", "MF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF"]
 __version__ = "0.1.0"

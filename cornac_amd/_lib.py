@@ -26,7 +26,8 @@ SYMBOLS = [
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
-    "cornac_hip_bpr_debug_ownership",
+    "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
+    "cornac_hip_vebpr_fit_epochs",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -90,6 +91,10 @@ def lib():
         L.cornac_hip_bpr_sync.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_draw.argtypes = [_vp, C.c_int, C.c_uint64, C.c_int64, _i64]
         L.cornac_hip_bpr_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_bpr_set_views.argtypes = [_vp, _i32, _i32, C.c_int64]
+        L.cornac_hip_bpr_seed_view_stream.argtypes = [_vp, C.c_uint32]
+        L.cornac_hip_vebpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -211,6 +216,21 @@ class BprTrainer:
         out = np.empty(n, np.int64)
         check(lib().cornac_hip_bpr_debug_draw(self.h, stream, hi, n, out))
         return out
+
+    def set_views(self, view_indptr, view_indices):
+        self.v_indptr = np.ascontiguousarray(view_indptr, np.int32)
+        self.v_indices = np.ascontiguousarray(view_indices, np.int32)
+        if len(self.v_indices) == 0:
+            self.v_indices = np.zeros(1, np.int32)
+        check(lib().cornac_hip_bpr_set_views(self.h, self.v_indptr, self.v_indices, int(self.v_indptr[-1])))
+
+    def seed_view_stream(self, seed_view):
+        check(lib().cornac_hip_bpr_seed_view_stream(self.h, seed_view))
+
+    def fit_epochs_vebpr(self, n_epochs, lr, reg, alpha, mode=MODE_HOGWILD):
+        c, s = C.c_int64(), C.c_int64()
+        check(lib().cornac_hip_vebpr_fit_epochs(self.h, n_epochs, lr, reg, alpha, mode, C.byref(c), C.byref(s)))
+        return c.value, s.value
 
     def debug_ownership(self):
         """(wave_ptr, own_u, own_i) of the hogwild sampler's user-row ownership, or None if unused"""

@@ -177,3 +177,89 @@ class WBPR(BPR):
         else:
             lo, hi = int(self.rng.randint(2 ** 31)), int(self.rng.randint(2 ** 31))
             trainer.seed_hogwild((hi << 32) | lo)
+
+
+class VEBPR(Recommender):
+    """View-Enhanced BPR (Ding et al., TKDE 2019) — constructor, attributes (`u_factor`, `i_factor`) and
+    `fit/score/rank` surface of cornac/models/bpr/recom_vebpr.pyx:43-380; `train_set` must be a
+    PurchaseViewDataset (purchases in `matrix`, views in `view_matrix`)."""
+
+    def __init__(self, name="VEBPR", k=10, max_iter=100, learning_rate=0.01, lambda_reg=0.1, num_threads=0,
+                 trainable=True, verbose=False, init_params=None, seed=None, alpha=0.5, mode=None, device=0):
+        super().__init__(name=name, trainable=trainable, verbose=verbose)
+        self.k = int(k)
+        self.max_iter = max_iter
+        self.learning_rate = learning_rate
+        self.lambda_reg = lambda_reg
+        self.alpha = float(alpha)
+        self.seed = seed
+        self.rng = np.random.RandomState(seed)
+        self.num_threads = num_threads
+        if mode not in (None, "deterministic", "hogwild"):
+            raise ValueError(f"mode={mode} is not supported")
+        self.mode = mode
+        self.device = device
+        self.init_params = {} if init_params is None else init_params
+        self.u_factor = self.init_params.get("U", None)
+        self.i_factor = self.init_params.get("V", None)
+
+    @property
+    def effective_mode(self):
+        if self.mode is not None:
+            return self.mode
+        return "deterministic" if self.seed is not None else "hogwild"
+
+    def fit(self, train_set, val_set=None):
+        Recommender.fit(self, train_set, val_set)
+        if not hasattr(train_set, "view_matrix"):
+            raise ValueError("VEBPR requires a PurchaseViewDataset. Build one with "
+                             "PurchaseViewDataset.build(purchase_data, view_data) or "
+                             "PurchaseViewDataset.attach_view(dataset, view_data).")
+        self.view_matrix = train_set.view_matrix
+        n_users, n_items = self.total_users, self.total_items
+        if self.u_factor is None:
+            self.u_factor = (_uniform((n_users, self.k), self.rng) - 0.5) / self.k
+        if self.i_factor is None:
+            self.i_factor = (_uniform((n_items, self.k), self.rng) - 0.5) / self.k
+        if not self.trainable:
+            return self
+        X, Vw = train_set.matrix, train_set.view_matrix
+        if not X.has_sorted_indices:
+            X.sort_indices()
+        trainer = _lib.BprTrainer(X.indptr, X.indices, train_set.num_users, train_set.num_items, n_users, n_items,
+                                  self.k, device=self.device)
+        try:
+            trainer.set_views(Vw.indptr, Vw.indices)
+            trainer.set_factors(self.u_factor, self.i_factor, None)
+            if self.effective_mode == "deterministic":
+                # recom_vebpr.pyx:191-193: rng_pos, rng_view, rng_neg drawn in this order
+                sp = rngvector_mt_seed(self.rng.randint(2 ** 31))
+                sv = rngvector_mt_seed(self.rng.randint(2 ** 31))
+                sn = rngvector_mt_seed(self.rng.randint(2 ** 31))
+                trainer.seed_mt19937(sp, sn, shared_stream=False)
+                trainer.seed_view_stream(sv)
+                mode = _lib.MODE_DETERMINISTIC
+            else:
+                lo, hi = int(self.rng.randint(2 ** 31)), int(self.rng.randint(2 ** 31))
+                trainer.seed_hogwild((hi << 32) | lo)
+                mode = _lib.MODE_HOGWILD
+            self.fit_stats = [trainer.fit_epochs_vebpr(self.max_iter, self.learning_rate, self.lambda_reg,
+                                                       self.alpha, mode)]
+            U, V, _ = trainer.get_factors()
+            self.u_factor[...] = U
+            self.i_factor[...] = V
+        finally:
+            trainer.close()
+        self._drop_scorer()
+        return self
+
+    def _scoring_tables(self):
+        return self.u_factor, self.i_factor, None, None
+
+    def _scorer_row(self, user_idx):
+        return int(user_idx) if user_idx is not None and 0 <= user_idx < len(self.u_factor) else None
+
+    def score(self, user_idx, item_idx=None):
+        if item_idx is None:
+            return self._get_scorer().score_user(user_idx)
+        return np.dot(self.u_factor[user_idx], self.i_factor[item_idx])

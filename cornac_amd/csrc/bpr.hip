@@ -539,6 +539,10 @@ struct cornac_hip_bpr {
     DevBuf<int64_t> wave_ptr;
     std::vector<int32_t> h_own_u, h_own_i;
     std::vector<int64_t> h_wave_ptr;
+    // VEBPR: view CSR + third sampler stream
+    bool has_views = false, view_seeded = false;
+    DevBuf<int32_t> v_indptr, v_indices, view_rank;
+    DevBuf<uint8_t> has_view;
 };
 
 static constexpr int64_t kDetChunk = int64_t(1) << 24;
@@ -672,11 +676,12 @@ int cornac_hip_bpr_seed_mt19937(cornac_hip_bpr_t h, uint32_t mt_seed_pos, uint32
         mt_init_genrand(mt_seed_pos, st.data());
         mt_init_genrand(mt_seed_neg, st.data() + MT_N);
         const int32_t idx[2] = {MT_N, MT_N};
-        h->mt_state.ensure(2 * MT_N);
-        h->mt_idx.ensure(2);
+        h->mt_state.ensure(3 * MT_N);  // [0] positive, [1] negative, [2] view (VEBPR)
+        h->mt_idx.ensure(3);
         h->mt_params.ensure(2);
         h->mt_state.upload(st.data(), 2 * MT_N, h->stream);
         h->mt_idx.upload(idx, 2, h->stream);
+        h->view_seeded = false;
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->mt_seeded = true;
         h->shared_stream = shared_stream != 0;
@@ -1129,3 +1134,5 @@ int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4) {
     });
 }
 }
+
+#include "vebpr.inc"

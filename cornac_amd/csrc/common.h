@@ -179,6 +179,11 @@ void build_level_schedule(const int32_t *su, const int32_t *si, const int32_t *s
                           std::vector<int32_t> &scratch_lvl_u, std::vector<int32_t> &scratch_lvl_i,
                           std::vector<int32_t> &scratch_level);
 
+void build_level_schedule4(const int32_t *su, const int32_t *si, const int32_t *sv, const int32_t *sj, int64_t n,
+                           int64_t n_users, int64_t n_items, int32_t *out_u, int32_t *out_i, int32_t *out_v,
+                           int32_t *out_j, LevelSchedule &sched, std::vector<int32_t> &scratch_lvl_u,
+                           std::vector<int32_t> &scratch_lvl_i, std::vector<int32_t> &scratch_level);
+
 // per-device properties cached at first use
 struct DeviceInfo {
     int cus = 256;

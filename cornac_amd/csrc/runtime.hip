@@ -87,6 +87,49 @@ void build_level_schedule(const int32_t *su, const int32_t *si, const int32_t *s
     sched.n_active = sched.level_ptr.back();
 }
 
+// 4-row variant (VEBPR: user, purchased item, viewed item or -1, negative item)
+void build_level_schedule4(const int32_t *su, const int32_t *si, const int32_t *sv, const int32_t *sj, int64_t n,
+                           int64_t n_users, int64_t n_items, int32_t *out_u, int32_t *out_i, int32_t *out_v,
+                           int32_t *out_j, LevelSchedule &sched, std::vector<int32_t> &lvl_u,
+                           std::vector<int32_t> &lvl_i, std::vector<int32_t> &level) {
+    lvl_u.assign((size_t)n_users, 0);
+    lvl_i.assign((size_t)n_items, 0);
+    level.resize((size_t)n);
+    int32_t max_level = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        const int32_t u = su[s];
+        if (u < 0) {
+            level[s] = 0;
+            continue;
+        }
+        const int32_t i = si[s], v = sv[s], j = sj[s];
+        int32_t l = std::max(std::max(lvl_u[u], lvl_i[i]), lvl_i[j]);
+        if (v >= 0) l = std::max(l, lvl_i[v]);
+        ++l;
+        lvl_u[u] = l;
+        lvl_i[i] = l;
+        lvl_i[j] = l;
+        if (v >= 0) lvl_i[v] = l;
+        level[s] = l;
+        max_level = std::max(max_level, l);
+    }
+    sched.level_ptr.assign((size_t)max_level + 2, 0);
+    for (int64_t s = 0; s < n; ++s)
+        if (level[s] > 0) ++sched.level_ptr[(size_t)level[s] + 1];
+    for (size_t l = 1; l < sched.level_ptr.size(); ++l) sched.level_ptr[l] += sched.level_ptr[l - 1];
+    std::vector<int64_t> cursor(sched.level_ptr.begin(), sched.level_ptr.end());
+    for (int64_t s = 0; s < n; ++s) {
+        const int32_t l = level[s];
+        if (l == 0) continue;
+        const int64_t pos = cursor[(size_t)l]++;
+        out_u[pos] = su[s];
+        out_i[pos] = si[s];
+        out_v[pos] = sv[s];
+        out_j[pos] = sj[s];
+    }
+    sched.n_active = sched.level_ptr.back();
+}
+
 }  // namespace chip
 
 extern "C" {

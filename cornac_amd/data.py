@@ -125,3 +125,31 @@ class _RangeMap:
 
     def items(self):
         return ((i, i) for i in range(self.n))
+
+
+class PurchaseViewDataset(Dataset):
+    """Purchases + a secondary "view" matrix in one id space — mirror of
+    cornac/data/dataset.py:1400-1521 (used by VEBPR).  View entries that are also purchases are
+    dropped, the view CSR has sorted indices."""
+
+    def __init__(self, dataset, view_matrix):
+        super().__init__(dataset.num_users, dataset.num_items, dataset.uid_map, dataset.iid_map, dataset.uir_tuple,
+                         timestamps=getattr(dataset, "timestamps", None), seed=getattr(dataset, "seed", None))
+        view_matrix = view_matrix - view_matrix.multiply(self.matrix > 0)
+        view_matrix.eliminate_zeros()
+        view_matrix.sort_indices()
+        self.view_matrix = view_matrix.tocsr()
+
+    @classmethod
+    def build(cls, purchase_data, view_data, seed=None):
+        gu, gi = OrderedDict(), OrderedDict()
+        purchase_set = Dataset.build(purchase_data, global_uid_map=gu, global_iid_map=gi, seed=seed)
+        view_set = Dataset.build(view_data, global_uid_map=gu, global_iid_map=gi, seed=seed)
+        full = Dataset(len(gu), len(gi), gu, gi, purchase_set.uir_tuple, seed=seed)
+        return cls(full, view_set.matrix)
+
+    @classmethod
+    def attach_view(cls, dataset, view_data):
+        view_set = Dataset.build(view_data, global_uid_map=dataset.uid_map, global_iid_map=dataset.iid_map,
+                                 exclude_unknowns=True)
+        return cls(dataset, view_set.matrix)

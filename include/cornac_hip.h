@@ -127,6 +127,21 @@ int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_m
 int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4);
 
 /* ------------------------------------------------------------------------- *
+ * VEBPR (view-enhanced BPR) on the same handle.
+ * Replaces: VEBPR._fit_sgd_viewloss(rng_pos, rng_view, rng_neg, ..., U, V)
+ *           cornac/models/bpr/recom_vebpr.pyx:211-337 and its caller loop :189-207.
+ * The handle's CSR is the purchase matrix; set_views adds the view matrix
+ * (train_set.view_matrix: views minus purchases, sorted rows,
+ * cornac/data/dataset.py:1400-1440).  No item biases.
+ * ------------------------------------------------------------------------- */
+int cornac_hip_bpr_set_views(cornac_hip_bpr_t h, const int32_t *view_indptr, const int32_t *view_indices,
+                             int64_t nnz_view);
+/* third mt19937 engine (rng_view, recom_vebpr.pyx:192); call after cornac_hip_bpr_seed_mt19937 */
+int cornac_hip_bpr_seed_view_stream(cornac_hip_bpr_t h, uint32_t mt_seed_view);
+int cornac_hip_vebpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, float alpha, int mode,
+                                int64_t *correct, int64_t *skipped);
+
+/* ------------------------------------------------------------------------- *
  * Matrix factorisation trainer.
  * Replaces: backend_cpu.fit_sgd(rid, cid, val, U, V, Bu, Bi, lr, reg, mu,
  *           max_iter, num_threads, use_bias, early_stop, verbose)

@@ -74,6 +74,9 @@ def _bind(L):
         L.oracle_bpr_epoch_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, i32p,
                                            i32p, i32p, i32p, f32p, f32p, f32p, C.c_int, C.c_float, C.c_float,
                                            C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.oracle_vebpr_epoch_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, i32p, i32p, i32p,
+                                             i32p, i32p, f32p, f32p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.oracle_mf_fit.argtypes = [i64p, i64p, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_fast_dot.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int, C.c_int]
@@ -209,6 +212,46 @@ class BPROracle:
 
 class WBPROracle(BPROracle):
     weighted = True
+
+
+class VEBPROracle:
+    """Seeded VEBPR (cornac/models/bpr/recom_vebpr.pyx:100-209): train_set must expose `matrix`
+    (purchases) and `view_matrix` (views minus purchases, sorted CSR)."""
+
+    def __init__(self, k=10, max_iter=100, learning_rate=0.01, lambda_reg=0.1, alpha=0.5, seed=None,
+                 init_params=None):
+        self.k, self.max_iter, self.lr, self.reg, self.alpha = int(k), max_iter, learning_rate, lambda_reg, float(alpha)
+        self.rng = np.random.RandomState(seed)
+        ip = init_params or {}
+        self.u_factor, self.i_factor = ip.get("U"), ip.get("V")
+
+    def fit(self, train_set):
+        L = lib()
+        nu, ni = len(train_set.uid_map), len(train_set.iid_map)
+        if self.u_factor is None:
+            self.u_factor = (_uniform((nu, self.k), self.rng) - 0.5) / self.k
+        if self.i_factor is None:
+            self.i_factor = (_uniform((ni, self.k), self.rng) - 0.5) / self.k
+        self.u_factor = np.ascontiguousarray(self.u_factor, np.float32)
+        self.i_factor = np.ascontiguousarray(self.i_factor, np.float32)
+        indptr, indices, user_ids = csr_arrays(train_set)
+        Vw = train_set.view_matrix
+        v_indptr = np.ascontiguousarray(Vw.indptr, np.int32)
+        v_indices = np.ascontiguousarray(Vw.indices, np.int32)
+        if len(v_indices) == 0:
+            v_indices = np.zeros(1, np.int32)
+        gp = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+        gv = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+        gn = MT19937(rngvector_seed(self.rng.randint(2 ** 31)))
+        self.correct, self.skipped = [], []
+        for _ in range(self.max_iter):
+            c, s = C.c_int64(), C.c_int64()
+            L.oracle_vebpr_epoch_seq(gp.ptr, gv.ptr, gn.ptr, len(user_ids), train_set.num_items, user_ids, indices,
+                                     indptr, v_indices, v_indptr, self.u_factor, self.i_factor, self.k, self.lr,
+                                     self.reg, self.alpha, C.byref(c), C.byref(s))
+            self.correct.append(c.value)
+            self.skipped.append(s.value)
+        return self
 
 
 def bpr_hogwild_epochs(indptr, indices, user_ids, n_items, U, V, B, k, lr, reg, use_bias, seed, num_threads,

@@ -97,6 +97,27 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
         print("wrote", name, {kk: getattr(vv, "shape", None) for kk, vv in list(fx.items())[:6]})
 
+    # VEBPR: purchases + views (some users without views -> BPR fallback branch), real reference
+    import importlib
+
+    RefPV = importlib.import_module("cornac.data").PurchaseViewDataset
+    RefVEBPR = importlib.import_module("cornac.models.bpr.recom_vebpr").VEBPR
+    for name, (nu, ni, n_p, n_v, nu_view, k, epochs, lr, reg, alpha, mseed) in {
+        "vebpr_small": (80, 60, 1200, 1500, 60, 8, 8, 0.05, 0.01, 0.5, 7),
+        "vebpr_odd": (150, 90, 2500, 2500, 150, 13, 5, 0.02, 0.05, 0.3, 11),
+    }.items():
+        pu, pi, _ = synth_pairs(nu, ni, n_p, 0.6, mseed)
+        vu, vi, _ = synth_pairs(nu_view, ni, n_v, 0.4, mseed + 100)
+        pur = [(int(a), int(b), 1.0) for a, b in zip(pu, pi)]
+        view = [(int(a), int(b), 1.0) for a, b in zip(vu, vi)]
+        ds = RefPV.build(pur, view, seed=1)
+        m = RefVEBPR(k=k, max_iter=epochs, learning_rate=lr, lambda_reg=reg, alpha=alpha, seed=mseed).fit(ds)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), pu=pu, pi=pi, vu=vu, vi=vi, k=np.int64(k),
+                            epochs=np.int64(epochs), lr=np.float64(lr), reg=np.float64(reg), alpha=np.float64(alpha),
+                            seed=np.int64(mseed), U=m.u_factor.copy(), V=m.i_factor.copy(),
+                            score0=m.score(0).astype(np.float32))
+        print("wrote", name)
+
     # the reference's own known-answer test for this path: tests/cornac/utils/test_fastdot.py:26-37
     vec = np.array([1, 2], np.float32)
     mat = np.array([[1, 2], [3, 4]], np.float32)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_dataset, load_golden, synth_dataset
-from cornac_amd import BPR, WBPR, _lib
+from cornac_amd import BPR, VEBPR, WBPR, PurchaseViewDataset, _lib
 
 pytestmark = pytest.mark.gpu
 CASES = ["tiny", "small", "odd_k", "ml100k_shape"]
@@ -293,3 +293,47 @@ def test_api_errors():
         _lib.BprTrainer(X.indptr, bad, ds.num_users, ds.num_items, ds.num_users, ds.num_items, 4)
     with pytest.raises(ValueError):
         BPR(mode="fast")
+
+
+def _vebpr_dataset(fx):
+    return PurchaseViewDataset.build([(int(a), int(b), 1.0) for a, b in zip(fx["pu"], fx["pi"])],
+                                     [(int(a), int(b), 1.0) for a, b in zip(fx["vu"], fx["vi"])], seed=1)
+
+
+@pytest.mark.parametrize("name", ["vebpr_small", "vebpr_odd"])
+def test_vebpr_deterministic_matches_oracle_and_reference_golden(oracle, name):
+    """three bit-faithful sampler streams (the view stream is consumed only by users with views),
+    4-row level schedule, the reference's mixed float/double update expressions."""
+    fx = load_golden(name)
+    ds = _vebpr_dataset(fx)
+    kw = dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]), lambda_reg=float(fx["reg"]),
+              alpha=float(fx["alpha"]), seed=int(fx["seed"]))
+    m = VEBPR(**kw).fit(ds)
+    o = oracle.VEBPROracle(**kw).fit(ds)
+    assert m.fit_stats[0] == (sum(o.correct), sum(o.skipped))
+    assert np.abs(m.u_factor - o.u_factor).max() <= 1e-6 and np.abs(m.i_factor - o.i_factor).max() <= 1e-6
+    assert np.mean(m.u_factor == o.u_factor) > 0.999
+    assert np.abs(m.u_factor - fx["U"]).max() <= 1e-4 and np.abs(m.i_factor - fx["V"]).max() <= 1e-4
+    assert np.abs(m.score(0) - fx["score0"]).max() < 2e-5
+
+
+def test_vebpr_hogwild_learns_like_the_sequential_oracle(oracle):
+    rs = np.random.RandomState(0)
+
+    def pairs(nu, ni, n, seed):
+        r = np.random.RandomState(seed)
+        keys = r.permutation(np.unique(r.randint(nu, size=3 * n).astype(np.int64) * ni + r.randint(ni, size=3 * n)))[:n]
+        return [(int(k // ni), int(k % ni), 1.0) for k in keys]
+
+    ds = PurchaseViewDataset.build(pairs(1500, 800, 60000, 1), pairs(1200, 800, 80000, 2), seed=1)
+    kw = dict(k=32, max_iter=12, learning_rate=0.05, lambda_reg=0.005, alpha=0.5)
+    o = oracle.VEBPROracle(seed=3, **kw).fit(ds)
+    m = VEBPR(seed=3, mode="hogwild", **kw).fit(ds)
+    c_o, s_o = sum(o.correct), sum(o.skipped)
+    c_m, s_m = m.fit_stats[0]
+    nnz = ds.matrix.nnz * 12
+    assert abs(s_m - s_o) < 0.05 * s_o + 100
+    assert abs(c_m / (nnz - s_m) - c_o / (nnz - s_o)) < 0.03, (c_m / (nnz - s_m), c_o / (nnz - s_o))
+    assert np.isfinite(m.u_factor).all()
+    with pytest.raises(ValueError):
+        VEBPR().fit(synth_dataset(20, 15, 100, seed=1))

@@ -122,3 +122,17 @@ def test_numpy_seeding_equals_mt19937_init_genrand(oracle):
         raw = oracle.MT19937(seed).raw(8)
         rs = np.random.RandomState(seed)
         assert np.array_equal(raw, rs.randint(0, 2 ** 32, size=8, dtype=np.uint64).astype(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["vebpr_small", "vebpr_odd"])
+def test_vebpr_oracle_matches_reference_golden(oracle, name):
+    from cornac_amd import PurchaseViewDataset
+
+    fx = load_golden(name)
+    ds = PurchaseViewDataset.build([(int(a), int(b), 1.0) for a, b in zip(fx["pu"], fx["pi"])],
+                                   [(int(a), int(b), 1.0) for a, b in zip(fx["vu"], fx["vi"])], seed=1)
+    assert (np.diff(ds.view_matrix.indptr) == 0).any() or name == "vebpr_odd"
+    o = oracle.VEBPROracle(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+                           lambda_reg=float(fx["reg"]), alpha=float(fx["alpha"]), seed=int(fx["seed"])).fit(ds)
+    assert_close(o.u_factor, fx["U"])
+    assert_close(o.i_factor, fx["V"])
