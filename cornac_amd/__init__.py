@@ -9,7 +9,8 @@ from .data import Dataset, PurchaseViewDataset
 from .recommender import Recommender, ScoreException
 from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
+from .vbpr import VBPR
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR"]
 __version__ = "0.1.0"

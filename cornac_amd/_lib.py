@@ -28,6 +28,8 @@ SYMBOLS = [
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs",
+    "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
+    "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -98,6 +100,13 @@ def lib():
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.cornac_hip_vbpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _f32]
+        L.cornac_hip_vbpr_destroy.argtypes = [_vp]
+        L.cornac_hip_vbpr_set_params.argtypes = [_vp] + [_vp] * 6
+        L.cornac_hip_vbpr_get_params.argtypes = [_vp] + [_vp] * 6
+        L.cornac_hip_vbpr_fit_batches.argtypes = [_vp, _i32, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float,
+                                                  C.c_float, C.c_float, C.POINTER(C.c_double)]
+        L.cornac_hip_vbpr_item_tables.argtypes = [_vp, _f32, _f32]
         L.cornac_hip_mf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i64, _f32,
                                            C.c_int64]
         L.cornac_hip_mf_destroy.argtypes = [_vp]
@@ -368,3 +377,53 @@ class Scorer:
         ms = C.c_double()
         check(lib().cornac_hip_rank_topk_device(self.h, u0, n, topk, repeats, C.byref(ms)))
         return ms.value
+
+
+class VbprTrainer:
+    NAMES = ("Bi", "Gu", "Gi", "Tu", "E", "Bp")
+
+    def __init__(self, features, n_users, n_items, k, k2, device=0):
+        self.F = np.ascontiguousarray(features, np.float32)
+        assert self.F.shape[0] == n_items
+        self.dims = dict(n_users=int(n_users), n_items=int(n_items), k=int(k), k2=int(k2), n_feat=self.F.shape[1])
+        self.h = _vp()
+        check(lib().cornac_hip_vbpr_create(C.byref(self.h), device, n_users, n_items, k, k2, self.F.shape[1], self.F))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().cornac_hip_vbpr_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _shapes(self):
+        d = self.dims
+        return {"Bi": (d["n_items"],), "Gu": (d["n_users"], d["k"]), "Gi": (d["n_items"], d["k"]),
+                "Tu": (d["n_users"], d["k2"]), "E": (d["n_feat"], d["k2"]), "Bp": (d["n_feat"],)}
+
+    def set_params(self, **params):
+        arrs = []
+        for n in self.NAMES:
+            a = params.get(n)
+            if a is not None:
+                a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(self._shapes()[n]))
+            arrs.append(a)
+        check(lib().cornac_hip_vbpr_set_params(self.h, *[_ptr(a) for a in arrs]))
+
+    def get_params(self):
+        out = {n: np.empty(s, np.float32) for n, s in self._shapes().items()}
+        check(lib().cornac_hip_vbpr_get_params(self.h, *[out[n].ctypes.data for n in self.NAMES]))
+        return out
+
+    def fit_batches(self, u, i, j, batch_size, lr, lambda_w, lambda_b, lambda_e):
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        nll = C.c_double()
+        check(lib().cornac_hip_vbpr_fit_batches(self.h, u, i, j, len(u), batch_size, lr, lambda_w, lambda_b, lambda_e,
+                                                C.byref(nll)))
+        return nll.value
+
+    def item_tables(self):
+        d = self.dims
+        th, vb = np.empty((d["n_items"], d["k2"]), np.float32), np.empty(d["n_items"], np.float32)
+        check(lib().cornac_hip_vbpr_item_tables(self.h, th, vb))
+        return th, vb

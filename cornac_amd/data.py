@@ -98,6 +98,58 @@ class Dataset:
     def item_ids(self):
         return list(self.iid_map.keys())
 
+    # ---- batch iterators used by minibatch models (VBPR) -------------------------------------------
+    item_image = None  # optional modality: any object with a `.features` [n_items, d] array
+
+    def num_batches(self, batch_size):
+        return int(np.ceil(len(self.uir_tuple[0]) / batch_size))
+
+    @property
+    def dok(self):
+        """{(user, item): rating} — what the reference's `dok_matrix` lookups return (dataset.py:237-245)"""
+        if getattr(self, "_dok", None) is None:
+            u, i, r = self.uir_tuple
+            self._dok = dict(zip(zip(u.tolist(), i.tolist()), r.tolist()))
+        return self._dok
+
+    def idx_iter(self, idx_range, batch_size=1, shuffle=False):
+        """dataset.py:418-443: one `rng.shuffle` of arange(idx_range), then consecutive slices"""
+        indices = np.arange(idx_range)
+        if shuffle:
+            self.rng.shuffle(indices)
+        for b in range(int(np.ceil(len(indices) / batch_size))):
+            yield indices[batch_size * b: min(batch_size * b + batch_size, len(indices))]
+
+    def uij_iter(self, batch_size=1, shuffle=False, neg_sampling="uniform"):
+        """(users, positive items, negative items) batches, reproducing the reference's sampler
+        draw for draw (dataset.py:490-526): per observation `rng.choice(neg_population)`, redrawn
+        while the user's rating of the drawn item is >= the positive's rating."""
+        if neg_sampling.lower() == "uniform":
+            neg_population = np.arange(self.num_items)
+        elif neg_sampling.lower() == "popularity":
+            neg_population = self.uir_tuple[1]
+        else:
+            raise ValueError("Unsupported negative sampling option: {}".format(neg_sampling))
+        dok = self.dok
+        for batch_ids in self.idx_iter(len(self.uir_tuple[0]), batch_size, shuffle):
+            batch_users = self.uir_tuple[0][batch_ids]
+            batch_pos_items = self.uir_tuple[1][batch_ids]
+            batch_pos_ratings = self.uir_tuple[2][batch_ids]
+            batch_neg_items = np.empty_like(batch_pos_items)
+            for t, (user, pos_rating) in enumerate(zip(batch_users.tolist(), batch_pos_ratings.tolist())):
+                neg_item = self.rng.choice(neg_population)
+                while dok.get((user, int(neg_item)), 0.0) >= pos_rating:
+                    neg_item = self.rng.choice(neg_population)
+                batch_neg_items[t] = neg_item
+            yield batch_users, batch_pos_items, batch_neg_items
+
+
+class ImageFeatures:
+    """Minimal stand-in for cornac.data.ImageModality: item visual features [n_items, d]."""
+
+    def __init__(self, features):
+        self.features = np.asarray(features)
+
 
 class _RangeMap:
     """Identity raw-id -> index map over range(n) that behaves like the OrderedDict id maps

@@ -170,6 +170,32 @@ int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms,
 int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 
 /* ------------------------------------------------------------------------- *
+ * VBPR (visual BPR) minibatch trainer.
+ * Replaces: the per-batch body of VBPR._fit_torch (forward, autograd backward,
+ *           torch.optim.Adam step over all tables) cornac/models/vbpr/recom_vbpr.py:228-262.
+ * The (u, i, j) batches are produced by the host sampler Dataset.uij_iter
+ * (cornac/data/dataset.py:490-526) exactly as in the reference and handed over
+ * per call; Adam moments and the step counter persist in the handle.
+ * ------------------------------------------------------------------------- */
+typedef struct cornac_hip_vbpr *cornac_hip_vbpr_t;
+
+/* features: item visual features [n_items, n_feat] fp32 (train_set.item_image.features) */
+int cornac_hip_vbpr_create(cornac_hip_vbpr_t *out, int device, int64_t n_users, int64_t n_items, int k, int k2,
+                           int n_feat, const float *features);
+int cornac_hip_vbpr_destroy(cornac_hip_vbpr_t h);
+/* Bi [n_items], Gu [n_users,k], Gi [n_items,k], Tu [n_users,k2], E [n_feat,k2], Bp [n_feat]; NULL skips */
+int cornac_hip_vbpr_set_params(cornac_hip_vbpr_t h, const float *Bi, const float *Gu, const float *Gi, const float *Tu,
+                               const float *E, const float *Bp);
+int cornac_hip_vbpr_get_params(cornac_hip_vbpr_t h, float *Bi, float *Gu, float *Gi, float *Tu, float *E, float *Bp);
+/* runs ceil(n_total / batch_size) Adam steps over consecutive batches of the triplet arrays;
+ * sum_nll (may be NULL) receives sum over all triplets of -logsigmoid(x_uij) */
+int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int32_t *i, const int32_t *j,
+                                int64_t n_total, int batch_size, float lr, float lambda_w, float lambda_b,
+                                float lambda_e, double *sum_nll);
+/* theta_item = F E [n_items, k2], visual_bias = F Bp [n_items] (recom_vbpr.py:132-133) */
+int cornac_hip_vbpr_item_tables(cornac_hip_vbpr_t h, float *theta_item, float *visual_bias);
+
+/* ------------------------------------------------------------------------- *
  * Scoring / ranking.
  * Replaces: fast_dot(vec, mat, output)  cornac/utils/fast_dot.pyx:40-43 as used by
  *           BPR.score (recom_bpr.pyx:288-291) and MF.score (recom_mf.py:273-278),

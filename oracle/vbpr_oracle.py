@@ -1,0 +1,84 @@
+"""TEST INFRASTRUCTURE ONLY — oracle of the VBPR path (cornac/models/vbpr/recom_vbpr.py:116-275).
+
+VBPR's arithmetic lives in a third-party dependency, PyTorch (`torch>=0.4.1`,
+cornac/models/vbpr/requirements.txt): minibatch autograd + `torch.optim.Adam` over ALL tables.
+torch (CPU) is present on every box this repo runs on, so the oracle restates `_fit_torch` with the
+same torch operations in the same order; the sampler (`Dataset.uij_iter`, cornac/data/dataset.py:490-526)
+is restated in cornac_amd/data.py and validated draw-for-draw against the reference's
+(tests/test_oracle_vs_reference.py).  The reference's own tests never touch VBPR ("parity unpinned" by
+its test-suite); this oracle is pinned against the live reference here
+(tests/test_oracle_vs_reference.py::test_vbpr_oracle_matches_live_reference) and by goldens the real
+reference produced (tests/golden/vbpr_small.npz).
+"""
+import numpy as np
+
+
+def xavier_uniform(shape, rng):
+    # cornac/utils/init_utils.py:116-144
+    std = np.sqrt(2.0 / np.sum(shape))
+    limit = np.sqrt(3.0) * std
+    return rng.uniform(-limit, limit, shape).astype(np.float32)
+
+
+class VBPROracle:
+    def __init__(self, k=10, k2=10, n_epochs=50, batch_size=100, learning_rate=0.005, lambda_w=0.01, lambda_b=0.01,
+                 lambda_e=0.0, seed=None):
+        self.k, self.k2, self.n_epochs, self.batch_size = k, k2, n_epochs, batch_size
+        self.lr, self.lambda_w, self.lambda_b, self.lambda_e, self.seed = learning_rate, lambda_w, lambda_b, lambda_e, seed
+
+    def init(self, n_users, n_items, features):
+        rng = np.random.RandomState(self.seed)  # get_rng(seed), recom_vbpr.py:117
+        self.beta_item = np.zeros(n_items)       # zeros() -> float64 like the reference (init_utils.zeros default)
+        self.gamma_user = xavier_uniform((n_users, self.k), rng)
+        self.gamma_item = xavier_uniform((n_items, self.k), rng)
+        self.theta_user = xavier_uniform((n_users, self.k2), rng)
+        self.emb_matrix = xavier_uniform((features.shape[1], self.k2), rng)
+        self.beta_prime = xavier_uniform((features.shape[1], 1), rng)
+
+    def fit(self, train_set, batches=None, record_batches=False):
+        import torch
+
+        train_set.reset()  # Recommender.fit re-seeds the dataset RNG (recommender.py:327)
+        F_np = np.asarray(train_set.item_image.features[: len(train_set.iid_map)]).astype(np.float32)
+        self.init(len(train_set.uid_map), len(train_set.iid_map), F_np)
+        dt = torch.float
+        F = torch.tensor(F_np, dtype=dt)
+        Bi = torch.tensor(self.beta_item, dtype=dt, requires_grad=True)
+        Gu = torch.tensor(self.gamma_user, dtype=dt, requires_grad=True)
+        Gi = torch.tensor(self.gamma_item, dtype=dt, requires_grad=True)
+        Tu = torch.tensor(self.theta_user, dtype=dt, requires_grad=True)
+        E = torch.tensor(self.emb_matrix, dtype=dt, requires_grad=True)
+        Bp = torch.tensor(self.beta_prime, dtype=dt, requires_grad=True)
+        opt = torch.optim.Adam([Bi, Gu, Gi, Tu, E, Bp], lr=self.lr)
+
+        def l2(*ts):
+            return sum(t.pow(2).sum() for t in ts) / 2
+
+        self.batches, self.losses = [], []
+        for epoch in range(self.n_epochs):
+            it = batches[epoch] if batches is not None else train_set.uij_iter(self.batch_size, shuffle=True)
+            for bu, bi, bj in it:
+                if record_batches:
+                    self.batches.append((np.array(bu), np.array(bi), np.array(bj)))
+                gu, tu = Gu[bu], Tu[bu]
+                beta_i, beta_j = Bi[bi], Bi[bj]
+                gi, gj = Gi[bi], Gi[bj]
+                gamma_diff = gi - gj
+                feat_diff = F[bi] - F[bj]
+                X = (beta_i - beta_j + (gu * gamma_diff).sum(dim=1) + (tu * feat_diff.mm(E)).sum(dim=1)
+                     + feat_diff.mm(Bp))
+                ll = torch.nn.functional.logsigmoid(X).sum()
+                reg = (l2(gu, gi, gj, tu) * self.lambda_w + l2(beta_i) * self.lambda_b
+                       + l2(beta_j) * self.lambda_b / 10 + l2(E, Bp) * self.lambda_e)
+                loss = -ll + reg
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                self.losses.append(float(loss.data.item()))
+        self.beta_item = Bi.data.numpy().copy()
+        self.gamma_user, self.gamma_item = Gu.data.numpy().copy(), Gi.data.numpy().copy()
+        self.theta_user = Tu.data.numpy().copy()
+        self.emb_matrix, self.beta_prime = E.data.numpy().copy(), Bp.data.numpy().copy()
+        self.theta_item = F.mm(E).data.numpy()
+        self.visual_bias = F.mm(Bp).data.numpy().ravel()
+        return self

@@ -118,6 +118,25 @@ def main():
                             score0=m.score(0).astype(np.float32))
         print("wrote", name)
 
+    # VBPR (torch autograd + Adam in the reference): small case with visual features
+    import types
+
+    RefVBPR = importlib.import_module("cornac.models.vbpr").VBPR
+    rs = np.random.RandomState(3)
+    vu, vi, vr = synth_pairs(40, 30, 400, 0.5, 21)
+    vr = (1 + (vu + vi) % 3).astype(np.float64)
+    feats = rs.uniform(0, 1, (30, 50)).astype(np.float32)
+    ds = ns.Dataset.from_uir([(int(a), int(b), float(c)) for a, b, c in zip(vu, vi, vr)], seed=5)
+    ds.item_image = types.SimpleNamespace(features=feats)
+    kw = dict(k=6, k2=5, n_epochs=4, batch_size=50, learning_rate=0.01, lambda_w=0.01, lambda_b=0.01, lambda_e=0.001,
+              seed=9)
+    m = RefVBPR(verbose=False, **kw).fit(ds)
+    np.savez_compressed(os.path.join(OUT, "vbpr_small.npz"), users=vu, items=vi, ratings=vr, features=feats,
+                        Bi=m.beta_item, Gu=m.gamma_user, Gi=m.gamma_item, Tu=m.theta_user, E=m.emb_matrix,
+                        Bp=m.beta_prime, theta_item=m.theta_item, visual_bias=m.visual_bias,
+                        score0=m.score(0).astype(np.float32), **{k_: np.float64(v_) for k_, v_ in kw.items()})
+    print("wrote vbpr_small")
+
     # the reference's own known-answer test for this path: tests/cornac/utils/test_fastdot.py:26-37
     vec = np.array([1, 2], np.float32)
     mat = np.array([[1, 2], [3, 4]], np.float32)

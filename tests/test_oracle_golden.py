@@ -136,3 +136,29 @@ def test_vebpr_oracle_matches_reference_golden(oracle, name):
                            lambda_reg=float(fx["reg"]), alpha=float(fx["alpha"]), seed=int(fx["seed"])).fit(ds)
     assert_close(o.u_factor, fx["U"])
     assert_close(o.i_factor, fx["V"])
+
+
+def _vbpr_case():
+    from cornac_amd.data import Dataset, ImageFeatures
+
+    fx = load_golden("vbpr_small")
+    ds = Dataset.from_uir([(int(a), int(b), float(c)) for a, b, c in zip(fx["users"], fx["items"], fx["ratings"])],
+                          seed=5)
+    ds.item_image = ImageFeatures(fx["features"])
+    kw = dict(k=int(fx["k"]), k2=int(fx["k2"]), n_epochs=int(fx["n_epochs"]), batch_size=int(fx["batch_size"]),
+              learning_rate=float(fx["learning_rate"]), lambda_w=float(fx["lambda_w"]), lambda_b=float(fx["lambda_b"]),
+              lambda_e=float(fx["lambda_e"]), seed=int(fx["seed"]))
+    return fx, ds, kw
+
+
+def test_vbpr_oracle_matches_reference_golden():
+    """torch restatement of VBPR._fit_torch + the mirrored uij_iter sampler == what the real reference
+    learned (same torch kernels => agreement to float rounding)."""
+    from oracle.vbpr_oracle import VBPROracle
+
+    fx, ds, kw = _vbpr_case()
+    o = VBPROracle(**kw).fit(ds)
+    for name, key in (("beta_item", "Bi"), ("gamma_user", "Gu"), ("gamma_item", "Gi"), ("theta_user", "Tu"),
+                      ("emb_matrix", "E"), ("beta_prime", "Bp"), ("theta_item", "theta_item"),
+                      ("visual_bias", "visual_bias")):
+        assert np.abs(getattr(o, name) - fx[key]).max() < 1e-6, name
