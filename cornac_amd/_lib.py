@@ -64,6 +64,31 @@ _i64 = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _vp = C.c_void_p
 
 
+def _preload_torch_hip_runtime():
+    """One process must use ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so; if
+    torch is imported after this library has pulled in /opt/rocm's copy, torch finds no GPUs (and the other
+    way round works).  So when a torch wheel with a bundled runtime is installed, load that copy first
+    (by path, without importing torch); the multi-GPU driver (torch.distributed + this library in one
+    process) then shares it."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    except Exception:
+        return
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load the shared library (raises if it has not been built — no CPU fallback)."""
     global _lib
@@ -72,6 +97,7 @@ def lib():
             raise RuntimeError(
                 "libcornac_hip.so not found at %s. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C cornac_amd/csrc`. cornac_amd has no CPU fallback." % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.cornac_hip_last_error.restype = C.c_char_p
         L.cornac_hip_version.restype = C.c_char_p

@@ -9,9 +9,13 @@ reconciled with RCCL all-reduce of its deltas (regime 1 "item ta
   * RCCL runs over xGMI via torch.distributed (backend "nccl"); on CPU-only hosts the same code
     path runs over gloo with a host stand-in for the trainer (tests/test_dist_cpu.py).
 
-The trainer kernels are launched on torch's current stream (cornac_hip_bpr_set_stream) so the
-delta computation, the collective and the next chunk are stream-ordered without host syncs.
+The trainer kernels, the delta computation and the collective all run on ONE dedicated torch stream
+(handed to the library with cornac_hip_bpr_set_stream), so chunk -> delta -> all-reduce -> rebase ->
+next chunk is stream-ordered without host syncs.  (torch's default stream is the NULL stream, which
+the C ABI reserves for "use the handle's own stream" — hence the explicit side stream.)
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -59,24 +63,38 @@ class ShardedBprTrainer:
         self.table = ItemTableReplica(total_items, k, device, group)
         self.sync_every = int(sync_every)
         self.device = device
-        if device.type == "cuda" and trainer is not None:
-            trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
-            trainer.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.stream = None
+        if device.type == "cuda":
+            self.stream = torch.cuda.Stream(device)
+            if trainer is not None:
+                torch.cuda.synchronize(device)
+                trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
+                trainer.set_stream(self.stream.cuda_stream)
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def load_items(self, V, B):
-        self.table.load(V, B)
+        with self._on_stream():
+            self.table.load(V, B)
+        if self.stream is not None:
+            self.stream.synchronize()
 
     def run(self, n_samples, lr, reg, use_bias=True, neg_population=0, flags=0):
         """enqueue n_samples hogwild samples in sync_every-sized chunks with a table sync after each"""
         left = int(n_samples)
-        while left > 0:
-            n = min(left, self.sync_every)
-            self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
-            self.table.sync()
-            left -= n
+        with self._on_stream():
+            while left > 0:
+                n = min(left, self.sync_every)
+                self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
+                self.table.sync()
+                left -= n
 
     def finish(self):
-        return self.trainer.sync()
+        out = self.trainer.sync()
+        if self.stream is not None:
+            self.stream.synchronize()
+        return out
 
 
 def partition_users_by_nnz(indptr, world_size):

@@ -337,3 +337,47 @@ def test_vebpr_hogwild_learns_like_the_sequential_oracle(oracle):
     assert np.isfinite(m.u_factor).all()
     with pytest.raises(ValueError):
         VEBPR().fit(synth_dataset(20, 15, 100, seed=1))
+
+
+def test_sharded_trainer_single_rank_stream_ordering():
+    """the multi-GPU driver on one rank (NCCL group of size 1): kernels write the torch-owned item table on the
+    driver's side stream, interleaved with delta / all-reduce / rebase ops.  With reg = 0 the column sums of V
+    and the sum of B are conserved by exact updates; a mis-ordered rebase would break them."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from cornac_amd import synth
+    from cornac_amd.dist import ShardedBprTrainer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n_users, n_items, k = 6000, 3000, 64
+        users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
+        indptr, indices = synth.csr_from_sorted(users, items, n_users)
+        rs = np.random.RandomState(0)
+        U = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+        V = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.set_factors(U, V, np.zeros(n_items, np.float32))
+        tr.seed_hogwild(5)
+        sh = ShardedBprTrainer(tr, n_items, k, dev, sync_every=100_000)
+        sh.load_items(V, np.zeros(n_items, np.float32))
+        for _ in range(3):
+            sh.run(len(indices), 0.05, 0.0)
+        c, s = sh.finish()
+        V2 = sh.table.V.cpu().numpy()
+        B2 = sh.table.B.cpu().numpy()
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+    assert 0 < s < 0.2 * 3 * len(indices) and c > 0
+    assert np.abs(V2 - V).max() > 1e-3
+    moved = np.abs(V2.astype(np.float64) - V).sum(0)
+    assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+    assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
