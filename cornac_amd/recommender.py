@@ -37,6 +37,9 @@ def clip(values, lower_bound, upper_bound):
 
 
 class Recommender:
+    # what prediction needs to remember about the training set (recommender.py:330-337)
+    _DATASET_FACTS = ("num_users", "num_items", "uid_map", "iid_map", "min_rating", "max_rating", "global_mean")
+
     def __init__(self, name, trainable=True, verbose=False):
         self.name = name
         self.trainable = trainable
@@ -44,13 +47,8 @@ class Recommender:
         self.is_fitted = False
         # not pickled / deep-copied: datasets and device-side state
         self.ignored_attrs = ["train_set", "val_set", "test_set", "_scorer", "_scorer_key", "_trainer"]
-        self.num_users = None
-        self.num_items = None
-        self.uid_map = None
-        self.iid_map = None
-        self.max_rating = None
-        self.min_rating = None
-        self.global_mean = None
+        for attr in self._DATASET_FACTS:
+            setattr(self, attr, None)
         self._item_ids = None
 
     # ---- bookkeeping -------------------------------------------------------------------------
@@ -110,25 +108,23 @@ class Recommender:
         """Pickle the model (+ .meta json, optional .trainset) under save_dir/<name>/ (recommender.py:223-276)."""
         if save_dir is None:
             return None
-        model_dir = os.path.join(save_dir, self.name)
-        os.makedirs(model_dir, exist_ok=True)
-        stamp = datetime.now().strftime("%Y-%m-%d_%H-%M-%S-%f")
-        model_file = os.path.join(model_dir, "{}.pkl".format(stamp))
-        saved = copy.deepcopy(self)
-        with open(model_file, "wb") as f:
-            pickle.dump(saved, f, protocol=pickle.HIGHEST_PROTOCOL)
+        folder = os.path.join(save_dir, self.name)
+        os.makedirs(folder, exist_ok=True)
+        model_file = os.path.join(folder, datetime.now().strftime("%Y-%m-%d_%H-%M-%S-%f") + ".pkl")
+
+        def dump(obj, path):
+            with open(path, "wb") as fh:
+                pickle.dump(obj, fh, protocol=pickle.HIGHEST_PROTOCOL)
+
+        dump(copy.deepcopy(self), model_file)  # deep copy drops ignored_attrs (datasets, device handles)
+        meta = dict(metadata or {}, model_classname=type(self).__name__, model_file=os.path.basename(model_file))
+        if save_trainset:
+            dump(self.train_set, model_file + ".trainset")
+            meta["trainset_file"] = os.path.basename(model_file) + ".trainset"
+        with open(model_file + ".meta", "w", encoding="utf-8") as fh:
+            json.dump(meta, fh, ensure_ascii=False, indent=4)
         if self.verbose:
             print("{} model is saved to {}".format(self.name, model_file))
-        metadata = {} if metadata is None else metadata
-        metadata["model_classname"] = type(saved).__name__
-        metadata["model_file"] = os.path.basename(model_file)
-        if save_trainset:
-            trainset_file = model_file + ".trainset"
-            with open(trainset_file, "wb") as f:
-                pickle.dump(self.train_set, f, protocol=pickle.HIGHEST_PROTOCOL)
-            metadata["trainset_file"] = os.path.basename(trainset_file)
-        with open(model_file + ".meta", "w", encoding="utf-8") as f:
-            json.dump(metadata, f, ensure_ascii=False, indent=4)
         return model_file
 
     @staticmethod
@@ -149,18 +145,12 @@ class Recommender:
         if self.is_fitted:
             warnings.warn("Model is already fitted. Re-fitting will overwrite the previous model.")
         self.reset_info()
-        train_set.reset()
-        if val_set is not None:
-            val_set.reset()
-        self.num_users = train_set.num_users
-        self.num_items = train_set.num_items
-        self.uid_map = train_set.uid_map
-        self.iid_map = train_set.iid_map
-        self.min_rating = train_set.min_rating
-        self.max_rating = train_set.max_rating
-        self.global_mean = train_set.global_mean
-        self.train_set = train_set
-        self.val_set = val_set
+        for ds in (train_set, val_set):
+            if ds is not None:
+                ds.reset()  # re-seed the dataset samplers for reproducibility
+        for attr in self._DATASET_FACTS:
+            setattr(self, attr, getattr(train_set, attr))
+        self.train_set, self.val_set = train_set, val_set
         self.is_fitted = True
         self._item_ids = None
         self._drop_scorer()
@@ -297,17 +287,15 @@ class Recommender:
         user_idx = self.uid_map.get(user_id, -1)
         if user_idx == -1:
             raise ValueError(f"{user_id} is unknown to the model.")
-        if k < -1 or k > self.total_items:
+        if not -1 <= k <= self.total_items:
             raise ValueError(f"k={k} is invalid, there are {self.total_users} users in total.")
-        item_indices = np.arange(self.total_items)
+        candidates = np.arange(self.total_items)
         if remove_seen:
             if train_set is None:
                 raise ValueError("train_set must be provided to remove seen items.")
-            seen = np.zeros(len(item_indices), dtype=bool)
-            if user_idx < train_set.csr_matrix.shape[0]:
-                seen[train_set.csr_matrix.getrow(user_idx).indices] = True
-                item_indices = item_indices[~seen]
-        item_rank, _ = self.rank(user_idx, item_indices)
-        if k != -1:
-            item_rank = item_rank[:k]
-        return [self.item_ids[i] for i in item_rank]
+            X = train_set.csr_matrix
+            if user_idx < X.shape[0]:
+                candidates = np.setdiff1d(candidates, X.indices[X.indptr[user_idx]:X.indptr[user_idx + 1]])
+        ranked, _ = self.rank(user_idx, candidates, k=k)
+        names = self.item_ids
+        return [names[i] for i in ranked]

@@ -109,3 +109,44 @@ def test_rank_full_size_fused_equals_materialised(oracle, ml20m):
         assert not np.intersect1d(items_x[b], seen).size
     assert (np.diff(scores, axis=1) <= 0).all()
     sc.close()
+
+
+def test_hogwild_full_size_statistical_parity_with_cpu_threads(oracle, ml20m):
+    """Throughput mode at BASELINE size vs the reference's OpenMP Hogwild path (CPU port, all host
+    threads): same data, init, hyper-parameters and epochs -> same pairwise loss / accuracy on a fixed
+    sample of (u, i, j) and the same per-epoch 'correct' fraction, within noise."""
+    n_users, n_items, indptr, indices, init_factors = ml20m
+    k, lr, reg, epochs = 64, 0.05, 0.01, 4
+    nnz = len(indices)
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+
+    def sample_loss(U, V, B, n=200000):
+        rs = np.random.RandomState(1)
+        pick = rs.randint(nnz, size=n)
+        u, i = user_ids[pick], indices[pick]
+        j = rs.randint(n_items, size=n)
+        x = B[i] - B[j] + np.einsum("nk,nk->n", U[u], V[i] - V[j])
+        return float(np.mean(np.log1p(np.exp(-x)))), float(np.mean(x > 0))
+
+    U, V, B = init_factors(n_users, n_items, k, 3)
+    l0, _ = sample_loss(U, V, B)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(11)
+    tr.fit_epochs(epochs - 1, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c_gpu, s_gpu = tr.fit_epochs(1, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    Ug, Vg, Bg = tr.get_factors()
+    tr.close()
+    Uc, Vc, Bc = init_factors(n_users, n_items, k, 3)
+    threads = min(32, oracle.lib().oracle_num_threads())
+    oracle.bpr_hogwild_epochs(indptr, indices, user_ids, n_items, Uc, Vc, Bc, k, lr, reg, True, 5, threads, epochs - 1)
+    c_cpu, s_cpu = oracle.bpr_hogwild_epochs(indptr, indices, user_ids, n_items, Uc, Vc, Bc, k, lr, reg, True, 6,
+                                             threads, 1)
+    lg, ag = sample_loss(Ug, Vg, Bg)
+    lc, ac = sample_loss(Uc, Vc, Bc)
+    print("full-size hogwild parity: loss0 %.4f gpu %.4f cpu %.4f | acc gpu %.4f cpu %.4f | correct gpu %.4f cpu %.4f"
+          % (l0, lg, lc, ag, ac, c_gpu / (nnz - s_gpu), c_cpu / (nnz - s_cpu)))
+    assert lc < 0.97 * l0, "the task must be learnable for the gate to mean anything"
+    assert abs(lg - lc) < 0.03 * l0 and abs(ag - ac) < 0.015
+    assert abs(c_gpu / (nnz - s_gpu) - c_cpu / (nnz - s_cpu)) < 0.015
+    assert abs(s_gpu - s_cpu) < 0.02 * s_cpu
