@@ -30,6 +30,8 @@ SYMBOLS = [
     "cornac_hip_vebpr_fit_epochs",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
+    "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
+    "cornac_hip_wmf_fit_batches", "cornac_hip_wmf_kernel_timing", "cornac_hip_wmf_last_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -133,6 +135,16 @@ def lib():
         L.cornac_hip_vbpr_fit_batches.argtypes = [_vp, _i32, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float,
                                                   C.c_float, C.c_float, C.POINTER(C.c_double)]
         L.cornac_hip_vbpr_item_tables.argtypes = [_vp, _f32, _f32]
+        L.cornac_hip_wmf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i32, _f32,
+                                            C.c_int64]
+        L.cornac_hip_wmf_destroy.argtypes = [_vp]
+        L.cornac_hip_wmf_destroy.restype = None
+        L.cornac_hip_wmf_set_factors.argtypes = [_vp, _f32, _f32]
+        L.cornac_hip_wmf_get_factors.argtypes = [_vp, _f32, _f32]
+        L.cornac_hip_wmf_fit_batches.argtypes = [_vp, _i32, _i64, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, _vp]
+        L.cornac_hip_wmf_kernel_timing.argtypes = [_vp, C.c_int]
+        L.cornac_hip_wmf_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
         L.cornac_hip_mf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i64, _f32,
                                            C.c_int64]
         L.cornac_hip_mf_destroy.argtypes = [_vp]
@@ -453,3 +465,57 @@ class VbprTrainer:
         th, vb = np.empty((d["n_items"], d["k2"]), np.float32), np.empty(d["n_items"], np.float32)
         check(lib().cornac_hip_vbpr_item_tables(self.h, th, vb))
         return th, vb
+
+
+class WmfTrainer:
+    """Resident WMF trainer: CSC rating matrix, U/V and the Adam state live on the device."""
+
+    def __init__(self, csc, k, device=0):
+        csc = csc.tocsc()
+        self.n_users, self.n_items = (int(x) for x in csc.shape)
+        self.k = int(k)
+        self._indptr = np.ascontiguousarray(csc.indptr, np.int64)
+        self._rows = np.ascontiguousarray(csc.indices, np.int32)
+        self._vals = np.ascontiguousarray(csc.data, np.float32)
+        self.h = _vp()
+        check(lib().cornac_hip_wmf_create(C.byref(self.h), device, self.n_users, self.n_items, self.k, self._indptr,
+                                          self._rows if len(self._rows) else np.zeros(1, np.int32),
+                                          self._vals if len(self._vals) else np.zeros(1, np.float32), len(self._vals)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().cornac_hip_wmf_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_factors(self, U, V):
+        U = np.ascontiguousarray(np.asarray(U, np.float32).reshape(self.n_users, self.k))
+        V = np.ascontiguousarray(np.asarray(V, np.float32).reshape(self.n_items, self.k))
+        check(lib().cornac_hip_wmf_set_factors(self.h, U, V))
+
+    def get_factors(self):
+        U, V = np.empty((self.n_users, self.k), np.float32), np.empty((self.n_items, self.k), np.float32)
+        check(lib().cornac_hip_wmf_get_factors(self.h, U, V))
+        return U, V
+
+    def fit_batches(self, batches, lambda_u, lambda_v, a, b, lr):
+        """batches: sequence of item-id arrays (1..128 distinct ids each); returns the per-step losses"""
+        batches = [np.asarray(x, np.int32).ravel() for x in batches]
+        if not batches:
+            return np.zeros(0)
+        ptr = np.zeros(len(batches) + 1, np.int64)
+        np.cumsum([len(x) for x in batches], out=ptr[1:])
+        ids = np.ascontiguousarray(np.concatenate(batches), np.int32)
+        loss = np.zeros(len(batches), np.float64)
+        check(lib().cornac_hip_wmf_fit_batches(self.h, ids, ptr, len(batches), lambda_u, lambda_v, a, b, lr,
+                                               loss.ctypes.data))
+        return loss
+
+    def kernel_timing(self, enabled=True):
+        check(lib().cornac_hip_wmf_kernel_timing(self.h, int(enabled)))
+
+    def last_device_ms(self):
+        ms = C.c_double()
+        check(lib().cornac_hip_wmf_last_timing(self.h, C.byref(ms)))
+        return ms.value

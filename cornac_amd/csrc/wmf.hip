@@ -1,0 +1,561 @@
+// WMF (weighted matrix factorisation) training step on gfx950.
+//
+// Reference: cornac/models/wmf/wmf.py:34-55 (graph) and cornac/models/wmf/recom_wmf.py:160-207 (loop):
+// per batch of <= 128 items,   P = U V_b^T  over ALL users,  loss = sum C (R_b - P)^2 + l2 terms,
+// gradients clipped to [-5, 5], TF1 Adam on U (dense) and V (IndexedSlices: every row's moments decay,
+// every row moves).  The three GEMM-shaped pieces run on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32) through one LDS-tiled block routine with fused epilogues:
+//
+//   wmf_pred_kernel    G  = 2 b (U V_b^T)                   [n_users x B]   (+ b sum P^2 into the loss)
+//   wmf_fixup_kernel   G[u,c] = 2 a (U_u . V_c - r)  at the batch's non-zeros (CSC columns), loss fix-up
+//   wmf_grad_v_kernel  dV = G^T U   split over user chunks  [B x k]         (fp32 atomics into 64 KB)
+//   wmf_update_u_kernel  dU = G V_b, g = clip(dU + lambda_u U), Adam on U, m_U, v_U   (fused epilogue)
+//   wmf_update_v_*     g = clip(dV + lambda_v V_b) scattered into a dense gradient, dense Adam over V
+//
+// The dense R_b / C of the reference (n_users x B each per step) are never materialised.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace chip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWb = 256;        // threads per workgroup: 4 waves as 2 x 2, each wave a 64 x 64 block of C
+constexpr int kBM = 128, kBN = 128, kBK = 16;
+constexpr int kLdT = kBM + 4;   // LDS row length of a k-major tile (+4 floats: rows 16-byte aligned, banks skewed)
+constexpr int kMaxBatch = 128;  // items per step (the reference's default batch_size); one N tile
+
+struct GemmSmem {
+    float a[2][kBK][kLdT];
+    float b[2][kBK][kLdT];
+};
+
+// One 128 x 128 block of  C = A B  over k in [k_begin, k_end).
+//   A element (m, kk) at A[m * a_sm + kk * a_sk], B element (kk, n) at B[kk * b_sk + n * b_sn];
+//   A_KC: a_sk == 1 (k contiguous) else a_sm == 1;   B_NC: b_sn == 1 (n contiguous) else b_sk == 1.
+// Out-of-range rows/cols/k read as zero.  acc[i][j] is the 32 x 32 block (i, j) of this wave's 64 x 64 part:
+// register r of lane l holds C[row = wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][col = wn*64 + j*32 + (l&31)].
+template <bool A_KC, bool B_NC>
+__device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t a_sm, int64_t a_sk,
+                                           const float *__restrict__ B, int64_t b_sk, int64_t b_sn, int64_t M,
+                                           int64_t N, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
+                                           GemmSmem &sm, f32x16 (&acc)[2][2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto load_tile = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (A_KC) {  // thread: one row, 4 consecutive k
+                const int64_t m = m0 + (tid >> 2) + 64 * i, kk = k0 + (tid & 3) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < M) {
+                    const float *p = A + m * a_sm + kk;
+                    if (kk + 3 < k_end && ((a_sm | kk) & 3) == 0) {
+                        v = *reinterpret_cast<const f32x4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (kk + q < k_end) v[q] = p[q];
+                    }
+                }
+                ra[i] = v;
+            } else {  // thread: one k, 4 consecutive m
+                const int64_t kk = k0 + (tid >> 5) + 8 * i, m = m0 + (tid & 31) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kk < k_end) {
+                    const float *p = A + kk * a_sk + m;
+                    if (m + 3 < M && ((a_sk | m) & 3) == 0) {
+                        v = *reinterpret_cast<const f32x4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (m + q < M) v[q] = p[q];
+                    }
+                }
+                ra[i] = v;
+            }
+            if (B_NC) {  // thread: one k, 4 consecutive n
+                const int64_t kk = k0 + (tid >> 5) + 8 * i, n = n0 + (tid & 31) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kk < k_end) {
+                    const float *p = B + kk * b_sk + n;
+                    if (n + 3 < N && ((b_sk | n) & 3) == 0) {
+                        v = *reinterpret_cast<const f32x4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < N) v[q] = p[q];
+                    }
+                }
+                rb[i] = v;
+            } else {  // thread: one column n, 4 consecutive k
+                const int64_t n = n0 + (tid >> 2) + 64 * i, kk = k0 + (tid & 3) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < N) {
+                    const float *p = B + n * b_sn + kk;
+                    if (kk + 3 < k_end && ((b_sn | kk) & 3) == 0) {
+                        v = *reinterpret_cast<const f32x4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (kk + q < k_end) v[q] = p[q];
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (A_KC) {
+                const int m = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sm.a[buf][kq + q][m] = ra[i][q];
+            } else {
+                const int kk = (tid >> 5) + 8 * i, m = (tid & 31) * 4;
+                *reinterpret_cast<f32x4 *>(&sm.a[buf][kk][m]) = ra[i];
+            }
+            if (B_NC) {
+                const int kk = (tid >> 5) + 8 * i, n = (tid & 31) * 4;
+                *reinterpret_cast<f32x4 *>(&sm.b[buf][kk][n]) = rb[i];
+            } else {
+                const int n = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sm.b[buf][kq + q][n] = rb[i][q];
+            }
+        }
+    };
+
+    const int64_t n_steps = (k_end - k_begin + kBK - 1) / kBK;
+    if (n_steps <= 0) return;
+    load_tile(k_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int64_t s = 0; s < n_steps; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < n_steps) load_tile(k_begin + (s + 1) * kBK);
+#pragma unroll
+        for (int t = 0; t < kBK / 2; ++t) {
+            const float a0 = sm.a[buf][2 * t + half][wm * 64 + l31];
+            const float a1 = sm.a[buf][2 * t + half][wm * 64 + 32 + l31];
+            const float b0 = sm.b[buf][2 * t + half][wn * 64 + l31];
+            const float b1 = sm.b[buf][2 * t + half][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < n_steps) store_tile(buf ^ 1);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+}
+
+// visits every accumulator element of this thread: f(row, col, value&)
+template <class F>
+__device__ __forceinline__ void for_each_acc(f32x16 (&acc)[2][2], int64_t m0, int64_t n0, F &&f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t col = n0 + wn * 64 + j * 32 + l31;
+                f(row, col, acc[i][j][r]);
+            }
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double *scratch) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < kWb / 64; ++w) s += scratch[w];
+    return s;
+}
+
+// V_b = V[ids]  (contiguous [B x ld]);  also lambda_v/2 * |V_b|^2 into the loss
+__global__ __launch_bounds__(kWb) void wmf_gather_kernel(const float *__restrict__ V, const int32_t *__restrict__ ids,
+                                                         int B, int ld, float *__restrict__ Vb, float half_lambda_v,
+                                                         double *loss) {
+    __shared__ double scratch[kWb / 64];
+    double part = 0;
+    const int64_t n = (int64_t)B * ld;
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const int c = (int)(e / ld), f = (int)(e % ld);
+        const float v = V[(int64_t)ids[c] * ld + f];
+        Vb[e] = v;
+        part += (double)v * v;
+    }
+    const double s = block_sum_f64(part, scratch);
+    if (threadIdx.x == 0 && s != 0) atomicAdd(loss, (double)half_lambda_v * s);
+}
+
+// G[u, c] = 2 b P[u, c];   loss += b sum P^2     (the C = b, R = 0 case for every cell)
+__global__ __launch_bounds__(kWb) void wmf_pred_kernel(const float *__restrict__ U, const float *__restrict__ Vb,
+                                                       int64_t n_users, int B, int k, int ld,
+                                                       float *__restrict__ G, float b, double *loss) {
+    __shared__ GemmSmem sm;
+    __shared__ double scratch[kWb / 64];
+    f32x16 acc[2][2];
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    gemm_block<true, false>(U, ld, 1, Vb, 1, ld, n_users, B, m0, 0, 0, k, sm, acc);
+    double part = 0;
+    const float two_b = 2.f * b;
+    for_each_acc(acc, m0, 0, [&](int64_t row, int64_t col, float p) {
+        if (row < n_users && col < kMaxBatch) {
+            const bool live = col < B;
+            G[row * kMaxBatch + col] = live ? two_b * p : 0.f;
+            if (live) part += (double)p * p;
+        }
+    });
+    const double s = block_sum_f64(part, scratch);
+    if (threadIdx.x == 0) atomicAdd(loss, (double)b * s);
+}
+
+// non-zeros of the batch's columns: G[u, c] = 2 a (p - r), loss += a (r - p)^2 - b p^2.
+// One 16-lane group per non-zero; grid.y = column of the batch.
+__global__ __launch_bounds__(kWb) void wmf_fixup_kernel(const float *__restrict__ U, const float *__restrict__ Vb,
+                                                        const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ rows,
+                                                        const float *__restrict__ vals,
+                                                        const int32_t *__restrict__ ids, int k, int ld,
+                                                        float *__restrict__ G, float a, float b, double *loss) {
+    __shared__ double scratch[kWb / 64];
+    const int c = blockIdx.y;
+    const int64_t beg = indptr[ids[c]], end = indptr[ids[c] + 1];
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const float *vrow = Vb + (int64_t)c * ld;
+    double part = 0;
+    for (int64_t e = beg + (int64_t)blockIdx.x * (kWb / 16) + grp; e < end; e += (int64_t)gridDim.x * (kWb / 16)) {
+        const float r = vals[e];
+        const int64_t u = rows[e];
+        const float *urow = U + u * ld;
+        float p = 0.f;
+        for (int f = gl * 4; f < k; f += 64) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(urow + f), y = *reinterpret_cast<const f32x4 *>(vrow + f);
+            p += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) p += __shfl_xor(p, o, 16);
+        if (gl == 0 && r != 0.f) {  // explicit zeros stay "unobserved" (batch_R.nonzero(), recom_wmf.py:186)
+            G[u * kMaxBatch + c] = 2.f * a * (p - r);
+            part += (double)a * (double)(r - p) * (double)(r - p) - (double)b * (double)p * (double)p;
+        }
+    }
+    const double s = block_sum_f64(part, scratch);
+    if (threadIdx.x == 0 && s != 0) atomicAdd(loss, s);
+}
+
+// dV[c, f] += sum_{u in chunk} G[u, c] U[u, f]
+__global__ __launch_bounds__(kWb) void wmf_grad_v_kernel(const float *__restrict__ G, const float *__restrict__ U,
+                                                         int64_t n_users, int B, int ld, int64_t chunk,
+                                                         float *__restrict__ dV) {
+    __shared__ GemmSmem sm;
+    f32x16 acc[2][2];
+    const int64_t n0 = (int64_t)blockIdx.y * kBN;
+    const int64_t k_begin = (int64_t)blockIdx.x * chunk;
+    const int64_t k_end = k_begin + chunk < n_users ? k_begin + chunk : n_users;
+    gemm_block<false, true>(G, 1, kMaxBatch, U, ld, 1, B, ld, 0, n0, k_begin, k_end, sm, acc);
+    for_each_acc(acc, 0, n0, [&](int64_t row, int64_t col, float v) {
+        if (row < B && col < ld && v != 0.f) atomicAdd(dV + row * ld + col, v);
+    });
+}
+
+struct TfAdam {
+    float beta1, beta2, one_minus_beta1, one_minus_beta2, lr_t, eps;
+};
+
+// dU = G V_b; g = clip(dU + lambda_u U, -5, 5); dense TF1 Adam on the tile; loss += lambda_u/2 |U|^2 (pre-update)
+__global__ __launch_bounds__(kWb) void wmf_update_u_kernel(const float *__restrict__ G, const float *__restrict__ Vb,
+                                                           int64_t n_users, int B, int k, int ld,
+                                                           float *__restrict__ U, float *__restrict__ mU,
+                                                           float *__restrict__ vU, float lambda_u, const TfAdam ad,
+                                                           double *loss) {
+    __shared__ GemmSmem sm;
+    __shared__ double scratch[kWb / 64];
+    f32x16 acc[2][2];
+    const int64_t m0 = (int64_t)blockIdx.x * kBM, n0 = (int64_t)blockIdx.y * kBN;
+    gemm_block<true, true>(G, kMaxBatch, 1, Vb, ld, 1, n_users, ld, m0, n0, 0, B, sm, acc);
+    double part = 0;
+    for_each_acc(acc, m0, n0, [&](int64_t row, int64_t col, float du) {
+        if (row < n_users && col < k) {
+            const int64_t o = row * ld + col;
+            const float u = U[o];
+            part += (double)u * u;
+            float g = du + lambda_u * u;
+            g = fminf(fmaxf(g, -5.f), 5.f);
+            float m = mU[o], v = vU[o];
+            m = m + ad.one_minus_beta1 * (g - m);
+            v = v + ad.one_minus_beta2 * (g * g - v);
+            mU[o] = m;
+            vU[o] = v;
+            U[o] = u - ad.lr_t * m / (sqrtf(v) + ad.eps);
+        }
+    });
+    const double s = block_sum_f64(part, scratch);
+    if (threadIdx.x == 0) atomicAdd(loss, 0.5 * (double)lambda_u * s);
+}
+
+// gV rows of the batch: clip(dV + lambda_v V_b) scattered into the dense (otherwise zero) gradient; dV re-zeroed
+__global__ __launch_bounds__(kWb) void wmf_scatter_gv_kernel(float *__restrict__ dV, const float *__restrict__ Vb,
+                                                             const int32_t *__restrict__ ids, int B, int k, int ld,
+                                                             float lambda_v, float *__restrict__ gV) {
+    const int64_t n = (int64_t)B * ld;
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const int c = (int)(e / ld), f = (int)(e % ld);
+        float g = 0.f;
+        if (f < k) {
+            g = dV[e] + lambda_v * Vb[e];
+            g = fminf(fmaxf(g, -5.f), 5.f);
+        }
+        dV[e] = 0.f;
+        gV[(int64_t)ids[c] * ld + f] = g;
+    }
+}
+
+// TF1 Adam for an IndexedSlices gradient: m = beta1 m (+ (1-beta1) g on the slice rows), same for v, every row moves
+__global__ __launch_bounds__(kWb) void wmf_adam_v_kernel(float *__restrict__ V, float *__restrict__ mV,
+                                                         float *__restrict__ vV, float *__restrict__ gV, int64_t n,
+                                                         const TfAdam ad) {
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const float g = gV[e];
+        float m = mV[e] * ad.beta1, v = vV[e] * ad.beta2;
+        if (g != 0.f) {
+            m = m + ad.one_minus_beta1 * g;
+            v = v + ad.one_minus_beta2 * (g * g);
+            gV[e] = 0.f;
+        }
+        mV[e] = m;
+        vV[e] = v;
+        V[e] = V[e] - ad.lr_t * m / (sqrtf(v) + ad.eps);
+    }
+}
+
+__global__ __launch_bounds__(kWb) void wmf_pad_kernel(const float *__restrict__ src, int64_t rows, int k, int ld,
+                                                      float *__restrict__ dst) {
+    const int64_t n = rows * ld;
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const int64_t r = e / ld;
+        const int f = (int)(e % ld);
+        dst[e] = f < k ? src[r * k + f] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kWb) void wmf_unpad_kernel(const float *__restrict__ src, int64_t rows, int k, int ld,
+                                                        float *__restrict__ dst) {
+    const int64_t n = rows * k;
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const int64_t r = e / k;
+        const int f = (int)(e % k);
+        dst[e] = src[r * ld + f];
+    }
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+struct cornac_hip_wmf {
+    int device = 0;
+    int64_t n_users = 0, n_items = 0, nnz = 0;
+    int k = 0, ld = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<float> U, V, mU, vU, mV, vV, gV;   // [rows x ld], zero padded columns
+    DevBuf<float> G, Vb, dV, stage;           // [n_users x 128], [128 x ld], [128 x ld], host<->device staging
+    DevBuf<int64_t> indptr;                   // CSC
+    DevBuf<int32_t> rows, ids;          // ids: all batches of the current call, back to back
+    DevBuf<float> vals;
+    DevBuf<double> loss;
+    std::vector<int64_t> h_indptr;
+    int64_t step = 0;
+    EventTimer timer;
+    double last_kernel_ms = 0;
+};
+
+static void wmf_check(cornac_hip_wmf_t h) {
+    REQUIRE(h != nullptr, "WMF handle is NULL");
+    HIP_CHECK(hipSetDevice(h->device));
+}
+
+static int grid_for(int64_t n, int cap = 4096) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kWb - 1) / kWb, cap)); }
+
+extern "C" {
+
+int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, int64_t n_items, int k,
+                          const int64_t *csc_indptr, const int32_t *csc_rows, const float *csc_vals, int64_t nnz) {
+    return guarded([&] {
+        REQUIRE(out != nullptr, "out handle pointer is NULL");
+        *out = nullptr;
+        REQUIRE(n_users > 0 && n_items > 0 && k > 0, "sizes must be positive");
+        REQUIRE(k <= 1024, "k <= 1024 supported");
+        REQUIRE(csc_indptr && (nnz == 0 || (csc_rows && csc_vals)), "CSC arrays are NULL");
+        REQUIRE(csc_indptr[0] == 0 && csc_indptr[n_items] == nnz, "CSC indptr does not match nnz");
+        for (int64_t i = 0; i < n_items; ++i) REQUIRE(csc_indptr[i] <= csc_indptr[i + 1], "CSC indptr not monotone");
+        for (int64_t e = 0; e < nnz; ++e) REQUIRE(csc_rows[e] >= 0 && csc_rows[e] < n_users, "CSC row out of range");
+        use_device(device);
+        std::unique_ptr<cornac_hip_wmf> h(new cornac_hip_wmf());
+        h->device = device; h->n_users = n_users; h->n_items = n_items; h->k = k; h->nnz = nnz;
+        h->ld = (k + 31) / 32 * 32;
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t nu = (size_t)n_users * h->ld, ni = (size_t)n_items * h->ld;
+        for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
+        for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV, &h->gV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
+        h->G.alloc((size_t)n_users * kMaxBatch);
+        h->Vb.alloc((size_t)kMaxBatch * h->ld);
+        h->dV.alloc((size_t)kMaxBatch * h->ld);
+        HIP_CHECK(hipMemsetAsync(h->dV.p, 0, h->dV.n * 4, h->stream));
+        h->stage.alloc(std::max(nu, ni));
+        h->indptr.alloc((size_t)n_items + 1);
+        h->indptr.upload(csc_indptr, (size_t)n_items + 1, h->stream);
+        h->h_indptr.assign(csc_indptr, csc_indptr + n_items + 1);
+        h->rows.alloc((size_t)std::max<int64_t>(nnz, 1));
+        h->vals.alloc((size_t)std::max<int64_t>(nnz, 1));
+        if (nnz) { h->rows.upload(csc_rows, (size_t)nnz, h->stream); h->vals.upload(csc_vals, (size_t)nnz, h->stream); }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        *out = h.release();
+    });
+}
+
+void cornac_hip_wmf_destroy(cornac_hip_wmf_t h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+// uploads U [n_users x k], V [n_items x k] and resets the Adam state (a fresh TF graph per fit, recom_wmf.py:166-178)
+int cornac_hip_wmf_set_factors(cornac_hip_wmf_t h, const float *U, const float *V) {
+    return guarded([&] {
+        wmf_check(h);
+        REQUIRE(U && V, "factor pointers are NULL");
+        h->stage.upload(U, (size_t)h->n_users * h->k, h->stream);
+        wmf_pad_kernel<<<grid_for(h->n_users * h->ld), kWb, 0, h->stream>>>(h->stage.p, h->n_users, h->k, h->ld, h->U.p);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->stage.upload(V, (size_t)h->n_items * h->k, h->stream);
+        wmf_pad_kernel<<<grid_for(h->n_items * h->ld), kWb, 0, h->stream>>>(h->stage.p, h->n_items, h->k, h->ld, h->V.p);
+        for (DevBuf<float> *b : {&h->mU, &h->vU, &h->mV, &h->vV, &h->gV}) HIP_CHECK(hipMemsetAsync(b->p, 0, b->n * 4, h->stream));
+        h->step = 0;
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_wmf_get_factors(cornac_hip_wmf_t h, float *U, float *V) {
+    return guarded([&] {
+        wmf_check(h);
+        REQUIRE(U && V, "factor pointers are NULL");
+        wmf_unpad_kernel<<<grid_for(h->n_users * h->k), kWb, 0, h->stream>>>(h->U.p, h->n_users, h->k, h->ld, h->stage.p);
+        h->stage.download(U, (size_t)h->n_users * h->k, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        wmf_unpad_kernel<<<grid_for(h->n_items * h->k), kWb, 0, h->stream>>>(h->V.p, h->n_items, h->k, h->ld, h->stage.p);
+        h->stage.download(V, (size_t)h->n_items * h->k, h->stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+// One Adam step per batch of item ids (batch_ptr[b] .. batch_ptr[b+1]), in order; loss_out[b] = the step's loss
+// (the `_loss` the reference sums for its progress bar, recom_wmf.py:195-199).
+int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, const int64_t *batch_ptr,
+                               int64_t n_batches, float lambda_u, float lambda_v, float a, float b,
+                               float learning_rate, double *loss_out) {
+    return guarded([&] {
+        wmf_check(h);
+        REQUIRE(n_batches >= 0, "n_batches < 0");
+        if (n_batches == 0) return;
+        REQUIRE(item_ids && batch_ptr, "batch arrays are NULL");
+        for (int64_t bi = 0; bi < n_batches; ++bi) {
+            const int64_t B = batch_ptr[bi + 1] - batch_ptr[bi];
+            REQUIRE(B > 0 && B <= kMaxBatch, "batch %lld has %lld items; 1..%d supported", (long long)bi, (long long)B, kMaxBatch);
+            for (int64_t c = 0; c < B; ++c) {
+                const int32_t it = item_ids[batch_ptr[bi] + c];
+                REQUIRE(it >= 0 && it < h->n_items, "item id %d out of range", it);
+            }
+        }
+        const double beta1 = 0.9, beta2 = 0.999;
+        hipStream_t s = h->stream;
+        const int ld = h->ld, k = h->k;
+        const int64_t nu = h->n_users;
+        const int m_tiles = (int)((nu + kBM - 1) / kBM), n_tiles = (ld + kBN - 1) / kBN;
+        // user chunks of the split-K gradient: enough workgroups to fill the chip, chunk a multiple of the k tile
+        int64_t chunk = std::max<int64_t>(kBK, (nu + 511) / 512);
+        chunk = (chunk + kBK - 1) / kBK * kBK;
+        const int n_chunks = (int)((nu + chunk - 1) / chunk);
+        const int64_t n_ids = batch_ptr[n_batches] - batch_ptr[0];
+        h->ids.ensure((size_t)n_ids);
+        h->loss.ensure((size_t)n_batches);
+        HIP_CHECK(hipMemcpyAsync(h->ids.p, item_ids + batch_ptr[0], (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(h->loss.p, 0, (size_t)n_batches * sizeof(double), s));
+        h->timer.before(s);
+        for (int64_t bi = 0; bi < n_batches; ++bi) {
+            const int32_t *ids = item_ids + batch_ptr[bi];
+            const int32_t *d_ids = h->ids.p + (batch_ptr[bi] - batch_ptr[0]);
+            double *d_loss = h->loss.p + bi;
+            const int B = (int)(batch_ptr[bi + 1] - batch_ptr[bi]);
+            int64_t max_col = 0;
+            for (int c = 0; c < B; ++c) max_col = std::max(max_col, h->h_indptr[ids[c] + 1] - h->h_indptr[ids[c]]);
+            ++h->step;
+            TfAdam ad;
+            ad.beta1 = (float)beta1; ad.beta2 = (float)beta2;
+            ad.one_minus_beta1 = 1.f - ad.beta1; ad.one_minus_beta2 = 1.f - ad.beta2;
+            ad.lr_t = (float)((double)learning_rate * std::sqrt(1.0 - std::pow(beta2, (double)h->step)) /
+                              (1.0 - std::pow(beta1, (double)h->step)));
+            ad.eps = 1e-8f;
+            wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, 0.5f * lambda_v, d_loss);
+            wmf_pred_kernel<<<m_tiles, kWb, 0, s>>>(h->U.p, h->Vb.p, nu, B, k, ld, h->G.p, b, d_loss);
+            if (max_col > 0) {
+                const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((max_col + kWb / 16 - 1) / (kWb / 16), 64));
+                wmf_fixup_kernel<<<dim3(gx, B), kWb, 0, s>>>(h->U.p, h->Vb.p, h->indptr.p, h->rows.p, h->vals.p, d_ids, k, ld, h->G.p, a, b, d_loss);
+            }
+            wmf_grad_v_kernel<<<dim3(n_chunks, n_tiles), kWb, 0, s>>>(h->G.p, h->U.p, nu, B, ld, chunk, h->dV.p);
+            wmf_update_u_kernel<<<dim3(m_tiles, n_tiles), kWb, 0, s>>>(h->G.p, h->Vb.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, lambda_u, ad, d_loss);
+            wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
+            wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
+            HIP_CHECK(hipGetLastError());
+        }
+        h->timer.after(s);
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (h->timer.enabled) {
+            int64_t launches = 0;
+            h->timer.collect(&h->last_kernel_ms, &launches);
+        }
+        if (loss_out) {
+            h->loss.download(loss_out, (size_t)n_batches, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+    });
+}
+
+int cornac_hip_wmf_kernel_timing(cornac_hip_wmf_t h, int enabled) {
+    return guarded([&] {
+        wmf_check(h);
+        h->timer.enabled = enabled != 0;
+    });
+}
+
+int cornac_hip_wmf_last_timing(cornac_hip_wmf_t h, double *device_ms) {
+    return guarded([&] {
+        wmf_check(h);
+        if (device_ms) *device_ms = h->last_kernel_ms;
+    });
+}
+
+}  // extern "C"

@@ -91,6 +91,13 @@ class Dataset:
         return self._csr
 
     @property
+    def csc_matrix(self):
+        """item-major view of the same ratings (dataset.py:247-255)"""
+        if getattr(self, "_csc", None) is None:
+            self._csc = self.csr_matrix.tocsc()
+        return self._csc
+
+    @property
     def user_ids(self):
         return list(self.uid_map.keys())
 
@@ -119,6 +126,13 @@ class Dataset:
             self.rng.shuffle(indices)
         for b in range(int(np.ceil(len(indices) / batch_size))):
             yield indices[batch_size * b: min(batch_size * b + batch_size, len(indices))]
+
+    def item_iter(self, batch_size=1, shuffle=False):
+        """batches of item indices (dataset.py:546-562); the candidate order is the iteration order of
+        the set of observed items, as in the reference"""
+        item_indices = np.fromiter(set(self.uir_tuple[1].tolist()), "int")
+        for batch_ids in self.idx_iter(len(item_indices), batch_size, shuffle):
+            yield item_indices[batch_ids]
 
     def uij_iter(self, batch_size=1, shuffle=False, neg_sampling="uniform"):
         """(users, positive items, negative items) batches, reproducing the reference's sampler

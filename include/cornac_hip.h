@@ -196,6 +196,33 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
 int cornac_hip_vbpr_item_tables(cornac_hip_vbpr_t h, float *theta_item, float *visual_bias);
 
 /* ------------------------------------------------------------------------- *
+ * WMF (weighted matrix factorisation) minibatch trainer.
+ * Replaces: the TensorFlow graph of cornac/models/wmf/wmf.py:34-55 (P = U V_b^T, weighted
+ *           squared error, gradient clipping to [-5, 5], tf.train.AdamOptimizer) and the
+ *           per-batch sess.run of cornac/models/wmf/recom_wmf.py:181-199.
+ * Batches of item ids come from the host iterator Dataset.item_iter (cornac/data/dataset.py:546-562)
+ * exactly as in the reference; Adam moments and the step counter persist in the handle and are
+ * reset by set_factors (the reference builds a fresh graph per fit).
+ * ------------------------------------------------------------------------- */
+typedef struct cornac_hip_wmf *cornac_hip_wmf_t;
+
+/* CSC of the rating matrix (train_set.csc_matrix): indptr int64[n_items+1], rows = user ids, vals fp32 */
+int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, int64_t n_items, int k,
+                          const int64_t *csc_indptr, const int32_t *csc_rows, const float *csc_vals, int64_t nnz);
+void cornac_hip_wmf_destroy(cornac_hip_wmf_t h);
+/* U [n_users,k], V [n_items,k] fp32 */
+int cornac_hip_wmf_set_factors(cornac_hip_wmf_t h, const float *U, const float *V);
+int cornac_hip_wmf_get_factors(cornac_hip_wmf_t h, float *U, float *V);
+/* one Adam step per batch b = item_ids[batch_ptr[b] .. batch_ptr[b+1]) (1..128 distinct items), in order;
+ * loss_out[b] (may be NULL) = that step's loss value (`_loss`, recom_wmf.py:195) */
+int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, const int64_t *batch_ptr,
+                               int64_t n_batches, float lambda_u, float lambda_v, float a, float b,
+                               float learning_rate, double *loss_out);
+/* HIP-event timing of fit_batches (device ms of the last call) */
+int cornac_hip_wmf_kernel_timing(cornac_hip_wmf_t h, int enabled);
+int cornac_hip_wmf_last_timing(cornac_hip_wmf_t h, double *device_ms);
+
+/* ------------------------------------------------------------------------- *
  * Scoring / ranking.
  * Replaces: fast_dot(vec, mat, output)  cornac/utils/fast_dot.pyx:40-43 as used by
  *           BPR.score (recom_bpr.pyx:288-291) and MF.score (recom_mf.py:273-278),

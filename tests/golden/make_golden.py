@@ -153,5 +153,39 @@ def main():
     print("wrote fast_dot", out)
 
 
+
+def make_wmf_fixture():
+    """WMF: the reference cannot run here (TensorFlow absent) -> fixture from oracle/wmf_oracle.py, with the
+    reference's host-side iterator protocol (Dataset.item_iter after train_set.reset())."""
+    sys.path.insert(0, ROOT)
+    from cornac_amd.data import Dataset
+    from oracle.wmf_oracle import WmfOracle
+
+    rs = np.random.RandomState(11)
+    nu, ni, k, nnz, bs, iters = 150, 70, 12, 1500, 32, 4
+    keys = rs.permutation(nu * ni)[:nnz]
+    u, i = keys // ni, keys % ni
+    r = rs.randint(1, 6, nnz).astype(np.float32)
+    ds = Dataset.from_uir([(int(a), int(b), float(c)) for a, b, c in zip(u, i, r)], seed=123)
+    ds.reset()
+    U0 = rs.uniform(-0.2, 0.2, (ds.num_users, k)).astype(np.float32)
+    V0 = rs.uniform(-0.2, 0.2, (ds.num_items, k)).astype(np.float32)
+    hp = dict(lambda_u=0.02, lambda_v=0.03, a=1.0, b=0.01, lr=0.005)
+    o = WmfOracle(U0, V0, ds.csc_matrix, **hp)
+    batches = []
+    for _ in range(iters):
+        batches += list(ds.item_iter(bs, shuffle=True))
+    losses = o.fit_batches(batches)
+    ptr = np.zeros(len(batches) + 1, np.int64)
+    np.cumsum([len(b) for b in batches], out=ptr[1:])
+    u, i = ds.uir_tuple[0], ds.uir_tuple[1]  # mapped ids: identity under a rebuild with from_uir
+    np.savez_compressed(os.path.join(OUT, "wmf_small.npz"), users=u, items=i, ratings=r, n_users=ds.num_users,
+                        n_items=ds.num_items, k=k, batch_size=bs, max_iter=iters, U0=U0, V0=V0, U=o.U, V=o.V,
+                        losses=np.array(losses), batch_ids=np.concatenate(batches), batch_ptr=ptr, **hp)
+    print("wrote wmf_small")
+
+
 if __name__ == "__main__":
-    main()
+    if "--wmf-only" not in sys.argv:
+        main()
+    make_wmf_fixture()
