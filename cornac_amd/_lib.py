@@ -34,6 +34,7 @@ SYMBOLS = [
     "cornac_hip_wmf_fit_batches", "cornac_hip_wmf_kernel_timing", "cornac_hip_wmf_last_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
+    "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
 ]
@@ -135,6 +136,9 @@ def lib():
         L.cornac_hip_vbpr_fit_batches.argtypes = [_vp, _i32, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float,
                                                   C.c_float, C.c_float, C.POINTER(C.c_double)]
         L.cornac_hip_vbpr_item_tables.argtypes = [_vp, _f32, _f32]
+        L.cornac_hip_mf_fit_minibatch.argtypes = [_vp, _i64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                  C.c_float, C.c_int, C.POINTER(C.c_double)]
+        L.cornac_hip_mf_reset_optimizer.argtypes = [_vp]
         L.cornac_hip_wmf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i32, _f32,
                                             C.c_int64]
         L.cornac_hip_wmf_destroy.argtypes = [_vp]
@@ -337,6 +341,20 @@ class MfTrainer:
         check(lib().cornac_hip_mf_fit(self.h, max_iter, lr, reg, mu, int(use_bias), int(early_stop), mode,
                                       loss.ctypes.data, C.byref(n)))
         return loss[:n.value], n.value
+
+    OPTIMIZERS = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3}
+
+    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True):
+        """one optimiser step per consecutive slice of `batch_size` entries of `order` (indices into the
+        rating arrays); returns the summed squared error over all visited ratings"""
+        order = np.ascontiguousarray(order, np.int64)
+        loss = C.c_double()
+        check(lib().cornac_hip_mf_fit_minibatch(self.h, order, len(order), int(batch_size), self.OPTIMIZERS[optimizer],
+                                                lr, reg, mu, int(use_bias), C.byref(loss)))
+        return loss.value
+
+    def reset_optimizer(self):
+        check(lib().cornac_hip_mf_reset_optimizer(self.h))
 
     def kernel_timing(self, enable=True):
         ms, n = C.c_double(), C.c_int64()

@@ -287,6 +287,11 @@ struct cornac_hip_mf {
     DevBuf<int32_t> own_u, own_i;
     DevBuf<float> own_r;
     DevBuf<int64_t> wave_ptr;
+    // minibatch path (mf_minibatch.inc): dense gradients and optimiser state of [U, V, Bu, Bi]
+    DevBuf<float> opt_g[4], opt_s1[4], opt_s2[4];
+    DevBuf<int64_t> opt_order;
+    int64_t opt_step = 0;
+    int opt_kind = -1;
 };
 
 static void mf_check(cornac_hip_mf_t h) {
@@ -684,3 +689,5 @@ int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4) {
     });
 }
 }
+
+#include "mf_minibatch.inc"

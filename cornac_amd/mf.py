@@ -1,8 +1,12 @@
 """Biased matrix factorisation on MI355X — constructor, `fit/score/rank` surface and learned
 attributes (`u_factors, i_factors, u_biases, i_biases, global_mean`) of the reference's
-`cornac.models.MF` (cornac/models/mf/recom_mf.py:29-302); the `backend_cpu.fit_sgd` call
-(recom_mf.py:189-209) is replaced by `cornac_hip_mf_fit` through a new `backend="hip"` next to the
-reference's `"cpu"` / `"pytorch"` switch (recom_mf.py:177-183).
+`cornac.models.MF` (cornac/models/mf/recom_mf.py:29-302).  Two backends next to the reference's
+`"cpu"` / `"pytorch"` switch (recom_mf.py:177-183):
+
+  * `backend="hip"`            replaces `backend_cpu.fit_sgd` (recom_mf.py:189-209) by `cornac_hip_mf_fit`;
+  * `backend="hip-minibatch"`  replaces `backend_pt.learn` (recom_mf.py:211-252, backend_pt.py:67-106: batches of
+                               `batch_size` ratings, `optimizer` in {sgd, adam, rmsprop, adagrad} with
+                               weight_decay = lambda_reg over the dense tables) by `cornac_hip_mf_fit_minibatch`.
 """
 import numpy as np
 
@@ -18,8 +22,8 @@ def _normal(shape, rng, std):
 
 
 class MF(Recommender):
-    """Parameters are those of the reference (recom_mf.py:32-131); `backend` accepts "hip" only
-    (the reference raises ValueError for an unknown backend, recom_mf.py:183 — so does this).
+    """Parameters are those of the reference (recom_mf.py:32-131); `backend` accepts "hip" and
+    "hip-minibatch" (the reference raises ValueError for an unknown backend, recom_mf.py:183 — so does this).
     `mode` as in BPR: None -> deterministic when seeded, hogwild otherwise."""
 
     def __init__(self, name="MF", k=10, backend="hip", optimizer="sgd", max_iter=20, learning_rate=0.01,
@@ -71,6 +75,8 @@ class MF(Recommender):
         if self.trainable:
             if self.backend == "hip":
                 self._fit_hip(train_set, val_set)
+            elif self.backend == "hip-minibatch":
+                self._fit_minibatch(train_set, val_set)
             else:
                 raise ValueError(f"{self.backend} is not supported")
         self._drop_scorer()
@@ -96,6 +102,31 @@ class MF(Recommender):
             trainer.close()
         if self.verbose:
             print("Optimization finished!")
+
+    def _fit_minibatch(self, train_set, val_set):
+        if self.optimizer not in _lib.MfTrainer.OPTIMIZERS:
+            raise KeyError(self.optimizer)  # OPTIMIZER_DICT[optimizer], backend_pt.py:79
+        if self.dropout != 0.0:
+            raise ValueError("dropout is not supported by the HIP backend (it would consume torch's RNG stream)")
+        rid, cid, val = train_set.uir_tuple
+        trainer = _lib.MfTrainer(rid, cid, val.astype(DTYPE), self.num_users, self.num_items, self.k,
+                                 device=self.device)
+        try:
+            trainer.set_factors(self.u_factors, self.i_factors, self.u_biases, self.i_biases)
+            trainer.reset_optimizer()
+            self.loss_history = []
+            for _ in range(self.max_iter):
+                # backend_pt.py:85-88: uir_iter(batch_size, shuffle=True) = consecutive slices of one shuffle
+                order = np.concatenate(list(train_set.idx_iter(len(val), self.batch_size, shuffle=True)))
+                sse = trainer.fit_minibatch(order, self.batch_size, self.optimizer, self.learning_rate,
+                                            self.lambda_reg, float(self.global_mean), self.use_bias)
+                self.loss_history.append(sse / len(val))
+            U, V, Bu, Bi = trainer.get_factors()
+            self.u_factors, self.i_factors = U, V
+            if self.use_bias:
+                self.u_biases, self.i_biases = Bu, Bi
+        finally:
+            trainer.close()
 
     # ---- prediction -------------------------------------------------------------------------------
     def _scoring_tables(self):

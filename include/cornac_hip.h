@@ -169,6 +169,21 @@ int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, co
 int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms, int64_t *launches);
 int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 
+/* Minibatch path with dense optimisers on the same handle.
+ * Replaces: backend_pt.learn(model, train_set, n_epochs, batch_size, learning_rate, reg, optimizer)
+ *           cornac/models/mf/backend_pt.py:67-106 and the forward of backend_pt.MF (:56-65), selected by
+ *           MF(backend="pytorch", optimizer=...) (cornac/models/mf/recom_mf.py:211-252); dropout = 0 only.
+ * order: indices into the handle's rating arrays in visiting order (the concatenated batches of
+ * Dataset.uir_iter(batch_size, shuffle=True), cornac/data/dataset.py:445-488); consecutive slices of batch_size
+ * form the optimiser steps (the last one may be shorter).  Optimiser state persists across calls. */
+#define CORNAC_HIP_OPT_SGD 0
+#define CORNAC_HIP_OPT_ADAM 1
+#define CORNAC_HIP_OPT_RMSPROP 2
+#define CORNAC_HIP_OPT_ADAGRAD 3
+int cornac_hip_mf_fit_minibatch(cornac_hip_mf_t h, const int64_t *order, int64_t n_total, int batch_size,
+                                int optimizer, float lr, float reg, float mu, int use_bias, double *loss_sum);
+int cornac_hip_mf_reset_optimizer(cornac_hip_mf_t h);
+
 /* ------------------------------------------------------------------------- *
  * VBPR (visual BPR) minibatch trainer.
  * Replaces: the per-batch body of VBPR._fit_torch (forward, autograd backward,

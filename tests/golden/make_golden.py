@@ -185,7 +185,31 @@ def make_wmf_fixture():
     print("wrote wmf_small")
 
 
+def make_mf_minibatch_fixture():
+    """MF(backend="pytorch", optimizer=...) of the REAL reference on CPU torch, all four optimisers."""
+    build_ref.build()
+    ns = ref_loader.load()
+    u, i, r = synth_pairs(90, 50, 1100, 0.7, 21)
+    ds = dataset(ns, u, i, r)
+    fx = {"users": u, "items": i, "ratings": r, "k": np.int64(6), "epochs": np.int64(3), "batch_size": np.int64(64),
+          "lr": np.float64(0.02), "reg": np.float64(0.03), "seed": np.int64(5)}
+    for opt in ("sgd", "adam", "rmsprop", "adagrad"):
+        for use_bias in (True, False):
+            m = ns.MF(k=6, backend="pytorch", optimizer=opt, max_iter=3, batch_size=64, learning_rate=0.02,
+                      lambda_reg=0.03, use_bias=use_bias, seed=5).fit(ds)
+            tag = opt + ("" if use_bias else "_nobias")
+            fx[tag + "_U"], fx[tag + "_V"] = m.u_factors.copy(), m.i_factors.copy()
+            fx[tag + "_Bu"], fx[tag + "_Bi"] = np.asarray(m.u_biases).copy(), np.asarray(m.i_biases).copy()
+    np.savez_compressed(os.path.join(OUT, "mf_minibatch.npz"), **fx)
+    print("wrote mf_minibatch")
+
+
 if __name__ == "__main__":
-    if "--wmf-only" not in sys.argv:
+    if "--wmf-only" in sys.argv:
+        make_wmf_fixture()
+    elif "--mf-minibatch-only" in sys.argv:
+        make_mf_minibatch_fixture()
+    else:
         main()
-    make_wmf_fixture()
+        make_mf_minibatch_fixture()
+        make_wmf_fixture()

@@ -117,3 +117,29 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
     avg2, _ = ev.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)  # k = -1 -> per-user full-rank flow
     ref_avg2, _ = ns.eval_methods.base_method.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)
     assert np.allclose(avg2, ref_avg2)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])
+def test_mf_minibatch_oracle_matches_live_reference(opt):
+    """MF(backend="pytorch") of the real reference vs oracle/mf_minibatch_oracle.py on a fresh random case"""
+    from cornac_amd import Dataset
+    from oracle import mf_minibatch_oracle
+
+    ns = ref_loader.load()
+    data = _pairs(70, 45, 700, 9)
+    ref_ds = ns.Dataset.from_uir(data, seed=11)
+    m = ns.MF(k=7, backend="pytorch", optimizer=opt, max_iter=2, batch_size=48, learning_rate=0.03, lambda_reg=0.01,
+              use_bias=True, seed=4, verbose=False).fit(ref_ds)
+    ds = Dataset.from_uir(data, seed=11)
+    ds.reset()
+    rng = np.random.RandomState(4)
+    U = rng.normal(0.0, 0.01, (ds.num_users, 7)).astype(np.float32)
+    V = rng.normal(0.0, 0.01, (ds.num_items, 7)).astype(np.float32)
+    rid, cid, val = ds.uir_tuple
+    batches = []
+    for _ in range(2):
+        batches += list(ds.idx_iter(len(val), 48, shuffle=True))
+    got = mf_minibatch_oracle.fit(U, V, np.zeros(ds.num_users), np.zeros(ds.num_items), np.float32(ds.global_mean), rid, cid,
+                                  val.astype(np.float32), batches, opt, 0.03, 0.01, True)
+    for a, b in zip(got[:4], (m.u_factors, m.i_factors, m.u_biases, m.i_biases)):
+        assert_close(a, np.asarray(b))

@@ -13,10 +13,21 @@ ap.add_argument("--config", default="ml20m")
 ap.add_argument("--k", type=int, default=128)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--shape", default=None, help="users,items,nnz: uniform random matrix instead of a named config "
+                "(the step cost depends on n_users, batch, k and the batch's nnz only)")
 args = ap.parse_args()
-n_users, n_items, nnz, a, seed = synth.CONFIGS[args.config]
+if args.shape:
+    n_users, n_items, nnz = (int(x) for x in args.shape.split(","))
+    args.config = "uniform:" + args.shape
+    rs0 = np.random.RandomState(0)
+    keys = np.unique(rs0.randint(0, n_users * n_items, size=int(nnz * 1.05), dtype=np.int64))[:nnz]
+    users, items = keys // n_items, keys % n_items
+else:
+    n_users, n_items, nnz, a, seed = synth.CONFIGS[args.config]
 path = "/tmp/cornac_amd_mf_%s.npz" % args.config
-if os.path.exists(path):
+if args.shape:
+    pass
+elif os.path.exists(path):
     z = np.load(path); users, items = z["u"], z["i"]
 else:
     users, items = synth.zipf_interactions(n_users, n_items, nnz, a, seed)
