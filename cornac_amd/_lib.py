@@ -28,6 +28,8 @@ SYMBOLS = [
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs",
+    "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
+    "cornac_hip_bpr_scatter_add_rows",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
@@ -126,6 +128,11 @@ def lib():
         L.cornac_hip_bpr_seed_view_stream.argtypes = [_vp, C.c_uint32]
         L.cornac_hip_vebpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_sample_triplets.argtypes = [_vp, C.c_int64, C.c_int, _vp, _vp, _vp]
+        L.cornac_hip_bpr_apply_triplets.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_float,
+                                                    C.c_float, C.c_int]
+        L.cornac_hip_bpr_gather_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
+        L.cornac_hip_bpr_scatter_add_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -212,7 +219,7 @@ class BprTrainer:
                                           self.indptr, self.indices, self.nnz))
 
     def close(self):
-        if getattr(self, "h", None) is not None and self.h:
+        if getattr(self, "h", None) is not None and self.h and lib is not None:
             lib().cornac_hip_bpr_destroy(self.h)
             self.h = None
 
@@ -262,6 +269,20 @@ class BprTrainer:
 
     def set_stream(self, stream_ptr):
         check(lib().cornac_hip_bpr_set_stream(self.h, stream_ptr))
+
+    # ---- row-sharded item table building blocks (device pointers; see cornac_amd/dist.py) -----------
+    def sample_triplets(self, n_draws, d_u, d_i, d_j, neg_population=NEG_UNIFORM):
+        check(lib().cornac_hip_bpr_sample_triplets(self.h, int(n_draws), neg_population, d_u, d_i, d_j))
+
+    def apply_triplets(self, d_u, d_slot_i, d_slot_j, n, d_rows, d_bias, bias_stride, lr, reg, use_bias=True):
+        check(lib().cornac_hip_bpr_apply_triplets(self.h, d_u, d_slot_i, d_slot_j, int(n), d_rows, d_bias,
+                                                  int(bias_stride), lr, reg, int(use_bias)))
+
+    def gather_rows(self, d_table, d_ids, n, width, d_out):
+        check(lib().cornac_hip_bpr_gather_rows(self.h, d_table, d_ids, int(n), int(width), d_out))
+
+    def scatter_add_rows(self, d_table, d_ids, n, width, d_delta):
+        check(lib().cornac_hip_bpr_scatter_add_rows(self.h, d_table, d_ids, int(n), int(width), d_delta))
 
     def debug_draw(self, stream, hi, n):
         out = np.empty(n, np.int64)
@@ -318,7 +339,7 @@ class MfTrainer:
                                          len(self.val)))
 
     def close(self):
-        if getattr(self, "h", None) is not None and self.h:
+        if getattr(self, "h", None) is not None and self.h and lib is not None:
             lib().cornac_hip_mf_destroy(self.h)
             self.h = None
 
@@ -392,7 +413,7 @@ class Scorer:
         check(lib().cornac_hip_scorer_set(self.h, _f32c(U), _f32c(V), _ptr(ib), _ptr(ub)))
 
     def close(self):
-        if getattr(self, "h", None) is not None and self.h:
+        if getattr(self, "h", None) is not None and self.h and lib is not None:
             lib().cornac_hip_scorer_destroy(self.h)
             self.h = None
 
@@ -446,7 +467,7 @@ class VbprTrainer:
         check(lib().cornac_hip_vbpr_create(C.byref(self.h), device, n_users, n_items, k, k2, self.F.shape[1], self.F))
 
     def close(self):
-        if getattr(self, "h", None) is not None and self.h:
+        if getattr(self, "h", None) is not None and self.h and lib is not None:
             lib().cornac_hip_vbpr_destroy(self.h)
             self.h = None
 
@@ -501,7 +522,7 @@ class WmfTrainer:
                                           self._vals if len(self._vals) else np.zeros(1, np.float32), len(self._vals)))
 
     def close(self):
-        if getattr(self, "h", None) is not None and self.h:
+        if getattr(self, "h", None) is not None and self.h and lib is not None:
             lib().cornac_hip_wmf_destroy(self.h)
             self.h = None
 

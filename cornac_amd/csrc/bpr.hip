@@ -1136,3 +1136,4 @@ int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4) {
 }
 
 #include "vebpr.inc"
+#include "sharded.inc"

@@ -1,5 +1,6 @@
-"""Multi-GPU BPR: one process per GPU, users partitioned across ranks, item table replicated and
-reconciled with RCCL all-reduce of its deltas (regime 1 "item table fits per GPU").
+"""Multi-GPU BPR: one process per GPU, users partitioned across ranks.  Two regimes for the item table
+(SURVEY.md §8e): (1) replicated and reconciled with RCCL all-reduce of its deltas — `ShardedBprTrainer`,
+described first; (2) sharded by row with all-to-all exchanges of the touched rows — `RowShardedBprTrainer`.
 
   * every rank owns a disjoint user population (its CSR slice and its U rows) -> user rows never
     leave the GPU and never conflict across GPUs: no data-path collective for them;
@@ -89,6 +90,173 @@ class ShardedBprTrainer:
                 self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
                 self.table.sync()
                 left -= n
+
+    def finish(self):
+        out = self.trainer.sync()
+        if self.stream is not None:
+            self.stream.synchronize()
+        return out
+
+
+class RowShardedItemTable:
+    """Item factors and biases sharded by row (SURVEY.md §8e regime 2): item i lives on rank i % N at local row
+    i // N.  `fetch` pulls a de-duplicated set of rows from their owners, `push` returns deltas to them:
+
+        ids  --all_to_all-->  owners            (int32 local rows, variable split sizes)
+        rows <--all_to_all--  owners gather     ([n, k] fp32 + [n] bias)
+        ...  local BPR updates on the staged rows ...
+        deltas --all_to_all--> owners scatter-add (atomic: the same row may come from several ranks)
+
+    Row gather / scatter-add are HIP kernels of libcornac_hip reached through `ops` (`gather(table, ids, out)`,
+    `scatter_add(table, ids, delta)`); RCCL moves the data (torch.distributed, backend nccl).  Requests are
+    addressed in "owner-major" order g(i) = (i % N) * rows_per_rank + i // N, so a sorted unique list of g is
+    already bucketed by owner."""
+
+    def __init__(self, total_items, k, device, ops, group=None):
+        self.total_items, self.k, self.device, self.ops, self.group = int(total_items), int(k), device, ops, group
+        on = dist.is_available() and dist.is_initialized()
+        self.collective = on  # a size-1 group still goes through RCCL (exercised by the single-GPU tests)
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.rows_per_rank = (self.total_items + self.world - 1) // self.world
+        self.V = torch.zeros(self.rows_per_rank, self.k, dtype=torch.float32, device=device)
+        self.B = torch.zeros(self.rows_per_rank, dtype=torch.float32, device=device)
+
+    def owner_major(self, item_ids):
+        return (item_ids % self.world) * self.rows_per_rank + item_ids // self.world
+
+    def load(self, V, B):
+        """keeps this rank's rows of the full host tables"""
+        mine = np.arange(self.rank, self.total_items, self.world)
+        self.V[: len(mine)].copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(V, np.float32)[mine])))
+        self.B[: len(mine)].copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(B, np.float32)[mine])))
+
+    def _exchange(self, send, send_counts, recv_counts):
+        if not self.collective:
+            return send
+        recv = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                               group=self.group)
+        return recv
+
+    def fetch(self, uniq_g):
+        """uniq_g: sorted unique owner-major indices (int64, on `device`).  Returns (rows [n,k], bias [n], plan)."""
+        bounds = torch.arange(self.world + 1, device=uniq_g.device, dtype=uniq_g.dtype) * self.rows_per_rank
+        cuts = torch.searchsorted(uniq_g, bounds).tolist()  # host sync: the split sizes of the exchange
+        send_counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+        if self.collective:
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv_counts = rc.tolist()
+        else:
+            recv_counts = list(send_counts)
+        local_rows = (uniq_g % self.rows_per_rank).to(torch.int32)
+        wanted = self._exchange(local_rows, send_counts, recv_counts)          # rows the others want from me
+        out_rows = torch.empty(len(wanted), self.k, dtype=torch.float32, device=self.device)
+        out_bias = torch.empty(len(wanted), 1, dtype=torch.float32, device=self.device)
+        self.ops.gather(self.V, wanted, out_rows)
+        self.ops.gather(self.B.view(-1, 1), wanted, out_bias)
+        rows = self._exchange(out_rows, recv_counts, send_counts)
+        bias = self._exchange(out_bias, recv_counts, send_counts).view(-1)
+        return rows, bias, (send_counts, recv_counts, wanted)
+
+    def push(self, plan, d_rows, d_bias):
+        send_counts, recv_counts, wanted = plan
+        got_rows = self._exchange(d_rows.contiguous(), send_counts, recv_counts)
+        got_bias = self._exchange(d_bias.contiguous().view(-1, 1), send_counts, recv_counts)
+        self.ops.scatter_add(self.V, wanted, got_rows)
+        self.ops.scatter_add(self.B.view(-1, 1), wanted, got_bias)
+
+    def gather_full(self):
+        """(V [total_items, k], B [total_items]) assembled on every rank (for get_factors / evaluation)"""
+        if not self.collective:
+            return self.V[: self.total_items].clone(), self.B[: self.total_items].clone()
+        Vs = [torch.empty_like(self.V) for _ in range(self.world)]
+        Bs = [torch.empty_like(self.B) for _ in range(self.world)]
+        dist.all_gather(Vs, self.V, group=self.group)
+        dist.all_gather(Bs, self.B, group=self.group)
+        V = torch.stack(Vs, 1).reshape(-1, self.k)[: self.total_items]   # row r of rank q -> item r * N + q
+        B = torch.stack(Bs, 1).reshape(-1)[: self.total_items]
+        return V, B
+
+
+class DeviceRowOps:
+    """row gather / scatter-add through libcornac_hip on the trainer's stream (device tensors only)"""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+
+    def gather(self, table, ids, out):
+        self.trainer.gather_rows(table.data_ptr(), ids.data_ptr(), len(ids), table.shape[1], out.data_ptr())
+
+    def scatter_add(self, table, ids, delta):
+        self.trainer.scatter_add_rows(table.data_ptr(), ids.data_ptr(), len(ids), table.shape[1], delta.data_ptr())
+
+
+class RowShardedBprTrainer:
+    """One rank of BPR with the item table sharded by row.  Users (CSR slice, U rows) are rank-local as in
+    regime 1; each micro-batch samples triplets, fetches the touched item rows, applies the hogwild update on
+    the staged rows and pushes the deltas back.  Between a fetch and the matching push other ranks may fetch the
+    same rows: the usual bounded-staleness asynchrony, one micro-batch deep."""
+
+    BIAS_STRIDE = 32  # staged biases sit one per 128-byte line (see DESIGN.md "padded bias table")
+
+    def __init__(self, trainer, total_items, k, device, micro_batch, group=None, ops=None):
+        self.trainer, self.device, self.micro_batch, self.group = trainer, device, int(micro_batch), group
+        self.stream = None
+        if device.type == "cuda":
+            self.stream = torch.cuda.Stream(device)
+            torch.cuda.synchronize(device)
+            trainer.set_stream(self.stream.cuda_stream)
+        with self._on_stream():
+            self.table = RowShardedItemTable(total_items, k, device, ops or DeviceRowOps(trainer), group)
+        if device.type == "cuda":
+            # the handle's own (full-size) item table is not used in this mode: release it
+            trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
+        self.rows_fetched = 0
+        self.triplets = 0
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def load_items(self, V, B):
+        with self._on_stream():
+            self.table.load(V, B)
+        if self.stream is not None:
+            self.stream.synchronize()
+
+    def _sample(self, n):
+        u = torch.empty(n, dtype=torch.int32, device=self.device)
+        i, j = torch.empty_like(u), torch.empty_like(u)
+        self.trainer.sample_triplets(n, u.data_ptr(), i.data_ptr(), j.data_ptr())
+        return u, i, j
+
+    def _apply(self, u, slot_i, slot_j, rows, bias_pad, lr, reg, use_bias):
+        self.trainer.apply_triplets(u.data_ptr(), slot_i.data_ptr(), slot_j.data_ptr(), len(u), rows.data_ptr(),
+                                    bias_pad.data_ptr(), self.BIAS_STRIDE, lr, reg, use_bias)
+
+    def run(self, n_samples, lr, reg, use_bias=True):
+        """n_samples draws on this rank, in micro-batches; every rank must call with the same micro-batch count"""
+        left = int(n_samples)
+        with self._on_stream():
+            while left > 0:
+                n = min(left, self.micro_batch)
+                left -= n
+                u, i, j = self._sample(n)
+                keep = u >= 0                                       # skipped draws carry -1
+                u, i, j = u[keep], i[keep].long(), j[keep].long()
+                g = torch.cat([self.table.owner_major(i), self.table.owner_major(j)])
+                uniq, inv = torch.unique(g, return_inverse=True)   # sorted -> bucketed by owner
+                rows, bias, plan = self.table.fetch(uniq)
+                rows0, bias0 = rows.clone(), bias
+                bias_pad = torch.zeros(len(bias), self.BIAS_STRIDE, dtype=torch.float32, device=self.device)
+                bias_pad[:, 0] = bias
+                inv = inv.to(torch.int32)
+                self._apply(u, inv[: len(u)].contiguous(), inv[len(u):].contiguous(), rows, bias_pad, lr, reg, use_bias)
+                self.table.push(plan, rows - rows0, bias_pad[:, 0] - bias0)
+                self.rows_fetched += len(uniq)
+                self.triplets += len(u)
 
     def finish(self):
         out = self.trainer.sync()

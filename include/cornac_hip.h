@@ -127,6 +127,27 @@ int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_m
 int cornac_hip_bpr_last_timing(cornac_hip_bpr_t h, double *ms4);
 
 /* ------------------------------------------------------------------------- *
+ * Building blocks of the row-sharded item table (multi-GPU regime 2): the same
+ * _fit_sgd step (cornac/models/bpr/recom_bpr.pyx:208-269) cut into sample / fetch / apply / push
+ * because the item rows of a triplet live on other GPUs.  All pointers are DEVICE pointers; all
+ * launches go to the handle's stream.  Driven by cornac_amd/dist.py:RowShardedBprTrainer.
+ * ------------------------------------------------------------------------- */
+/* draws n_draws (u, i, j) with the hogwild sampler (continues the handle's sample counter); a draw whose
+ * negative is a positive of u ("skipped", recom_bpr.pyx:236-238) is written as u = i = j = -1 */
+int cornac_hip_bpr_sample_triplets(cornac_hip_bpr_t h, int64_t n_draws, int neg_population, int32_t *d_u,
+                                   int32_t *d_i, int32_t *d_j);
+/* BPR update of the handle's U rows and of STAGED item rows: d_slot_i/j index rows of d_rows [n_slots, k]
+ * and d_bias [n_slots * bias_stride]; entries with d_u < 0 are ignored */
+int cornac_hip_bpr_apply_triplets(cornac_hip_bpr_t h, const int32_t *d_u, const int32_t *d_slot_i,
+                                  const int32_t *d_slot_j, int64_t n, float *d_rows, float *d_bias, int bias_stride,
+                                  float lr, float reg, int use_bias);
+/* d_out[r, :] = d_table[d_ids[r], :] and d_table[d_ids[r], :] += d_delta[r, :] (atomic), rows of `width` floats */
+int cornac_hip_bpr_gather_rows(cornac_hip_bpr_t h, const float *d_table, const int32_t *d_ids, int64_t n, int width,
+                               float *d_out);
+int cornac_hip_bpr_scatter_add_rows(cornac_hip_bpr_t h, float *d_table, const int32_t *d_ids, int64_t n, int width,
+                                    const float *d_delta);
+
+/* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.
  * Replaces: VEBPR._fit_sgd_viewloss(rng_pos, rng_view, rng_neg, ..., U, V)
  *           cornac/models/bpr/recom_vebpr.pyx:211-337 and its caller loop :189-207.

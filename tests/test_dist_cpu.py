@@ -93,3 +93,107 @@ def test_partition_users_by_nnz_and_slice():
             assert np.array_equal(ix, indices[indptr[cuts[r]]:indptr[cuts[r + 1]]])
             total += len(ix)
         assert total == indptr[-1]
+
+
+# ---- regime 2: row-sharded item table (all-to-all of rows) ----------------------------------------
+class _HostRowOps:
+    """host stand-in for DeviceRowOps (the HIP gather / scatter-add kernels) on CPU tensors"""
+
+    def gather(self, table, ids, out):
+        out.copy_(table[ids.long()])
+
+    def scatter_add(self, table, ids, delta):
+        table.index_add_(0, ids.long(), delta)
+
+
+class _FakeShardTrainer:
+    """stands in for _lib.BprTrainer: fixed triplets per rank, `apply` adds recognisable increments"""
+
+    def __init__(self, rank, n_items):
+        self.rank, self.n_items, self.batches = rank, n_items, 0
+
+    def make(self, n):
+        rs = np.random.RandomState(100 * self.rank + self.batches)
+        self.batches += 1
+        u = rs.randint(0, 5, n).astype(np.int32)
+        u[::7] = -1  # skipped draws
+        return u, rs.randint(0, self.n_items, n).astype(np.int32), rs.randint(0, self.n_items, n).astype(np.int32)
+
+    def sync(self):
+        return (0, 0)
+
+
+def _shard_worker(rank, world, port, out):
+    from cornac_amd.dist import RowShardedBprTrainer, RowShardedItemTable
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        n_items, k = 11, 3
+        V0 = np.arange(n_items, dtype=np.float32)[:, None] * np.ones((1, k), np.float32)
+        B0 = -np.arange(n_items, dtype=np.float32)
+        # (a) the table alone: fetch returns the owners' rows, push adds every requester's delta
+        t = RowShardedItemTable(n_items, k, dev, _HostRowOps())
+        t.load(V0, B0)
+        want_items = torch.tensor([0, 1, 4, 9, 10] if rank == 0 else [1, 2, 9], dtype=torch.int64)
+        uniq = torch.unique(t.owner_major(want_items))
+        rows, bias, plan = t.fetch(uniq)
+        items_back = (uniq % t.rows_per_rank) * world + uniq // t.rows_per_rank
+        assert torch.equal(rows[:, 0], items_back.float()) and torch.equal(bias, -items_back.float())
+        t.push(plan, torch.full_like(rows, float(rank + 1)), torch.full_like(bias, 10.0 * (rank + 1)))
+        Vf, Bf = t.gather_full()
+        # (b) the trainer loop with stand-ins: every valid triplet adds +1 to its i-row, -1 to its j-row, +0.5 bias i
+        fake = _FakeShardTrainer(rank, n_items)
+        sh = RowShardedBprTrainer(fake, n_items, k, dev, micro_batch=20, ops=_HostRowOps())
+        sh.load_items(V0, B0)
+        seen = []
+
+        def sample(n):
+            u, i, j = fake.make(n)
+            seen.append((u.copy(), i.copy(), j.copy()))
+            i[u < 0] = -1
+            j[u < 0] = -1
+            return torch.tensor(u), torch.tensor(i), torch.tensor(j)
+
+        def apply(u, si, sj, rows, bias_pad, lr, reg, use_bias):
+            rows.index_add_(0, si.long(), torch.ones(len(si), k))
+            rows.index_add_(0, sj.long(), -torch.ones(len(sj), k))
+            bias_pad[:, 0].index_add_(0, si.long(), torch.full((len(si),), 0.5))
+
+        sh._sample, sh._apply = sample, apply
+        sh.run(50, 0.1, 0.0)  # micro-batches of 20, 20, 10
+        V2, B2 = sh.table.gather_full()
+        out[rank] = (Vf.numpy().copy(), Bf.numpy().copy(), V2.numpy().copy(), B2.numpy().copy(), seen, sh.triplets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_table_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    n_items, k = 11, 3
+    V0 = np.arange(n_items, dtype=np.float32)[:, None] * np.ones((1, k), np.float32)
+    B0 = -np.arange(n_items, dtype=np.float32)
+    Vf0, Bf0, V20, B20, seen0, n0 = out[0]
+    Vf1, Bf1, V21, B21, seen1, n1 = out[1]
+    assert np.array_equal(Vf0, Vf1) and np.array_equal(V20, V21) and np.array_equal(B20, B21)
+    want = V0.copy()
+    wb = B0.copy()
+    for items, r in (([0, 1, 4, 9, 10], 0), ([1, 2, 9], 1)):
+        want[items] += r + 1
+        wb[items] += 10.0 * (r + 1)
+    assert np.array_equal(Vf0, want) and np.array_equal(Bf0, wb)
+    want, wb, n_valid = V0.copy(), B0.copy(), 0
+    for seen in (seen0, seen1):
+        assert [len(b[0]) for b in seen] == [20, 20, 10]
+        for u, i, j in seen:
+            ok = u >= 0
+            n_valid += int(ok.sum())
+            np.add.at(want, i[ok], 1.0)
+            np.add.at(want, j[ok], -1.0)
+            np.add.at(wb, i[ok], 0.5)
+    assert n0 + n1 == n_valid
+    assert np.allclose(V20, want) and np.allclose(B20, wb)

@@ -1,0 +1,160 @@
+"""GPU tests of the row-sharded item table path (multi-GPU regime 2): the sample / gather / apply /
+scatter-add kernels behind cornac_hip_bpr_{sample_triplets,apply_triplets,gather_rows,scatter_add_rows}
+and the RowShardedBprTrainer loop on one rank through a real NCCL (RCCL) group of size 1."""
+import os
+
+import numpy as np
+import pytest
+
+from cornac_amd import _lib
+from conftest import synth_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(ds, k):
+    X = ds.matrix
+    return _lib.BprTrainer(X.indptr, X.indices, ds.num_users, ds.num_items, len(ds.uid_map), len(ds.iid_map), k)
+
+
+def test_sample_triplets_match_the_cpu_restatement_of_the_hogwild_sampler(oracle):
+    import torch
+
+    ds = synth_dataset(300, 50, 6000, zipf=0.5, seed=8)
+    X = ds.matrix
+    indptr, indices, user_ids = oracle.csr_arrays(ds)
+    tr = _trainer(ds, 8)
+    tr.seed_hogwild(0xABCDEF0123)
+    n = 2 * X.nnz + 777  # crosses two epoch boundaries of the sample counter
+    dev = torch.device("cuda", 0)
+    u, i, j = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    torch.cuda.synchronize()
+    tr.sample_triplets(n, u.data_ptr(), i.data_ptr(), j.data_ptr())
+    c, s = tr.sync()
+    u, i, j = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+    tr.close()
+    want_u, want_i, want_j = [], [], []
+    for epoch, cnt in enumerate((X.nnz, X.nnz, 777)):
+        ii, jj = oracle.hogwild_sample(0xABCDEF0123, epoch, 0, cnt, X.nnz, ds.num_items)
+        uu = user_ids[ii]
+        skip = np.asarray(X[uu, jj]).ravel() != 0
+        want_u.append(np.where(skip, -1, uu)); want_i.append(np.where(skip, -1, indices[ii])); want_j.append(np.where(skip, -1, jj))
+    assert np.array_equal(u, np.concatenate(want_u)) and np.array_equal(i, np.concatenate(want_i))
+    assert np.array_equal(j, np.concatenate(want_j))
+    assert s == int((u < 0).sum()) and 0 < s < n // 2
+
+
+@pytest.mark.parametrize("k", [5, 64, 100])
+def test_apply_gather_scatter_kernels(k):
+    import torch
+
+    rs = np.random.RandomState(k)
+    ds = synth_dataset(200, 80, 3000, seed=2)
+    nu = len(ds.uid_map)
+    tr = _trainer(ds, k)
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    tr.set_factors(U, np.zeros((len(ds.iid_map), k), np.float32), np.zeros(len(ds.iid_map), np.float32))
+    dev = torch.device("cuda", 0)
+    n_slots, n = 150, 60
+    rows = rs.normal(0, 0.3, (n_slots, k)).astype(np.float32)
+    bias = rs.normal(0, 0.3, n_slots).astype(np.float32)
+    # conflict-free batch: distinct users, distinct slots -> exact sequential semantics
+    users = rs.permutation(nu)[:n].astype(np.int32)
+    slots = rs.permutation(n_slots)[: 2 * n].astype(np.int32)
+    si, sj = slots[:n].copy(), slots[n:].copy()
+    users[5] = -1  # ignored entry
+    t_rows = torch.tensor(rows, device=dev)
+    stride = 32
+    t_bias = torch.zeros(n_slots, stride, device=dev)
+    t_bias[:, 0] = torch.tensor(bias, device=dev)
+    lr, reg = 0.05, 0.01
+    t_u, t_si, t_sj = (torch.tensor(x, device=dev) for x in (users, si, sj))
+    torch.cuda.synchronize()  # the handle runs on its own stream here: inputs must be complete before the launch
+    tr.apply_triplets(t_u.data_ptr(), t_si.data_ptr(), t_sj.data_ptr(), n, t_rows.data_ptr(), t_bias.data_ptr(), stride,
+                      lr, reg, True)
+    c, _ = tr.sync()
+    U2 = tr.get_factors()[0]
+    wantU, wantR, wantB, correct = U.astype(np.float64), rows.astype(np.float64), bias.astype(np.float64), 0
+    for t in range(n):
+        u = users[t]
+        if u < 0:
+            continue
+        a, b = si[t], sj[t]
+        uf, vi, vj = U[u].astype(np.float64), rows[a].astype(np.float64), rows[b].astype(np.float64)
+        z = 1.0 / (1.0 + np.exp(bias[a] - bias[b] + uf @ (vi - vj)))
+        correct += z < 0.5
+        wantU[u] += lr * (z * (vi - vj) - reg * uf)
+        wantR[a] += lr * (z * uf - reg * vi)
+        wantR[b] += lr * (-z * uf - reg * vj)
+        wantB[a] += lr * (z - reg * bias[a])
+        wantB[b] += lr * (-z - reg * bias[b])
+    assert c == correct
+    assert np.abs(U2 - wantU).max() < 2e-6 and np.abs(t_rows.cpu().numpy() - wantR).max() < 2e-6
+    assert np.abs(t_bias[:, 0].cpu().numpy() - wantB).max() < 2e-6 and float(t_bias[:, 1:].abs().max()) == 0.0
+    # gather / scatter-add with repeated ids
+    table = torch.tensor(rs.normal(0, 1, (90, k)).astype(np.float32), device=dev)
+    ids = torch.tensor(rs.randint(0, 90, 400).astype(np.int32), device=dev)
+    out = torch.empty(400, k, device=dev)
+    delta = torch.tensor(rs.normal(0, 1, (400, k)).astype(np.float32), device=dev)
+    torch.cuda.synchronize()
+    tr.gather_rows(table.data_ptr(), ids.data_ptr(), 400, k, out.data_ptr())
+    tr.sync()
+    assert torch.equal(out, table[ids.long()])
+    want = table.double().index_add(0, ids.long(), delta.double())
+    torch.cuda.synchronize()
+    tr.scatter_add_rows(table.data_ptr(), ids.data_ptr(), 400, k, delta.data_ptr())
+    tr.sync()
+    assert (table.double() - want).abs().max() < 1e-5
+    tr.close()
+
+
+def test_row_sharded_trainer_single_rank_through_rccl():
+    """the whole regime-2 loop on one rank with a real NCCL group (all_to_all_single through RCCL): learns like
+    the fused hogwild kernel on the same data, and with reg = 0 conserves the column sums of V / the sum of B
+    (every triplet adds +d to row i and -d to row j), which a mis-routed or double-applied delta would break."""
+    import torch
+    import torch.distributed as dist
+
+    from cornac_amd import synth
+    from cornac_amd.dist import RowShardedBprTrainer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_users, n_items, k = 6000, 3000, 64
+    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    rs = np.random.RandomState(0)
+    U = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    epochs, lr = 3, 0.05
+    ref = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    ref.set_factors(U, V, np.zeros(n_items, np.float32))
+    ref.seed_hogwild(5)
+    c_ref, s_ref = ref.fit_epochs(epochs, lr, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    ref.close()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.set_factors(U, None, None)
+        tr.seed_hogwild(5)
+        sh = RowShardedBprTrainer(tr, n_items, k, dev, micro_batch=100_000)
+        assert sh.table.collective
+        sh.load_items(V, np.zeros(n_items, np.float32))
+        sh.run(epochs * len(indices), lr, 0.0)
+        c, s = sh.finish()
+        V2t, B2t = sh.table.gather_full()
+        V2, B2 = V2t.cpu().numpy(), B2t.cpu().numpy()
+        fetched, trip = sh.rows_fetched, sh.triplets
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+    n = epochs * len(indices)
+    assert trip == n - s and 0 < s < 0.2 * n
+    assert abs(c / trip - c_ref / (n - s_ref)) < 0.02, (c / trip, c_ref / (n - s_ref))
+    assert fetched <= 2 * trip and fetched >= n_items
+    moved = np.abs(V2.astype(np.float64) - V).sum(0)
+    assert moved.min() > 1.0
+    assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+    assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
