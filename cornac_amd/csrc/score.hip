@@ -150,12 +150,12 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
 // threshold.  Expected survivors per row over N items is ~topk*ln(N/topk), so the epilogue is a few
 // percent of the MFMA time.  Optional exclusion lists (sorted CSR per row) are consulted only for
 // survivors.  Each strip emits topk keys per row; rank_merge_kernel merges the strips.
-template <int KT, int CAP>
+template <int KT, int CAP, bool UB>
 __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ item_base,
                                                           const float *__restrict__ user_base,
                                                           const int32_t *__restrict__ users, int64_t u0,
-                                                          int64_t n_rows, int64_t n_items, int k, int tiles_per_strip,
+                                                          int64_t n_rows, int64_t n_items, int64_t work_per_wg,
                                                           int topk, const int64_t *__restrict__ excl_indptr,
                                                           const int32_t *__restrict__ excl_indices, int64_t excl_row0,
                                                           unsigned long long *__restrict__ part, int ablate) {
@@ -169,39 +169,15 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
     __shared__ float ibase[2][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
-    const int64_t row_tile = (int64_t)blockIdx.y * (kBlk / 64) + wave;
-    if (lane < 32) {
-        cnt[wave][lane] = 0;
-        tau[wave][lane] = -INFINITY;
-    }
-    // A fragments + this lane's user bias
-    float a[KT];
-    {
-        const int64_t r = row_tile * 32 + col;
-        const bool ok = r < n_rows;
-        const int64_t u = ok ? (users ? (int64_t)users[r] : u0 + r) : 0;
-        const float *p = U + u * (2 * KT) + half;  // tables are zero-padded to 2*KT columns
-#pragma unroll
-        for (int t = 0; t < KT; ++t) a[t] = p[2 * t];
-    }
-    // per accumulator register: the row it belongs to, that row's user bias and threshold
-    float ubias[16], thr[16];
-    bool row_ok[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int64_t row = row_tile * 32 + rl;
-        row_ok[r] = row < n_rows;
-        ubias[r] = 0.f;
-        if (user_base && row_ok[r]) ubias[r] = user_base[users ? (int64_t)users[row] : u0 + row];
-        thr[r] = row_ok[r] ? -INFINITY : INFINITY;
-    }
-    // rows beyond n_rows: tau = +inf (nothing ever passes); items beyond n_items get a NaN item base
-    // (NaN >= thr is false), so the hot compare needs no validity masks
-    if (lane < 32 && row_tile * 32 + lane >= n_rows) tau[wave][lane] = INFINITY;
     const int64_t n_item_tiles = (n_items + 31) / 32;
-    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_strip;
-    const int64_t t_end = min(n_item_tiles, t_begin + tiles_per_strip);
+    // Balanced persistent decomposition: the (row block, item tile) space is linearised and cut into equal
+    // contiguous ranges, one per resident workgroup, so the grid is exactly one wave of workgroups with no
+    // ragged last round.  A range covers the tail of one row block, whole row blocks and the head of another;
+    // every piece ("segment") emits topk candidates per row into part[segment ordinal within its row block].
+    const int64_t n_row_blocks = (n_rows + 127) / 128;
+    const int64_t work_total = n_row_blocks * n_item_tiles;
+    int64_t pos = (int64_t)blockIdx.x * work_per_wg;
+    const int64_t work_end = min(work_total, pos + work_per_wg);
     float bcur[KT];
     // staging: 32 items x KP floats = 8*KP float4; thread i moves float4 #i, #i+256, ...
     constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
@@ -230,133 +206,229 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         }
         if (threadIdx.x < 32) ibase[buf][threadIdx.x] = stg_ib;
     };
-    // wave-wide compaction of the rows whose buffer could overflow on the next tile (all rows if force)
-    auto compact = [&](bool force) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int rl = 0; rl < 32; ++rl) {
-            const int c = cnt[wave][rl];
-            if (c <= CAP - 32 && !force) continue;  // only rows that could overflow on the next tile
-            unsigned long long key = lane < c ? keys[wave][rl][lane] : 0ull;
-            if (excl_indptr && key != 0ull) {  // drop excluded items before they can raise the threshold
-                const int32_t item = (int32_t)(uint32_t)key;
-                const int64_t grow = excl_row0 + row_tile * 32 + rl;
-                int64_t lo = excl_indptr[grow], hi = excl_indptr[grow + 1];
-                const int64_t end = hi;
-                while (lo < hi) {
-                    const int64_t mid = lo + ((hi - lo) >> 1);
-                    if (excl_indices[mid] < item) lo = mid + 1; else hi = mid;
-                }
-                if (lo < end && excl_indices[lo] == item) key = 0ull;
-            }
-            // 64-lane bitonic sort, descending
+    // B fragments of one tile: issued in groups of FG so that the loads of group g+1 are in flight while the
+    // MFMAs of group g run (the scheduling barriers keep the compiler from sinking every load to its use)
+    constexpr int FG = KT < 8 ? KT : 8;
+    auto load_frags = [&](int buf, int g) {
 #pragma unroll
-            for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-                for (int j = kk >> 1; j > 0; j >>= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)key, j, 64);
-                    const unsigned hi = __shfl_xor((unsigned)(key >> 32), j, 64);
-                    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-                    const bool up = (lane & j) == 0;          // lower lane of the pair
-                    const bool desc = (lane & kk) == 0;       // direction of this bitonic block
-                    const bool take_max = up == desc;
-                    key = take_max ? (key > other ? key : other) : (key < other ? key : other);
-                }
-            }
-            const int n_live = __popcll(__ballot(key != 0ull));  // excluded entries sorted to the tail
-            const int keep = min(n_live, topk);
-            if (lane < CAP) keys[wave][rl][lane] = lane < keep ? key : 0ull;
-            const unsigned long long kth = __shfl(key, topk - 1, 64);  // 0 when fewer than topk candidates
-            if (lane == 0 && row_tile * 32 + rl < n_rows) {
-                cnt[wave][rl] = keep;
-                tau[wave][rl] = kth != 0ull ? key_to_float((unsigned)(kth >> 32)) : -INFINITY;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) thr[r] = tau[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int t = g * FG; t < (g + 1) * FG; ++t) bcur[t] = btile[buf][col][2 * t + half];
     };
-    // Software pipeline: iteration `it` issues the MFMA chain of tile it+1 and, interleaved between
-    // those MFMAs in program order, evaluates the finished accumulators of tile it (a wave issues in
-    // order, so VALU work only overlaps its own MFMAs when it sits between them).  The two
-    // workgroups of a CU run in phase, so without this the matrix pipe idles during every epilogue.
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc_cur = zero16;
-    float ib_cur2 = 0.f;
-    if (t_begin < t_end) {
-        stage_load(t_begin);
-        stage_store(0);
-    }
-    __syncthreads();
-    if (t_begin + 1 < t_end) stage_load(t_begin + 1);
-    {
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bcur[t] = btile[0][col][2 * t + half];
-        ib_cur2 = ibase[0][col];
-#pragma unroll
-        for (int t = 0; t < KT; ++t) acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_cur, 0, 0, 0);
-    }
-    if (t_begin + 1 < t_end) stage_store(1);
-    __syncthreads();
-    for (int64_t it = t_begin; it < t_end; ++it) {
-        const int buf_next = (int)((it + 1 - t_begin) & 1);
-        if (it + 2 < t_end) stage_load(it + 2);
-        // ---- one basic block: B fragments + MFMA chain of tile it+1, compare of tile it ----------------
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bcur[t] = btile[buf_next][col][2 * t + half];
-        const float ib_next = ibase[buf_next][col];
-        f32x16 acc_nxt = zero16;
-        const int64_t item = it * 32 + col;
-        unsigned hitbits = 0;
-        float sc[16];
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            acc_nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_nxt, 0, 0, 0);
-            if (t < 16) {
-                const int r = t;
-                sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
-                hitbits |= (sc[r] >= thr[r]) ? (1u << r) : 0u;
-            }
+
+    while (pos < work_end) {
+        const int64_t rb = pos / n_item_tiles;
+        const int64_t t_begin = pos - rb * n_item_tiles;
+        const int64_t t_end = min(n_item_tiles, t_begin + (work_end - pos));
+        const int64_t seg = (int64_t)blockIdx.x - (rb * n_item_tiles) / work_per_wg;
+        pos += t_end - t_begin;
+        const int64_t row_tile = rb * (kBlk / 64) + wave;
+        if (lane < 32) {
+            cnt[wave][lane] = 0;
+            // rows beyond n_rows: tau = +inf (nothing ever passes); items beyond n_items get a NaN item base
+            // (NaN >= thr is false), so the hot compare needs no validity masks
+            tau[wave][lane] = row_tile * 32 + lane >= n_rows ? INFINITY : -INFINITY;
         }
-        if (KT < 16) {
+        // A fragments + this lane's user bias
+        float a[KT];
+        {
+            const int64_t r = row_tile * 32 + col;
+            const bool ok = r < n_rows;
+            const int64_t u = ok ? (users ? (int64_t)users[r] : u0 + r) : 0;
+            const float *p = U + u * (2 * KT) + half;  // tables are zero-padded to 2*KT columns
 #pragma unroll
-            for (int r = KT; r < 16; ++r) {
-                sc[r] = (ib_cur2 + ubias[r]) + acc_cur[r];
-                hitbits |= (sc[r] >= thr[r]) ? (1u << r) : 0u;
-            }
+            for (int t = 0; t < KT; ++t) a[t] = p[2 * t];
         }
-        if (ablate & 1) hitbits = 0;
-        // ---- rare path: append the survivors of tile it ---------------------------------------------------
-        if (__any(hitbits != 0u)) {
+        // per accumulator register: the row it belongs to, that row's user bias, threshold and the number of
+        // candidates buffered for it (cnt_r is uniform inside each half-wave: kept in registers so that the
+        // append path needs no LDS atomic and no LDS read to decide about compaction)
+        float ubias[16], thr[16];
+        int cnt_r[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (hitbits & (1u << r)) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int pos = atomicAdd(&cnt[wave][rl], 1);
-                    keys[wave][rl][pos] =
-                        ((unsigned long long)order_key(sc[r]) << 32) | (unsigned long long)(uint32_t)item;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t row = row_tile * 32 + rl;
+            const bool row_ok = row < n_rows;
+            ubias[r] = 0.f;
+            if (user_base && row_ok) ubias[r] = user_base[users ? (int64_t)users[row] : u0 + row];
+            thr[r] = row_ok ? -INFINITY : INFINITY;
+            cnt_r[r] = 0;
+        }
+        // wave-wide compaction of the rows whose buffer would overflow with this tile's survivors (or all rows at
+        // the end of the segment): keep the topk best candidates of the row (in descending order) and raise its threshold to the topk-th.
+        // Selection by RANK COUNTING — lane i holds candidate i and counts the candidates that beat it, each read
+        // as an LDS broadcast: c independent loads and 3c VALU instructions with a single LDS round trip of
+        // latency, instead of a 64-lane bitonic network's 21 DEPENDENT cross-lane exchanges (which held the whole
+        // workgroup at the tile barrier for thousands of cycles per sort).
+        // need_l: this half-wave's rows to compact (bit = row within the wave's 32-row tile)
+        auto compact = [&](unsigned need_l) __attribute__((always_inline)) {
+            unsigned need = __builtin_amdgcn_readlane(need_l, 0) | __builtin_amdgcn_readlane(need_l, 32);
+            if (col == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cnt[wave][(r & 3) + 8 * (r >> 2) + 4 * half] = cnt_r[r];
             }
-            // a tile adds at most 32 entries per row: compact before any buffer can exceed CAP
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int mx = cnt[wave][lane & 31];
+            while (need) {
+                const int rl = __builtin_ctz(need);
+                need &= need - 1u;
+                const int c = cnt[wave][rl];
+                unsigned long long *krow = keys[wave][rl];
+                unsigned long long mine = lane < c ? krow[lane] : 0ull;
+                if (excl_indptr) {  // drop excluded items before they can raise the threshold
+                    bool dropped = false;
+                    if (mine != 0ull) {
+                        const int32_t item = (int32_t)(uint32_t)mine;
+                        const int64_t grow = excl_row0 + row_tile * 32 + rl;
+                        int64_t lo = excl_indptr[grow], hi = excl_indptr[grow + 1];
+                        const int64_t end = hi;
+                        while (lo < hi) {
+                            const int64_t mid = lo + ((hi - lo) >> 1);
+                            if (excl_indices[mid] < item) lo = mid + 1; else hi = mid;
+                        }
+                        dropped = lo < end && excl_indices[lo] == item;
+                    }
+                    if (dropped) {
+                        mine = 0ull;
+                        krow[lane] = 0ull;  // the broadcast reads below must see it as absent
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                int rank = 0;
+                for (int j0 = 0; j0 < c; j0 += 8) {  // 8 independent broadcast loads in flight, then 8 compares
+                    unsigned long long kj[8];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-            if (__builtin_amdgcn_readfirstlane(mx) > CAP - 32) compact(false);  // wave-uniform decision
+                    for (int q = 0; q < 8; ++q) kj[q] = krow[min(j0 + q, CAP - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rank += (j0 + q < c && kj[q] > mine) ? 1 : 0;
+                }
+                const bool live = mine != 0ull;
+                const int n_keep = min(__popcll(__ballot(live)), topk);
+                const unsigned long long kth_mask = __ballot(live && rank == topk - 1);
+                if (lane < CAP) krow[lane] = 0ull;       // LDS operations of one wave execute in order
+                if (live && rank < topk) krow[rank] = mine;
+                if (kth_mask != 0ull) {  // wave-uniform
+                    const int src = __builtin_ctzll(kth_mask);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), src);
+                    if (lane == 0 && row_tile * 32 + rl < n_rows) tau[wave][rl] = key_to_float(hi);
+                }
+                if (lane == 0) cnt[wave][rl] = n_keep;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                thr[r] = tau[wave][rl];
+                cnt_r[r] = cnt[wave][rl];
+            }
+        };
+        // Software pipeline: step `it` issues the MFMA chain of tile it+1 and, interleaved between those MFMAs
+        // in program order, evaluates the finished accumulators of tile it.  On this hardware VALU issue cycles
+        // ADD to the matrix pipe's time (tools/mfma_probe: 2048 + ~4 cycles per VALU instruction per tile), so the
+        // compare is kept to one add and one v_cmp (lane mask straight into SGPRs) per accumulator register, and
+        // the loop is unrolled by two so that the accumulators ping-pong instead of being copied.
+        f32x16 acc_a = zero16, acc_b = zero16;
+        float ib_a = 0.f, ib_b = 0.f;
+        stage_load(t_begin);
+        stage_store(0);
+        __syncthreads();
+        if (t_begin + 1 < t_end) stage_load(t_begin + 1);
+        {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bcur[t] = btile[0][col][2 * t + half];
+            ib_a = ibase[0][col];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_a, 0, 0, 0);
         }
-        if (it + 2 < t_end) stage_store((int)((it + 2 - t_begin) & 1));
-        __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
-        acc_cur = acc_nxt;
-        ib_cur2 = ib_next;
-    }
-    compact(true);
-    // emit this strip's candidates: part[strip][row][topk]
-    for (int rl = 0; rl < 32; ++rl) {
-        const int64_t row = row_tile * 32 + rl;
-        if (row >= n_rows) break;  // also covers waves whose whole row tile is out of range
-        if (lane < topk) part[((int64_t)blockIdx.x * n_rows + row) * topk + lane] = keys[wave][rl][lane];
+        if (t_begin + 1 < t_end) stage_store(1);
+        __syncthreads();
+        auto step = [&](int64_t it, f32x16 &acc_cur, f32x16 &acc_nxt, float &ib_cur, float &ib_nxt) __attribute__((always_inline)) {
+            const int buf_next = (int)((it + 1 - t_begin) & 1);
+            if (it + 2 < t_end && !(ablate & 2)) stage_load(it + 2);
+            // ---- B fragments + MFMA chain of tile it+1, compare of tile it -----------------------------------
+            load_frags(buf_next, 0);
+            ib_nxt = ibase[buf_next][col];
+            const int64_t item = it * 32 + col;
+            unsigned long long hm[16];
+            float sc[16];
+#pragma unroll
+            for (int g = 0; g < KT / FG; ++g) {
+                if (g + 1 < KT / FG) load_frags(buf_next, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = g * FG; t < (g + 1) * FG; ++t) {
+                    if (t == 0) acc_nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], zero16, 0, 0, 0);
+                    else acc_nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_nxt, 0, 0, 0);
+                    if (t < 16) {
+                        const int r = t;
+                        sc[r] = UB ? (ib_cur + ubias[r]) + acc_cur[r] : ib_cur + acc_cur[r];
+                        hm[r] = __ballot(sc[r] >= thr[r]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (KT < 16) {
+#pragma unroll
+                for (int r = KT; r < 16; ++r) {
+                    sc[r] = UB ? (ib_cur + ubias[r]) + acc_cur[r] : ib_cur + acc_cur[r];
+                    hm[r] = __ballot(sc[r] >= thr[r]);
+                }
+            }
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) any |= hm[r];
+            if (ablate & 1) any = 0ull;
+            // ---- rare path: append the survivors of tile it ---------------------------------------------------
+            if (any != 0ull) {
+                // rows whose buffer cannot take this tile's survivors are compacted first (their thresholds rise,
+                // so the survivors are re-evaluated); CAP >= topk + 32 guarantees room afterwards
+                // (VALU work only under wave-uniform `hm[r] != 0` branches: scalar instructions are free here, vector
+                // instructions are not)
+                unsigned over_l = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (hm[r] != 0ull) {
+                        const unsigned mine = half ? (unsigned)(hm[r] >> 32) : (unsigned)hm[r];
+                        if (cnt_r[r] + __popc(mine) > CAP) over_l |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
+                    }
+                }
+                if ((__builtin_amdgcn_readlane(over_l, 0) | __builtin_amdgcn_readlane(over_l, 32)) != 0u) {
+                    compact(over_l);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hm[r] = __ballot(sc[r] >= thr[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long m = hm[r];
+                    if (m != 0ull) {  // wave-uniform
+                        const unsigned mine = half ? (unsigned)(m >> 32) : (unsigned)m;
+                        if ((mine >> col) & 1u) {
+                            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int slot = cnt_r[r] + __popc(mine & ((1u << col) - 1u));
+                            keys[wave][rl][slot] =
+                                ((unsigned long long)order_key(sc[r]) << 32) | (unsigned long long)(uint32_t)item;
+                        }
+                        cnt_r[r] += __popc(mine);
+                    }
+                }
+            }
+            if (it + 2 < t_end && !(ablate & 8)) stage_store((int)((it + 2 - t_begin) & 1));
+            if (!(ablate & 4)) __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
+        };
+        for (int64_t it = t_begin; it < t_end; it += 2) {
+            step(it, acc_a, acc_b, ib_a, ib_b);
+            if (it + 1 < t_end) step(it + 1, acc_b, acc_a, ib_b, ib_a);
+        }
+        compact(0xffffffffu);
+        // emit this segment's candidates: part[segment][row][topk]
+        for (int rl = 0; rl < 32; ++rl) {
+            const int64_t row = row_tile * 32 + rl;
+            if (row >= n_rows) break;  // also covers waves whose whole row tile is out of range
+            if (lane < topk) part[(seg * n_rows + row) * topk + lane] = keys[wave][rl][lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -909,16 +981,32 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
         HIP_CHECK(hipGetLastError());
         return;
     }
-    dim3 grid((unsigned)gx, (unsigned)wg_rows), block(kBlk);
+    // balanced persistent decomposition (see rank_fused_kernel): one range of (row block, item tile) work per
+    // resident workgroup, at least 16 tiles long
+    const int wgs_per_cu = h->ld <= 64 ? 2 : 1;
+    const int64_t work_total = wg_rows * n_item_tiles;
+    int64_t work_per_wg = std::max<int64_t>((work_total + (int64_t)di.cus * wgs_per_cu - 1) / ((int64_t)di.cus * wgs_per_cu),
+                                            std::min<int64_t>(16, n_item_tiles));
+    const int64_t n_wgs = (work_total + work_per_wg - 1) / work_per_wg;
+    const int64_t max_segs = (n_item_tiles + work_per_wg - 1) / work_per_wg + 1;
+    h->part.ensure((size_t)(max_segs * n * topk));
+    HIP_CHECK(hipMemsetAsync(h->part.p, 0, (size_t)(max_segs * n * topk) * sizeof(unsigned long long), h->stream));
+    dim3 grid((unsigned)n_wgs), block(kBlk);
 #define FUSED(KT_, CAP_) do {                                                                                    \
     if (getenv("CORNAC_HIP_RANK_ABLATE")) {                                                                       \
         int occ = 0;                                                                                              \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rank_fused_kernel<KT_, CAP_>, kBlk, 0);           \
-        fprintf(stderr, "[rank_fused<%d,%d>] grid %ux%u, %d workgroups/CU\n", KT_, CAP_, grid.x, grid.y, occ);     \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rank_fused_kernel<KT_, CAP_, true>, kBlk, 0);     \
+        fprintf(stderr, "[rank_fused<%d,%d>] %u workgroups x %lld block-tiles, <= %lld segments/row, %d workgroups/CU\n", \
+                KT_, CAP_, grid.x, (long long)work_per_wg, (long long)max_segs, occ);                              \
     }                                                                                                             \
-    hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_>), grid, block, 0, h->stream, h->U.p, h->V.p, h->item_base.p, \
-                       ub, d_users, u0, n, h->n_items, k, tiles_per_strip, topk, d_excl_indptr, d_excl_indices,   \
-                       excl_row0, h->part.p, ablate); } while (0)
+    if (ub)                                                                                                       \
+        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, true>), grid, block, 0, h->stream, h->U.p, h->V.p,        \
+                           h->item_base.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,      \
+                           d_excl_indices, excl_row0, h->part.p, ablate);                                         \
+    else                                                                                                          \
+        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->V.p,       \
+                           h->item_base.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,      \
+                           d_excl_indices, excl_row0, h->part.p, ablate); } while (0)
     if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
         if (h->ld == 16) FUSED(8, 56);
         else if (h->ld == 32) FUSED(16, 56);
@@ -932,9 +1020,9 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     }
 #undef FUSED
     int pad = 1;
-    while (pad < (int)gx * topk) pad <<= 1;
-    hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)n), dim3(64), (size_t)pad * 8, h->stream, h->part.p, (int)gx,
-                       n, topk, pad, items_out, scores_out);
+    while (pad < (int)max_segs * topk) pad <<= 1;
+    hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)n), dim3(64), (size_t)pad * 8, h->stream, h->part.p,
+                       (int)max_segs, n, topk, pad, items_out, scores_out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -17,8 +17,11 @@ __device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; 
 // mode 5: as 0 but f64 atomics on 32 lanes x double (same bytes)
 // mode 6: as 0 but nt load + sc1 (atomic-store) write-through
 // mode 7: load only (nt), lane = float
-template <int MODE>
-__global__ __launch_bounds__(256) void probe(float *tab, unsigned n_rows, int iters, unsigned seed) {
+// PRIV: every XCD (block b runs on XCD b % 8) touches only its own eighth of the table
+template <int MODE, bool PRIV = false>
+__global__ __launch_bounds__(256) void probe(float *tab, unsigned n_rows_total, int iters, unsigned seed) {
+    const unsigned n_rows = PRIV ? n_rows_total / 8 : n_rows_total;
+    if (PRIV) tab += (size_t)(blockIdx.x & 7) * n_rows * 64;
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
@@ -56,15 +59,15 @@ __global__ __launch_bounds__(256) void probe(float *tab, unsigned n_rows, int it
     if (acc == 123.456f) tab[0] = acc;
 }
 
-template <int MODE>
+template <int MODE, bool PRIV = false>
 void run(float *tab, unsigned n_rows, const char *name) {
     const int blocks = 256 * 8, iters = 64;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    probe<MODE><<<blocks, 256>>>(tab, n_rows, 4, 1u);
+    probe<MODE, PRIV><<<blocks, 256>>>(tab, n_rows, 4, 1u);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    probe<MODE><<<blocks, 256>>>(tab, n_rows, iters, 7u);
+    probe<MODE, PRIV><<<blocks, 256>>>(tab, n_rows, iters, 7u);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -84,6 +87,16 @@ int main() {
         run<3>(tab, n_rows, "plain RMW, 16 lanes x float4");
         run<6>(tab, n_rows, "nt load + sc1 store, lane=float");
         run<7>(tab, n_rows, "nt load only, lane=float");
+        hipFree(tab);
+    }
+    // XCD-private replicas: 8 x 26 744 rows (8 x 6.85 MB) and 8 x 8 192 rows (8 x 2 MB: fits each 4 MB L2)
+    for (unsigned per : {26744u, 8192u}) {
+        float *tab; hipMalloc(&tab, (size_t)per * 8 * 256); hipMemset(tab, 0, (size_t)per * 8 * 256);
+        run<0, true>(tab, per * 8, "XCD-private: atomic agent");
+        run<4, true>(tab, per * 8, "XCD-private: atomic workgroup");
+        run<2, true>(tab, per * 8, "XCD-private: plain RMW");
+        run<6, true>(tab, per * 8, "XCD-private: nt load + sc1 store");
+        run<7, true>(tab, per * 8, "XCD-private: nt load only");
         hipFree(tab);
     }
     return 0;
