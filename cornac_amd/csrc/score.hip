@@ -158,9 +158,13 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
                                                           int64_t n_rows, int64_t n_items, int64_t work_per_wg,
                                                           int topk, const int64_t *__restrict__ excl_indptr,
                                                           const int32_t *__restrict__ excl_indices, int64_t excl_row0,
+                                                          const int32_t *__restrict__ perm,
                                                           unsigned long long *__restrict__ part, int ablate) {
+    // V / item_base are the scorer's RANK-ORDER copies: row p is item perm[p] (items sorted by a cheap upper
+    // estimate of their scores, see build_rank_order); the candidates carry the original item ids.
     constexpr int KP = 2 * KT;  // padded row length of the device tables
     __shared__ unsigned long long keys[kBlk / 64][32][CAP];
+    __shared__ int32_t ipos[2][32];
     __shared__ int cnt[kBlk / 64][32];
     __shared__ float tau[kBlk / 64][32];
     // the 4 waves of a workgroup walk the same item tiles: the B tile is staged once per workgroup
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
     constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
     v4f32 stg[STG];
     float stg_ib = 0.f;
+    int32_t stg_id = 0;
     auto stage_load = [&](int64_t it) {
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         if (threadIdx.x < 32) {
             const int64_t item = it * 32 + threadIdx.x;
             stg_ib = item < n_items ? (item_base ? item_base[item] : 0.f) : __builtin_nanf("");
+            stg_id = item < n_items ? (perm ? perm[item] : (int32_t)item) : 0;
         }
     };
     auto stage_store = [&](int buf) {
@@ -204,7 +210,10 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
                 dst[0] = stg[q].x; dst[1] = stg[q].y; dst[2] = stg[q].z; dst[3] = stg[q].w;
             }
         }
-        if (threadIdx.x < 32) ibase[buf][threadIdx.x] = stg_ib;
+        if (threadIdx.x < 32) {
+            ibase[buf][threadIdx.x] = stg_ib;
+            ipos[buf][threadIdx.x] = stg_id;
+        }
     };
     // B fragments of one tile: issued in groups of FG so that the loads of group g+1 are in flight while the
     // MFMAs of group g run (the scheduling barriers keep the compiler from sinking every load to its use)
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
         // the loop is unrolled by two so that the accumulators ping-pong instead of being copied.
         f32x16 acc_a = zero16, acc_b = zero16;
         float ib_a = 0.f, ib_b = 0.f;
+        int32_t id_a = 0, id_b = 0;
         stage_load(t_begin);
         stage_store(0);
         __syncthreads();
@@ -338,18 +348,21 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
 #pragma unroll
             for (int t = 0; t < KT; ++t) bcur[t] = btile[0][col][2 * t + half];
             ib_a = ibase[0][col];
+            id_a = ipos[0][col];
 #pragma unroll
             for (int t = 0; t < KT; ++t) acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_a, 0, 0, 0);
         }
         if (t_begin + 1 < t_end) stage_store(1);
         __syncthreads();
-        auto step = [&](int64_t it, f32x16 &acc_cur, f32x16 &acc_nxt, float &ib_cur, float &ib_nxt) __attribute__((always_inline)) {
+        auto step = [&](int64_t it, f32x16 &acc_cur, f32x16 &acc_nxt, float &ib_cur, float &ib_nxt, int32_t &id_cur,
+                        int32_t &id_nxt) __attribute__((always_inline)) {
             const int buf_next = (int)((it + 1 - t_begin) & 1);
             if (it + 2 < t_end && !(ablate & 2)) stage_load(it + 2);
             // ---- B fragments + MFMA chain of tile it+1, compare of tile it -----------------------------------
             load_frags(buf_next, 0);
             ib_nxt = ibase[buf_next][col];
-            const int64_t item = it * 32 + col;
+            id_nxt = ipos[buf_next][col];
+            const int32_t item = id_cur;
             unsigned long long hm[16];
             float sc[16];
 #pragma unroll
@@ -417,8 +430,8 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
             if (!(ablate & 4)) __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
         };
         for (int64_t it = t_begin; it < t_end; it += 2) {
-            step(it, acc_a, acc_b, ib_a, ib_b);
-            if (it + 1 < t_end) step(it + 1, acc_b, acc_a, ib_b, ib_a);
+            step(it, acc_a, acc_b, ib_a, ib_b, id_a, id_b);
+            if (it + 1 < t_end) step(it + 1, acc_b, acc_a, ib_b, ib_a, id_b, id_a);
         }
         compact(0xffffffffu);
         // emit this segment's candidates: part[segment][row][topk]
@@ -858,6 +871,9 @@ struct cornac_hip_scorer {
     int ld = 0;  // row stride of the device tables: k zero-padded to 16/32/64/128 for the MFMA kernels
     hipStream_t stream = nullptr;
     DevBuf<float> U, V, item_base, user_base;
+    // rank-order copies for the fused top-k kernel: row p = item perm[p] (build_rank_order)
+    DevBuf<float> Vr, ibr;
+    DevBuf<int32_t> perm;
     bool has_user_base = false, is_set = false;
     DevBuf<float> scores;  // workspace [rows_cap, n_items]
     DevBuf<uint8_t> excl;
@@ -866,6 +882,56 @@ struct cornac_hip_scorer {
     DevBuf<float> d_scores_out;
     DevBuf<unsigned long long> sort_scratch, part, cand;
 };
+
+// The fused top-k kernel appends every score that beats its row's running topk-th score, so its cost depends on
+// the order in which items are visited: ~topk ln(N/topk) survivors per row in random order, far fewer when
+// likely-high items come first.  Items are therefore visited in descending order of a cheap upper estimate of
+// their scores,  item_base[i] + 2 |V_i| rms|U_u| / sqrt(k)  (two standard deviations of <u, v_i> for a user of
+// typical norm in a random direction; the Cauchy-Schwarz bound is far too loose in k dimensions).  Any order gives
+// the same result (candidates carry original item ids; ties are decided on those).
+static __global__ __launch_bounds__(256) void permute_rows_kernel(const float *__restrict__ V, const float *__restrict__ ib,
+                                                                  const int32_t *__restrict__ perm, int64_t n, int ld,
+                                                                  float *__restrict__ Vr, float *__restrict__ ibr) {
+    const int gl = threadIdx.x & 15;
+    for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; p < n; p += ((int64_t)gridDim.x * 256) >> 4) {
+        const int64_t src = perm[p];
+        for (int f = gl * 4; f < ld; f += 64)
+            *reinterpret_cast<v4f32 *>(Vr + p * ld + f) = *reinterpret_cast<const v4f32 *>(V + src * ld + f);
+        if (gl == 0) ibr[p] = ib[src];
+    }
+}
+
+static void build_rank_order(cornac_hip_scorer_t h, const float *U, const float *V, const float *item_base) {
+    const int64_t ni = h->n_items, nu = h->n_users;
+    const int k = h->k;
+    const int64_t sample = std::min<int64_t>(nu, 65536), stride = std::max<int64_t>(1, nu / sample);
+    double ss = 0;
+    int64_t cnt = 0;
+    for (int64_t u = 0; u < nu; u += stride, ++cnt)
+        for (int f = 0; f < k; ++f) ss += (double)U[u * k + f] * U[u * k + f];
+    const float unorm = 2.f * (float)std::sqrt(ss / (double)std::max<int64_t>(cnt, 1) / (double)k);
+    std::vector<float> pri((size_t)ni);
+    for (int64_t i = 0; i < ni; ++i) {
+        double s2 = 0;
+        for (int f = 0; f < k; ++f) s2 += (double)V[i * k + f] * V[i * k + f];
+        pri[(size_t)i] = (item_base ? item_base[i] : 0.f) + unorm * (float)std::sqrt(s2);
+    }
+    std::vector<int32_t> order((size_t)ni);
+    for (int64_t i = 0; i < ni; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        const float pa = pri[(size_t)a], pb = pri[(size_t)b];
+        return (pa > pb) || (pa != pa && pb == pb);  // NaN priorities first: any order is valid, this one is total
+    });
+    h->perm.ensure((size_t)ni);
+    h->Vr.ensure((size_t)ni * h->ld);
+    h->ibr.ensure((size_t)ni);
+    h->perm.upload(order.data(), (size_t)ni, h->stream);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ni * 16 + 255) / 256, 8192));
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid), dim3(256), 0, h->stream, h->V.p, h->item_base.p, h->perm.p, ni, h->ld,
+                       h->Vr.p, h->ibr.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(h->stream));  // `order` is pageable host memory
+}
 
 static void sc_check(cornac_hip_scorer_t h, bool need_set = true) {
     REQUIRE(h != nullptr, "scorer handle is NULL");
@@ -1000,13 +1066,13 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
                 KT_, CAP_, grid.x, (long long)work_per_wg, (long long)max_segs, occ);                              \
     }                                                                                                             \
     if (ub)                                                                                                       \
-        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, true>), grid, block, 0, h->stream, h->U.p, h->V.p,        \
-                           h->item_base.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,      \
-                           d_excl_indices, excl_row0, h->part.p, ablate);                                         \
+        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, true>), grid, block, 0, h->stream, h->U.p, h->Vr.p,       \
+                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
+                           d_excl_indices, excl_row0, h->perm.p, h->part.p, ablate);                              \
     else                                                                                                          \
-        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->V.p,       \
-                           h->item_base.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,      \
-                           d_excl_indices, excl_row0, h->part.p, ablate); } while (0)
+        hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->Vr.p,      \
+                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
+                           d_excl_indices, excl_row0, h->perm.p, h->part.p, ablate); } while (0)
     if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
         if (h->ld == 16) FUSED(8, 56);
         else if (h->ld == 32) FUSED(16, 56);
@@ -1075,6 +1141,7 @@ int cornac_hip_scorer_set(cornac_hip_scorer_t h, const float *U, const float *V,
         else HIP_CHECK(hipMemsetAsync(h->item_base.p, 0, (size_t)h->n_items * 4, h->stream));
         h->has_user_base = user_base != nullptr;
         if (user_base) h->user_base.upload(user_base, (size_t)h->n_users, h->stream);
+        build_rank_order(h, U, V, item_base);
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->is_set = true;
     });
