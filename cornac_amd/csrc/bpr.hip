@@ -110,6 +110,9 @@ struct HogArgs {
     int64_t nnz;
     int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
     int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
+    // experiment (hogwild_flags bit 4): one replica of V / padded B per XCD, plain read-modify-write inside the
+    // XCD's L2, replicas reconciled between launches (element strides of the replicas; 0 = off)
+    int64_t rep_stride_v, rep_stride_b;
 };
 
 // per-lane: draw one (u, i, j) and test membership; returns validity
@@ -248,9 +251,12 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
 // positives only from their interactions, so a user row is read and written by exactly one wave:
 // plain load/store instead of 2 atomic line-requests per triplet, and no lost or stale U update.
 // Heavy users (more interactions than half a wave's share) are split over all waves and keep atomics.
-template <int G, int R, int UNR, bool ATOMIC, bool OWNED>
+template <int G, int R, int UNR, bool ATOMIC, bool OWNED, bool REPL = false>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
     static_assert(!OWNED || G == kWave, "ownership needs one triplet per wave step");
+    static_assert(!REPL || OWNED, "the replica experiment builds on the ownership kernel");
+    float *const Vt = REPL ? a.V + (size_t)(__builtin_amdgcn_s_getreg(6164) & 7) * a.rep_stride_v : a.V;  // HW_REG_XCC_ID
+    float *const Bt = REPL ? a.B + (size_t)(__builtin_amdgcn_s_getreg(6164) & 7) * a.rep_stride_b : a.B;
     __shared__ int32_t stage[kWavesPerBlock][3][kWave];
     constexpr int TPW = kWave / G;
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -314,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 ti[q] = stage[wave][1][sl];
                 tj[q] = stage[wave][2][sl];
                 pu[q] = a.U + (size_t)tu * a.k + lg;
-                pi[q] = a.V + (size_t)ti[q] * a.k + lg;
-                pj[q] = a.V + (size_t)tj[q] * a.k + lg;
+                pi[q] = Vt + (size_t)ti[q] * a.k + lg;
+                pj[q] = Vt + (size_t)tj[q] * a.k + lg;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const bool ld = inb[r] && !(a.ablate & 4);
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                     vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : 0.02f;
                     vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : 0.03f;
                 }
-                bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(a.B + (size_t)ti[q] * a.bstride);
-                bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(a.B + (size_t)tj[q] * a.bstride);
+                bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)ti[q] * a.bstride);
+                bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)tj[q] * a.bstride);
             }
             float du_all[UNR][R];
 #pragma unroll
@@ -343,7 +349,11 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                             const float du = du_all[q][r];
                             const float dvi = a.lr * (z * u[q][r] - a.reg * vi[q][r]);
                             const float dvj = a.lr * (-z * u[q][r] - a.reg * vj[q][r]);
-                            if (OWNED) {
+                            if (REPL) {
+                                if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
+                                pi[q][G * r] = vi[q][r] + dvi;  // XCD-private replica: plain RMW in this XCD's L2
+                                pj[q][G * r] = vj[q][r] + dvj;
+                            } else if (OWNED) {
                                 if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
                                 atomic_add_f32(pi[q] + G * r, dvi);
                                 atomic_add_f32(pj[q] + G * r, dvj);
@@ -361,7 +371,10 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                     if (lg == 0) {
                         if (a.use_bias && !(a.ablate & 8)) {
                             const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
-                            if (ATOMIC || OWNED) {
+                            if (REPL) {
+                                Bt[(size_t)ti[q] * a.bstride] = bi[q] + dbi;
+                                Bt[(size_t)tj[q] * a.bstride] = bj[q] + dbj;
+                            } else if (ATOMIC || OWNED) {
                                 atomic_add_f32(a.B + (size_t)ti[q] * a.bstride, dbi);
                                 atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, dbj);
                             } else {
@@ -512,6 +525,7 @@ struct cornac_hip_bpr {
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
+    DevBuf<float> Vrep, Brep;  // XCD-replica experiment
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped
     // deterministic sampler state
     DevBuf<uint32_t> mt_state;  // 2 x 624
@@ -825,6 +839,30 @@ static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int
     }
 }
 
+// ---- XCD-replica experiment (hogwild_flags bit 4): broadcast / reconcile of the item-side tables ----------
+namespace chip {
+constexpr int kXcds = 8;
+__global__ __launch_bounds__(kBlock) void replicate_kernel(const float *__restrict__ src, float *__restrict__ rep,
+                                                           int64_t n, int64_t stride) {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+        const float v = src[e];
+#pragma unroll
+        for (int x = 0; x < kXcds; ++x) rep[x * stride + e] = v;
+    }
+}
+// base += sum_x (rep_x - base): every XCD's updates since the broadcast are applied once
+__global__ __launch_bounds__(kBlock) void reconcile_kernel(float *__restrict__ base, const float *__restrict__ rep,
+                                                           int64_t n, int64_t stride) {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+        const float b = base[e];
+        float acc = b;
+#pragma unroll
+        for (int x = 0; x < kXcds; ++x) acc += rep[x * stride + e] - b;
+        base[e] = acc;
+    }
+}
+}  // namespace chip
+
 // ---- hogwild launch -------------------------------------------------------------------------------
 typedef void (*HogKernel)(const HogArgs);
 
@@ -837,6 +875,10 @@ static HogKernel pick_hogwild_kernel(int k, int flags) {
         if (k <= 8) return bpr_hogwild_rowwise_kernel<8, 1, 2, ATOMIC, false>;
         if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC, false>;
         if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC, false>;
+        if (owned && (flags & 16)) {  // experiment: XCD-private replicas (see hogwild_enqueue)
+            if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true, true>;
+            if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true, true>;
+        }
         if (owned) {
             if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true>;
             if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true>;
@@ -980,9 +1022,20 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
     if ((flags & 8) == 0) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
+    const bool repl = (flags & 16) != 0 && (flags & 8) == 0 && hogwild_uses_ownership(h, flags) && h->k <= 128;
+    static const int repl_syncs = getenv("CORNAC_HIP_REPL_SYNCS") ? std::max(1, atoi(getenv("CORNAC_HIP_REPL_SYNCS"))) : 16;
+    const int64_t repl_chunk = (h->nnz + repl_syncs - 1) / repl_syncs;
+    const int64_t nv = h->total_items * h->k, nb = h->total_items * kBiasStride;
+    if (repl) {
+        h->Vrep.ensure((size_t)nv * kXcds);
+        h->Brep.ensure((size_t)nb * kXcds);
+    } else {
+        flags &= ~16;
+    }
     int64_t left = n_samples;
     while (left > 0) {
-        const int64_t n = std::min(left, h->nnz - h->hog_offset);
+        int64_t n = std::min(left, h->nnz - h->hog_offset);
+        if (repl) n = std::min(n, repl_chunk);
         HogArgs a;
         a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
         const bool pad_bias = (flags & 8) == 0;  // bit3: experiment switch, dense bias table
@@ -1007,8 +1060,20 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         if (pad_bias)
             hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p,
                                h->total_items);
+        a.rep_stride_v = 0; a.rep_stride_b = 0;
         h->ktimer.before(h->stream);
-        launch_hogwild(h, a, flags);
+        if (repl) {
+            const unsigned gv = (unsigned)std::min<int64_t>((nv + kBlock - 1) / kBlock, 4096), gb = (unsigned)std::min<int64_t>((nb + kBlock - 1) / kBlock, 4096);
+            hipLaunchKernelGGL(replicate_kernel, dim3(gv), dim3(kBlock), 0, h->stream, h->V.p, h->Vrep.p, nv, nv);
+            hipLaunchKernelGGL(replicate_kernel, dim3(gb), dim3(kBlock), 0, h->stream, h->Bpad.p, h->Brep.p, nb, nb);
+            HogArgs ar = a;
+            ar.V = h->Vrep.p; ar.B = h->Brep.p; ar.rep_stride_v = nv; ar.rep_stride_b = nb;
+            launch_hogwild(h, ar, flags);
+            hipLaunchKernelGGL(reconcile_kernel, dim3(gv), dim3(kBlock), 0, h->stream, h->V.p, h->Vrep.p, nv, nv);
+            hipLaunchKernelGGL(reconcile_kernel, dim3(gb), dim3(kBlock), 0, h->stream, h->Bpad.p, h->Brep.p, nb, nb);
+        } else {
+            launch_hogwild(h, a, flags);
+        }
         h->ktimer.after(h->stream);
         if (pad_bias)
             hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p,
