@@ -31,6 +31,7 @@ class ItemTableReplica:
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.base = torch.zeros(n, dtype=torch.float32, device=device)
         self.group = group
+        self._pending = None
 
     @property
     def V(self):
@@ -46,14 +47,36 @@ class ItemTableReplica:
         self.base.copy_(self.flat)
 
     def sync(self):
-        """flat <- base + sum_over_ranks(flat - base); base <- flat"""
+        """flat <- base + sum_over_ranks(flat - base); base <- flat   (blocking form)"""
+        self.begin_sync()
+        self.finish_sync()
+
+    # Overlapped form: the all-reduce of chunk c's delta runs (on RCCL's stream) while chunk c+1 trains.
+    #   begin_sync:   d = flat - base (local updates since the last rebase); keep a copy; all-reduce d asynchronously
+    #   finish_sync:  R = sum over ranks of d arrived -> flat += R - d_local (the others' updates), base += R
+    # After finish_sync, flat - base is exactly the local delta accumulated since begin_sync, so the next
+    # begin_sync sends only new work; other ranks' updates reach a replica one chunk later than with sync().
+    def begin_sync(self):
+        assert self._pending is None, "finish_sync() the previous exchange first"
         if not (dist.is_available() and dist.is_initialized()):
-            self.base.copy_(self.flat)
+            self._pending = (None, None, None)
             return
         delta = self.flat - self.base
-        dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
+        local = delta.clone()
+        work = dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = (work, delta, local)
+
+    def finish_sync(self):
+        if self._pending is None:
+            return
+        work, delta, local = self._pending
+        self._pending = None
+        if work is None:
+            self.base.copy_(self.flat)
+            return
+        work.wait()  # stream-level wait on CUDA, blocking on gloo
+        self.flat.add_(delta - local)
         self.base.add_(delta)
-        self.flat.copy_(self.base)
 
 
 class ShardedBprTrainer:
@@ -82,16 +105,20 @@ class ShardedBprTrainer:
             self.stream.synchronize()
 
     def run(self, n_samples, lr, reg, use_bias=True, neg_population=0, flags=0):
-        """enqueue n_samples hogwild samples in sync_every-sized chunks with a table sync after each"""
+        """enqueue n_samples hogwild samples in sync_every-sized chunks; the item-table exchange of chunk c is
+        in flight while chunk c+1 trains (ItemTableReplica.begin_sync / finish_sync)"""
         left = int(n_samples)
         with self._on_stream():
             while left > 0:
                 n = min(left, self.sync_every)
                 self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
-                self.table.sync()
+                self.table.finish_sync()   # chunk c-1's exchange: its all-reduce overlapped this chunk's launch
+                self.table.begin_sync()
                 left -= n
 
     def finish(self):
+        with self._on_stream():
+            self.table.finish_sync()
         out = self.trainer.sync()
         if self.stream is not None:
             self.stream.synchronize()
