@@ -9,18 +9,20 @@
 // (Dataset.uij_iter, a Python-level iterator in the reference too) and are uploaded per fit call.
 //
 // Per Adam step (batch of B triplets):
-//   vbpr_forward_kernel   one workgroup per triplet: feature difference staged in LDS, (1 x F)·(F x k2)
-//                         projection, the two score parts s_b and v_b
-//   vbpr_pair_grad_kernel the reference's B x B broadcast objective -> gs_b, gv_b
+//   vbpr_featdiff_kernel  one workgroup per triplet: DF[b] = F[i_b] - F[j_b] (the "auxiliary-feature gather"),
+//                         v_b = DF[b] . b'
+//   vbpr_proj_kernel      proj = DF E on the fp32 matrix cores (mfma_gemm.h), split over feature chunks
+//   vbpr_score_kernel     s_b from the gathered rows and proj_b (one wave per triplet)
+//   vbpr_pair_grad_kernel the reference's B x B broadcast objective -> gs_b, gv_b (one workgroup per b)
 //   vbpr_scatter_kernel   sparse row gradients scattered with fp32 atomics
 //   vbpr_feat_adam_kernel gradient of E / beta' (dense F x k2 GEMM over the batch) fused with their Adam step
 //   adam_rows_kernel      dense Adam over Bi, Gu, Gi, Tu (reads the scattered gradient, clears it)
-// HBM-bound by the dense Adam sweep (all parameters + two moments per step); the feature GEMMs are
-// ~50 MFLOP per step and are left on the vector ALUs.
+// HBM-bound by the dense Adam sweep (all parameters + two moments per step).
 #include <algorithm>
 #include <cmath>
 
 #include "common.h"
+#include "mfma_gemm.h"
 
 namespace chip {
 
@@ -42,17 +44,15 @@ struct VbprTables {
 //   d loss / d s_b = gs_b = sum_a G[a, b]   (drives b_i, b_j, g_u, g_i, g_j, t_u and E)
 //   d loss / d v_a = gv_a = sum_b G[a, b]   (drives b')
 
-// stage 1 — one workgroup per triplet: feature difference (LDS), projection, s_b and v_b
-__global__ __launch_bounds__(kVb) void vbpr_forward_kernel(const VbprTables t, const int32_t *__restrict__ bu,
-                                                           const int32_t *__restrict__ bi,
-                                                           const int32_t *__restrict__ bj, int n,
-                                                           float *__restrict__ s_out, float *__restrict__ v_out,
-                                                           float *__restrict__ proj_out) {
-    extern __shared__ float sh[];  // df[n_feat] | red[kVb] | proj[k2]
-    float *df = sh, *red = sh + t.n_feat, *proj = red + kVb;
+// stage 1a — one workgroup per triplet: feature difference DF[b, :] = F[i_b] - F[j_b] (coalesced row reads,
+// written once for the two feature GEMMs of the step) and v_b = DF[b] . b'
+__global__ __launch_bounds__(kVb) void vbpr_featdiff_kernel(const VbprTables t, const int32_t *__restrict__ bi,
+                                                            const int32_t *__restrict__ bj, float *__restrict__ DF,
+                                                            float *__restrict__ v_out) {
+    __shared__ float red[kVb];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t u = bu[b], i = bi[b], j = bj[b];
-    const float *fi = t.F + i * t.n_feat, *fj = t.F + j * t.n_feat;
+    const float *fi = t.F + (int64_t)bi[b] * t.n_feat, *fj = t.F + (int64_t)bj[b] * t.n_feat;
+    float *df = DF + (int64_t)b * t.n_feat;
     float vb = 0.f;
     for (int f = tid; f < t.n_feat; f += kVb) {
         const float d = fi[f] - fj[f];
@@ -65,59 +65,83 @@ __global__ __launch_bounds__(kVb) void vbpr_forward_kernel(const VbprTables t, c
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    vb = red[0];
-    __syncthreads();
-    // projection proj[c] = sum_f df[f] * E[f, c]: thread = (c, slice); rows of E are read coalesced
-    const int k2 = t.k2;
-    const int n_slices = max(1, kVb / k2), c = tid % k2, sl = tid / k2;
-    float acc = 0.f;
-    if (sl < n_slices) {
-        for (int f = sl; f < t.n_feat; f += n_slices) acc = fmaf(df[f], t.E[(size_t)f * k2 + c], acc);
-    }
-    red[tid] = (sl < n_slices) ? acc : 0.f;
-    __syncthreads();
-    if (tid < k2) {
-        float sum = 0.f;
-        for (int q = 0; q < n_slices; ++q) sum += red[q * k2 + tid];
-        proj[tid] = sum;
-        proj_out[(size_t)b * k2 + tid] = sum;
-    }
-    __syncthreads();
-    const float *gu = t.Gu + u * t.k, *gi = t.Gi + i * t.k, *gj = t.Gi + j * t.k, *tu = t.Tu + u * k2;
-    float part = 0.f;
-    for (int q = tid; q < t.k; q += kVb) part = fmaf(gu[q], gi[q] - gj[q], part);
-    for (int q = tid; q < k2; q += kVb) part = fmaf(tu[q], proj[q], part);
-    red[tid] = part;
-    __syncthreads();
-    for (int o = kVb / 2; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        s_out[b] = (t.Bi[i] - t.Bi[j]) + red[0];
-        v_out[b] = vb;
-    }
+    if (tid == 0) v_out[b] = red[0];
 }
 
-// stage 2 — the B x B broadcast objective: gs_b = sum_a G[a,b], gv_a = sum_b G[a,b], NLL = sum softplus(-X)
+// stage 1b — proj = DF E  ([B, n_feat] x [n_feat, k2]) on the fp32 matrix cores, split over feature chunks
+// (blockIdx.x) with fp32 atomics into the zeroed proj; blockIdx.y / .z tile B and k2 when they exceed 128
+__global__ __launch_bounds__(kWb) void vbpr_proj_kernel(const float *__restrict__ DF, const float *__restrict__ E, int n,
+                                                        int n_feat, int k2, int chunk, float *__restrict__ proj) {
+    __shared__ GemmSmem sm;
+    f32x16 acc[2][2];
+    const int64_t m0 = (int64_t)blockIdx.y * kBM, n0 = (int64_t)blockIdx.z * kBN;
+    const int64_t k_begin = (int64_t)blockIdx.x * chunk;
+    const int64_t k_end = k_begin + chunk < n_feat ? k_begin + chunk : n_feat;
+    gemm_block<true, true>(DF, n_feat, 1, E, k2, 1, n, k2, m0, n0, k_begin, k_end, sm, acc);
+    for_each_acc(acc, m0, n0, [&](int64_t row, int64_t col, float v) {
+        if (row < n && col < k2 && v != 0.f) atomicAdd(proj + row * k2 + col, v);
+    });
+}
+
+// stage 1c — s_b = b_i - b_j + <g_u, g_i - g_j> + <t_u, proj_b>: one wave per triplet
+__global__ __launch_bounds__(kVb) void vbpr_score_kernel(const VbprTables t, const int32_t *__restrict__ bu,
+                                                         const int32_t *__restrict__ bi,
+                                                         const int32_t *__restrict__ bj, int n,
+                                                         const float *__restrict__ proj, float *__restrict__ s_out) {
+    const int b = (blockIdx.x * kVb + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const int64_t u = bu[b], i = bi[b], j = bj[b];
+    const float *gu = t.Gu + u * t.k, *gi = t.Gi + i * t.k, *gj = t.Gi + j * t.k, *tu = t.Tu + u * t.k2;
+    float part = 0.f;
+    for (int q = lane; q < t.k; q += 64) part = fmaf(gu[q], gi[q] - gj[q], part);
+    for (int q = lane; q < t.k2; q += 64) part = fmaf(tu[q], proj[(size_t)b * t.k2 + q], part);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) s_out[b] = (t.Bi[i] - t.Bi[j]) + part;
+}
+
+// stage 2 — the B x B broadcast objective: gs_b = sum_a G[a,b], gv_a = sum_b G[a,b], NLL = sum softplus(-X).
+// One workgroup per b, threads over a (strided): column b and row b of G in one pass.
 __global__ __launch_bounds__(kVb) void vbpr_pair_grad_kernel(const float *__restrict__ s, const float *__restrict__ v,
                                                              int n, float *__restrict__ gs, float *__restrict__ gv,
                                                              double *__restrict__ loss_acc) {
+    __shared__ float red_c[kVb / 64], red_r[kVb / 64];
+    __shared__ double red_n[kVb / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float sb = s[b], vb = v[b];
+    float col = 0.f, row = 0.f;
     double nll = 0.0;
-    for (int b = blockIdx.x * kVb + threadIdx.x; b < n; b += gridDim.x * kVb) {
-        const float sb = s[b], vb = v[b];
-        float col = 0.f, row = 0.f;
-        for (int a = 0; a < n; ++a) {
-            const float X = sb + v[a];                 // X[a, b]
-            col += -1.0f / (1.0f + expf(X));
-            nll += (X > 0.f) ? log1p(exp(-(double)X)) : (-(double)X + log1p(exp((double)X)));
-            const float Y = s[a] + vb;                 // X[b, a]
-            row += -1.0f / (1.0f + expf(Y));
-        }
-        gs[b] = col;
-        gv[b] = row;
+    for (int a = tid; a < n; a += kVb) {
+        const float X = sb + v[a];                 // X[a, b]
+        col += -1.0f / (1.0f + expf(X));
+        nll += (X > 0.f) ? log1p(exp(-(double)X)) : (-(double)X + log1p(exp((double)X)));
+        const float Y = s[a] + vb;                 // X[b, a]
+        row += -1.0f / (1.0f + expf(Y));
     }
-    atomicAdd(loss_acc, nll);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        col += __shfl_xor(col, o, 64);
+        row += __shfl_xor(row, o, 64);
+        nll += __shfl_xor(nll, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        red_c[tid >> 6] = col;
+        red_r[tid >> 6] = row;
+        red_n[tid >> 6] = nll;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float c = 0.f, r = 0.f;
+        double l = 0.0;
+        for (int w = 0; w < kVb / 64; ++w) {
+            c += red_c[w];
+            r += red_r[w];
+            l += red_n[w];
+        }
+        gs[b] = c;
+        gv[b] = r;
+        atomicAdd(loss_acc, l);
+    }
 }
 
 // stage 3 — sparse row gradients (duplicates inside a batch accumulate, like autograd's index_put accumulate)
@@ -257,7 +281,7 @@ struct cornac_hip_vbpr {
     DevBuf<float> gBi, gGu, gGi, gTu;
     DevBuf<float> mBi, vBi, mGu, vGu, mGi, vGi, mTu, vTu, mE, vE, mBp, vBp;
     DevBuf<int32_t> bu, bi, bj;
-    DevBuf<float> sX, vX, gS, gV, proj;
+    DevBuf<float> sX, vX, gS, gV, proj, DF;
     DevBuf<double> loss;
     int64_t step = 0;
 };
@@ -372,7 +396,11 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         HIP_CHECK(hipMemsetAsync(h->loss.p, 0, sizeof(double), h->stream));
         const VbprTables t = vb_tables(h);
         const DeviceInfo &di = device_info(h->device);
-        const size_t lds_fwd = (size_t)(h->n_feat + kVb + h->k2) * sizeof(float);
+        h->DF.ensure((size_t)batch_size * h->n_feat);
+        // feature chunks of the split-K projection GEMM: a multiple of the k tile, ~2 workgroups per CU
+        int feat_chunk = std::max(kBK, (h->n_feat + 2 * di.cus - 1) / (2 * di.cus));
+        feat_chunk = (feat_chunk + kBK - 1) / kBK * kBK;
+        const int n_chunks = (h->n_feat + feat_chunk - 1) / feat_chunk;
         for (int64_t b0 = 0; b0 < n_total; b0 += batch_size) {
             const int n = (int)std::min<int64_t>(batch_size, n_total - b0);
             ++h->step;
@@ -385,10 +413,15 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             a.step_size = (float)((double)lr / bc1);
             a.bc2_sqrt = (float)std::sqrt(bc2);
             a.eps = 1e-8f;
-            hipLaunchKernelGGL(vbpr_forward_kernel, dim3(n), dim3(kVb), lds_fwd, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, n, h->sX.p, h->vX.p, h->proj.p);
-            hipLaunchKernelGGL(vbpr_pair_grad_kernel, dim3((n + kVb - 1) / kVb), dim3(kVb), 0, h->stream, h->sX.p,
-                               h->vX.p, n, h->gS.p, h->gV.p, h->loss.p);
+            hipLaunchKernelGGL(vbpr_featdiff_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bi.p + b0, h->bj.p + b0,
+                               h->DF.p, h->vX.p);
+            HIP_CHECK(hipMemsetAsync(h->proj.p, 0, (size_t)n * h->k2 * sizeof(float), h->stream));
+            hipLaunchKernelGGL(vbpr_proj_kernel, dim3(n_chunks, (n + kBM - 1) / kBM, (h->k2 + kBN - 1) / kBN), dim3(kWb), 0,
+                               h->stream, h->DF.p, h->E.p, n, h->n_feat, h->k2, feat_chunk, h->proj.p);
+            hipLaunchKernelGGL(vbpr_score_kernel, dim3((n * 64 + kVb - 1) / kVb), dim3(kVb), 0, h->stream, t, h->bu.p + b0,
+                               h->bi.p + b0, h->bj.p + b0, n, h->proj.p, h->sX.p);
+            hipLaunchKernelGGL(vbpr_pair_grad_kernel, dim3(n), dim3(kVb), 0, h->stream, h->sX.p, h->vX.p, n, h->gS.p,
+                               h->gV.p, h->loss.p);
             hipLaunchKernelGGL(vbpr_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
                                h->bj.p + b0, n, h->gS.p, h->proj.p, lambda_w, lambda_b);
             hipLaunchKernelGGL(vbpr_feat_adam_kernel, dim3((h->n_feat + kFeatPerBlock - 1) / kFeatPerBlock), dim3(kVb),
