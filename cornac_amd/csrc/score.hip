@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
                                                           int64_t n_rows, int64_t n_items, int64_t work_per_wg,
                                                           int topk, const int64_t *__restrict__ excl_indptr,
                                                           const int32_t *__restrict__ excl_indices, int64_t excl_row0,
-                                                          const int32_t *__restrict__ perm,
+                                                          const int32_t *__restrict__ perm, float *tau_pub,
                                                           unsigned long long *__restrict__ part, int ablate) {
     // V / item_base are the scorer's RANK-ORDER copies: row p is item perm[p] (items sorted by a cheap upper
     // estimate of their scores, see build_rank_order); the candidates carry the original item ids.
@@ -224,18 +224,28 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    while (pos < work_end) {
-        const int64_t rb = pos / n_item_tiles;
-        const int64_t t_begin = pos - rb * n_item_tiles;
-        const int64_t t_end = min(n_item_tiles, t_begin + (work_end - pos));
+    // The range is walked from its END: the head of a row block (tiles from 0: the likely winners, visited first)
+    // is then the first thing its workgroup does, while the tail of the same row block is the LAST thing the
+    // next workgroup does — by then the head's final thresholds are published in tau_pub and the tail starts
+    // from them instead of -inf.  A value read too early is -inf: any lower bound keeps the result exact.
+    int64_t pos_hi = work_end;
+    while (pos_hi > pos) {
+        const int64_t rb = (pos_hi - 1) / n_item_tiles;
+        const int64_t seg_lo = max(pos, rb * n_item_tiles);
+        const int64_t t_begin = seg_lo - rb * n_item_tiles;
+        const int64_t t_end = pos_hi - rb * n_item_tiles;
         const int64_t seg = (int64_t)blockIdx.x - (rb * n_item_tiles) / work_per_wg;
-        pos += t_end - t_begin;
+        pos_hi = seg_lo;
         const int64_t row_tile = rb * (kBlk / 64) + wave;
         if (lane < 32) {
             cnt[wave][lane] = 0;
             // rows beyond n_rows: tau = +inf (nothing ever passes); items beyond n_items get a NaN item base
             // (NaN >= thr is false), so the hot compare needs no validity masks
-            tau[wave][lane] = row_tile * 32 + lane >= n_rows ? INFINITY : -INFINITY;
+            const int64_t row = row_tile * 32 + lane;
+            float t0 = -INFINITY;
+            if (row >= n_rows) t0 = INFINITY;
+            else if (t_begin > 0) t0 = __hip_atomic_load(tau_pub + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tau[wave][lane] = t0;
         }
         // A fragments + this lane's user bias
         float a[KT];
@@ -261,6 +271,12 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
             if (user_base && row_ok) ubias[r] = user_base[users ? (int64_t)users[row] : u0 + row];
             thr[r] = row_ok ? -INFINITY : INFINITY;
             cnt_r[r] = 0;
+        }
+        if (t_begin > 0) {  // thresholds published by the row block's head segment (wave-uniform branch)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) thr[r] = tau[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
         }
         // wave-wide compaction of the rows whose buffer would overflow with this tile's survivors (or all rows at
         // the end of the segment): keep the topk best candidates of the row (in descending order) and raise its threshold to the topk-th.
@@ -440,6 +456,8 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
             if (row >= n_rows) break;  // also covers waves whose whole row tile is out of range
             if (lane < topk) part[(seg * n_rows + row) * topk + lane] = keys[wave][rl][lane];
         }
+        if (t_begin == 0 && t_end < n_item_tiles && lane < 32 && row_tile * 32 + lane < n_rows)
+            __hip_atomic_store(tau_pub + row_tile * 32 + lane, tau[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -874,6 +892,7 @@ struct cornac_hip_scorer {
     // rank-order copies for the fused top-k kernel: row p = item perm[p] (build_rank_order)
     DevBuf<float> Vr, ibr;
     DevBuf<int32_t> perm;
+    DevBuf<float> tau_pub;  // per row: threshold published by the head segment of its row block
     bool has_user_base = false, is_set = false;
     DevBuf<float> scores;  // workspace [rows_cap, n_items]
     DevBuf<uint8_t> excl;
@@ -1057,6 +1076,8 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     const int64_t max_segs = (n_item_tiles + work_per_wg - 1) / work_per_wg + 1;
     h->part.ensure((size_t)(max_segs * n * topk));
     HIP_CHECK(hipMemsetAsync(h->part.p, 0, (size_t)(max_segs * n * topk) * sizeof(unsigned long long), h->stream));
+    h->tau_pub.ensure((size_t)n);
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->tau_pub.p, 0xff800000u /* -inf */, (size_t)n, h->stream));
     dim3 grid((unsigned)n_wgs), block(kBlk);
 #define FUSED(KT_, CAP_) do {                                                                                    \
     if (getenv("CORNAC_HIP_RANK_ABLATE")) {                                                                       \
@@ -1068,11 +1089,11 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     if (ub)                                                                                                       \
         hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, true>), grid, block, 0, h->stream, h->U.p, h->Vr.p,       \
                            h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
-                           d_excl_indices, excl_row0, h->perm.p, h->part.p, ablate);                              \
+                           d_excl_indices, excl_row0, h->perm.p, h->tau_pub.p, h->part.p, ablate);              \
     else                                                                                                          \
         hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->Vr.p,      \
                            h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
-                           d_excl_indices, excl_row0, h->perm.p, h->part.p, ablate); } while (0)
+                           d_excl_indices, excl_row0, h->perm.p, h->tau_pub.p, h->part.p, ablate); } while (0)
     if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
         if (h->ld == 16) FUSED(8, 56);
         else if (h->ld == 32) FUSED(16, 56);
