@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
 // its rows: 64-lane bitonic sort of the 64-bit (score, item) keys, keep the topk best, raise the
 // threshold.  Expected survivors per row over N items is ~topk*ln(N/topk), so the epilogue is a few
 // percent of the MFMA time.  Optional exclusion lists (sorted CSR per row) are consulted only for
-// survivors.  Each strip emits topk keys per row; rank_merge_kernel merges the strips.
+// survivors.  Each segment emits topk keys per row; rank_merge_kernel merges the segments.
 template <int KT, int CAP, bool UB>
 __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ item_base,
@@ -463,249 +463,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
     }
 }
 
-// wave-wide compaction of per-row candidate buffers kept in global memory (rank_fused2_kernel): for every
-// row whose buffer could overflow on the next tile (all rows if force) — drop excluded items, 64-lane
-// bitonic sort of the 64-bit keys, keep the topk best, raise the row's threshold.  Deliberately NOT
-// inlined: it runs a few times per strip and would otherwise inflate the hot loop's register budget.
-__device__ __attribute__((noinline)) void rank_compact_rows(int *cnt_w, float *tau_w, unsigned long long *my_cand,
-                                                            int64_t row0, int64_t n_rows, int topk,
-                                                            const int64_t *__restrict__ excl_indptr,
-                                                            const int32_t *__restrict__ excl_indices,
-                                                            int64_t excl_row0, bool force) {
-    constexpr int CAP = 64, RW = 64;
-    const int lane = threadIdx.x & 63;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's key stores have reached L2
-    for (int rl = 0; rl < RW; ++rl) {
-        const int c = cnt_w[rl];
-        if (c <= CAP - 32 && !force) continue;
-        if (row0 + rl >= n_rows) continue;
-        unsigned long long *rk = my_cand + (int64_t)rl * CAP;
-        unsigned long long key = lane < c ? __builtin_nontemporal_load(rk + lane) : 0ull;
-        if (excl_indptr && key != 0ull) {
-            const int32_t item = (int32_t)(uint32_t)key;
-            const int64_t grow = excl_row0 + row0 + rl;
-            int64_t lo = excl_indptr[grow], hi = excl_indptr[grow + 1];
-            const int64_t end = hi;
-            while (lo < hi) {
-                const int64_t mid = lo + ((hi - lo) >> 1);
-                if (excl_indices[mid] < item) lo = mid + 1; else hi = mid;
-            }
-            if (lo < end && excl_indices[lo] == item) key = 0ull;
-        }
-#pragma unroll
-        for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                const unsigned lo = __shfl_xor((unsigned)key, j, 64);
-                const unsigned hi = __shfl_xor((unsigned)(key >> 32), j, 64);
-                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-                const bool take_max = ((lane & j) == 0) == ((lane & kk) == 0);
-                key = take_max ? (key > other ? key : other) : (key < other ? key : other);
-            }
-        }
-        const int n_live = __popcll(__ballot(key != 0ull));
-        const int keep = min(n_live, topk);
-        rk[lane] = lane < keep ? key : 0ull;
-        const unsigned long long kth = __shfl(key, topk - 1, 64);
-        if (lane == 0) {
-            cnt_w[rl] = keep;
-            tau_w[rl] = kth != 0ull ? key_to_float((unsigned)(kth >> 32)) : -INFINITY;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// ---- second-generation fused kernel: 64 users per wave (two MFMA chains), candidates in global memory ----
-// Same algorithm as rank_fused_kernel with three structural changes aimed at matrix-pipe occupancy:
-//  * a wave owns TWO stacked 32-user tiles: two independent accumulator chains keep the MFMA pipe of
-//    its SIMD busy from a single wave, and each B fragment read from LDS feeds two MFMAs;
-//  * the per-row candidate buffers (64 keys each) live in global memory (L2-resident, written by rare
-//    fire-and-forget stores); only the cursors and thresholds stay in LDS, so the workgroup's LDS is
-//    just the double-buffered B tile and two workgroups per CU fit by registers, not by LDS;
-//  * the MFMA phase per workgroup barrier doubles (8192 pipe-cycles per SIMD pair).
-template <int KT, bool HAS_UB>
-__global__ __launch_bounds__(kBlk, 2) void rank_fused2_kernel(const float *__restrict__ U, const float *__restrict__ V,
-                                                             const float *__restrict__ item_base,
-                                                             const float *__restrict__ user_base,
-                                                             const int32_t *__restrict__ users, int64_t u0,
-                                                             int64_t n_rows, int64_t n_items, int tiles_per_strip,
-                                                             int topk, const int64_t *__restrict__ excl_indptr,
-                                                             const int32_t *__restrict__ excl_indices,
-                                                             int64_t excl_row0, unsigned long long *__restrict__ cand,
-                                                             unsigned long long *__restrict__ part) {
-    constexpr int KP = 2 * KT, CAP = 64, RW = 64;  // rows per wave
-    __shared__ int cnt[kBlk / 64][RW];
-    __shared__ float tau[kBlk / 64][RW];
-    __shared__ float btile[2][32][KP + 1];
-    __shared__ float ibase[2][32];
-    __shared__ float sc_scratch[kBlk / 64][16][64];  // rare path: the 16 scores of a lane, indexed dynamically
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col = lane & 31, half = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.y * (kBlk / 64) + wave) * RW;  // first row of this wave
-    unsigned long long *my_cand = cand + ((int64_t)blockIdx.x * n_rows + min(row0, n_rows - 1)) * CAP;
-    {
-        cnt[wave][lane] = 0;
-        tau[wave][lane] = row0 + lane < n_rows ? -INFINITY : INFINITY;
-    }
-    float a[2][KT], thr[2][16], ubias[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int64_t r = row0 + m * 32 + col;
-        const bool ok = r < n_rows;
-        const int64_t u = ok ? (users ? (int64_t)users[r] : u0 + r) : 0;
-        const float *p = U + u * KP + half;
-#pragma unroll
-        for (int t = 0; t < KT; ++t) a[m][t] = p[2 * t];
-#pragma unroll
-        for (int r16 = 0; r16 < 16; ++r16) {
-            const int rl = m * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * half;
-            const int64_t row = row0 + rl;
-            thr[m][r16] = row < n_rows ? -INFINITY : INFINITY;
-            ubias[m][r16] = 0.f;
-            if (HAS_UB && row < n_rows) ubias[m][r16] = user_base[users ? (int64_t)users[row] : u0 + row];
-        }
-    }
-    const int64_t n_item_tiles = (n_items + 31) / 32;
-    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_strip;
-    const int64_t t_end = min(n_item_tiles, t_begin + tiles_per_strip);
-    constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
-    v4f32 stg[STG];
-    float stg_ib = 0.f;
-    auto stage_load = [&](int64_t it) {
-#pragma unroll
-        for (int q = 0; q < STG; ++q) {
-            const int idx = threadIdx.x + q * kBlk;
-            const int64_t item = min(it * 32 + idx / (KP / 4), n_items - 1);
-            stg[q] = *reinterpret_cast<const v4f32 *>(V + item * KP + 4 * (idx % (KP / 4)));
-        }
-        if (threadIdx.x < 32) {
-            const int64_t item = it * 32 + threadIdx.x;
-            stg_ib = item < n_items ? (item_base ? item_base[item] : 0.f) : __builtin_nanf("");
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < STG; ++q) {
-            const int idx = threadIdx.x + q * kBlk;
-            if (idx < 32 * KP / 4) {
-                float *dst = &btile[buf][idx / (KP / 4)][4 * (idx % (KP / 4))];
-                dst[0] = stg[q].x; dst[1] = stg[q].y; dst[2] = stg[q].z; dst[3] = stg[q].w;
-            }
-        }
-        if (threadIdx.x < 32) ibase[buf][threadIdx.x] = stg_ib;
-    };
-    auto compact = [&](bool force) {
-        rank_compact_rows(cnt[wave], tau[wave], my_cand, row0, n_rows, topk, excl_indptr, excl_indices, excl_row0,
-                          force);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) thr[m][r] = tau[wave][m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-    };
-    // Software pipeline across tiles with TWO interleaved accumulator chains: iteration `it` issues
-    // MFMA(A), MFMA(B), MFMA(A), ... of tile it+1 and, in the gaps, compares the finished accumulators of
-    // tile it with their thresholds.  Consecutive MFMAs on the same accumulator are separated by the other
-    // chain's MFMA (VALU work wedged between dependent MFMAs costs ~40 extra cycles per MFMA on gfx950,
-    // MI355X_MICROARCH.md "per-instruction cycle constants"), so the compares ride for free.
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc_cur[2] = {zero16, zero16};
-    float bcur[KT], ib_cur = 0.f;
-    auto append_hits = [&](unsigned hitbits, int64_t item) {
-        if (__any(hitbits != 0u)) {
-            // spill the lane's scores to LDS so the append loop can stay rolled (keeps the hot loop's
-            // register budget free of 32 speculated key/address computations)
-#pragma unroll 1
-            for (int m = 0; m < 2; ++m) {
-                if (!__any(((hitbits >> (16 * m)) & 0xffffu) != 0u)) continue;
-                if (m == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc_scratch[wave][r][lane] = (ib_cur + ubias[0][r]) + acc_cur[0][r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc_scratch[wave][r][lane] = (ib_cur + ubias[1][r]) + acc_cur[1][r];
-                }
-#pragma unroll 1
-                for (int r = 0; r < 16; ++r) {
-                    if (hitbits & (1u << (16 * m + r))) {
-                        const int rl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int pos = atomicAdd(&cnt[wave][rl], 1);
-                        my_cand[(int64_t)rl * CAP + pos] =
-                            ((unsigned long long)order_key(sc_scratch[wave][r][lane]) << 32) |
-                            (unsigned long long)(uint32_t)item;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int mx = cnt[wave][lane];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-            if (__builtin_amdgcn_readfirstlane(mx) > CAP - 32) compact(false);
-        }
-    };
-    if (t_begin < t_end) {
-        stage_load(t_begin);
-        stage_store(0);
-    }
-    __syncthreads();
-    if (t_begin + 1 < t_end) stage_load(t_begin + 1);
-    {
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bcur[t] = btile[0][col][2 * t + half];
-        ib_cur = ibase[0][col];
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            acc_cur[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][t], bcur[t], acc_cur[0], 0, 0, 0);
-            acc_cur[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][t], bcur[t], acc_cur[1], 0, 0, 0);
-        }
-    }
-    if (t_begin + 1 < t_end) stage_store(1);
-    __syncthreads();
-    for (int64_t it = t_begin; it < t_end; ++it) {
-        const int buf_next = (int)((it + 1 - t_begin) & 1);
-        if (it + 2 < t_end) stage_load(it + 2);
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bcur[t] = btile[buf_next][col][2 * t + half];
-        const float ib_next = ibase[buf_next][col];
-        f32x16 acc_nxt[2] = {zero16, zero16};
-        unsigned hitbits = 0;  // bit (m * 16 + r)
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            acc_nxt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][t], bcur[t], acc_nxt[0], 0, 0, 0);
-            acc_nxt[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][t], bcur[t], acc_nxt[1], 0, 0, 0);
-            if (t < 16) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    hitbits |= ((ib_cur + ubias[m][t]) + acc_cur[m][t] >= thr[m][t]) ? (1u << (m * 16 + t)) : 0u;
-            }
-        }
-        if (KT < 16) {
-#pragma unroll
-            for (int r = KT; r < 16; ++r)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    hitbits |= ((ib_cur + ubias[m][r]) + acc_cur[m][r] >= thr[m][r]) ? (1u << (m * 16 + r)) : 0u;
-        }
-        append_hits(hitbits, it * 32 + col);
-        if (it + 2 < t_end) stage_store((int)((it + 2 - t_begin) & 1));
-        __syncthreads();
-        acc_cur[0] = acc_nxt[0];
-        acc_cur[1] = acc_nxt[1];
-        ib_cur = ib_next;
-    }
-    compact(true);
-    for (int rl = 0; rl < RW; ++rl) {
-        const int64_t row = row0 + rl;
-        if (row >= n_rows) break;
-        if (lane < topk)
-            part[((int64_t)blockIdx.x * n_rows + row) * topk + lane] = __builtin_nontemporal_load(my_cand + (int64_t)rl * CAP + lane);
-    }
-}
-
-// merge the strips' candidates of one row: bitonic sort of n_strips*topk keys in LDS, emit the topk best
+// merge the segments' candidates of one row: bitonic sort of n_strips*topk keys in LDS, emit the topk best
 __global__ __launch_bounds__(64) void rank_merge_kernel(const unsigned long long *__restrict__ part, int n_strips,
                                                         int64_t n_rows, int topk, int pad,
                                                         int32_t *__restrict__ items_out,
@@ -899,7 +657,7 @@ struct cornac_hip_scorer {
     DevBuf<int32_t> d_users, d_items_out, d_excl_indices;
     DevBuf<int64_t> d_excl_indptr;
     DevBuf<float> d_scores_out;
-    DevBuf<unsigned long long> sort_scratch, part, cand;
+    DevBuf<unsigned long long> sort_scratch, part;
 };
 
 // The fused top-k kernel appends every score that beats its row's running topk-th score, so its cost depends on
@@ -1021,51 +779,9 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
                               int32_t *items_out, float *scores_out) {
     const float *ub = h->has_user_base ? h->user_base.p : nullptr;
     const DeviceInfo &di = device_info(h->device);
-    const int k = h->k;
     static const int ablate = getenv("CORNAC_HIP_RANK_ABLATE") ? atoi(getenv("CORNAC_HIP_RANK_ABLATE")) : 0;  // profiling only
     const int64_t n_item_tiles = (h->n_items + 31) / 32;
     const int64_t wg_rows = (n + 127) / 128;  // 4 waves x 32 rows per workgroup
-    int64_t strips = std::max<int64_t>(1, ((int64_t)di.cus * 8 + wg_rows - 1) / wg_rows);
-    strips = std::min<int64_t>(strips, std::max<int64_t>(1, n_item_tiles / 16));
-    strips = std::min<int64_t>(strips, 16);
-    const int tiles_per_strip = (int)((n_item_tiles + strips - 1) / strips);
-    const int64_t gx = (n_item_tiles + tiles_per_strip - 1) / tiles_per_strip;
-    h->part.ensure((size_t)(gx * n * topk));
-    if (h->ld <= 64 && getenv("CORNAC_HIP_RANK_V2")) {
-        // experimental second-generation kernel (64 users per wave, candidates in global memory): correct
-        // (same tests) but measured SLOWER than rank_fused_kernel on ML-20M shape (9.6 vs 7.3 ms): twice the
-        // rows per wave doubles the compaction work per strip while the matrix pipe gains nothing, because
-        // one dependent v_mfma_f32_32x32x2 chain already saturates it.  Kept for the round-2 investigation.
-        const int64_t wg_rows2 = (n + 255) / 256;
-        int64_t strips2 = std::max<int64_t>(1, ((int64_t)di.cus * 8 + wg_rows2 - 1) / wg_rows2);
-        strips2 = std::min<int64_t>(strips2, std::max<int64_t>(1, n_item_tiles / 16));
-        strips2 = std::min<int64_t>(strips2, 16);
-        const int tps = (int)((n_item_tiles + strips2 - 1) / strips2);
-        const int64_t gx2 = (n_item_tiles + tps - 1) / tps;
-        h->part.ensure((size_t)(gx2 * n * topk));
-        h->cand.ensure((size_t)(gx2 * n * 64));
-        dim3 grid2((unsigned)gx2, (unsigned)wg_rows2), block2(kBlk);
-#define FUSED2(KT_, UB_)                                                                                          \
-    hipLaunchKernelGGL((rank_fused2_kernel<KT_, UB_>), grid2, block2, 0, h->stream, h->U.p, h->V.p, h->item_base.p, \
-                       ub, d_users, u0, n, h->n_items, tps, topk, d_excl_indptr, d_excl_indices, excl_row0,         \
-                       h->cand.p, h->part.p)
-        if (ub) {
-            if (h->ld == 16) FUSED2(8, true);
-            else if (h->ld == 32) FUSED2(16, true);
-            else FUSED2(32, true);
-        } else {
-            if (h->ld == 16) FUSED2(8, false);
-            else if (h->ld == 32) FUSED2(16, false);
-            else FUSED2(32, false);
-        }
-#undef FUSED2
-        int pad2 = 1;
-        while (pad2 < (int)gx2 * topk) pad2 <<= 1;
-        hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)n), dim3(64), (size_t)pad2 * 8, h->stream, h->part.p,
-                           (int)gx2, n, topk, pad2, items_out, scores_out);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
     // balanced persistent decomposition (see rank_fused_kernel): one range of (row block, item tile) work per
     // resident workgroup, at least 16 tiles long
     const int wgs_per_cu = h->ld <= 64 ? 2 : 1;
