@@ -272,6 +272,10 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         // this launch covers the epoch fraction [s_begin, s_begin + n) / nnz of every wave's samples
         own_lo = (int64_t)(((unsigned __int128)own_len * a.s_begin) / (uint64_t)a.nnz);
         own_hi = (int64_t)(((unsigned __int128)own_len * (a.s_begin + (uint64_t)a.n)) / (uint64_t)a.nnz);
+        // chunked epochs (multi-GPU exchange points): cut the wave's samples at whole 64-sample tiles so that
+        // no launch ends on a nearly empty tile; consecutive launches still cover every sample exactly once
+        own_lo &= ~(int64_t)(kWave - 1);
+        if (a.s_begin + (uint64_t)a.n < (uint64_t)a.nnz) own_hi &= ~(int64_t)(kWave - 1);
         n_tiles = own_len ? (own_hi - own_lo + kWave - 1) / kWave : 0;
         tile0 = 0;
         tile_step = 1;
