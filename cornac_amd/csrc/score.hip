@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(co
     __shared__ float tau[kBlk / 64][32];
     // the 4 waves of a workgroup walk the same item tiles: the B tile is staged once per workgroup
     // (coalesced 16-byte global loads, double-buffered) instead of gathered 4x through the TA
-    __shared__ float btile[2][32][KP + 1];
+    __shared__ float btile[2][32][KP + 2];  // row stride == 2 (mod 64): the 64 lanes of a fragment read hit 64 banks
     __shared__ float ibase[2][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
