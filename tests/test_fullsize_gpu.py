@@ -150,3 +150,40 @@ def test_hogwild_full_size_statistical_parity_with_cpu_threads(oracle, ml20m):
     assert abs(lg - lc) < 0.03 * l0 and abs(ag - ac) < 0.015
     assert abs(c_gpu / (nnz - s_gpu) - c_cpu / (nnz - s_cpu)) < 0.015
     assert abs(s_gpu - s_cpu) < 0.02 * s_cpu
+
+
+def test_mf_full_size_deterministic_and_hogwild(oracle, ml20m):
+    """BASELINE configs[2] family at ML-20M size (20 M ratings, k = 128): one deterministic epoch against the
+    sequential oracle (the reference's seeded loop), then the hogwild kernel's loss against the same oracle."""
+    n_users, n_items, indptr, indices, _ = ml20m
+    k, lr, reg = 128, 0.01, 0.02
+    rs = np.random.RandomState(11)
+    rid = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(indptr))
+    cid = indices.astype(np.int64)
+    order = rs.permutation(len(cid))  # insertion order != CSR order, like a real uir_tuple
+    rid, cid = rid[order], cid[order]
+    bu, bi = rs.normal(0, 0.5, n_users), rs.normal(0, 0.5, n_items)
+    val = np.clip(np.rint(3.5 + bu[rid] + bi[cid] + rs.normal(0, 0.7, len(rid))), 1, 5).astype(np.float32)
+    mu = np.float32(val.mean())
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    Uo, Vo, Buo, Bio = U0.copy(), V0.copy(), zu.copy(), zi.copy()
+    loss_o = np.zeros(1, np.float32)
+    n_run = oracle.lib().oracle_mf_fit(rid, cid, val, len(val), Uo, Vo, Buo, Bio, k, lr, reg, float(mu), 1, 1, 1, 0,
+                                       loss_o.ctypes.data)
+    assert n_run == 1
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.set_factors(U0, V0, zu, zi)
+    loss_d, n = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_DETERMINISTIC)
+    Ud, Vd, Bud, Bid = tr.get_factors()
+    err = max(np.abs(Ud - Uo).max(), np.abs(Vd - Vo).max(), np.abs(Bud - Buo).max(), np.abs(Bid - Bio).max())
+    print("full-size MF deterministic epoch: max |err| = %.3g" % err)
+    assert err <= 1e-4 and np.mean(Ud == Uo) > 0.99
+    # the reference accumulates 20 M squared errors sequentially in float32 (backend_cpu.pyx:61,85): at this size
+    # its own loss value carries several percent of rounding error; the device sums in fp64
+    assert abs(loss_d[0] - loss_o[0]) <= 0.1 * loss_o[0]
+    tr.set_factors(U0, V0, zu, zi)
+    loss_h, _ = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_HOGWILD)
+    tr.close()
+    assert abs(loss_h[0] - loss_d[0]) <= 0.02 * loss_d[0], (loss_h, loss_d)
