@@ -663,8 +663,8 @@ struct cornac_hip_scorer {
 // The fused top-k kernel appends every score that beats its row's running topk-th score, so its cost depends on
 // the order in which items are visited: ~topk ln(N/topk) survivors per row in random order, far fewer when
 // likely-high items come first.  Items are therefore visited in descending order of a cheap upper estimate of
-// their scores,  item_base[i] + 2 |V_i| rms|U_u| / sqrt(k)  (two standard deviations of <u, v_i> for a user of
-// typical norm in a random direction; the Cauchy-Schwarz bound is far too loose in k dimensions).  Any order gives
+// their scores over the user population,  item_base[i] + <mean u, v_i> + 2 sqrt(v_i^T Cov(u) v_i)  (moments of the
+// user vectors from a sample of users; the Cauchy-Schwarz bound is far too loose in k dimensions).  Any order gives
 // the same result (candidates carry original item ids; ties are decided on those).
 static __global__ __launch_bounds__(256) void permute_rows_kernel(const float *__restrict__ V, const float *__restrict__ ib,
                                                                   const int32_t *__restrict__ perm, int64_t n, int ld,
@@ -681,17 +681,50 @@ static __global__ __launch_bounds__(256) void permute_rows_kernel(const float *_
 static void build_rank_order(cornac_hip_scorer_t h, const float *U, const float *V, const float *item_base) {
     const int64_t ni = h->n_items, nu = h->n_users;
     const int k = h->k;
-    const int64_t sample = std::min<int64_t>(nu, 65536), stride = std::max<int64_t>(1, nu / sample);
+    // first and second moments of the user vectors from a sample of users: the score of item i over users has
+    // mean  b_i + <ubar, v_i>  and variance  v_i^T Cov(u) v_i ; the priority is mean + 2 standard deviations
+    // (when the k x k quadratic form per item is too expensive, the isotropic estimate |v_i| rms|u| / sqrt(k))
+    const int64_t sample = std::min<int64_t>(nu, 16384), stride = std::max<int64_t>(1, nu / sample);
+    const bool full_cov = (double)ni * k * k <= 4e9;
+    std::vector<double> mean((size_t)k, 0.0), cov(full_cov ? (size_t)k * k : 0, 0.0);
     double ss = 0;
     int64_t cnt = 0;
-    for (int64_t u = 0; u < nu; u += stride, ++cnt)
-        for (int f = 0; f < k; ++f) ss += (double)U[u * k + f] * U[u * k + f];
-    const float unorm = 2.f * (float)std::sqrt(ss / (double)std::max<int64_t>(cnt, 1) / (double)k);
+    for (int64_t u = 0; u < nu; u += stride, ++cnt) {
+        const float *ur = U + u * k;
+        for (int f = 0; f < k; ++f) {
+            mean[(size_t)f] += ur[f];
+            ss += (double)ur[f] * ur[f];
+        }
+        if (full_cov)
+            for (int f = 0; f < k; ++f)
+                for (int g = f; g < k; ++g) cov[(size_t)f * k + g] += (double)ur[f] * ur[g];
+    }
+    const double inv = 1.0 / (double)std::max<int64_t>(cnt, 1);
+    for (int f = 0; f < k; ++f) mean[(size_t)f] *= inv;
+    if (full_cov)
+        for (int f = 0; f < k; ++f)
+            for (int g = f; g < k; ++g) {
+                const double c = cov[(size_t)f * k + g] * inv - mean[(size_t)f] * mean[(size_t)g];
+                cov[(size_t)f * k + g] = cov[(size_t)g * k + f] = c;
+            }
+    const double iso = std::max(0.0, ss * inv - [&] { double m2 = 0; for (int f = 0; f < k; ++f) m2 += mean[(size_t)f] * mean[(size_t)f]; return m2; }()) / (double)k;
     std::vector<float> pri((size_t)ni);
+    std::vector<double> tmp((size_t)k);
     for (int64_t i = 0; i < ni; ++i) {
-        double s2 = 0;
-        for (int f = 0; f < k; ++f) s2 += (double)V[i * k + f] * V[i * k + f];
-        pri[(size_t)i] = (item_base ? item_base[i] : 0.f) + unorm * (float)std::sqrt(s2);
+        const float *vr = V + i * k;
+        double m = 0, var = 0;
+        for (int f = 0; f < k; ++f) m += mean[(size_t)f] * vr[f];
+        if (full_cov) {
+            for (int f = 0; f < k; ++f) {
+                double t = 0;
+                for (int g = 0; g < k; ++g) t += cov[(size_t)f * k + g] * vr[g];
+                var += t * vr[f];
+            }
+        } else {
+            for (int f = 0; f < k; ++f) var += (double)vr[f] * vr[f];
+            var *= iso;
+        }
+        pri[(size_t)i] = (float)((item_base ? (double)item_base[i] : 0.0) + m + 2.0 * std::sqrt(std::max(var, 0.0)));
     }
     std::vector<int32_t> order((size_t)ni);
     for (int64_t i = 0; i < ni; ++i) order[(size_t)i] = (int32_t)i;
