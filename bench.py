@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-rank", action="store_true")
     ap.add_argument("--rank-users", type=int, default=0, help="users ranked in the scoring leg (0 = all)")
+    ap.add_argument("--rank-full-users", type=int, default=10000, help="users of the full-ranking (k = -1) probe")
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
@@ -232,12 +233,22 @@ def main():
         n_rank = n_users if args.rank_users <= 0 else min(args.rank_users, n_users)
         sc.rank_topk_device_ms(0, min(n_rank, 4096), 10, 1)  # warm-up
         ms = sc.rank_topk_device_ms(0, n_rank, 10, 1)
+        # full ranking (rank(k=-1)): materialised score tile + per-row sort, 10 000 users
+        n_full = min(args.rank_full_users, n_users)
+        ms_full = None
+        if n_full > 0:
+            sc.rank_topk_device_ms(0, min(n_full, 512), n_items, 1)
+            ms_full = sc.rank_topk_device_ms(0, n_full, n_items, 1)
         pairs = float(n_rank) * n_items
         out["rank"] = {"metric": "rank_items_scored_per_sec", "value": pairs / (ms / 1e3), "unit": "items/s",
                        "users": n_rank, "items": n_items, "topk": 10, "ms": ms,
                        "roofline": {"bound": "mfma", "achieved": 2.0 * k * pairs / (ms / 1e3) / 1e12,
                                     "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                     "frac": 2.0 * k * pairs / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF}}
+        if ms_full is not None:
+            out["rank"]["full_ranking"] = {"topk": -1, "users": n_full, "ms": ms_full,
+                                           "value": float(n_full) * n_items / (ms_full / 1e3), "unit": "items/s",
+                                           "note": "rank(k=-1): score tile materialised, every row fully sorted"}
         sc.close()
     trainer.close()
 

@@ -599,22 +599,55 @@ __global__ __launch_bounds__(kBlk) void topk_select_kernel(const float *__restri
     }
 }
 
-// ---- full ranking: bitonic sort of all keys of a row in a global scratch (one workgroup per row) ---------
+// ---- full ranking: bitonic sort of all keys of a row (one workgroup per row) ---------------------------------
+// The network's stages with a partner distance below kSortChunk run inside LDS on 64 KB chunks; only the few
+// stages with a larger distance (3 of 120 for 32 768 keys) touch the global scratch.  Directions follow the
+// GLOBAL key index, so the chunks assemble into the standard bitonic sort.
 constexpr int kSortBlk = 1024;
+constexpr int kSortChunk = 8192;  // keys per LDS chunk
 __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__restrict__ scores,
                                                              const uint8_t *__restrict__ excl_mask, int64_t n_items,
                                                              int64_t n_pad, unsigned long long *__restrict__ scratch,
                                                              int topk, int32_t *__restrict__ items_out,
                                                              float *__restrict__ scores_out) {
+    __shared__ unsigned long long lk[kSortChunk];
     const int64_t row = blockIdx.x;
     const float *srow = scores + row * n_items;
     const uint8_t *erow = excl_mask ? excl_mask + row * n_items : nullptr;
     unsigned long long *keys = scratch + row * n_pad;
     const int tid = threadIdx.x;
-    for (int64_t i = tid; i < n_pad; i += kSortBlk) keys[i] = i < n_items ? composite_key(srow, erow, i) : 0ull;
-    __syncthreads();
-    for (int64_t kk = 2; kk <= n_pad; kk <<= 1) {
-        for (int64_t j = kk >> 1; j > 0; j >>= 1) {
+    const int64_t ch = n_pad < kSortChunk ? n_pad : kSortChunk;  // both powers of two
+    // stages j = j_hi .. 1 of merge step kk on the chunk starting at global index c0, in LDS
+    auto lds_stages = [&](int64_t c0, int64_t kk, int64_t j_hi) {
+        for (int64_t j = j_hi; j > 0; j >>= 1) {
+            for (int64_t i = tid; i < ch; i += kSortBlk) {
+                const int64_t ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = lk[i], y = lk[ixj];
+                    const bool desc = ((c0 + i) & kk) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        lk[i] = y;
+                        lk[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    // phase A: build the keys chunk by chunk and sort every chunk completely (merge steps kk <= ch)
+    for (int64_t c0 = 0; c0 < n_pad; c0 += ch) {
+        for (int64_t i = tid; i < ch; i += kSortBlk) {
+            const int64_t g = c0 + i;
+            lk[i] = g < n_items ? composite_key(srow, erow, g) : 0ull;
+        }
+        __syncthreads();
+        for (int64_t kk = 2; kk <= ch; kk <<= 1) lds_stages(c0, kk, kk >> 1);
+        for (int64_t i = tid; i < ch; i += kSortBlk) keys[c0 + i] = lk[i];
+        __syncthreads();
+    }
+    // phase B: merge steps across chunks — far stages in the global scratch, the rest per chunk in LDS
+    for (int64_t kk = ch << 1; kk <= n_pad; kk <<= 1) {
+        for (int64_t j = kk >> 1; j >= ch; j >>= 1) {
             for (int64_t i = tid; i < n_pad; i += kSortBlk) {
                 const int64_t ixj = i ^ j;
                 if (ixj > i) {
@@ -627,6 +660,13 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
                 }
             }
             __syncthreads();  // workgroup-scope: one workgroup owns the row, L1 is shared by its waves
+        }
+        for (int64_t c0 = 0; c0 < n_pad; c0 += ch) {
+            for (int64_t i = tid; i < ch; i += kSortBlk) lk[i] = keys[c0 + i];
+            __syncthreads();
+            lds_stages(c0, kk, ch >> 1);
+            for (int64_t i = tid; i < ch; i += kSortBlk) keys[c0 + i] = lk[i];
+            __syncthreads();
         }
     }
     for (int64_t i = tid; i < topk; i += kSortBlk) {
@@ -1036,7 +1076,7 @@ int cornac_hip_rank_topk_device(cornac_hip_scorer_t h, int64_t u0, int64_t n, in
     return guarded([&] {
         sc_check(h);
         REQUIRE(u0 >= 0 && n > 0 && u0 + n <= h->n_users, "user range out of bounds");
-        REQUIRE(topk >= 1 && topk <= h->n_items && topk <= TOPK_MAX, "topk out of range for the device probe");
+        REQUIRE(topk >= 1 && topk <= h->n_items, "topk out of range");
         REQUIRE(repeats >= 1 && ms, "bad arguments");
         const bool fused = can_fuse(h, topk);
         const int64_t cap = fused ? n : rows_per_batch(h);
