@@ -620,15 +620,13 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
     // stages j = j_hi .. 1 of merge step kk on the chunk starting at global index c0, in LDS
     auto lds_stages = [&](int64_t c0, int64_t kk, int64_t j_hi) {
         for (int64_t j = j_hi; j > 0; j >>= 1) {
-            for (int64_t i = tid; i < ch; i += kSortBlk) {
-                const int64_t ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = lk[i], y = lk[ixj];
-                    const bool desc = ((c0 + i) & kk) == 0;
-                    if (desc ? (x < y) : (x > y)) {
-                        lk[i] = y;
-                        lk[ixj] = x;
-                    }
+            for (int64_t p = tid; p < (ch >> 1); p += kSortBlk) {  // one thread per compare-exchange pair
+                const int64_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+                const unsigned long long x = lk[i], y = lk[ixj];
+                const bool desc = ((c0 + i) & kk) == 0;
+                if (desc ? (x < y) : (x > y)) {
+                    lk[i] = y;
+                    lk[ixj] = x;
                 }
             }
             __syncthreads();
@@ -648,15 +646,13 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
     // phase B: merge steps across chunks — far stages in the global scratch, the rest per chunk in LDS
     for (int64_t kk = ch << 1; kk <= n_pad; kk <<= 1) {
         for (int64_t j = kk >> 1; j >= ch; j >>= 1) {
-            for (int64_t i = tid; i < n_pad; i += kSortBlk) {
-                const int64_t ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = keys[i], y = keys[ixj];
-                    const bool desc = (i & kk) == 0;
-                    if (desc ? (x < y) : (x > y)) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
+            for (int64_t p = tid; p < (n_pad >> 1); p += kSortBlk) {
+                const int64_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+                const unsigned long long x = keys[i], y = keys[ixj];
+                const bool desc = (i & kk) == 0;
+                if (desc ? (x < y) : (x > y)) {
+                    keys[i] = y;
+                    keys[ixj] = x;
                 }
             }
             __syncthreads();  // workgroup-scope: one workgroup owns the row, L1 is shared by its waves
