@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
 // percent of the MFMA time.  Optional exclusion lists (sorted CSR per row) are consulted only for
 // survivors.  Each segment emits topk keys per row; rank_merge_kernel merges the segments.
 template <int KT, int CAP, bool UB>
-__global__ __launch_bounds__(kBlk, (KT <= 32 ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
+__global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ item_base,
                                                           const float *__restrict__ user_base,
                                                           const int32_t *__restrict__ users, int64_t u0,
@@ -853,7 +853,7 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     const int64_t wg_rows = (n + 127) / 128;  // 4 waves x 32 rows per workgroup
     // balanced persistent decomposition (see rank_fused_kernel): one range of (row block, item tile) work per
     // resident workgroup, at least 16 tiles long
-    const int wgs_per_cu = h->ld <= 64 ? 2 : 1;
+    const int wgs_per_cu = (h->ld <= 64 || topk <= 10) ? 2 : 1;
     const int64_t work_total = wg_rows * n_item_tiles;
     int64_t work_per_wg = std::max<int64_t>((work_total + (int64_t)di.cus * wgs_per_cu - 1) / ((int64_t)di.cus * wgs_per_cu),
                                             std::min<int64_t>(16, n_item_tiles));
@@ -879,7 +879,9 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
         hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->Vr.p,      \
                            h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
                            d_excl_indices, excl_row0, h->perm.p, h->tau_pub.p, h->part.p, ablate); } while (0)
-    if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
+    if (topk <= 10 && h->ld == 128) {
+        FUSED(64, 42);  // k = 128: the smallest buffer (topk + 32) lets two workgroups share a CU's LDS
+    } else if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
         if (h->ld == 16) FUSED(8, 56);
         else if (h->ld == 32) FUSED(16, 56);
         else if (h->ld == 64) FUSED(32, 56);
