@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--rank-users", type=int, default=0, help="users ranked in the scoring leg (0 = all)")
     ap.add_argument("--rank-full-users", type=int, default=10000, help="users of the full-ranking (k = -1) probe")
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
+    ap.add_argument("--sharded-items", action="store_true",
+                    help="multi-GPU regime 2: item table sharded by row, all-to-all of the touched rows "
+                         "(default for N > 1 is regime 1: replicated item table + all-reduce of deltas)")
+    ap.add_argument("--micro-batch", type=int, default=2_000_000, help="draws per exchange with --sharded-items")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
     args = ap.parse_args()
@@ -155,7 +159,12 @@ def main():
     trainer.seed_hogwild(0xC0FFEE + 7919 * rank)
 
     sharded = None
-    if distributed:
+    if distributed and args.sharded_items:
+        from cornac_amd.dist import RowShardedBprTrainer
+
+        sharded = RowShardedBprTrainer(trainer, n_items, k, dev, micro_batch=args.micro_batch)
+        sharded.load_items(V, B)
+    elif distributed:
         from cornac_amd.dist import ShardedBprTrainer
 
         sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
@@ -165,7 +174,10 @@ def main():
     def step():
         if sharded is None:
             return trainer.fit_epochs(1, args.lr, args.reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, args.flags)
-        sharded.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags)
+        if args.sharded_items:
+            sharded.run(nnz, args.lr, args.reg, True)
+        else:
+            sharded.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags)
         return (0, 0)
 
     for _ in range(args.warmup):
@@ -200,8 +212,11 @@ def main():
         "config": {"workload": "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
                                "GPU), hogwild mode, fp32 tables resident in HBM" % (k, n_users, n_items, nnz),
                    "k": k, "lr": args.lr, "reg": args.reg, "hogwild_flags": args.flags,
-                   "parallelism": "1 gpu" if world == 1 else "user-partitioned dp%d, item table all-reduce x%d/epoch"
-                                  % (world, args.sync_per_epoch)},
+                   "parallelism": "1 gpu" if world == 1 and not distributed else
+                                  ("user-partitioned dp%d, item table sharded by row, all-to-all every %d draws"
+                                   % (world, args.micro_batch)) if args.sharded_items else
+                                  ("user-partitioned dp%d, item table all-reduce x%d/epoch"
+                                   % (world, args.sync_per_epoch))},
     }
     if rank == 0:
         mean_deg = nnz / n_users
@@ -221,14 +236,23 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                           "kernel": "bpr_hogwild_rowwise_kernel<64,1,4,atomic,owned>", "launches": launches,
+                           "kernel": "bpr_hogwild_rowwise_kernel<64,1,4,atomic,owned>" if not args.sharded_items
+                                     else "sample/apply kernels of the row-sharded path (no fused SGD kernel)",
+                           "launches": launches,
                            "avg_launch_ms": 1e3 * avg_launch_s, "algorithmic_bytes_per_triplet": b_full,
                            "skip_fraction": skip_frac}
         out["train_stats"] = {"correct_frac": correct / max(n_draws - skipped, 1.0), "skipped_frac": skip_frac}
 
     # ---- scoring leg: batched rank() over users with fused top-10 --------------------------------------------
+    full_items = None
+    if not args.no_rank and distributed and args.sharded_items:
+        Vt, Bt = sharded.table.gather_full()  # collective: every rank assembles the sharded item table
+        full_items = (Vt.cpu().numpy(), Bt.cpu().numpy())
     if not args.no_rank and rank == 0:
-        U2, V2, B2 = trainer.get_factors()
+        if full_items is not None:
+            U2, (V2, B2) = trainer.get_user_factors(), full_items
+        else:
+            U2, V2, B2 = trainer.get_factors()
         sc = _lib.Scorer(U2, V2, B2, None, device=local_rank)
         n_rank = n_users if args.rank_users <= 0 else min(args.rank_users, n_users)
         sc.rank_topk_device_ms(0, min(n_rank, 4096), 10, 1)  # warm-up

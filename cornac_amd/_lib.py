@@ -239,6 +239,13 @@ class BprTrainer:
         check(lib().cornac_hip_bpr_get_factors(self.h, U.ctypes.data, V.ctypes.data, B.ctypes.data))
         return U, V, B
 
+    def get_user_factors(self):
+        """U only (the item tables may live elsewhere: row-sharded multi-GPU mode binds a local shard)"""
+        tu, _, k = self.shape
+        U = np.empty((tu, k), np.float32)
+        check(lib().cornac_hip_bpr_get_factors(self.h, U.ctypes.data, None, None))
+        return U
+
     def seed_mt19937(self, seed_pos, seed_neg, shared_stream=False):
         check(lib().cornac_hip_bpr_seed_mt19937(self.h, seed_pos, seed_neg, int(shared_stream)))
 
