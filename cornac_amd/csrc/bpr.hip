@@ -9,9 +9,12 @@
 //                   level schedule of the row-conflict DAG (levels = kernels, samples of a level
 //                   touch disjoint rows), with the reference's float expression order.
 //   hogwild       — throughput mode (the reference's num_threads > 1 path): counter-based
-//                   sampling, one 64-sample tile per wave staged through LDS, G lanes per
-//                   triplet with 16-byte row gathers, wave-shuffle dot products and fp32 atomic
-//                   scatter-updates.  HBM/fabric-bandwidth bound; no MFMA (nothing is GEMM-shaped).
+//                   sampling, one 64-sample tile per wave compacted through LDS, then row-wise lanes
+//                   (the lanes of a group own consecutive floats of a row: fully coalesced gathers, one
+//                   atomic instruction per row), wave-shuffle dot products, user rows owned by waves
+//                   (plain stores) and fp32 device-scope atomics on the item side.  Bound by the atomic
+//                   line-touch rate of the L2s; no MFMA (nothing is GEMM-shaped).
+// sharded.inc adds the sample / gather / apply / scatter-add pieces of the row-sharded multi-GPU regime.
 #include <algorithm>
 #include <numeric>
 #include <queue>

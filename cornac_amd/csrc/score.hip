@@ -9,7 +9,9 @@
 //  * score_gemm_mfma          : the batched users x items scoring GEMM on the fp32 matrix cores
 //                               (v_mfma_f32_32x32x2_f32: exact fp32, and — because an MFMA is a
 //                               k-ordered fma chain — bit-identical to the fmaf chain above).
-//  * topk_select / full_sort  : per-user ranking.  Every (score, item) pair is mapped to a unique
+//  * rank_fused               : scoring GEMM + top-k (topk <= 32) without materialising the scores.
+//  * topk_select / full_sort  : per-user ranking of a materialised score tile (larger topk, full rankings,
+//                               candidate lists).  Every (score, item) pair is mapped to a unique
 //                               64-bit key  [order-preserving score bits | item index], so
 //                               "descending score, ties by higher item index" (the oracle's pinned
 //                               tie rule) is a plain descending sort of integers.
@@ -141,15 +143,16 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
 }
 
 // ---- fused scoring GEMM + top-k: the users x items score tile never leaves the registers ------------------
-// One wave owns a 32-user tile (A fragments in registers) and walks a strip of 32-item tiles with
-// v_mfma_f32_32x32x2_f32.
+// One wave owns a 32-user tile (A fragments in registers) and walks a range of 32-item tiles with
+// v_mfma_f32_32x32x2_f32; the 4 waves of a workgroup share each B tile through LDS.
 // Every accumulator value is compared with its row's running threshold (the score of the row's
-// current topk-th candidate); the rare survivors are appended to a per-row candidate buffer in LDS
-// (CAP slots, LDS atomic cursor).  When a buffer could overflow on the next tile the wave compacts
-// its rows: 64-lane bitonic sort of the 64-bit (score, item) keys, keep the topk best, raise the
-// threshold.  Expected survivors per row over N items is ~topk*ln(N/topk), so the epilogue is a few
-// percent of the MFMA time.  Optional exclusion lists (sorted CSR per row) are consulted only for
-// survivors.  Each segment emits topk keys per row; rank_merge_kernel merges the segments.
+// current topk-th candidate); the survivors are appended to a per-row candidate buffer in LDS (CAP
+// slots; slot = register-resident count + ballot prefix, no LDS atomics).  When a buffer would overflow the
+// wave compacts the row by rank counting (lane i counts the candidates that beat candidate i from LDS
+// broadcast reads), keeps the topk best and raises the threshold.  Optional exclusion lists (sorted CSR per
+// row) are consulted only at compaction.  Work is cut into equal contiguous ranges of (row block, item tile),
+// one per resident workgroup; every piece ("segment") of a row block emits topk keys per row and
+// rank_merge_kernel merges them.  See DESIGN.md section 4 for the measurements behind each choice.
 template <int KT, int CAP, bool UB>
 __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_fused_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ item_base,
