@@ -66,24 +66,68 @@ __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__
     const int64_t t = off + (active ? gid : cnt - 1);
     const int32_t u = su[t], i = si[t], j = sj[t];
     float *pu = U + (size_t)u * k, *pi = V + (size_t)i * k, *pj = V + (size_t)j * k;
-    float score = B[i] - B[j];
-    for (int base = 0; base < k; base += G) {
-        const int f = base + lg;
-        float p = 0.f;
-        if (f < k) p = pu[f] * (pi[f] - pj[f]);
-        const int lim = min(G, k - base);
-        for (int l = 0; l < lim; ++l) score = score + __shfl(p, l, G);
+    const float bi = B[i], bj = B[j];
+    float score = bi - bj;
+    // rows are read ONCE (kept in registers for the update when k <= 4 G): a level's latency is its chain of
+    // dependent memory round trips, ids -> rows -> stores
+    constexpr int RMAX = 4;
+    float ru[RMAX], ri[RMAX], rj[RMAX];
+    const bool in_regs = k <= RMAX * G;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int f = r * G + lg;
+        ru[r] = ri[r] = rj[r] = 0.f;
+        if (in_regs && f < k) {
+            ru[r] = pu[f];
+            ri[r] = pi[f];
+            rj[r] = pj[f];
+        }
+    }
+    auto ordered_add = [&](float p, int lim) {
+        if (G == kWave) {
+            // one group per wave: the index-ordered sum reads each product with v_readlane (constant lane after
+            // unrolling) instead of a chain of 64 LDS-routed shuffles
+#pragma unroll
+            for (int l = 0; l < kWave; ++l)
+                if (l < lim) score = score + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), l));
+        } else {
+            for (int l = 0; l < lim; ++l) score = score + __shfl(p, l, G);
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int base = r * G;
+            if (base < k) ordered_add(base + lg < k ? ru[r] * (ri[r] - rj[r]) : 0.f, min(G, k - base));
+        }
+    } else {
+        for (int base = 0; base < k; base += G) {
+            const int f = base + lg;
+            ordered_add(f < k ? pu[f] * (pi[f] - pj[f]) : 0.f, min(G, k - base));
+        }
     }
     const float z = sigmoid_neg_exact(score);
     if (active) {
-        for (int f = lg; f < k; f += G) {
-            const float uf = pu[f], vi = pi[f], vj = pj[f];
-            pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
-            pi[f] = vi + lr * (z * uf - reg * vi);
-            pj[f] = vj + lr * (-z * uf - reg * vj);
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int f = r * G + lg;
+                if (f < k) {
+                    const float uf = ru[r], vi = ri[r], vj = rj[r];
+                    pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
+                    pi[f] = vi + lr * (z * uf - reg * vi);
+                    pj[f] = vj + lr * (-z * uf - reg * vj);
+                }
+            }
+        } else {
+            for (int f = lg; f < k; f += G) {
+                const float uf = pu[f], vi = pi[f], vj = pj[f];
+                pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
+                pi[f] = vi + lr * (z * uf - reg * vi);
+                pj[f] = vj + lr * (-z * uf - reg * vj);
+            }
         }
         if (lg == 0 && use_bias) {
-            const float bi = B[i], bj = B[j];
             B[i] = bi + lr * (z - reg * bi);
             B[j] = bj + lr * (-z - reg * bj);
         }
