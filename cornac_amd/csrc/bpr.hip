@@ -83,17 +83,7 @@ __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__
             rj[r] = pj[f];
         }
     }
-    auto ordered_add = [&](float p, int lim) {
-        if (G == kWave) {
-            // one group per wave: the index-ordered sum reads each product with v_readlane (constant lane after
-            // unrolling) instead of a chain of 64 LDS-routed shuffles
-#pragma unroll
-            for (int l = 0; l < kWave; ++l)
-                if (l < lim) score = score + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), l));
-        } else {
-            for (int l = 0; l < lim; ++l) score = score + __shfl(p, l, G);
-        }
-    };
+    auto ordered_add = [&](float p, int lim) { score = ordered_lane_sum<G>(score, p, lim); };
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {

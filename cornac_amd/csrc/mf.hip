@@ -38,8 +38,7 @@ __global__ __launch_bounds__(kBlock) void mf_det_level_kernel(const int32_t *__r
         const int f = base + lg;
         float p = 0.f;
         if (f < k) p = pu[f] * pi[f];
-        const int lim = min(G, k - base);
-        for (int l = 0; l < lim; ++l) pred = pred + __shfl(p, l, G);
+        pred = ordered_lane_sum<G>(pred, p, min(G, k - base));
     }
     const float err = r - pred;
     if (active) {

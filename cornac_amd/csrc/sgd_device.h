@@ -26,6 +26,21 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// acc = ((acc + p[0]) + p[1]) + ... + p[lim-1] over the lanes of a G-lane group, in lane order (the reference's
+// sequential float sum over factors).  With one group per wave every term is read with v_readlane (constant
+// lane after unrolling); smaller groups need a per-group source lane and go through the cross-lane network.
+template <int G>
+__device__ __forceinline__ float ordered_lane_sum(float acc, float p, int lim) {
+    if (G == kWave) {
+#pragma unroll
+        for (int l = 0; l < kWave; ++l)
+            if (l < lim) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), l));
+    } else {
+        for (int l = 0; l < lim; ++l) acc = acc + __shfl(p, l, G);
+    }
+    return acc;
+}
+
 // sigmoid(-score) exactly as the reference evaluates it (cornac/models/bpr/recom_bpr.pyx:250):
 // exp on a float, then 1.0/(1.0+e) in double, rounded to float on assignment.
 __device__ __forceinline__ float sigmoid_neg_exact(float score) {
