@@ -196,3 +196,27 @@ def test_batched_evaluation_equals_per_user_flow():
     pred = np.array([float(mf.rate(int(a), int(b))) for a, b in zip(u, i)])
     assert rmse == pytest.approx(np.sqrt(np.mean((r - pred) ** 2)), rel=1e-6)
     assert mae == pytest.approx(np.mean(np.abs(r - pred)), rel=1e-6)
+
+
+@pytest.mark.parametrize("k,topk", [(100, 10), (64, 7), (128, 24)])
+def test_fused_rank_long_item_ranges_and_many_segments(oracle, k, topk):
+    """large catalogue, few users: one row block is cut into many segments (threshold hand-off between them),
+    k = 100/128 takes the two-workgroups-per-CU variant with topk + 32 candidate slots; exact order and scores
+    against the oracle's fma-chain scores, with user and item bases and tied scores in the data"""
+    rs = np.random.RandomState(k + topk)
+    nu, ni = 300, 150_000
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (ni, k)).astype(np.float32)
+    V[1000:1040] = V[2000:2040]  # exact ties across distant tiles
+    ib = rs.normal(0, 0.2, ni).astype(np.float32)
+    ib[1000:1040] = ib[2000:2040]
+    ub = rs.normal(0, 0.2, nu).astype(np.float32)
+    sc = _lib.Scorer(U, V, ib, ub)
+    users = np.arange(nu, dtype=np.int32)
+    items, scores = sc.rank_topk(users, topk)
+    sc.close()
+    full = oracle.score_block(U, V, ib, ub, users)
+    for b in range(nu):
+        want, _ = oracle.rank(full[b], ni, ni, k=topk)
+        assert np.array_equal(items[b], want[:topk]), b
+        assert np.array_equal(scores[b], full[b][want[:topk]])
