@@ -60,10 +60,54 @@ def init_factors(n_users, n_items, k, seed):
     return U, V, np.zeros(n_items, np.float32)
 
 
+def cpu_baseline_reference(indptr, indices, n_items, k, lr, reg, budget_s):
+    """The REAL reference kernel: `BPR._fit_sgd` + `RNGVector` of the compiled extension in oracle/_ref (built from
+    the sources under /root/reference by oracle/build_ref.py; loaded over the stand-in Python modules of
+    oracle/ref_stubs where the reference tree itself is absent), driven with raw arrays exactly as `BPR.fit` drives
+    it (cornac/models/bpr/recom_bpr.pyx:186-201).  One call = one epoch = nnz draws."""
+    from oracle import ref_loader
+
+    RNGVector, RefBPR = ref_loader.load_kernel_only()
+    n_users = len(indptr) - 1
+    nnz = len(indices)
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+    item_ids = np.ascontiguousarray(indices, np.int32)
+    neg_item_ids = np.arange(n_items, dtype=np.int32)
+    ip = np.ascontiguousarray(indptr, np.int32)
+    U, V, B = init_factors(n_users, n_items, k, 1)
+    model = RefBPR(k=k, learning_rate=lr, lambda_reg=reg)
+    max_threads = os.cpu_count() or 1
+
+    def epoch(t, seed):
+        t0 = time.time()
+        model._fit_sgd(RNGVector(t, nnz - 1, seed), RNGVector(t, n_items - 1, seed + 1), t, user_ids, item_ids,
+                       neg_item_ids, ip, U, V, B)
+        return time.time() - t0
+
+    epoch(max_threads, 1)  # page in
+    cands = sorted({t for t in (8, 16, 32, 64, max_threads) if t <= max_threads} | {max_threads})
+    best = min((epoch(t, 10 + t), t) for t in cands)
+    threads = best[1]
+    n_epochs = int(max(1, min(8, round(budget_s / max(best[0], 1e-3)))))
+    dt = sum(epoch(threads, 100 + e) for e in range(n_epochs))
+    n = float(nnz) * n_epochs
+    return {"value": n / dt, "unit": "triplets/s", "cores": threads, "kind": "reference",
+            "sample": "%d epochs (%d triplets) of the same ML-20M-shaped matrix through the reference's compiled "
+                      "BPR._fit_sgd (Cython/OpenMP, k=%d), %d threads (best of %s on a %d-thread host), %.1f s"
+                      % (n_epochs, int(n), k, threads, cands, max_threads, dt)}
+
+
 def cpu_baseline(indptr, indices, n_items, k, lr, reg, budget_s):
-    """The reference's OpenMP Hogwild path (restated in oracle/cornac_oracle.c, same loop, same
-    boost sampler, compiled with the reference's flags) timed on this host's cores over a bounded
-    sample of the same workload."""
+    """The reference's OpenMP Hogwild path timed on this host's cores over a bounded sample of the same workload:
+    the real compiled reference kernel when oracle/_ref is present (kind "reference"), otherwise its restatement in
+    oracle/cornac_oracle.c (same loop, same boost sampler, compiled with the reference's flags; kind "port")."""
+    try:
+        from oracle import ref_loader
+
+        if ref_loader.kernel_available():
+            return cpu_baseline_reference(indptr, indices, n_items, k, lr, reg, budget_s)
+    except Exception as e:  # fall back to the port, but say why
+        print("[bench] reference kernel unavailable (%s): timing the port" % e, file=sys.stderr)
     from oracle import oracle as orc
 
     L = orc.lib()

@@ -83,3 +83,32 @@ def load():
     ns.metrics = importlib.import_module("cornac.metrics")
     ns.eval_methods = importlib.import_module("cornac.eval_methods")
     return ns
+
+
+def kernel_available():
+    """the compiled reference kernel (oracle/_ref) can be loaded, with or without /root/reference"""
+    need = ("cornac/models/bpr/recom_bpr", "cornac/utils/fast_dot")
+    return all(os.path.exists(build_ref.so_path(r)) for r in need)
+
+
+def load_kernel_only():
+    """RNGVector and BPR of the REAL compiled reference extension, loaded over the stand-in Python modules of
+    oracle/ref_stubs when /root/reference is absent (the GPU box): enough to drive and time `BPR._fit_sgd`
+    (bench.py cpu_baseline kind "reference").  Where the reference tree exists, load() is used instead."""
+    global _loaded
+    if available():
+        ns = load()
+        return ns.RNGVector, ns.BPR
+    if not kernel_available():
+        raise RuntimeError("oracle/_ref is not built")
+    import importlib
+
+    if not _loaded:
+        if "cornac" in sys.modules:
+            raise RuntimeError("a `cornac` package is already imported")
+        stubs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs")
+        sys.meta_path.insert(0, _RefExtFinder())
+        sys.path.insert(0, stubs)
+        _loaded = True
+    m = importlib.import_module("cornac.models.bpr.recom_bpr")
+    return m.RNGVector, m.BPR
