@@ -97,6 +97,56 @@ def cpu_baseline_reference(indptr, indices, n_items, k, lr, reg, budget_s):
                       % (n_epochs, int(n), k, threads, cands, max_threads, dt)}
 
 
+def cpu_rank_baseline(U, V, B, topk, n_sample=200):
+    """The reference's per-user scoring + ranking flow on the host, timed over a sample of users: BPR.score
+    (copy of the item biases + fast_dot, cornac/models/bpr/recom_bpr.pyx:272-297) followed by Recommender.rank's
+    argpartition / argsort (cornac/models/recommender.py:503-530).  fast_dot is the reference's compiled extension
+    when oracle/_ref is present, otherwise the C restatement in oracle/cornac_oracle.c."""
+    kind = "port"
+    fast_dot = None
+    try:
+        from oracle import ref_loader
+
+        if ref_loader.kernel_available():
+            ref_loader.load_kernel_only()
+            import importlib
+
+            fast_dot = importlib.import_module("cornac.utils.fast_dot").fast_dot
+            kind = "reference fast_dot + numpy ranking as in Recommender.rank"
+    except Exception:
+        fast_dot = None
+    if fast_dot is None:
+        from oracle import oracle as orc
+
+        fast_dot = orc.fast_dot
+    n_items = V.shape[0]
+    users = np.random.RandomState(0).randint(0, U.shape[0], n_sample)
+
+    def one(u, k):
+        scores = B.copy()
+        fast_dot(U[u], V, scores)
+        if k != -1:
+            part = np.argpartition(scores, -k)
+            top = part[-k:]
+            part[-k:] = top[np.argsort(scores[top])]
+            return part[::-1]
+        return scores.argsort()[::-1]
+
+    out = {}
+    for name, k, n in (("topk", topk, n_sample), ("full", -1, max(10, n_sample // 4))):
+        t_w = time.time()
+        while time.time() - t_w < 0.5:  # the OpenMP team of fast_dot needs many calls to settle
+            one(int(users[0]), k)
+        t0 = time.time()
+        for u in users[:n]:
+            one(int(u), k)
+        dt = time.time() - t0
+        out[name] = {"ms_per_user": 1e3 * dt / n, "items_per_s": n * n_items / dt, "users_timed": int(n)}
+    out["kind"] = kind
+    out["cores"] = os.cpu_count() or 1
+    return out
+
+
 def cpu_baseline(indptr, indices, n_items, k, lr, reg, budget_s):
     """The reference's OpenMP Hogwild path timed on this host's cores over a bounded sample of the same workload:
     the real compiled reference kernel when oracle/_ref is present (kind "reference"), otherwise its restatement in
@@ -318,6 +368,8 @@ def main():
                                            "value": float(n_full) * n_items / (ms_full / 1e3), "unit": "items/s",
                                            "note": "rank(k=-1): score tile materialised, every row fully sorted"}
         sc.close()
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out["rank"]["cpu_baseline"] = cpu_rank_baseline(U2, V2, B2, 10)
     trainer.close()
 
     # ---- CPU baseline leg (rank 0, N = 1 only) ------------------------------------------------------------------
