@@ -1,5 +1,5 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU path's host logic (cornac_amd/dist.py): user
-partitioning and the item-table delta all-reduce.  The HIP trainer is replaced by a host stand-in
+partitioning and the item-table delta exchange (sum of the deltas divided by the number of touching ranks, per row).  The HIP trainer is replaced by a host stand-in
 that applies known per-rank updates, so the reduction algebra is checked exactly."""
 import os
 import socket
@@ -61,11 +61,12 @@ def test_item_table_allreduce_of_deltas_world2():
     assert np.array_equal(V_a, V_b) and np.array_equal(B_a, B_b), "replicas must agree after every sync"
     V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
     want = V0.copy()
-    want[0::2] += 0.01 * 250  # rank 0's stripe
+    want[0::2] += 0.01 * 250  # rank 0's stripe: rows only rank 0 touched keep its steps unchanged
     want[1::2] += 0.01 * 250  # rank 1's stripe
-    want[0] += 2.0 * 3        # both ranks, three chunks
+    # row 0 is touched by BOTH ranks in every chunk (rank 0: lr*n + 1, rank 1: + 1): it receives the AVERAGE
+    want[0] = V0[0] + sum((0.01 * n + 2.0) / 2.0 for n in (100, 100, 50))
     assert np.allclose(V_a, want, atol=1e-5)
-    assert np.allclose(B_a, 3 * (0.5 + 1.0))
+    assert np.allclose(B_a, 3 * (0.5 + 1.0) / 2.0)  # every bias touched by both ranks: averaged
 
 
 def test_single_process_sync_is_a_rebase():

@@ -158,3 +158,44 @@ def test_row_sharded_trainer_single_rank_through_rccl():
     assert moved.min() > 1.0
     assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
     assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
+
+
+def test_fused_table_delta_kernels_equal_the_torch_algebra():
+    """ItemTableReplica's two elementwise passes as HIP kernels vs the torch formulation (the gloo tests' path),
+    with a hand-made 'all-reduced' bucket in between: summed deltas of 3 virtual ranks and their touch counts."""
+    import torch
+
+    ds = synth_dataset(50, 40, 300, seed=1)
+    tr = _trainer(ds, 4)
+    dev = torch.device("cuda", 0)
+    n, k = 37, 5
+    g = torch.Generator(device="cpu").manual_seed(0)
+    base = torch.randn(n * k + n, generator=g).to(dev)
+    flat = base.clone()
+    touched_rows = torch.tensor([0, 3, 4, 20, 36])
+    flat[: n * k].view(n, k)[touched_rows] += torch.randn(len(touched_rows), k, generator=g).to(dev)
+    flat[n * k + 7] += 0.5
+    bucket = torch.empty(n * k + 3 * n, device=dev)
+    local = torch.empty(n * k + n, device=dev)
+    torch.cuda.synchronize()
+    tr.table_delta_begin(flat.data_ptr(), base.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr())
+    tr.sync()
+    d = flat - base
+    assert torch.equal(bucket[: n * k + n], d) and torch.equal(local, d)
+    assert torch.equal(bucket[n * k + n: n * k + 2 * n], (d[: n * k].view(n, k) != 0).any(1).float())
+    assert torch.equal(bucket[n * k + 2 * n:], (d[n * k:] != 0).float())
+    # pretend two more ranks contributed: other deltas on overlapping and distinct rows
+    other = torch.zeros_like(bucket)
+    other[: n * k].view(n, k)[[0, 1, 36]] = torch.randn(3, k, generator=g).to(dev)
+    other[n * k + n + 0] = 2; other[n * k + n + 1] = 1; other[n * k + n + 36] = 2
+    other[n * k + 7] = 0.25; other[n * k + 2 * n + 7] = 1
+    red = bucket + other
+    cv = red[n * k + n: n * k + 2 * n].clamp(min=1).unsqueeze(1)
+    cb = red[n * k + 2 * n:].clamp(min=1)
+    R = torch.cat([(red[: n * k].view(n, k) / cv).reshape(-1), red[n * k: n * k + n] / cb])
+    want_flat, want_base = flat + (R - local), base + R
+    torch.cuda.synchronize()
+    tr.table_delta_finish(flat.data_ptr(), base.data_ptr(), red.data_ptr(), local.data_ptr(), n, k)
+    tr.sync()
+    assert torch.allclose(flat, want_flat, atol=1e-6) and torch.allclose(base, want_base, atol=1e-6)
+    tr.close()
