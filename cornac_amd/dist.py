@@ -217,9 +217,18 @@ class RowShardedItemTable:
         return rows, bias, (send_counts, recv_counts, wanted)
 
     def push(self, plan, d_rows, d_bias):
+        """owners apply  sum of the received deltas of a row / number of ranks that sent one  (the same
+        reconciliation rule as ItemTableReplica: several ranks' stale steps on one popular row are averaged)"""
         send_counts, recv_counts, wanted = plan
         got_rows = self._exchange(d_rows.contiguous(), send_counts, recv_counts)
         got_bias = self._exchange(d_bias.contiguous().view(-1, 1), send_counts, recv_counts)
+        if self.world > 1 and len(wanted):
+            idx = wanted.long()
+            senders = torch.zeros(self.rows_per_rank, dtype=torch.float32, device=self.device)
+            senders.index_add_(0, idx, torch.ones(len(idx), dtype=torch.float32, device=self.device))
+            scale = (1.0 / senders[idx]).unsqueeze(1)
+            got_rows = got_rows * scale
+            got_bias = got_bias * scale
         self.ops.scatter_add(self.V, wanted, got_rows)
         self.ops.scatter_add(self.B.view(-1, 1), wanted, got_bias)
 

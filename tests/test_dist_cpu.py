@@ -181,20 +181,35 @@ def test_row_sharded_table_world2():
     Vf0, Bf0, V20, B20, seen0, n0 = out[0]
     Vf1, Bf1, V21, B21, seen1, n1 = out[1]
     assert np.array_equal(Vf0, Vf1) and np.array_equal(V20, V21) and np.array_equal(B20, B21)
+    # (a) rows requested by one rank receive its delta, rows requested by both the AVERAGE of the two deltas
     want = V0.copy()
     wb = B0.copy()
-    for items, r in (([0, 1, 4, 9, 10], 0), ([1, 2, 9], 1)):
-        want[items] += r + 1
-        wb[items] += 10.0 * (r + 1)
-    assert np.array_equal(Vf0, want) and np.array_equal(Bf0, wb)
+    reqs = (([0, 1, 4, 9, 10], 0), ([1, 2, 9], 1))
+    senders = np.zeros(n_items)
+    for items, r in reqs:
+        senders[items] += 1
+    for items, r in reqs:
+        want[items] += (r + 1) / senders[items][:, None]
+        wb[items] += 10.0 * (r + 1) / senders[items]
+    assert np.allclose(Vf0, want) and np.allclose(Bf0, wb)
+    # (b) the trainer loop: per micro-batch every rank's delta per row, owners apply sum / number of sending ranks
     want, wb, n_valid = V0.copy(), B0.copy(), 0
-    for seen in (seen0, seen1):
-        assert [len(b[0]) for b in seen] == [20, 20, 10]
-        for u, i, j in seen:
+    for (u0, i0, j0), (u1, i1, j1) in zip(seen0, seen1):
+        dV = [np.zeros_like(V0), np.zeros_like(V0)]
+        dB = [np.zeros_like(B0), np.zeros_like(B0)]
+        touched = np.zeros(n_items)
+        for r, (u, i, j) in enumerate(((u0, i0, j0), (u1, i1, j1))):
             ok = u >= 0
             n_valid += int(ok.sum())
-            np.add.at(want, i[ok], 1.0)
-            np.add.at(want, j[ok], -1.0)
-            np.add.at(wb, i[ok], 0.5)
+            np.add.at(dV[r], i[ok], 1.0)
+            np.add.at(dV[r], j[ok], -1.0)
+            np.add.at(dB[r], i[ok], 0.5)
+            t = np.zeros(n_items)
+            t[np.unique(np.concatenate([i[ok], j[ok]]))] = 1
+            touched += t
+        div = np.maximum(touched, 1)
+        want += (dV[0] + dV[1]) / div[:, None]
+        wb += (dB[0] + dB[1]) / div
+    assert [len(b[0]) for b in seen0] == [20, 20, 10] == [len(b[0]) for b in seen1]
     assert n0 + n1 == n_valid
     assert np.allclose(V20, want) and np.allclose(B20, wb)
