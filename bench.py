@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--reg", type=float, default=0.01)
     ap.add_argument("--flags", type=int, default=0, help="hogwild_flags of cornac_hip_bpr_fit_epochs")
-    ap.add_argument("--sync-per-epoch", type=int, default=4, help="item-table exchanges per epoch (N > 1)")
+    ap.add_argument("--sync-per-epoch", type=int, default=16, help="item-table exchanges per epoch (N > 1)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-rank", action="store_true")
     ap.add_argument("--rank-users", type=int, default=0, help="users ranked in the scoring leg (0 = all)")

@@ -144,6 +144,7 @@ struct HogArgs {
     // own_u/own_i[wave_ptr[w] .. wave_ptr[w+1]); own_u < 0 encodes a shared (heavy) user as ~u
     const int32_t *own_u, *own_i;
     const int64_t *wave_ptr;
+    int64_t own_tmax;  // tiles of 64 samples of the longest wave slice
     int64_t nnz;
     int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
     int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
@@ -307,12 +308,15 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         own_base = a.wave_ptr[wave_id];
         own_len = (uint32_t)(a.wave_ptr[wave_id + 1] - own_base);
         // this launch covers the epoch fraction [s_begin, s_begin + n) / nnz of every wave's samples
-        own_lo = (int64_t)(((unsigned __int128)own_len * a.s_begin) / (uint64_t)a.nnz);
-        own_hi = (int64_t)(((unsigned __int128)own_len * (a.s_begin + (uint64_t)a.n)) / (uint64_t)a.nnz);
-        // chunked epochs (multi-GPU exchange points): cut the wave's samples at whole 64-sample tiles so that
-        // no launch ends on a nearly empty tile; consecutive launches still cover every sample exactly once
-        own_lo &= ~(int64_t)(kWave - 1);
-        if (a.s_begin + (uint64_t)a.n < (uint64_t)a.nnz) own_hi &= ~(int64_t)(kWave - 1);
+        // chunked epochs (multi-GPU exchange points): a launch covers the tile range [lo_tile, hi_tile) of EVERY
+        // wave's samples (tiles of 64 samples; own_tmax = the longest wave's tile count), so all waves run the same
+        // number of whole tiles per launch and consecutive launches cover every sample exactly once
+        const int64_t lo_tile = (int64_t)(((unsigned __int128)a.own_tmax * a.s_begin) / (uint64_t)a.nnz);
+        const int64_t hi_tile = a.s_begin + (uint64_t)a.n >= (uint64_t)a.nnz
+                                    ? a.own_tmax
+                                    : (int64_t)(((unsigned __int128)a.own_tmax * (a.s_begin + (uint64_t)a.n)) / (uint64_t)a.nnz);
+        own_lo = min((int64_t)own_len, lo_tile * kWave);
+        own_hi = min((int64_t)own_len, hi_tile * kWave);
         n_tiles = own_len ? (own_hi - own_lo + kWave - 1) / kWave : 0;
         tile0 = 0;
         tile_step = 1;
@@ -594,6 +598,7 @@ struct cornac_hip_bpr {
     DevBuf<int64_t> wave_ptr;
     std::vector<int32_t> h_own_u, h_own_i;
     std::vector<int64_t> h_wave_ptr;
+    int64_t own_tmax = 0;
     // VEBPR: view CSR + third sampler stream
     bool has_views = false, view_seeded = false;
     DevBuf<int32_t> v_indptr, v_indices, view_rank;
@@ -1016,6 +1021,9 @@ static void build_ownership(cornac_hip_bpr_t h, int64_t W) {
     h->wave_ptr.ensure((size_t)W + 1);
     h->own_u.upload(h->h_own_u.data(), (size_t)nnz, h->stream);
     h->own_i.upload(h->h_own_i.data(), (size_t)nnz, h->stream);
+    h->own_tmax = 0;
+    for (int64_t w = 0; w < W; ++w)
+        h->own_tmax = std::max(h->own_tmax, (h->h_wave_ptr[(size_t)w + 1] - h->h_wave_ptr[(size_t)w] + kWave - 1) / kWave);
     h->wave_ptr.upload(h->h_wave_ptr.data(), (size_t)W + 1, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->own_waves = W;
@@ -1050,6 +1058,7 @@ static void launch_hogwild(cornac_hip_bpr_t h, HogArgs a, int flags) {
         a.own_u = h->own_u.p;
         a.own_i = h->own_i.p;
         a.wave_ptr = h->wave_ptr.p;
+        a.own_tmax = h->own_tmax;
     } else {
         const int64_t n_tiles = (a.n + kWave - 1) / kWave;
         const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1094,7 +1103,7 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         a.th_neg = lemire_thresh(a.n_neg);
         a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
         a.lr = lr; a.reg = reg;
-        a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr;
+        a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr; a.own_tmax = 0;
         a.nnz = h->nnz;
         a.ablate = (flags >> 8) & 0xff;
         const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);

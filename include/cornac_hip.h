@@ -149,7 +149,8 @@ int cornac_hip_bpr_scatter_add_rows(cornac_hip_bpr_t h, float *d_table, const in
 /* Replicated item table (multi-GPU regime 1): the elementwise passes around the all-reduce of the table deltas.
  * flat = [V (n_items*k) | B (n_items)] is the replica the kernels train on, base its value at the last exchange.
  * begin : bucket = [flat - base | V rows touched (n_items) | biases touched (n_items)], local = copy of flat - base
- * finish: (after bucket was sum-all-reduced) R = delta / max(touching ranks, 1) per row; flat += R - local; base += R */
+ * finish: (after bucket was sum-all-reduced) R = delta / sqrt(max(touching ranks, 1)) per row; flat += R - local;
+ *         base += R */
 int cornac_hip_bpr_table_delta_begin(cornac_hip_bpr_t h, const float *d_flat, const float *d_base, int64_t n_items,
                                      int k, float *d_bucket, float *d_local);
 int cornac_hip_bpr_table_delta_finish(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket,

@@ -1,5 +1,5 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU path's host logic (cornac_amd/dist.py): user
-partitioning and the item-table delta exchange (sum of the deltas divided by the number of touching ranks, per row).  The HIP trainer is replaced by a host stand-in
+partitioning and the item-table delta exchange (sum of the deltas / sqrt of the number of touching ranks, per row).  The HIP trainer is replaced by a host stand-in
 that applies known per-rank updates, so the reduction algebra is checked exactly."""
 import os
 import socket
@@ -63,10 +63,10 @@ def test_item_table_allreduce_of_deltas_world2():
     want = V0.copy()
     want[0::2] += 0.01 * 250  # rank 0's stripe: rows only rank 0 touched keep its steps unchanged
     want[1::2] += 0.01 * 250  # rank 1's stripe
-    # row 0 is touched by BOTH ranks in every chunk (rank 0: lr*n + 1, rank 1: + 1): it receives the AVERAGE
-    want[0] = V0[0] + sum((0.01 * n + 2.0) / 2.0 for n in (100, 100, 50))
+    # row 0 is touched by BOTH ranks in every chunk (rank 0: lr*n + 1, rank 1: + 1): summed delta / sqrt(2)
+    want[0] = V0[0] + sum((0.01 * n + 2.0) / np.sqrt(2.0) for n in (100, 100, 50))
     assert np.allclose(V_a, want, atol=1e-5)
-    assert np.allclose(B_a, 3 * (0.5 + 1.0) / 2.0)  # every bias touched by both ranks: averaged
+    assert np.allclose(B_a, 3 * (0.5 + 1.0) / np.sqrt(2.0))  # every bias touched by both ranks
 
 
 def test_single_process_sync_is_a_rebase():
@@ -181,7 +181,7 @@ def test_row_sharded_table_world2():
     Vf0, Bf0, V20, B20, seen0, n0 = out[0]
     Vf1, Bf1, V21, B21, seen1, n1 = out[1]
     assert np.array_equal(Vf0, Vf1) and np.array_equal(V20, V21) and np.array_equal(B20, B21)
-    # (a) rows requested by one rank receive its delta, rows requested by both the AVERAGE of the two deltas
+    # (a) rows requested by one rank receive its delta, rows requested by both the summed delta / sqrt(2)
     want = V0.copy()
     wb = B0.copy()
     reqs = (([0, 1, 4, 9, 10], 0), ([1, 2, 9], 1))
@@ -189,10 +189,10 @@ def test_row_sharded_table_world2():
     for items, r in reqs:
         senders[items] += 1
     for items, r in reqs:
-        want[items] += (r + 1) / senders[items][:, None]
-        wb[items] += 10.0 * (r + 1) / senders[items]
+        want[items] += (r + 1) / np.sqrt(senders[items])[:, None]
+        wb[items] += 10.0 * (r + 1) / np.sqrt(senders[items])
     assert np.allclose(Vf0, want) and np.allclose(Bf0, wb)
-    # (b) the trainer loop: per micro-batch every rank's delta per row, owners apply sum / number of sending ranks
+    # (b) the trainer loop: per micro-batch every rank's delta per row, owners apply sum / sqrt(sending ranks)
     want, wb, n_valid = V0.copy(), B0.copy(), 0
     for (u0, i0, j0), (u1, i1, j1) in zip(seen0, seen1):
         dV = [np.zeros_like(V0), np.zeros_like(V0)]
@@ -207,7 +207,7 @@ def test_row_sharded_table_world2():
             t = np.zeros(n_items)
             t[np.unique(np.concatenate([i[ok], j[ok]]))] = 1
             touched += t
-        div = np.maximum(touched, 1)
+        div = np.sqrt(np.maximum(touched, 1))
         want += (dV[0] + dV[1]) / div[:, None]
         wb += (dB[0] + dB[1]) / div
     assert [len(b[0]) for b in seen0] == [20, 20, 10] == [len(b[0]) for b in seen1]

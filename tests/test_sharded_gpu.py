@@ -190,8 +190,8 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     other[n * k + n + 0] = 2; other[n * k + n + 1] = 1; other[n * k + n + 36] = 2
     other[n * k + 7] = 0.25; other[n * k + 2 * n + 7] = 1
     red = bucket + other
-    cv = red[n * k + n: n * k + 2 * n].clamp(min=1).unsqueeze(1)
-    cb = red[n * k + 2 * n:].clamp(min=1)
+    cv = red[n * k + n: n * k + 2 * n].clamp(min=1).sqrt().unsqueeze(1)
+    cb = red[n * k + 2 * n:].clamp(min=1).sqrt()
     R = torch.cat([(red[: n * k].view(n, k) / cv).reshape(-1), red[n * k: n * k + n] / cb])
     want_flat, want_base = flat + (R - local), base + R
     torch.cuda.synchronize()

@@ -12,10 +12,11 @@ from cornac_amd import _lib, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--epochs", type=int, default=6)
-ap.add_argument("--syncs", type=int, default=8)
+ap.add_argument("--syncs", type=int, default=16)
 ap.add_argument("--delay", type=int, default=1)
 ap.add_argument("--scale", type=float, default=0.25, help="fraction of the ML-20M shape per rank (memory/time)")
 ap.add_argument("--k", type=int, default=64)
+ap.add_argument("--rule", default=None, help="avg | sum | sqrt (divide by sqrt of the touching ranks)")
 ap.add_argument("--sum", dest="avg", action="store_false", help="plain summation of the deltas (the rule that diverges) instead of the "
                 "product's rule: summed delta of a row / number of ranks that touched it")
 args = ap.parse_args()
@@ -32,6 +33,12 @@ for r in range(args.ranks):
     tr.set_factors(((rs.uniform(0, 1, (n_users, k)) - .5) / k).astype(np.float32), V0, np.zeros(n_items, np.float32))
     tr.seed_hogwild(1000 + r)
     trainers.append((tr, len(indices)))
+    if r == 0:  # fixed probe triplets of rank 0's data: accuracy of the CONSOLIDATED item table after each epoch
+        prs = np.random.RandomState(99)
+        pp = prs.randint(0, len(indices), 200_000)
+        probe_u = np.repeat(np.arange(n_users), np.diff(indptr))[pp]
+        probe_i = indices[pp]
+        probe_j = prs.randint(0, n_items, len(pp))
 V, B = V0.copy(), np.zeros(n_items, np.float32)
 pending = []  # remote deltas not yet applied (overlap emulation)
 for e in range(args.epochs):
@@ -48,10 +55,16 @@ for e in range(args.epochs):
             dV += Vr - V; dB += Br - B
             cV += (np.abs(Vr - V).max(1) > 0); cB += ((Br - B) != 0)
             tot_c += cc; tot_n += n - ss
-        if args.avg:
+        rule = args.rule or ("sqrt" if args.avg else "sum")  # the product's rule is sqrt
+        if rule == "avg":
             dV /= np.maximum(cV, 1)[:, None]; dB /= np.maximum(cB, 1)
+        elif rule == "sqrt":
+            dV /= np.sqrt(np.maximum(cV, 1))[:, None]; dB /= np.sqrt(np.maximum(cB, 1))
         pending.append((dV, dB))
         if len(pending) > args.delay:
             d = pending.pop(0)
             V = V + d[0]; B = B + d[1]
-    print("epoch %d: pairwise accuracy %.4f  |V| max %.3f  finite %s" % (e, tot_c / tot_n, np.abs(V).max(), np.isfinite(V).all()))
+    U0 = trainers[0][0].get_factors()[0]
+    sc = np.einsum("nk,nk->n", U0[probe_u], V[probe_i] - V[probe_j]) + B[probe_i] - B[probe_j]
+    print("epoch %d: pairwise accuracy while training %.4f | consolidated table on rank 0's probe triplets %.4f | |V| max %.3f finite %s"
+          % (e, tot_c / tot_n, float((sc > 0).mean()), np.abs(V).max(), np.isfinite(V).all()))
