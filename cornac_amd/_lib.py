@@ -30,6 +30,7 @@ SYMBOLS = [
     "cornac_hip_vebpr_fit_epochs",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
+    "cornac_hip_bpr_table_delta_step",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
@@ -135,6 +136,7 @@ def lib():
         L.cornac_hip_bpr_scatter_add_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
         L.cornac_hip_bpr_table_delta_begin.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
+        L.cornac_hip_bpr_table_delta_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -292,6 +294,10 @@ class BprTrainer:
 
     def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k):
         check(lib().cornac_hip_bpr_table_delta_finish(self.h, d_flat, d_base, d_bucket, d_local, int(n_items), int(k)))
+
+    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local):
+        check(lib().cornac_hip_bpr_table_delta_step(self.h, d_flat, d_base, d_bucket_prev, d_local_prev, int(n_items),
+                                                    int(k), d_bucket, d_local))
 
     def gather_rows(self, d_table, d_ids, n, width, d_out):
         check(lib().cornac_hip_bpr_gather_rows(self.h, d_table, d_ids, int(n), int(width), d_out))

@@ -86,6 +86,24 @@ class ItemTableReplica:
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, bucket, local)
 
+    def step_sync(self):
+        """finish_sync() of the pending exchange followed by begin_sync() of the next one; on a GPU the two table
+        passes are one fused kernel"""
+        if self._pending is None or self._pending[0] is None or self.trainer is None or not self.flat.is_cuda:
+            self.finish_sync()
+            self.begin_sync()
+            return
+        work, bucket_prev, local_prev = self._pending
+        self._pending = None
+        work.wait()
+        n, k = self.total_items, self.k
+        bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
+        local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
+        self.trainer.table_delta_step(self.flat.data_ptr(), self.base.data_ptr(), bucket_prev.data_ptr(),
+                                      local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr())
+        work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = (work, bucket, local)
+
     def finish_sync(self):
         if self._pending is None:
             return
@@ -140,8 +158,7 @@ class ShardedBprTrainer:
             while left > 0:
                 n = min(left, self.sync_every)
                 self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
-                self.table.finish_sync()   # chunk c-1's exchange: its all-reduce overlapped this chunk's launch
-                self.table.begin_sync()
+                self.table.step_sync()   # finish chunk c-1's exchange (its all-reduce overlapped this launch), begin c's
                 left -= n
 
     def finish(self):

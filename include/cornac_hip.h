@@ -155,6 +155,9 @@ int cornac_hip_bpr_table_delta_begin(cornac_hip_bpr_t h, const float *d_flat, co
                                      int k, float *d_bucket, float *d_local);
 int cornac_hip_bpr_table_delta_finish(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket,
                                       const float *d_local, int64_t n_items, int k);
+/* finish of the previous exchange followed by begin of the next one, in one pass (adjacent in the overlapped schedule) */
+int cornac_hip_bpr_table_delta_step(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket_prev,
+                                    const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
 
 /* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.

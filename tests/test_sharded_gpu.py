@@ -194,8 +194,18 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     cb = red[n * k + 2 * n:].clamp(min=1).sqrt()
     R = torch.cat([(red[: n * k].view(n, k) / cv).reshape(-1), red[n * k: n * k + n] / cb])
     want_flat, want_base = flat + (R - local), base + R
+    flat2, base2 = flat.clone(), base.clone()  # for the fused finish + begin pass below
     torch.cuda.synchronize()
     tr.table_delta_finish(flat.data_ptr(), base.data_ptr(), red.data_ptr(), local.data_ptr(), n, k)
     tr.sync()
     assert torch.allclose(flat, want_flat, atol=1e-6) and torch.allclose(base, want_base, atol=1e-6)
+    # finish followed by begin == the fused step kernel
+    b_sep, l_sep = torch.empty_like(bucket), torch.empty_like(local)
+    tr.table_delta_begin(flat.data_ptr(), base.data_ptr(), n, k, b_sep.data_ptr(), l_sep.data_ptr())
+    b_fus, l_fus = torch.empty_like(bucket), torch.empty_like(local)
+    tr.table_delta_step(flat2.data_ptr(), base2.data_ptr(), red.data_ptr(), local.data_ptr(), n, k, b_fus.data_ptr(),
+                        l_fus.data_ptr())
+    tr.sync()
+    assert torch.equal(flat2, flat) and torch.equal(base2, base)
+    assert torch.equal(b_fus, b_sep) and torch.equal(l_fus, l_sep)
     tr.close()
