@@ -126,6 +126,25 @@ __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__
     if (lane_id() == 0 && m) atomicAdd(&counters[0], (unsigned long long)__popcll(m));
 }
 
+// bucket the sampled triplets by level on the device (they are already here): cursor[l] starts at level_ptr[l];
+// the order inside a level is irrelevant (its samples touch disjoint rows)
+__global__ __launch_bounds__(kBlock) void bpr_det_bucket_kernel(const int32_t *__restrict__ level,
+                                                                const int32_t *__restrict__ su,
+                                                                const int32_t *__restrict__ si,
+                                                                const int32_t *__restrict__ sj, int64_t n,
+                                                                unsigned long long *__restrict__ cursor,
+                                                                int32_t *__restrict__ ou, int32_t *__restrict__ oi,
+                                                                int32_t *__restrict__ oj) {
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        const int32_t l = level[s];
+        if (l <= 0) continue;
+        const unsigned long long pos = atomicAdd(&cursor[l], 1ull);
+        ou[pos] = su[s];
+        oi[pos] = si[s];
+        oj[pos] = sj[s];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // hogwild mode
 // ------------------------------------------------------------------------------------------------
@@ -582,6 +601,8 @@ struct cornac_hip_bpr {
     PinnedBuf<int32_t> h_trip;
     std::vector<int32_t> lvl_u, lvl_i, level;
     LevelSchedule sched;
+    DevBuf<int32_t> level_dev;
+    DevBuf<int64_t> cursor_dev;
     // hogwild sampler state
     bool hog_seeded = false;
     uint64_t hog_seed = 0;
@@ -849,22 +870,29 @@ static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int
                            h->indptr.p, neg_population, su, si, sj, h->counters.p);
         HIP_CHECK(hipGetLastError());
         int32_t *hsu = h->h_trip.p, *hsi = hsu + chunk, *hsj = hsi + chunk;
-        int32_t *hou = hsj + chunk, *hoi = hou + chunk, *hoj = hoi + chunk;
+        int32_t *hou = hsj + chunk;
         HIP_CHECK(hipMemcpyAsync(hsu, su, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipMemcpyAsync(hsi, si, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipMemcpyAsync(hsj, sj, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->timing[0] += t_s.ms();
         Timer t_l;
-        build_level_schedule(hsu, hsi, hsj, n, h->total_users, h->total_items, hou, hoi, hoj, h->sched, h->lvl_u,
-                             h->lvl_i, h->level);
+        // host: longest-path level of every sample (inherently sequential) into the pinned buffer; device: bucketing
+        int32_t *hlevel = hou;  // the pinned "sorted" region is free now: only the levels travel back
+        build_levels(hsu, hsi, hsj, n, h->total_users, h->total_items, h->sched, h->lvl_u, h->lvl_i, hlevel);
         h->timing[1] += t_l.ms();
         Timer t_k;
         const int64_t na = h->sched.n_active;
         if (na > 0) {
-            HIP_CHECK(hipMemcpyAsync(ou, hou, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
-            HIP_CHECK(hipMemcpyAsync(oi, hoi, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
-            HIP_CHECK(hipMemcpyAsync(oj, hoj, (size_t)na * 4, hipMemcpyHostToDevice, h->stream));
+            const std::vector<int64_t> &lp0 = h->sched.level_ptr;
+            h->level_dev.ensure((size_t)n);
+            h->cursor_dev.ensure(lp0.size());
+            HIP_CHECK(hipMemcpyAsync(h->level_dev.p, hlevel, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->cursor_dev.p, lp0.data(), lp0.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                                     h->stream));
+            const unsigned bg = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 8192);
+            hipLaunchKernelGGL(bpr_det_bucket_kernel, dim3(bg), dim3(kBlock), 0, h->stream, h->level_dev.p, su, si, sj, n,
+                               reinterpret_cast<unsigned long long *>(h->cursor_dev.p), ou, oi, oj);
         }
         const std::vector<int64_t> &lp = h->sched.level_ptr;
         for (size_t l = 1; l + 1 < lp.size(); ++l) {

@@ -179,6 +179,12 @@ void build_level_schedule(const int32_t *su, const int32_t *si, const int32_t *s
                           std::vector<int32_t> &scratch_lvl_u, std::vector<int32_t> &scratch_lvl_i,
                           std::vector<int32_t> &scratch_level);
 
+// levels only (BPR deterministic mode buckets the triplets on the device): level[s] in [1, n_levels] or 0 for a
+// skipped sample, sched.level_ptr as above
+void build_levels(const int32_t *su, const int32_t *si, const int32_t *sj, int64_t n, int64_t n_users, int64_t n_items,
+                  LevelSchedule &sched, std::vector<int32_t> &scratch_lvl_u, std::vector<int32_t> &scratch_lvl_i,
+                  int32_t *level);
+
 void build_level_schedule4(const int32_t *su, const int32_t *si, const int32_t *sv, const int32_t *sj, int64_t n,
                            int64_t n_users, int64_t n_items, int32_t *out_u, int32_t *out_i, int32_t *out_v,
                            int32_t *out_j, LevelSchedule &sched, std::vector<int32_t> &scratch_lvl_u,

@@ -87,6 +87,34 @@ void build_level_schedule(const int32_t *su, const int32_t *si, const int32_t *s
     sched.n_active = sched.level_ptr.back();
 }
 
+void build_levels(const int32_t *su, const int32_t *si, const int32_t *sj, int64_t n, int64_t n_users, int64_t n_items,
+                  LevelSchedule &sched, std::vector<int32_t> &lvl_u, std::vector<int32_t> &lvl_i, int32_t *level) {
+    lvl_u.assign((size_t)n_users, 0);
+    lvl_i.assign((size_t)n_items, 0);
+    int32_t max_level = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        const int32_t u = su[s];
+        if (u < 0) {
+            level[s] = 0;
+            continue;
+        }
+        const int32_t i = si[s], j = sj[s];
+        int32_t l = std::max(lvl_u[u], lvl_i[i]);
+        if (j >= 0) l = std::max(l, lvl_i[j]);
+        ++l;
+        lvl_u[u] = l;
+        lvl_i[i] = l;
+        if (j >= 0) lvl_i[j] = l;
+        level[s] = l;
+        max_level = std::max(max_level, l);
+    }
+    sched.level_ptr.assign((size_t)max_level + 2, 0);
+    for (int64_t s = 0; s < n; ++s)
+        if (level[s] > 0) ++sched.level_ptr[(size_t)level[s] + 1];
+    for (size_t l = 1; l < sched.level_ptr.size(); ++l) sched.level_ptr[l] += sched.level_ptr[l - 1];
+    sched.n_active = sched.level_ptr.back();
+}
+
 // 4-row variant (VEBPR: user, purchased item, viewed item or -1, negative item)
 void build_level_schedule4(const int32_t *su, const int32_t *si, const int32_t *sv, const int32_t *sj, int64_t n,
                            int64_t n_users, int64_t n_items, int32_t *out_u, int32_t *out_i, int32_t *out_v,
