@@ -21,6 +21,59 @@ def _pos_items(csr, user_idx, threshold):
     return csr.indices[lo:hi][csr.data[lo:hi] >= threshold].astype(np.int64)
 
 
+def _bool_csr(mat, threshold, shape):
+    """entries >= threshold of a CSR matrix as a boolean CSR of the given (larger or equal) shape"""
+    from scipy.sparse import csr_matrix
+
+    keep = mat.data >= threshold
+    rows = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr))[keep]
+    return csr_matrix((np.ones(int(keep.sum()), dtype=bool), (rows, mat.indices[keep])), shape=shape)
+
+
+def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
+    """Vectorised form of the per-user mask building of the reference's ranking_eval
+    (cornac/eval_methods/base_method.py:176-206), for all test users at once:
+
+      users   users with at least one test positive (ascending),
+      gt      their test positives below n_eval_items (sorted)                       -> (gt_ptr, gt_idx)
+      excl    (train positives U validation positives) minus test positives, < n_eval_items (sorted) -> (ex_ptr, ex_idx)
+
+    i.e. the candidate set of a user is everything that is not in `excl`.  CSR set algebra instead of three
+    numpy set operations per user."""
+    mats = [m for m in (train_mat, test_mat, val_mat) if m is not None]
+    shape = (max(m.shape[0] for m in mats), max(max(m.shape[1] for m in mats), n_eval_items))
+    T = _bool_csr(test_mat, rating_threshold, shape)
+    P = _bool_csr(train_mat, rating_threshold, shape)
+    if val_mat is not None:
+        P = P + _bool_csr(val_mat, rating_threshold, shape)
+    users = np.flatnonzero(np.diff(T.indptr) > 0)
+    E = (P - P.multiply(T)).tocsr()
+    E.eliminate_zeros()
+    E = E[users][:, :n_eval_items].tocsr()
+    G = T[users][:, :n_eval_items].tocsr()
+    E.sort_indices()
+    G.sort_indices()
+    return (users.astype(np.int64), G.indptr.astype(np.int64), G.indices.astype(np.int64), E.indptr.astype(np.int64),
+            E.indices.astype(np.int64))
+
+
+def eval_lists_loop(train_mat, test_mat, val_mat, rating_threshold, n_eval_items, test_users):
+    """the same lists user by user with numpy set operations (the reference's formulation); kept as the
+    specification eval_lists is tested against"""
+    users, gt_pos, excl = [], [], []
+    for user_idx in sorted(set(int(u) for u in test_users)):
+        tp = _pos_items(test_mat, user_idx, rating_threshold)
+        if len(tp) == 0:
+            continue
+        vp = np.empty(0, np.int64) if val_mat is None else _pos_items(val_mat, user_idx, rating_threshold)
+        trp = _pos_items(train_mat, user_idx, rating_threshold)
+        ex = np.setdiff1d(np.union1d(vp, trp), tp)
+        users.append(user_idx)
+        gt_pos.append(np.sort(tp[tp < n_eval_items]))
+        excl.append(ex[ex < n_eval_items])
+    return users, gt_pos, excl
+
+
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
                  verbose=False, batch_users=16384):
     if len(metrics) == 0:
@@ -32,25 +85,14 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     n_eval_items = train_set.num_items if exclude_unknowns else test_set.num_items
     user_results = [{} for _ in metrics]
 
-    users, gt_pos, excl = [], [], []
-    for user_idx in sorted(set(int(u) for u in test_set.uir_tuple[0])):
-        tp = _pos_items(test_mat, user_idx, rating_threshold)
-        if len(tp) == 0:
-            continue
-        vp = np.empty(0, np.int64) if val_mat is None else _pos_items(val_mat, user_idx, rating_threshold)
-        trp = _pos_items(train_mat, user_idx, rating_threshold)
-        tp_eval = tp[tp < n_eval_items]
-        # candidates = test positives + everything that is in no positive list; i.e. exclude the
-        # train/val positives that are not also test positives (base_method.py:188-206)
-        ex = np.setdiff1d(np.union1d(vp, trp), tp)
-        users.append(user_idx)
-        gt_pos.append(np.sort(tp_eval))
-        excl.append(ex[ex < n_eval_items].astype(np.int32))
+    users, gt_ptr, gt_idx, ex_ptr, ex_idx = eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items)
+    gt_pos = [gt_idx[gt_ptr[r]:gt_ptr[r + 1]] for r in range(len(users))]
 
     if need_full or not hasattr(model, "rank_batch"):
         all_items = np.arange(n_eval_items)
-        for user_idx, gp, ex in zip(users, gt_pos, excl):
-            item_indices = np.setdiff1d(all_items, ex)
+        for r, (user_idx, gp) in enumerate(zip(users, gt_pos)):
+            user_idx = int(user_idx)
+            item_indices = np.setdiff1d(all_items, ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
             gt_neg = np.setdiff1d(item_indices, gp)
             rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=max_k if not need_full else -1)
             for i, mt in enumerate(metrics):
@@ -58,10 +100,10 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
                                                        item_indices=item_indices)
     else:
         for b0 in range(0, len(users), batch_users):
-            ub = users[b0:b0 + batch_users]
-            eb = excl[b0:b0 + batch_users]
-            indptr = np.concatenate([[0], np.cumsum([len(e) for e in eb])]).astype(np.int64)
-            indices = np.concatenate(eb).astype(np.int32) if indptr[-1] else np.empty(0, np.int32)
+            b1 = min(b0 + batch_users, len(users))
+            ub = [int(u) for u in users[b0:b1]]
+            indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
+            indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
             items, _ = model.rank_batch(ub, k=max_k, exclude=(indptr, indices))
             for r, user_idx in enumerate(ub):
                 pd_rank = items[r][items[r] >= 0].astype(np.int64)
@@ -86,9 +128,11 @@ def rating_eval(model, metrics, test_set, user_based=False, verbose=False):
     for mt in metrics:
         if user_based:
             per_user = {}
-            for user_idx in np.unique(u_indices):
-                sel = u_indices == user_idx
-                per_user[int(user_idx)] = scalar(mt.compute(gt_ratings=r_values[sel], pd_ratings=r_preds[sel]))
+            order = np.argsort(u_indices, kind="stable")  # one sort instead of one mask per user
+            su = u_indices[order]
+            cuts = np.flatnonzero(np.diff(su)) + 1
+            for sel in np.split(order, cuts):
+                per_user[int(u_indices[sel[0]])] = scalar(mt.compute(gt_ratings=r_values[sel], pd_ratings=r_preds[sel]))
             user_results.append(per_user)
             avg_results.append(sum(per_user.values()) / len(per_user))
         else:
