@@ -86,12 +86,14 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     user_results = [{} for _ in metrics]
 
     users, gt_ptr, gt_idx, ex_ptr, ex_idx = eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items)
-    gt_pos = [gt_idx[gt_ptr[r]:gt_ptr[r + 1]] for r in range(len(users))]
+
+    def gt_of(r):
+        return gt_idx[gt_ptr[r]:gt_ptr[r + 1]]
 
     if need_full or not hasattr(model, "rank_batch"):
         all_items = np.arange(n_eval_items)
-        for r, (user_idx, gp) in enumerate(zip(users, gt_pos)):
-            user_idx = int(user_idx)
+        for r, user_idx in enumerate(users):
+            user_idx, gp = int(user_idx), gt_of(r)
             item_indices = np.setdiff1d(all_items, ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
             gt_neg = np.setdiff1d(item_indices, gp)
             rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=max_k if not need_full else -1)
@@ -105,10 +107,27 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
             indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
             items, _ = model.rank_batch(ub, k=max_k, exclude=(indptr, indices))
-            for r, user_idx in enumerate(ub):
+            # hits[r, p]: the p-th ranked item of user r is one of its test positives — one sorted-key lookup for the
+            # whole batch (key = batch row * n_items + item) instead of an np.isin per user and metric
+            n_cols = max(int(n_eval_items), 1)
+            rows = np.repeat(np.arange(b1 - b0), np.diff(gt_ptr[b0:b1 + 1]))
+            gt_keys = rows * n_cols + gt_idx[gt_ptr[b0]:gt_ptr[b1]]           # ascending: rows, then sorted items
+            pred = items.astype(np.int64)
+            pred_keys = np.where(pred >= 0, np.arange(b1 - b0)[:, None] * n_cols + pred, -1)
+            pos = np.searchsorted(gt_keys, pred_keys)
+            hits = (pos < len(gt_keys)) & (gt_keys[np.minimum(pos, max(len(gt_keys) - 1, 0))] == pred_keys) \
+                if len(gt_keys) else np.zeros(pred.shape, bool)
+            n_gt = np.diff(gt_ptr[b0:b1 + 1])
+            slow = []
+            for i, mt in enumerate(metrics):
+                if hasattr(mt, "compute_batch") and 0 < mt.k <= hits.shape[1]:
+                    user_results[i].update(zip(ub, mt.compute_batch(hits, n_gt).tolist()))
+                else:
+                    slow.append((i, mt))
+            for r, user_idx in enumerate(ub) if slow else ():
                 pd_rank = items[r][items[r] >= 0].astype(np.int64)
-                for i, mt in enumerate(metrics):
-                    user_results[i][user_idx] = mt.compute(gt_pos=gt_pos[b0 + r], gt_neg=None, pd_rank=pd_rank,
+                for i, mt in slow:
+                    user_results[i][user_idx] = mt.compute(gt_pos=gt_of(b0 + r), gt_neg=None, pd_rank=pd_rank,
                                                            pd_scores=None, item_indices=None)
     avg_results = [sum(ur.values()) / len(ur) for ur in user_results]
     return avg_results, user_results

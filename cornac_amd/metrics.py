@@ -13,11 +13,18 @@ class RankingMetric:
         self.higher_better = higher_better
 
 
+# Batched forms (`compute_batch`) evaluate all users of a ranked batch at once from
+#   hits [n_users, K] bool : the p-th ranked item of the user is one of its positives (False beyond the user's list),
+#   n_gt [n_users]         : number of positives of the user,
+# and return exactly what `compute` returns user by user (tests/test_eval_cpu.py); k must be > 0 and <= K.
 class _MeasureAtK(RankingMetric):
     def _tp(self, gt_pos, pd_rank):
         top = pd_rank[: self.k] if self.k > 0 else pd_rank
         tp = np.sum(np.isin(top, gt_pos))
         return tp, len(gt_pos), (self.k if self.k > 0 else len(top))
+
+    def _tp_batch(self, hits):
+        return hits[:, : self.k].sum(axis=1)
 
 
 class Precision(_MeasureAtK):
@@ -28,6 +35,9 @@ class Precision(_MeasureAtK):
         tp, _, tp_fp = self._tp(gt_pos, pd_rank)
         return tp / tp_fp
 
+    def compute_batch(self, hits, n_gt):
+        return self._tp_batch(hits) / self.k
+
 
 class Recall(_MeasureAtK):
     def __init__(self, k=-1):
@@ -37,6 +47,10 @@ class Recall(_MeasureAtK):
         tp, tp_fn, _ = self._tp(gt_pos, pd_rank)
         return tp / tp_fn
 
+    def compute_batch(self, hits, n_gt):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return self._tp_batch(hits) / n_gt
+
 
 class HitRatio(_MeasureAtK):
     def __init__(self, k=-1):
@@ -44,6 +58,9 @@ class HitRatio(_MeasureAtK):
 
     def compute(self, gt_pos, pd_rank, **kwargs):
         return 1.0 if self._tp(gt_pos, pd_rank)[0] > 0 else 0.0
+
+    def compute_batch(self, hits, n_gt):
+        return (self._tp_batch(hits) > 0).astype(float)
 
 
 class NDCG(RankingMetric):
@@ -58,6 +75,13 @@ class NDCG(RankingMetric):
 
     def compute(self, gt_pos, pd_rank, **kwargs):
         return self.dcg_score(gt_pos, pd_rank, self.k) / self.dcg_score(gt_pos, gt_pos, self.k)
+
+    def compute_batch(self, hits, n_gt):
+        disc = 1.0 / np.log2(np.arange(self.k) + 2)
+        dcg = (hits[:, : self.k] * disc).sum(axis=1)
+        ideal = np.concatenate([[0.0], np.cumsum(disc)])[np.minimum(n_gt, self.k)]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return dcg / ideal
 
 
 class RMSE:
