@@ -198,7 +198,7 @@ def test_batched_evaluation_equals_per_user_flow():
     assert mae == pytest.approx(np.mean(np.abs(r - pred)), rel=1e-6)
 
 
-@pytest.mark.parametrize("k,topk", [(100, 10), (64, 7), (128, 24)])
+@pytest.mark.parametrize("k,topk", [(100, 10), (64, 7), (128, 24), (128, 32), (64, 32), (16, 25), (10, 1)])
 def test_fused_rank_long_item_ranges_and_many_segments(oracle, k, topk):
     """large catalogue, few users: one row block is cut into many segments (threshold hand-off between them),
     k = 100/128 takes the two-workgroups-per-CU variant with topk + 32 candidate slots; exact order and scores
