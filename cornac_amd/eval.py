@@ -7,11 +7,14 @@ one-`rank()`-per-user / one-`rate()`-per-rating Python loops (SURVEY.md §8 rows
 `rank_batch` (fused scoring GEMM + top-k with the training/validation positives as per-user
 exclusion lists) and `rate_batch` (one gather-dot-clip kernel).
 
-Metrics whose `k` is -1 (AUC, MAP, MRR need the full ranked list / all scores) fall back to the
-reference's per-user flow through `model.rank(user, item_indices, k=-1)`, which is still
+Metrics over the full candidate list (AUC, MAP, MRR) are batched as well: full rankings of a block of users
+come from the device (score tile + per-row sort) and the metrics are evaluated in positional, tie-aware
+vectorised forms (`compute_full_batch`).  Metric objects without batched forms (e.g. the reference's own
+classes) go through the reference's per-user flow, `model.rank(user, item_indices, k)`, which is still
 device-scored and device-sorted.
 """
 import numpy as np
+from .metrics import positive_runs
 
 
 def _pos_items(csr, user_idx, threshold):
@@ -75,7 +78,7 @@ def eval_lists_loop(train_mat, test_mat, val_mat, rating_threshold, n_eval_items
 
 
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
-                 verbose=False, batch_users=16384):
+                 verbose=False, batch_users=16384, batch_users_full=1024):
     if len(metrics) == 0:
         return [], []
     max_k = max(m.k for m in metrics)
@@ -90,13 +93,58 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     def gt_of(r):
         return gt_idx[gt_ptr[r]:gt_ptr[r + 1]]
 
-    if need_full or not hasattr(model, "rank_batch"):
+    def batch_hits(items, b0, b1):
+        """hits[r, p]: the p-th ranked item of batch row r is one of its test positives — one sorted-key lookup for
+        the whole batch (key = batch row * n_items + item) instead of an np.isin per user and metric"""
+        n_cols = max(int(n_eval_items), 1)
+        rows = np.repeat(np.arange(b1 - b0), np.diff(gt_ptr[b0:b1 + 1]))
+        gt_keys = rows * n_cols + gt_idx[gt_ptr[b0]:gt_ptr[b1]]           # ascending: rows, then sorted items
+        pred = items.astype(np.int64)
+        if len(gt_keys) == 0:
+            return np.zeros(pred.shape, bool)
+        pred_keys = np.where(pred >= 0, np.arange(b1 - b0)[:, None] * n_cols + pred, -1)
+        pos = np.minimum(np.searchsorted(gt_keys, pred_keys), len(gt_keys) - 1)
+        return gt_keys[pos] == pred_keys
+
+    batchable = hasattr(model, "rank_batch") and getattr(model, "total_items", n_eval_items) == n_eval_items
+    full_ok = batchable and need_full and all(
+        hasattr(m, "compute_full_batch") if m.k <= 0 else hasattr(m, "compute_batch") for m in metrics)
+    if full_ok:
+        # metrics over the full candidate list (AUC, MAP, MRR) batched: full rankings of a block of users from the
+        # device (score tile + per-row sort), then positional / tie-aware vectorised forms of the metrics
+        topk_k = max([m.k for m in metrics if m.k > 0], default=0)
+        marks = np.zeros(max(int(n_eval_items), 1), bool)
+        for b0 in range(0, len(users), batch_users_full):
+            b1 = min(b0 + batch_users_full, len(users))
+            ub = [int(u) for u in users[b0:b1]]
+            indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)
+            indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
+            items, scores = model.rank_batch(ub, k=-1, exclude=(indptr, indices))
+            n_cand = (items >= 0).sum(axis=1)
+            n_gt = np.diff(gt_ptr[b0:b1 + 1])
+            hits = np.zeros(items.shape, bool)            # one table lookup per row (the lists are a whole catalogue long)
+            for r in range(b1 - b0):
+                marks[gt_of(b0 + r)] = True
+                hits[r, :n_cand[r]] = marks[items[r, :n_cand[r]]]
+                marks[gt_of(b0 + r)] = False
+            runs = positive_runs(hits, scores, n_cand)
+            for i, mt in enumerate(metrics):
+                if mt.k <= 0:
+                    # the per-user flow hands every metric pd_rank[:max_k] (base_method.py:208-210), full-list ones too
+                    vals = mt.compute_full_batch(hits, scores, n_cand, n_gt, rank_len=max_k if max_k > 0 else None,
+                                                 runs=runs)
+                elif getattr(mt, "name", "").startswith("NCRR"):
+                    vals = mt.compute_batch(hits[:, :topk_k], n_gt, n_pred=n_cand)
+                else:
+                    vals = mt.compute_batch(hits[:, :topk_k], n_gt)
+                user_results[i].update(zip(ub, np.asarray(vals, dtype=float).tolist()))
+    elif need_full or not batchable:
         all_items = np.arange(n_eval_items)
         for r, user_idx in enumerate(users):
             user_idx, gp = int(user_idx), gt_of(r)
             item_indices = np.setdiff1d(all_items, ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
             gt_neg = np.setdiff1d(item_indices, gp)
-            rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=max_k if not need_full else -1)
+            rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=max_k)
             for i, mt in enumerate(metrics):
                 user_results[i][user_idx] = mt.compute(gt_pos=gp, gt_neg=gt_neg, pd_rank=rank_, pd_scores=scores_,
                                                        item_indices=item_indices)
@@ -107,21 +155,16 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
             indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
             items, _ = model.rank_batch(ub, k=max_k, exclude=(indptr, indices))
-            # hits[r, p]: the p-th ranked item of user r is one of its test positives — one sorted-key lookup for the
-            # whole batch (key = batch row * n_items + item) instead of an np.isin per user and metric
-            n_cols = max(int(n_eval_items), 1)
-            rows = np.repeat(np.arange(b1 - b0), np.diff(gt_ptr[b0:b1 + 1]))
-            gt_keys = rows * n_cols + gt_idx[gt_ptr[b0]:gt_ptr[b1]]           # ascending: rows, then sorted items
-            pred = items.astype(np.int64)
-            pred_keys = np.where(pred >= 0, np.arange(b1 - b0)[:, None] * n_cols + pred, -1)
-            pos = np.searchsorted(gt_keys, pred_keys)
-            hits = (pos < len(gt_keys)) & (gt_keys[np.minimum(pos, max(len(gt_keys) - 1, 0))] == pred_keys) \
-                if len(gt_keys) else np.zeros(pred.shape, bool)
+            hits = batch_hits(items, b0, b1)
             n_gt = np.diff(gt_ptr[b0:b1 + 1])
             slow = []
             for i, mt in enumerate(metrics):
                 if hasattr(mt, "compute_batch") and 0 < mt.k <= hits.shape[1]:
-                    user_results[i].update(zip(ub, mt.compute_batch(hits, n_gt).tolist()))
+                    if getattr(mt, "name", "").startswith("NCRR"):
+                        vals = mt.compute_batch(hits, n_gt, n_pred=(items >= 0).sum(axis=1))
+                    else:
+                        vals = mt.compute_batch(hits, n_gt)
+                    user_results[i].update(zip(ub, np.asarray(vals, dtype=float).tolist()))
                 else:
                     slow.append((i, mt))
             for r, user_idx in enumerate(ub) if slow else ():

@@ -1,7 +1,8 @@
-"""Ranking/rating metrics consumed by the evaluation helpers — minimal mirrors of the reference's
-`cornac.metrics` classes for the @k family (cornac/metrics/ranking.py:226-430) and RMSE/MAE
-(cornac/metrics/rating.py), with the same `compute(...)` keyword interface, so the reference's own
-metric objects can be passed to `cornac_amd.eval.ranking_eval` interchangeably."""
+"""Ranking/rating metrics consumed by the evaluation helpers — mirrors of the reference's `cornac.metrics`
+classes (cornac/metrics/ranking.py: NDCG, NCRR, MRR, Precision, Recall, FMeasure, HitRatio, AUC, MAP;
+cornac/metrics/rating.py: RMSE, MAE) with the same `compute(...)` keyword interface, so the reference's own
+metric objects can be passed to `cornac_amd.eval.ranking_eval` interchangeably.  Each class adds a batched form
+(`compute_batch` / `compute_full_batch`) that evaluates all users of a ranked batch at once."""
 import numpy as np
 
 
@@ -82,6 +83,135 @@ class NDCG(RankingMetric):
         ideal = np.concatenate([[0.0], np.cumsum(disc)])[np.minimum(n_gt, self.k)]
         with np.errstate(divide="ignore", invalid="ignore"):
             return dcg / ideal
+
+
+class FMeasure(_MeasureAtK):
+    def __init__(self, k=-1):
+        super().__init__("F1@{}".format(k), k)
+
+    def compute(self, gt_pos, pd_rank, **kwargs):
+        tp, tp_fn, tp_fp = self._tp(gt_pos, pd_rank)
+        prec, rec = tp / tp_fp, tp / tp_fn
+        return 2 * (prec * rec) / (prec + rec) if (prec + rec) > 0 else 0
+
+    def compute_batch(self, hits, n_gt):
+        tp = self._tp_batch(hits)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prec, rec = tp / self.k, tp / n_gt
+            f1 = 2 * (prec * rec) / (prec + rec)
+        return np.where(prec + rec > 0, f1, 0.0)
+
+
+class NCRR(RankingMetric):
+    """normalised cumulative reciprocal rank (cornac/metrics/ranking.py:122-177)"""
+
+    def __init__(self, k=-1):
+        super().__init__("NCRR@{}".format(k), k)
+
+    def compute(self, gt_pos, pd_rank, **kwargs):
+        top = pd_rank[: self.k] if self.k > 0 else pd_rank
+        where = np.flatnonzero(np.isin(top, gt_pos))
+        if len(where) == 0:
+            return 0.0
+        ideal = min(len(gt_pos), len(top))
+        return np.sum(1.0 / (where + 1)) / np.sum(1.0 / (np.arange(ideal) + 1))
+
+    def compute_batch(self, hits, n_gt, n_pred=None):
+        """n_pred: length of each user's ranked list (the ideal run is min(n_gt, min(n_pred, k)))"""
+        inv = 1.0 / (np.arange(self.k) + 1)
+        crr = (hits[:, : self.k] * inv).sum(axis=1)
+        run = np.minimum(n_gt, self.k if n_pred is None else np.minimum(n_pred, self.k))
+        ideal = np.concatenate([[0.0], np.cumsum(inv)])[run]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(crr > 0, crr / ideal, 0.0)
+
+
+# Metrics over the FULL ranked candidate list.  Their batched forms take, per user row,
+#   hits   [n, L] bool   : the p-th ranked candidate is a positive (False beyond n_cand),
+#   scores [n, L] float  : the candidates' scores in ranked (descending) order,
+#   n_cand [n], n_gt [n] : number of candidates / of positives among them,
+#   rank_len             : length of the ranked prefix the per-user flow would pass as pd_rank (None = all),
+#   runs                 : `positive_runs(hits, scores, n_cand)` when the caller shares it between metrics,
+# and treat tied scores exactly like the score-based per-user definitions (strict ">" in AUC, "max" ranks in MAP).
+# Only the positives are visited (a few per row): one pass over `hits` finds them, a binary search in the row's
+# sorted scores finds the end of each one's run of tied scores.
+def positive_runs(hits, scores, n_cand):
+    """(rows, pos, end, cum_end, starts): for every positive, its row and position, the last position of its run of
+    equal scores, the number of the row's positives up to that position; starts[r]:starts[r+1] = positives of row r"""
+    n, L = hits.shape
+    rows, pos = np.nonzero(hits)                     # row-major: positions ascending within a row
+    starts = np.searchsorted(rows, np.arange(n + 1))
+    end = np.empty_like(pos)
+    for r in np.flatnonzero(np.diff(starts)):
+        a, b = starts[r], starts[r + 1]
+        row = scores[r, : n_cand[r]]
+        end[a:b] = len(row) - 1 - np.searchsorted(row[::-1], row[pos[a:b]], side="left")
+    key = rows * L + pos
+    cum_end = np.searchsorted(key, rows * L + end, side="right") - starts[rows]
+    return rows, pos, end, cum_end, starts
+
+
+class MRR(RankingMetric):
+    def __init__(self):
+        super().__init__("MRR")
+
+    def compute(self, gt_pos, pd_rank, **kwargs):
+        where = np.flatnonzero(np.isin(pd_rank, gt_pos))
+        if len(where) == 0:
+            raise ValueError("No matched between ground-truth items and recommendations")
+        return 1.0 / (where[0] + 1)
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):
+        hits = hits if rank_len is None else hits[:, :rank_len]
+        if runs is not None and rank_len is None:
+            _, pos, _, _, starts = runs
+            if (np.diff(starts) == 0).any():
+                raise ValueError("No matched between ground-truth items and recommendations")
+            return 1.0 / (pos[starts[:-1]] + 1)
+        if not hits.any(axis=1).all():
+            raise ValueError("No matched between ground-truth items and recommendations")
+        return 1.0 / (hits.argmax(axis=1) + 1)
+
+
+class AUC(RankingMetric):
+    """fraction of (positive, negative) candidate pairs ranked correctly (cornac/metrics/ranking.py:428-485)"""
+
+    def __init__(self):
+        super().__init__("AUC")
+
+    def compute(self, item_indices, pd_scores, gt_pos, gt_neg=None, **kwargs):
+        pos_mask = np.isin(item_indices, gt_pos)
+        neg_mask = np.logical_not(pos_mask) if gt_neg is None else np.isin(item_indices, gt_neg)
+        pos, neg = pd_scores[pos_mask], pd_scores[neg_mask]
+        return (pos[:, None] > neg[None, :]).sum() / (len(pos) * len(neg))
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):
+        rows, _, end, cum_end, _ = positive_runs(hits, scores, n_cand) if runs is None else runs
+        n_neg = n_cand - n_gt
+        # negatives scored strictly below a positive = all negatives - negatives up to the end of its run of ties
+        below = n_neg[rows] - ((end + 1) - cum_end)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.bincount(rows, weights=below, minlength=len(n_gt)) / (n_gt * n_neg)
+
+
+class MAP(RankingMetric):
+    """mean average precision with "max" ranks for tied scores (cornac/metrics/ranking.py:488-527)"""
+
+    def __init__(self):
+        super().__init__("MAP")
+
+    def compute(self, item_indices, pd_scores, gt_pos, **kwargs):
+        from scipy.stats import rankdata
+
+        relevant = np.isin(item_indices, gt_pos)
+        rank = rankdata(-pd_scores, "max")[relevant]
+        among = rankdata(-pd_scores[relevant], "max")
+        return (among / rank).mean()
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):
+        rows, _, end, cum_end, _ = positive_runs(hits, scores, n_cand) if runs is None else runs
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.bincount(rows, weights=cum_end / (end + 1.0), minlength=len(n_gt)) / n_gt
 
 
 class RMSE:

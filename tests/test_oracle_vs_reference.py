@@ -81,6 +81,17 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
                 assert mine(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank) == pytest.approx(
                     ref(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank))
 
+            for mine, ref in ((mm.FMeasure, rm.FMeasure), (mm.NCRR, rm.NCRR)):
+                assert mine(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank[:30]) == pytest.approx(
+                    ref(k=k).compute(gt_pos=gt_pos, pd_rank=pd_rank[:30]))
+        cand = np.sort(rs.choice(50, 35, replace=False))
+        gt_in = rs.choice(cand, 3, replace=False)
+        sc = (np.round(rs.normal(size=35) * 2) / 2).astype(np.float32)          # many tied scores
+        kw = dict(item_indices=cand, pd_scores=sc, gt_pos=gt_in, gt_neg=np.setdiff1d(cand, gt_in),
+                  pd_rank=cand[np.argsort(sc, kind="stable")[::-1]])
+        for mine, ref in ((mm.AUC, rm.AUC), (mm.MAP, rm.MAP), (mm.MRR, rm.MRR)):
+            assert mine().compute(**kw) == pytest.approx(ref().compute(**kw), rel=1e-12)
+
     class HostModel:  # scores from a fixed matrix; same tie rule as the device kernels
         def __init__(self, S, n_items):
             self.S, self.num_items, self.total_items = S, n_items, n_items
@@ -94,13 +105,16 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
             return (r if k == -1 else r[:k]), sc
 
         def rank_batch(self, users, k=10, exclude=None):
-            out = np.full((len(users), k), -1, np.int32)
+            width = self.num_items if k == -1 else k
+            out = np.full((len(users), width), -1, np.int32)
+            out_s = np.full((len(users), width), -np.inf, np.float32)
             for r, u in enumerate(users):
                 ex = exclude[1][exclude[0][r]:exclude[0][r + 1]]
                 cand = np.setdiff1d(np.arange(self.num_items), ex)
                 rr, _ = self.rank(u, cand, k)
                 out[r, :len(rr)] = rr
-            return out, None
+                out_s[r, :len(rr)] = self.S[u][rr]
+            return out, out_s
 
     data = _pairs(60, 45, 1200, 4)
     rs.shuffle(data)
@@ -117,6 +131,24 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
     avg2, _ = ev.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)  # k = -1 -> per-user full-rank flow
     ref_avg2, _ = ns.eval_methods.base_method.ranking_eval(model, ref_metrics + [rm.AUC()], train, test)
     assert np.allclose(avg2, ref_avg2)
+    # full-list metrics through the batched flow (mirrors with compute_full_batch), tied scores included
+    model_t = HostModel((np.round(S * 2) / 2).astype(np.float32), train.num_items)
+    sets = (([rm.AUC(), rm.MAP(), rm.MRR()], [mm.AUC(), mm.MAP(), mm.MRR()]),
+            ([rm.AUC(), rm.MAP(), rm.NCRR(k=10), rm.FMeasure(k=5), rm.Recall(k=10), rm.NDCG(k=3)],
+             [mm.AUC(), mm.MAP(), mm.NCRR(k=10), mm.FMeasure(k=5), mm.Recall(k=10), mm.NDCG(k=3)]))
+    for mdl in (model, model_t):
+        for ref_all, my_all in sets:
+            ref_avg3, ref_user3 = ns.eval_methods.base_method.ranking_eval(mdl, ref_all, train, test)
+            avg3, user3 = ev.ranking_eval(mdl, my_all, train, test, batch_users_full=16)
+            assert np.allclose(avg3, ref_avg3, rtol=1e-9), (avg3, ref_avg3)
+            for mine_u, ref_u in zip(user3, ref_user3):
+                assert mine_u.keys() == ref_u.keys()
+                assert np.allclose([mine_u[u] for u in ref_u], [ref_u[u] for u in ref_u], rtol=1e-9)
+    # mixed with an @k metric the reference ranks only max_k items, and MRR over that prefix finds users without a hit
+    with pytest.raises(ValueError):
+        ns.eval_methods.base_method.ranking_eval(model, [rm.MRR(), rm.Recall(k=3)], train, test)
+    with pytest.raises(ValueError):
+        ev.ranking_eval(model, [mm.MRR(), mm.Recall(k=3)], train, test)
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])

@@ -190,6 +190,16 @@ def test_batched_evaluation_equals_per_user_flow():
     for a, b in zip(user, user_ref):
         assert all(a[u] == pytest.approx(b[u]) for u in a)
     assert 0 < avg[0] < 1
+    # metrics over the full candidate list: device full rankings of user blocks + tie-aware batched forms vs the
+    # per-user flow (a pair of candidates whose scores differ in the last ulp between the two score kernels may
+    # swap: one pair moves a user's AUC by 1 / (positives * negatives))
+    for full in ([mm.AUC(), mm.MAP(), mm.MRR()], [mm.AUC(), mm.MAP(), mm.NCRR(k=10), mm.FMeasure(k=5)]):
+        avg_f, user_f = ev.ranking_eval(m, full, train, test, batch_users_full=96)
+        avg_fr, user_fr = ev.ranking_eval(PerUser(m), full, train, test)
+        assert np.allclose(avg_f, avg_fr, rtol=0, atol=2e-5), (avg_f, avg_fr)
+        for a, b in zip(user_f, user_fr):
+            assert a.keys() == b.keys() and all(abs(a[u] - b[u]) < 5e-3 for u in a)
+        assert 0.5 < avg_f[0] < 1
     mf = MF(k=8, max_iter=10, seed=2).fit(train)
     (rmse, mae), _ = ev.rating_eval(mf, [mm.RMSE(), mm.MAE()], test)
     u, i, r = test.uir_tuple
