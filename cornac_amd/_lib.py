@@ -40,6 +40,7 @@ SYMBOLS = [
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
+    "cornac_hip_rank_positions",
 ]
 
 
@@ -178,6 +179,7 @@ def lib():
         L.cornac_hip_score_block.argtypes = [_vp, _i32, C.c_int64, _f32]
         L.cornac_hip_score_pairs.argtypes = [_vp, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float, _f32]
         L.cornac_hip_rank_topk.argtypes = [_vp, _i32, C.c_int64, C.c_int, _vp, _vp, _i32, _f32]
+        L.cornac_hip_rank_positions.argtypes = [_vp, _i32, C.c_int64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32]
         L.cornac_hip_rank_topk_device.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -470,6 +472,24 @@ class Scorer:
             ix = np.ascontiguousarray(exclude[1], np.int32)
         check(lib().cornac_hip_rank_topk(self.h, users, len(users), topk, _ptr(ip), _ptr(ix), items, scores))
         return items, scores
+
+    def rank_positions(self, users, targets, exclude=None):
+        """targets / exclude: CSR `(indptr int64[n+1], indices int32)` per listed user.  Returns per target
+        `(greater, pos, ge, score)`: candidates scored strictly higher, its position in the ranked order, candidates
+        scored at least as high (itself included), its score — cornac_hip_rank_positions."""
+        users = np.ascontiguousarray(users, np.int32)
+        tp = np.ascontiguousarray(targets[0], np.int64)
+        tx = np.ascontiguousarray(targets[1], np.int32)
+        nt = int(tp[-1])
+        greater, pos, ge = (np.empty(nt, np.int32) for _ in range(3))
+        scores = np.empty(nt, np.float32)
+        ip = ix = None
+        if exclude is not None:
+            ip = np.ascontiguousarray(exclude[0], np.int64)
+            ix = np.ascontiguousarray(exclude[1], np.int32)
+        check(lib().cornac_hip_rank_positions(self.h, users, len(users), _ptr(ip), _ptr(ix), _ptr(tp), _ptr(tx), greater,
+                                              pos, ge, scores))
+        return greater, pos, ge, scores
 
     def rank_topk_device_ms(self, u0, n, topk, repeats=1):
         ms = C.c_double()

@@ -675,6 +675,86 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
     }
 }
 
+
+// ---- where listed items stand in a row's ranking, without ranking the row ------------------------------------
+// For every listed (row, item) "target" (the evaluation loop's test positives of that user) count the row's
+// candidates that precede it:  greater = candidates with a strictly higher score,  pos = its 0-based position in
+// the ranked order (descending score, ties by higher item index — the order rank_topk produces),  ge = candidates
+// with score >= its own (itself included).  That is everything the full-list metrics (AUC, MAP, MRR) read off a
+// full ranking, so neither the sort nor the [users, items] ranking ever has to exist.  One workgroup per row; the
+// row's targets go through registers kPosT at a time while the row's scores stream from the score tile (one row
+// is ~100 KB: L2-resident after the first pass).  Integer compares on the order-preserving score bits: exact.
+constexpr int kPosT = 4;
+__global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__restrict__ scores,
+                                                              const uint8_t *__restrict__ excl_mask, int64_t n_items,
+                                                              const int64_t *__restrict__ tgt_indptr,
+                                                              const int32_t *__restrict__ tgt_indices, int64_t row0,
+                                                              int32_t *__restrict__ greater_out,
+                                                              int32_t *__restrict__ pos_out,
+                                                              int32_t *__restrict__ ge_out,
+                                                              float *__restrict__ score_out) {
+    const int64_t row = blockIdx.x;
+    const float *srow = scores + row * n_items;
+    const uint8_t *erow = excl_mask ? excl_mask + row * n_items : nullptr;
+    const int64_t lo = tgt_indptr[row0 + row], hi = tgt_indptr[row0 + row + 1];
+    __shared__ int cnt[kPosT * 3];
+    for (int64_t t0 = lo; t0 < hi; t0 += kPosT) {
+        uint32_t ts[kPosT], ti[kPosT];
+        bool ok[kPosT];
+#pragma unroll
+        for (int q = 0; q < kPosT; ++q) {
+            const int64_t t = t0 + q;
+            const int32_t item = t < hi ? tgt_indices[t] : -1;
+            ok[q] = item >= 0 && item < n_items && !(erow && erow[item]);
+            ts[q] = ok[q] ? order_key(srow[item]) : 0xFFFFFFFFu;
+            ti[q] = (uint32_t)item;
+        }
+        int g[kPosT], ps[kPosT], e[kPosT];
+#pragma unroll
+        for (int q = 0; q < kPosT; ++q) g[q] = ps[q] = e[q] = 0;
+        for (int64_t i = threadIdx.x; i < n_items; i += kBlk) {
+            if (erow && erow[i]) continue;
+            const uint32_t oc = order_key(srow[i]);
+#pragma unroll
+            for (int q = 0; q < kPosT; ++q) {
+                const bool gt = oc > ts[q], eq = oc == ts[q];
+                g[q] += gt;
+                e[q] += gt | eq;
+                ps[q] += gt | (eq & ((uint32_t)i > ti[q]));
+            }
+        }
+        if (threadIdx.x < kPosT * 3) cnt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPosT; ++q) {
+            int a = g[q], b = ps[q], c = e[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+                c += __shfl_xor(c, o, 64);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&cnt[q * 3 + 0], a);
+                atomicAdd(&cnt[q * 3 + 1], b);
+                atomicAdd(&cnt[q * 3 + 2], c);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPosT; ++q) {
+            const int64_t t = t0 + q;
+            if (threadIdx.x == q && t < hi) {
+                greater_out[t] = ok[q] ? cnt[q * 3 + 0] : -1;
+                pos_out[t] = ok[q] ? cnt[q * 3 + 1] : -1;
+                ge_out[t] = ok[q] ? cnt[q * 3 + 2] : -1;
+                score_out[t] = ok[q] ? srow[ti[q]] : -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace chip
 
 using namespace chip;
@@ -696,6 +776,9 @@ struct cornac_hip_scorer {
     DevBuf<int32_t> d_users, d_items_out, d_excl_indices;
     DevBuf<int64_t> d_excl_indptr;
     DevBuf<float> d_scores_out;
+    DevBuf<int64_t> d_tgt_indptr;
+    DevBuf<int32_t> d_tgt_indices, d_tgt_counts;
+    DevBuf<float> d_tgt_scores;
     DevBuf<unsigned long long> sort_scratch, part;
 };
 
@@ -1046,6 +1129,64 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
             h->d_scores_out.download(scores_out + b0 * topk, (size_t)(nb * topk), h->stream);
             HIP_CHECK(hipStreamSynchronize(h->stream));
         }
+    });
+}
+
+int cornac_hip_rank_positions(cornac_hip_scorer_t h, const int32_t *users, int64_t n, const int64_t *excl_indptr,
+                              const int32_t *excl_indices, const int64_t *tgt_indptr, const int32_t *tgt_indices,
+                              int32_t *greater_out, int32_t *pos_out, int32_t *ge_out, float *tgt_scores_out) {
+    return guarded([&] {
+        sc_check(h);
+        REQUIRE(users && tgt_indptr && n > 0, "bad arguments");
+        REQUIRE(tgt_indptr[0] == 0, "tgt_indptr must start at 0");
+        for (int64_t b = 0; b < n; ++b) {
+            REQUIRE(users[b] >= 0 && users[b] < h->n_users, "user %d out of range", users[b]);
+            REQUIRE(tgt_indptr[b + 1] >= tgt_indptr[b], "tgt_indptr must not decrease");
+        }
+        const int64_t nt = tgt_indptr[n];
+        if (nt == 0) return;
+        REQUIRE(tgt_indices && greater_out && pos_out && ge_out && tgt_scores_out, "bad arguments");
+        const bool have_excl = excl_indptr != nullptr && excl_indices != nullptr;
+        if (have_excl) {
+            REQUIRE(excl_indptr[0] == 0, "excl_indptr must start at 0");
+            h->d_excl_indptr.ensure((size_t)n + 1);
+            h->d_excl_indptr.upload(excl_indptr, (size_t)n + 1, h->stream);
+            const int64_t ne = excl_indptr[n];
+            h->d_excl_indices.ensure((size_t)std::max<int64_t>(ne, 1));
+            if (ne > 0) h->d_excl_indices.upload(excl_indices, (size_t)ne, h->stream);
+        }
+        h->d_tgt_indptr.ensure((size_t)n + 1);
+        h->d_tgt_indptr.upload(tgt_indptr, (size_t)n + 1, h->stream);
+        h->d_tgt_indices.ensure((size_t)nt);
+        h->d_tgt_indices.upload(tgt_indices, (size_t)nt, h->stream);
+        h->d_tgt_counts.ensure((size_t)(3 * nt));
+        h->d_tgt_scores.ensure((size_t)nt);
+        const int64_t cap = rows_per_batch(h);
+        const int64_t nb_max = std::min(cap, n);
+        h->scores.ensure((size_t)(nb_max * h->n_items));
+        h->d_users.ensure((size_t)nb_max);
+        if (have_excl) h->excl.ensure((size_t)(nb_max * h->n_items));
+        for (int64_t b0 = 0; b0 < n; b0 += cap) {
+            const int64_t nb = std::min(cap, n - b0);
+            h->d_users.upload(users + b0, (size_t)nb, h->stream);
+            launch_scores(h, h->d_users.p, 0, nb, true);
+            if (have_excl) {
+                HIP_CHECK(hipMemsetAsync(h->excl.p, 0, (size_t)(nb * h->n_items), h->stream));
+                hipLaunchKernelGGL(mark_excluded_kernel, dim3((unsigned)nb), dim3(kBlk), 0, h->stream,
+                                   h->d_excl_indptr.p, h->d_excl_indices.p, b0, h->n_items, h->excl.p);
+            }
+            hipLaunchKernelGGL(rank_positions_kernel, dim3((unsigned)nb), dim3(kBlk), 0, h->stream, h->scores.p,
+                               have_excl ? h->excl.p : nullptr, h->n_items, h->d_tgt_indptr.p, h->d_tgt_indices.p, b0,
+                               h->d_tgt_counts.p, h->d_tgt_counts.p + nt, h->d_tgt_counts.p + 2 * nt,
+                               h->d_tgt_scores.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(h->stream));  // d_users is re-used by the next batch's upload
+        }
+        HIP_CHECK(hipMemcpyAsync(greater_out, h->d_tgt_counts.p, (size_t)nt * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(pos_out, h->d_tgt_counts.p + nt, (size_t)nt * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(ge_out, h->d_tgt_counts.p + 2 * nt, (size_t)nt * 4, hipMemcpyDeviceToHost, h->stream));
+        h->d_tgt_scores.download(tgt_scores_out, (size_t)nt, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
     });
 }
 

@@ -7,11 +7,13 @@ one-`rank()`-per-user / one-`rate()`-per-rating Python loops (SURVEY.md §8 rows
 `rank_batch` (fused scoring GEMM + top-k with the training/validation positives as per-user
 exclusion lists) and `rate_batch` (one gather-dot-clip kernel).
 
-Metrics over the full candidate list (AUC, MAP, MRR) are batched as well: full rankings of a block of users
-come from the device (score tile + per-row sort) and the metrics are evaluated in positional, tie-aware
-vectorised forms (`compute_full_batch`).  Metric objects without batched forms (e.g. the reference's own
-classes) go through the reference's per-user flow, `model.rank(user, item_indices, k)`, which is still
-device-scored and device-sorted.
+Metrics over the full candidate list (AUC, MAP, MRR) are batched as well.  They only depend on where each test
+positive stands among the user's candidates and on the length of its run of tied scores, so a model that offers
+`rank_positions_batch` (cornac_hip_rank_positions: counts over the score tile, no sort, no ranking copied back) is
+asked for exactly that; other models with `rank_batch` hand over full rankings of a block of users (score tile +
+per-row sort) and the same positional, tie-aware vectorised forms (`compute_full_batch`) are applied to them.
+Metric objects without batched forms (e.g. the reference's own classes) go through the reference's per-user flow,
+`model.rank(user, item_indices, k)`, which is still device-scored and device-sorted.
 """
 import numpy as np
 from .metrics import positive_runs
@@ -109,7 +111,42 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     batchable = hasattr(model, "rank_batch") and getattr(model, "total_items", n_eval_items) == n_eval_items
     full_ok = batchable and need_full and all(
         hasattr(m, "compute_full_batch") if m.k <= 0 else hasattr(m, "compute_batch") for m in metrics)
-    if full_ok:
+    if full_ok and hasattr(model, "rank_positions_batch"):
+        # the full-list metrics only need to know where each test positive stands among the user's candidates and
+        # how long its run of tied scores is: counted on the device, no ranking is produced or copied
+        topk_k = max([m.k for m in metrics if m.k > 0], default=0)
+        for b0 in range(0, len(users), batch_users):
+            b1 = min(b0 + batch_users, len(users))
+            ub = [int(u) for u in users[b0:b1]]
+            nb = b1 - b0
+            ex_ip = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)
+            ex_ix = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
+            gt_ip = (gt_ptr[b0:b1 + 1] - gt_ptr[b0]).astype(np.int64)
+            gt_ix = np.ascontiguousarray(gt_idx[gt_ptr[b0]:gt_ptr[b1]], dtype=np.int32)
+            _, pos, ge, _ = model.rank_positions_batch(ub, (gt_ip, gt_ix), exclude=(ex_ip, ex_ix))
+            n_cand = int(n_eval_items) - np.diff(ex_ip)
+            n_gt = np.diff(gt_ip)
+            rows = np.repeat(np.arange(nb), n_gt)
+            order = np.lexsort((pos, rows))                       # a row's positives in ranked order
+            rows, pos, end = rows[order], pos[order].astype(np.int64), ge[order].astype(np.int64) - 1
+            starts = gt_ip
+            key = rows * int(n_eval_items) + pos
+            cum_end = np.searchsorted(key, rows * int(n_eval_items) + end, side="right") - starts[rows]
+            runs = (rows, pos, end, cum_end, starts)
+            width = max(topk_k, max_k, 1)
+            hits = np.zeros((nb, width), bool)                    # what the @k metrics (and MRR over pd_rank[:max_k]) see
+            head = pos < width
+            hits[rows[head], pos[head]] = True
+            for i, mt in enumerate(metrics):
+                if mt.k <= 0:
+                    vals = mt.compute_full_batch(hits, None, n_cand, n_gt, rank_len=max_k if max_k > 0 else None,
+                                                 runs=runs)
+                elif getattr(mt, "name", "").startswith("NCRR"):
+                    vals = mt.compute_batch(hits[:, :topk_k], n_gt, n_pred=n_cand)
+                else:
+                    vals = mt.compute_batch(hits[:, :topk_k], n_gt)
+                user_results[i].update(zip(ub, np.asarray(vals, dtype=float).tolist()))
+    elif full_ok:
         # metrics over the full candidate list (AUC, MAP, MRR) batched: full rankings of a block of users from the
         # device (score tile + per-row sort), then positional / tie-aware vectorised forms of the metrics
         topk_k = max([m.k for m in metrics if m.k > 0], default=0)

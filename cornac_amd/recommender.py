@@ -278,6 +278,16 @@ class Recommender:
         topk = sc.n_items if k == -1 else min(int(k), sc.n_items)
         return sc.rank_topk(rows.astype(np.int32), topk, exclude=exclude)
 
+    def rank_positions_batch(self, user_indices, targets, exclude=None):
+        """Where each listed item stands in its user's ranking, without producing the rankings: `targets` and
+        `exclude` are CSR `(indptr int64[n+1], indices int32)` per listed user (test positives / training
+        positives in `ranking_eval`).  Returns per target `(greater, pos, ge, score)` — candidates scored strictly
+        higher, 0-based position in the order `rank()` gives, candidates scored at least as high, its score."""
+        rows = np.asarray([self._scorer_row(int(u)) for u in user_indices])
+        if (rows == None).any():  # noqa: E711
+            raise ScoreException("rank_positions_batch needs users known to the model")
+        return self._get_scorer().rank_positions(rows.astype(np.int32), targets, exclude=exclude)
+
     def _scorer_row(self, user_idx):
         """Row of the device user table for user_idx, or None if its score is not table-driven."""
         return int(user_idx) if self.knows_user(user_idx) else None

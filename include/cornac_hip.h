@@ -303,6 +303,19 @@ int cornac_hip_score_pairs(cornac_hip_scorer_t h, const int32_t *users, const in
  * are filled with -1 / -inf. */
 int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n, int topk, const int64_t *excl_indptr,
                          const int32_t *excl_indices, int32_t *items_out, float *scores_out);
+/* Where listed items stand in each user's ranking, without producing the ranking: for user users[b] the
+ * "targets" tgt_indices[tgt_indptr[b] .. tgt_indptr[b+1]) (the evaluation loop's test positives,
+ * cornac/eval_methods/base_method.py:185-206) among that user's candidates (all items minus the optional
+ * exclusion CSR row, as in cornac_hip_rank_topk).  Per target, in tgt_indices order:
+ *   greater_out = candidates with a strictly higher score,
+ *   pos_out     = its 0-based position in the order cornac_hip_rank_topk produces (ties: higher index first),
+ *   ge_out      = candidates with score >= its own (itself included),
+ *   tgt_scores_out = its score.
+ * These are what AUC / MAP / MRR (cornac/metrics/ranking.py:185-527) read off `rank(k=-1)` output.  A target that is
+ * out of range or excluded gets -1 / -1 / -1 / -inf. */
+int cornac_hip_rank_positions(cornac_hip_scorer_t h, const int32_t *users, int64_t n, const int64_t *excl_indptr,
+                              const int32_t *excl_indices, const int64_t *tgt_indptr, const int32_t *tgt_indices,
+                              int32_t *greater_out, int32_t *pos_out, int32_t *ge_out, float *tgt_scores_out);
 /* Device-resident throughput probe used by bench.py: ranks users
  * [u0, u0 + n) with fused top-k, keeps results on device; returns elapsed ms of
  * the kernels (hipEvent) in *ms. */

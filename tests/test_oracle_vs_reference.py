@@ -116,6 +116,25 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
                 out_s[r, :len(rr)] = self.S[u][rr]
             return out, out_s
 
+    class PositionsModel(HostModel):  # + the counting interface of the device scorer (cornac_hip_rank_positions)
+        calls = 0
+
+        def rank_positions_batch(self, users, targets, exclude=None):
+            PositionsModel.calls += 1
+            out = [[], [], [], []]
+            for r, u in enumerate(users):
+                ex = exclude[1][exclude[0][r]:exclude[0][r + 1]]
+                cand = np.setdiff1d(np.arange(self.num_items), ex)
+                sc = self.S[u][cand]
+                for t in targets[1][targets[0][r]:targets[0][r + 1]]:
+                    s = self.S[u][t]
+                    out[0].append(int((sc > s).sum()))
+                    out[1].append(int((sc > s).sum() + ((sc == s) & (cand > t)).sum()))
+                    out[2].append(int((sc >= s).sum()))
+                    out[3].append(s)
+            return (np.array(out[0], np.int32), np.array(out[1], np.int32), np.array(out[2], np.int32),
+                    np.array(out[3], np.float32))
+
     data = _pairs(60, 45, 1200, 4)
     rs.shuffle(data)
     train = ns.Dataset.build(data[:900])
@@ -136,19 +155,22 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
     sets = (([rm.AUC(), rm.MAP(), rm.MRR()], [mm.AUC(), mm.MAP(), mm.MRR()]),
             ([rm.AUC(), rm.MAP(), rm.NCRR(k=10), rm.FMeasure(k=5), rm.Recall(k=10), rm.NDCG(k=3)],
              [mm.AUC(), mm.MAP(), mm.NCRR(k=10), mm.FMeasure(k=5), mm.Recall(k=10), mm.NDCG(k=3)]))
-    for mdl in (model, model_t):
+    for mdl in (model, model_t, PositionsModel(model.S, train.num_items), PositionsModel(model_t.S, train.num_items)):
         for ref_all, my_all in sets:
             ref_avg3, ref_user3 = ns.eval_methods.base_method.ranking_eval(mdl, ref_all, train, test)
-            avg3, user3 = ev.ranking_eval(mdl, my_all, train, test, batch_users_full=16)
+            avg3, user3 = ev.ranking_eval(mdl, my_all, train, test, batch_users_full=16, batch_users=16)
             assert np.allclose(avg3, ref_avg3, rtol=1e-9), (avg3, ref_avg3)
             for mine_u, ref_u in zip(user3, ref_user3):
                 assert mine_u.keys() == ref_u.keys()
                 assert np.allclose([mine_u[u] for u in ref_u], [ref_u[u] for u in ref_u], rtol=1e-9)
+    assert PositionsModel.calls >= 8
     # mixed with an @k metric the reference ranks only max_k items, and MRR over that prefix finds users without a hit
     with pytest.raises(ValueError):
         ns.eval_methods.base_method.ranking_eval(model, [rm.MRR(), rm.Recall(k=3)], train, test)
     with pytest.raises(ValueError):
         ev.ranking_eval(model, [mm.MRR(), mm.Recall(k=3)], train, test)
+    with pytest.raises(ValueError):
+        ev.ranking_eval(PositionsModel(S, train.num_items), [mm.MRR(), mm.Recall(k=3)], train, test)
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])

@@ -162,6 +162,64 @@ def test_rate_batch_matches_per_pair_rate(oracle):
     assert np.array_equal(sc.score_pairs(u[known], i[known]), full[np.arange(known.sum()), i[known]])
 
 
+@pytest.mark.parametrize("k,with_excl", [(16, True), (64, False), (100, True)])
+def test_rank_positions_equal_counts_over_the_score_block(k, with_excl):
+    """cornac_hip_rank_positions vs NumPy counts over the same (bit-identical) device scores: tied scores, targets
+    at the extremes of a row, rows without targets, more targets per row than one register pass, excluded and
+    out-of-range targets"""
+    rs = np.random.RandomState(k)
+    nu, ni = 70, 3000
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (ni, k)).astype(np.float32)
+    V[100:160] = V[200:260]                       # runs of exactly tied scores
+    ib = np.zeros(ni, np.float32)
+    sc = _lib.Scorer(U, V, ib, None)
+    users = rs.permutation(nu)[:50].astype(np.int32)
+    S = sc.score_block(users)
+    excl = [np.sort(rs.choice(ni, rs.randint(0, 40), replace=False)).astype(np.int32) if with_excl else
+            np.empty(0, np.int32) for _ in users]
+    tgts = []
+    for r in range(len(users)):
+        n_t = [0, 1, 3, 4, 5, 9, 33][r % 7]
+        t = rs.choice(ni, n_t, replace=False).astype(np.int32)
+        if n_t >= 3:
+            t[0], t[1] = 120, 220                 # two members of one tie run
+            t[2] = int(np.argmax(S[r]))           # the row's best item
+        if n_t >= 9:
+            t[3] = ni + 5                         # out of range
+            if with_excl and len(excl[r]):
+                t[4] = excl[r][0]                 # an excluded item
+        tgts.append(t)
+    csr = lambda rows: (np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64),
+                        np.concatenate(rows).astype(np.int32))
+    greater, pos, ge, scores = sc.rank_positions(users, csr(tgts), exclude=csr(excl) if with_excl else None)
+    p = 0
+    for r in range(len(users)):
+        cand = np.setdiff1d(np.arange(ni), excl[r])
+        s_c = S[r][cand]
+        for t in tgts[r]:
+            if t >= ni or t in excl[r]:
+                want = (-1, -1, -1)
+                assert scores[p] == -np.inf
+            else:
+                s = S[r][t]
+                want = (int((s_c > s).sum()), int((s_c > s).sum() + ((s_c == s) & (cand > t)).sum()),
+                        int((s_c >= s).sum()))
+                assert scores[p] == s
+            assert (greater[p], pos[p], ge[p]) == want, (r, t, want)
+            p += 1
+    assert p == len(greater)
+    # consistent with the ranking itself
+    items, _ = sc.rank_topk(users[:8], ni, exclude=csr(excl[:8]) if with_excl else None)
+    p = 0
+    for r in range(8):
+        for t in tgts[r]:
+            if pos[p] >= 0:
+                assert items[r, pos[p]] == t
+            p += 1
+    sc.close()
+
+
 def test_batched_evaluation_equals_per_user_flow():
     """cornac_amd.eval.ranking_eval (one fused GEMM + top-k launch with exclusion lists) gives the
     same per-user metric values as the reference-style loop over model.rank(); rating_eval (one
@@ -193,13 +251,22 @@ def test_batched_evaluation_equals_per_user_flow():
     # metrics over the full candidate list: device full rankings of user blocks + tie-aware batched forms vs the
     # per-user flow (a pair of candidates whose scores differ in the last ulp between the two score kernels may
     # swap: one pair moves a user's AUC by 1 / (positives * negatives))
+    class RankBatchOnly(PerUser):  # without rank_positions_batch -> full rankings of user blocks are copied back
+        def rank_batch(self, *a, **kw):
+            return self.m.rank_batch(*a, **kw)
+
+        @property
+        def total_items(self):
+            return self.m.total_items
+
     for full in ([mm.AUC(), mm.MAP(), mm.MRR()], [mm.AUC(), mm.MAP(), mm.NCRR(k=10), mm.FMeasure(k=5)]):
-        avg_f, user_f = ev.ranking_eval(m, full, train, test, batch_users_full=96)
         avg_fr, user_fr = ev.ranking_eval(PerUser(m), full, train, test)
-        assert np.allclose(avg_f, avg_fr, rtol=0, atol=2e-5), (avg_f, avg_fr)
-        for a, b in zip(user_f, user_fr):
-            assert a.keys() == b.keys() and all(abs(a[u] - b[u]) < 5e-3 for u in a)
-        assert 0.5 < avg_f[0] < 1
+        for mdl in (m, RankBatchOnly(m)):     # device position counts / device full rankings
+            avg_f, user_f = ev.ranking_eval(mdl, full, train, test, batch_users_full=96, batch_users=150)
+            assert np.allclose(avg_f, avg_fr, rtol=0, atol=2e-5), (avg_f, avg_fr)
+            for a, b in zip(user_f, user_fr):
+                assert a.keys() == b.keys() and all(abs(a[u] - b[u]) < 5e-3 for u in a)
+            assert 0.5 < avg_f[0] < 1
     mf = MF(k=8, max_iter=10, seed=2).fit(train)
     (rmse, mae), _ = ev.rating_eval(mf, [mm.RMSE(), mm.MAE()], test)
     u, i, r = test.uir_tuple
