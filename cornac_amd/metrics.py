@@ -18,7 +18,24 @@ class RankingMetric:
 #   hits [n_users, K] bool : the p-th ranked item of the user is one of its positives (False beyond the user's list),
 #   n_gt [n_users]         : number of positives of the user,
 # and return exactly what `compute` returns user by user (tests/test_eval_cpu.py); k must be > 0 and <= K.
+def _listed_positives(hits, n_cand, rank_len, runs):
+    """(rows, pos, list_len): the positives inside each user's ranked list pd_rank (= the whole candidate list, or
+    its first rank_len entries) and that list's length — from `positive_runs`-style `runs` when given, else from
+    the dense `hits` matrix.  Used by the k = -1 forms of the @k metrics."""
+    if runs is not None:
+        rows, pos = runs[0], runs[1]
+    else:
+        rows, pos = np.nonzero(hits)
+    list_len = np.asarray(n_cand) if rank_len is None else np.minimum(n_cand, rank_len)
+    inside = pos < list_len[rows]
+    return rows[inside], pos[inside], list_len
+
+
 class _MeasureAtK(RankingMetric):
+    def _tp_full(self, hits, n_cand, rank_len, runs):
+        rows, _, list_len = _listed_positives(hits, n_cand, rank_len, runs)
+        return np.bincount(rows, minlength=len(list_len)).astype(float), list_len
+
     def _tp(self, gt_pos, pd_rank):
         top = pd_rank[: self.k] if self.k > 0 else pd_rank
         tp = np.sum(np.isin(top, gt_pos))
@@ -39,6 +56,11 @@ class Precision(_MeasureAtK):
     def compute_batch(self, hits, n_gt):
         return self._tp_batch(hits) / self.k
 
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        tp, list_len = self._tp_full(hits, n_cand, rank_len, runs)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return tp / list_len
+
 
 class Recall(_MeasureAtK):
     def __init__(self, k=-1):
@@ -52,6 +74,11 @@ class Recall(_MeasureAtK):
         with np.errstate(divide="ignore", invalid="ignore"):
             return self._tp_batch(hits) / n_gt
 
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        tp, _ = self._tp_full(hits, n_cand, rank_len, runs)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return tp / n_gt
+
 
 class HitRatio(_MeasureAtK):
     def __init__(self, k=-1):
@@ -62,6 +89,9 @@ class HitRatio(_MeasureAtK):
 
     def compute_batch(self, hits, n_gt):
         return (self._tp_batch(hits) > 0).astype(float)
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        return (self._tp_full(hits, n_cand, rank_len, runs)[0] > 0).astype(float)
 
 
 class NDCG(RankingMetric):
@@ -84,6 +114,14 @@ class NDCG(RankingMetric):
         with np.errstate(divide="ignore", invalid="ignore"):
             return dcg / ideal
 
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        rows, pos, list_len = _listed_positives(hits, n_cand, rank_len, runs)
+        dcg = np.bincount(rows, weights=1.0 / np.log2(pos + 2.0), minlength=len(list_len))
+        top = int(np.max(n_gt, initial=0))
+        ideal = np.concatenate([[0.0], np.cumsum(1.0 / np.log2(np.arange(top) + 2.0))])[n_gt]   # the positives ranked first
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return dcg / ideal
+
 
 class FMeasure(_MeasureAtK):
     def __init__(self, k=-1):
@@ -98,6 +136,13 @@ class FMeasure(_MeasureAtK):
         tp = self._tp_batch(hits)
         with np.errstate(divide="ignore", invalid="ignore"):
             prec, rec = tp / self.k, tp / n_gt
+            f1 = 2 * (prec * rec) / (prec + rec)
+        return np.where(prec + rec > 0, f1, 0.0)
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        tp, list_len = self._tp_full(hits, n_cand, rank_len, runs)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prec, rec = tp / list_len, tp / n_gt
             f1 = 2 * (prec * rec) / (prec + rec)
         return np.where(prec + rec > 0, f1, 0.0)
 
@@ -122,6 +167,14 @@ class NCRR(RankingMetric):
         crr = (hits[:, : self.k] * inv).sum(axis=1)
         run = np.minimum(n_gt, self.k if n_pred is None else np.minimum(n_pred, self.k))
         ideal = np.concatenate([[0.0], np.cumsum(inv)])[run]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(crr > 0, crr / ideal, 0.0)
+
+    def compute_full_batch(self, hits, scores, n_cand, n_gt, rank_len=None, runs=None):   # k = -1
+        rows, pos, list_len = _listed_positives(hits, n_cand, rank_len, runs)
+        crr = np.bincount(rows, weights=1.0 / (pos + 1.0), minlength=len(list_len))
+        run = np.minimum(n_gt, list_len)
+        ideal = np.concatenate([[0.0], np.cumsum(1.0 / (np.arange(int(np.max(run, initial=0))) + 1.0))])[run]
         with np.errstate(divide="ignore", invalid="ignore"):
             return np.where(crr > 0, crr / ideal, 0.0)
 

@@ -101,3 +101,10 @@ def test_full_list_metric_batch_forms_equal_per_user_with_ties(levels):
         got = mt.compute_full_batch(hits, scores, n_cand, n_gt)
         want = np.array([mt.compute(**kw) for kw in per_user], dtype=float)
         assert np.allclose(got, want, rtol=1e-12, atol=1e-15), cls.__name__
+    for cls in (mm.NDCG, mm.Recall, mm.Precision, mm.NCRR, mm.FMeasure, mm.HitRatio):   # their k = -1 forms
+        for rank_len in (None, 7):
+            mt = cls(k=-1)
+            got = mt.compute_full_batch(hits, scores, n_cand, n_gt, rank_len=rank_len)
+            want = np.array([mt.compute(gt_pos=kw["gt_pos"], pd_rank=kw["pd_rank"][:rank_len]) for kw in per_user],
+                            dtype=float)
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-15), (cls.__name__, rank_len)
