@@ -267,18 +267,33 @@ class MAP(RankingMetric):
             return np.bincount(rows, weights=cum_end / (end + 1.0), minlength=len(n_gt)) / n_gt
 
 
-class RMSE:
-    type, name = "rating", "RMSE"
+class _RatingMetric:
+    """rating metrics take optional per-rating weights like the reference's (cornac/metrics/rating.py:40-140)"""
+    type = "rating"
 
     @staticmethod
-    def compute(gt_ratings, pd_ratings, **kwargs):
-        d = np.asarray(gt_ratings, float) - np.asarray(pd_ratings, float)
-        return float(np.sqrt(np.mean(d * d)))
+    def _diff(gt_ratings, pd_ratings):
+        return np.asarray(gt_ratings, float) - np.asarray(pd_ratings, float)
 
 
-class MAE:
-    type, name = "rating", "MAE"
+class MSE(_RatingMetric):
+    name = "MSE"
 
-    @staticmethod
-    def compute(gt_ratings, pd_ratings, **kwargs):
-        return float(np.mean(np.abs(np.asarray(gt_ratings, float) - np.asarray(pd_ratings, float))))
+    def compute(self, gt_ratings, pd_ratings, weights=None, **kwargs):
+        d = self._diff(gt_ratings, pd_ratings)
+        return float(np.average(d * d, axis=0, weights=weights))
+
+
+class RMSE(_RatingMetric):
+    name = "RMSE"
+
+    def compute(self, gt_ratings, pd_ratings, weights=None, **kwargs):
+        d = self._diff(gt_ratings, pd_ratings)
+        return float(np.sqrt(np.average(d * d, axis=0, weights=weights)))
+
+
+class MAE(_RatingMetric):
+    name = "MAE"
+
+    def compute(self, gt_ratings, pd_ratings, weights=None, **kwargs):
+        return float(np.average(np.abs(self._diff(gt_ratings, pd_ratings)), axis=0, weights=weights))
