@@ -1,11 +1,12 @@
 """cornac_amd — MI355X (gfx950) backend for the embedding-SGD + scoring hot path of PreferredAI/cornac.
 
 Public surface mirrors the reference for this path: `BPR`, `WBPR`, `VEBPR`, `MF`, `VBPR`, `WMF` (models with the
-reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface) and `Dataset`.
+reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface), `Dataset` and `Reader`.
 All compute runs in libcornac_hip.so (hand-written HIP for gfx950, C ABI in include/cornac_hip.h);
 there is no CPU fallback.
 """
 from .data import Dataset, PurchaseViewDataset
+from .reader import Reader
 from .recommender import Recommender, ScoreException
 from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
@@ -13,5 +14,5 @@ from .vbpr import VBPR
 from .wmf import WMF
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
 __version__ = "0.1.0"

@@ -1,0 +1,63 @@
+"""cornac_amd.Reader: the reference's text formats for this path (UI / UIR / UIRT) and its filters."""
+import os
+
+import numpy as np
+import pytest
+
+from cornac_amd import Dataset, Reader
+
+LINES = ["u1\ti1\t4\t100", "u1\ti2\t2\t101", "u2\ti1\t5\t102", "u3\ti3\t1\t103", "u2\ti2\t3\t104", "u1\ti3\t5\t105",
+         "u4\ti1\t3\t106"]
+
+
+@pytest.fixture()
+def uirt_file(tmp_path):
+    path = tmp_path / "uirt.txt"
+    path.write_text("header\n" + "\n".join(LINES) + "\n")
+    return str(path)
+
+
+def test_formats_and_filters(uirt_file, tmp_path):
+    uir = Reader().read(uirt_file, skip_lines=1)
+    assert uir[0] == ("u1", "i1", 4.0) and len(uir) == 7 and all(len(t) == 3 for t in uir)
+    uirt = Reader().read(uirt_file, fmt="UIRT", skip_lines=1)
+    assert uirt[-1] == ("u4", "i1", 3.0, 106)
+    # binarise >= 3, then users seen at least twice
+    got = Reader(bin_threshold=3.0, min_user_freq=2).read(uirt_file, skip_lines=1)
+    assert got == [("u1", "i1", 1.0), ("u2", "i1", 1.0), ("u2", "i2", 1.0), ("u1", "i3", 1.0)]
+    # most frequent item first (i1: 3), ties keep first-seen order; then an allowed-user set
+    assert {t[1] for t in Reader(num_top_freq_item=1).read(uirt_file, skip_lines=1)} == {"i1"}
+    assert [t[0] for t in Reader(user_set=["u2", "u4"]).read(uirt_file, skip_lines=1)] == ["u2", "u2", "u4"]
+    # UI lists, with and without inline ids
+    ui = tmp_path / "ui.txt"
+    ui.write_text("a x y\nb y\n")
+    assert Reader().read(str(ui), fmt="UI", sep=" ") == [("a", "x", 1.0), ("a", "y", 1.0), ("b", "y", 1.0)]
+    assert Reader().read(str(ui), fmt="UI", sep=" ", id_inline=True) == [("1", "a", 1.0), ("1", "x", 1.0), ("1", "y", 1.0),
+                                                                        ("2", "b", 1.0), ("2", "y", 1.0)]
+    with pytest.raises(ValueError, match="Invalid line format"):
+        Reader().read(uirt_file, fmt="UBI")
+    # the tuples feed Dataset.from_uir directly
+    ds = Dataset.from_uir(uir)
+    assert (ds.num_users, ds.num_items, ds.num_ratings) == (4, 3, 7)
+
+
+def test_reader_matches_the_reference_reader_on_its_own_fixture():
+    """live comparison with cornac.data.Reader on the reference's tests/data.txt (this container only)"""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ref_loader.load()
+    import importlib
+
+    RefReader = importlib.import_module("cornac.data").Reader
+    path = os.path.join(ref_loader.REF, "tests", "data.txt")
+    combos = [dict(), dict(bin_threshold=4.0), dict(min_user_freq=2), dict(min_item_freq=2, bin_threshold=3.0),
+              dict(num_top_freq_user=3), dict(num_top_freq_item=2, min_user_freq=1), dict(user_set={"76", "768"}),
+              dict(item_set=["93", "257", "795"], min_item_freq=1)]
+    for kw in combos:
+        for fmt in ("UIR", "UIRT"):
+            assert Reader(**kw).read(path, fmt=fmt) == RefReader(**kw).read(path, fmt=fmt), (kw, fmt)
+    assert Reader().read(path, fmt="UI") == RefReader().read(path, fmt="UI")
+    assert Reader().read(path, fmt="UI", id_inline=True) == RefReader().read(path, fmt="UI", id_inline=True)
+    assert Reader().read(path, skip_lines=3) == RefReader().read(path, skip_lines=3)
