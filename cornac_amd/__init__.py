@@ -1,7 +1,7 @@
 """cornac_amd — MI355X (gfx950) backend for the embedding-SGD + scoring hot path of PreferredAI/cornac.
 
 Public surface mirrors the reference for this path: `BPR`, `WBPR`, `VEBPR`, `MF`, `VBPR`, `WMF` (models with the
-reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface), `Dataset` and `Reader`.
+reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface), `Dataset`, `Reader`, and the callers `RatioSplit` / `BaseMethod` / `Experiment` (+ `eval`, `metrics`).
 All compute runs in libcornac_hip.so (hand-written HIP for gfx950, C ABI in include/cornac_hip.h);
 there is no CPU fallback.
 """
@@ -12,7 +12,8 @@ from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
 from .vbpr import VBPR
 from .wmf import WMF
+from .experiment import BaseMethod, Experiment, RatioSplit, Result
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "RatioSplit", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
 __version__ = "0.1.0"

@@ -34,13 +34,16 @@ class Dataset:
         self._csr = None
 
     @classmethod
-    def build(cls, data, global_uid_map=None, global_iid_map=None, seed=None, exclude_unknowns=False):
-        """(user, item, rating) triplets -> Dataset; first occurrence of a (user, item) pair wins,
+    def build(cls, data, fmt="UIR", global_uid_map=None, global_iid_map=None, seed=None, exclude_unknowns=False):
+        """(user, item, rating[, timestamp]) tuples -> Dataset; first occurrence of a (user, item) pair wins,
         ids are numbered in order of first appearance (dataset.py:257-358)."""
+        fmt = fmt.upper()
+        if fmt not in ("UIR", "UIRT"):
+            raise ValueError("fmt should be in ['UIR', 'UIRT']")
         gu = OrderedDict() if global_uid_map is None else global_uid_map
         gi = OrderedDict() if global_iid_map is None else global_iid_map
         seen = set()
-        us, its, rs = [], [], []
+        us, its, rs, ts = [], [], [], []
         dups = 0
         for rec in data:
             uid, iid, rating = rec[0], rec[1], rec[2]
@@ -53,12 +56,19 @@ class Dataset:
             us.append(gu.setdefault(uid, len(gu)))
             its.append(gi.setdefault(iid, len(gi)))
             rs.append(float(rating))
+            if fmt == "UIRT":
+                ts.append(int(rec[3]))
         if dups:
             warnings.warn("%d duplicated observations are removed!" % dups)
         if not seen:
             raise ValueError("data is empty after being filtered!")
         uir = (np.asarray(us, dtype="int"), np.asarray(its, dtype="int"), np.asarray(rs, dtype="float"))
-        return cls(len(gu), len(gi), gu, gi, uir, seed=seed)
+        return cls(len(gu), len(gi), gu, gi, uir, timestamps=np.asarray(ts, dtype="int") if fmt == "UIRT" else None,
+                   seed=seed)
+
+    @classmethod
+    def from_uirt(cls, data, seed=None):
+        return cls.build(data, fmt="UIRT", seed=seed)
 
     @classmethod
     def from_uir(cls, data, seed=None):

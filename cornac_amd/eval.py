@@ -213,12 +213,20 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     return avg_results, user_results
 
 
+def scalar_of(v):
+    return v.item() if hasattr(v, "item") else v
+
+
 def rating_eval(model, metrics, test_set, user_based=False, verbose=False):
     """base_method.py:35-105 with one batched prediction kernel for all test ratings."""
     if len(metrics) == 0:
         return [], []
     u_indices, i_indices, r_values = test_set.uir_tuple
-    r_preds = model.rate_batch(u_indices, i_indices)
+    if hasattr(model, "rate_batch"):
+        r_preds = model.rate_batch(u_indices, i_indices)
+    else:   # a model without the batched kernel: the reference's pair-by-pair loop
+        r_preds = np.fromiter((scalar_of(model.rate(int(u), int(i))) for u, i in zip(u_indices, i_indices)),
+                              dtype="float", count=len(u_indices))
     avg_results, user_results = [], []
 
     def scalar(v):

@@ -156,6 +156,9 @@ class Recommender:
         self._drop_scorer()
         return self
 
+    def transform(self, test_set):
+        """hook called by the evaluation method before scoring a test set (recommender.py:410-421); nothing to cache here"""
+
     def knows_user(self, user_idx):
         return user_idx is not None and 0 <= user_idx < self.num_users
 
