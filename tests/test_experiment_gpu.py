@@ -22,7 +22,7 @@ def test_first_example_flow_end_to_end(capsys):
     mf_res, bpr_res = exp.result
     assert list(mf_res.metric_avg_results) == ["MAE", "RMSE", "AUC", "MAP", "Precision@20", "Recall@20", "Train (s)",
                                                "Test (s)"]
-    assert 0.5 < mf_res.metric_avg_results["MAE"] < 2.0 <= 2.0 and mf_res.metric_avg_results["RMSE"] >= mf_res.metric_avg_results["MAE"]
+    assert 0.5 < mf_res.metric_avg_results["MAE"] < 2.0 and mf_res.metric_avg_results["RMSE"] >= mf_res.metric_avg_results["MAE"]
     assert 0.3 < bpr_res.metric_avg_results["AUC"] < 1.0
     # the Result rows are exactly what the evaluation loops return for the fitted models
     avg, _ = ev.ranking_eval(models[1], [mm.AUC(), mm.MAP(), mm.Precision(k=20), mm.Recall(k=20)], method.train_set,
