@@ -129,6 +129,80 @@ class Dataset:
             self._dok = dict(zip(zip(u.tolist(), i.tolist()), r.tolist()))
         return self._dok
 
+    @property
+    def dok_matrix(self):
+        """the ratings as a scipy DOK matrix (dataset.py:247-255); the iterators use the plain dict `dok`"""
+        if getattr(self, "_dok_matrix", None) is None:
+            self._dok_matrix = self.csr_matrix.todok()
+        return self._dok_matrix
+
+    def _grouped(self, by, other, with_time):
+        """{key: (others, ratings[, timestamps])} in data order per key (dataset.py:136-220); with_time: each key's
+        lists sorted by np.argsort of its timestamps, exactly as the reference sorts them"""
+        if with_time and self.timestamps is None:
+            raise ValueError("Timestamps are required but None!")
+        keys, vals, ratings = self.uir_tuple[by], self.uir_tuple[other], self.uir_tuple[2]
+        order = np.argsort(keys, kind="stable")
+        cuts = np.flatnonzero(np.diff(keys[order])) + 1
+        out = {}
+        first_seen = {}
+        for sel in (np.split(order, cuts) if len(order) else []):
+            cols = [vals[sel].tolist(), ratings[sel].tolist()]
+            if with_time:
+                times = self.timestamps[sel].tolist()
+                chrono = np.argsort(times)
+                cols = [[c[p] for p in chrono] for c in cols + [times]]
+            first_seen[int(keys[sel[0]])] = (int(sel[0]), tuple(cols))
+        for key, (_, cols) in sorted(first_seen.items(), key=lambda kv: kv[1][0]):   # keys in order of first appearance
+            out[key] = cols
+        return out
+
+    @property
+    def user_data(self):
+        return self._grouped(0, 1, False)
+
+    @property
+    def item_data(self):
+        return self._grouped(1, 0, False)
+
+    @property
+    def chrono_user_data(self):
+        return self._grouped(0, 1, True)
+
+    @property
+    def chrono_item_data(self):
+        return self._grouped(1, 0, True)
+
+    def num_user_batches(self, batch_size):
+        return int(np.ceil(self.num_users / batch_size))
+
+    def num_item_batches(self, batch_size):
+        return int(np.ceil(self.num_items / batch_size))
+
+    def add_modalities(self, **kwargs):
+        for name in ("user_feature", "item_feature", "user_text", "item_text", "user_image", "item_image", "user_graph",
+                     "item_graph", "sentiment", "review_text"):
+            setattr(self, name, kwargs.get(name, None))
+
+    def save(self, fpath):
+        """pickle the dataset (dataset.py:585-597)"""
+        import copy
+        import os
+        import pickle
+
+        os.makedirs(os.path.dirname(fpath) or ".", exist_ok=True)
+        with open(fpath, "wb") as f:
+            pickle.dump(copy.deepcopy(self), f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    @staticmethod
+    def load(fpath):
+        import pickle
+
+        with open(fpath, "rb") as f:
+            dataset = pickle.load(f)
+        dataset.load_from = fpath
+        return dataset
+
     def idx_iter(self, idx_range, batch_size=1, shuffle=False):
         """dataset.py:418-443: one `rng.shuffle` of arange(idx_range), then consecutive slices"""
         indices = np.arange(idx_range)
@@ -136,6 +210,32 @@ class Dataset:
             self.rng.shuffle(indices)
         for b in range(int(np.ceil(len(indices) / batch_size))):
             yield indices[batch_size * b: min(batch_size * b + batch_size, len(indices))]
+
+    def uir_iter(self, batch_size=1, shuffle=False, binary=False, num_zeros=0):
+        """(users, items, ratings) batches (dataset.py:445-488); `num_zeros` unobserved items per observation are
+        appended with rating 0, drawn like the reference draws them: `rng.randint(0, num_items)` until the pair has
+        no positive rating"""
+        users, items, ratings = self.uir_tuple
+        dok = self.dok if num_zeros > 0 else None
+        for batch_ids in self.idx_iter(len(users), batch_size, shuffle):
+            bu, bi = users[batch_ids], items[batch_ids]
+            br = np.ones_like(bi) if binary else ratings[batch_ids]
+            if num_zeros > 0:
+                rep = bu.repeat(num_zeros)
+                neg = np.empty_like(rep)
+                for t, u in enumerate(rep.tolist()):
+                    j = self.rng.randint(0, self.num_items)
+                    while dok.get((u, int(j)), 0.0) > 0:
+                        j = self.rng.randint(0, self.num_items)
+                    neg[t] = j
+                bu, bi, br = np.concatenate((bu, rep)), np.concatenate((bi, neg)), np.concatenate((br, np.zeros_like(neg)))
+            yield bu, bi, br
+
+    def user_iter(self, batch_size=1, shuffle=False):
+        """batches of user indices (dataset.py:528-544), candidate order as in `item_iter`"""
+        user_indices = np.fromiter(set(self.uir_tuple[0].tolist()), dtype="int")
+        for batch_ids in self.idx_iter(len(user_indices), batch_size, shuffle):
+            yield user_indices[batch_ids]
 
     def item_iter(self, batch_size=1, shuffle=False):
         """batches of item indices (dataset.py:546-562); the candidate order is the iteration order of

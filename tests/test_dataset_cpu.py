@@ -1,0 +1,105 @@
+"""cornac_amd.Dataset vs the reference's Dataset (cornac/data/dataset.py) — live, draw for draw, where /root/reference is
+present — and the reference's own expectations for it (tests/cornac/data/test_dataset.py:33-215) on local data."""
+import os
+
+import numpy as np
+import pytest
+
+from cornac_amd import Dataset
+
+
+def _tuples(n_users=25, n_items=18, n=220, seed=3, with_time=False):
+    rs = np.random.RandomState(seed)
+    keys = rs.permutation(n_users * n_items)[:n]
+    out = []
+    for k in keys:
+        t = ("u%d" % (k // n_items), "i%d" % (k % n_items), float(rs.randint(1, 6)))
+        out.append(t + (int(rs.randint(0, 50)),) if with_time else t)   # few distinct timestamps: ties inside a user
+    return out
+
+
+def test_expectations_of_the_reference_dataset_tests(tmp_path):
+    data = _tuples()
+    ds = Dataset.from_uir(data, seed=123)
+    assert ds.matrix.shape == (ds.num_users, ds.num_items) and ds.csr_matrix.has_sorted_indices
+    assert ds.uid_map[data[0][0]] == 0 and ds.iid_map[data[0][1]] == 0
+    assert set(ds.user_ids) == {t[0] for t in data} and set(ds.item_ids) == {t[1] for t in data}
+    assert ds.csr_matrix[0, 0] == data[0][2] == ds.csc_matrix[0, 0] == ds.dok_matrix[0, 0]
+    assert len(ds.uir_tuple) == 3 and ds.num_batches(50) == 5
+    assert ds.num_user_batches(10) == 3 and ds.num_item_batches(10) == 2
+    # iterators: default order is the data order, shuffle changes it
+    assert np.array_equal(np.concatenate(list(ds.idx_iter(10, 1))), np.arange(10))
+    assert not np.array_equal(np.concatenate(list(ds.idx_iter(100, 1, shuffle=True))), np.arange(100))
+    u, i, r = (np.concatenate(x) for x in zip(*ds.uir_iter(batch_size=7)))
+    assert np.array_equal(u, ds.uir_tuple[0]) and np.array_equal(i, ds.uir_tuple[1]) and np.array_equal(r, ds.uir_tuple[2])
+    assert all((b == 1).all() for _, _, b in ds.uir_iter(batch_size=16, binary=True))
+    for bu, bi, br in ds.uir_iter(batch_size=5, num_zeros=2):
+        n = len(bu) // 3
+        assert (br[:n] > 0).all() and (br[n:] == 0).all() and np.array_equal(bu[n:], bu[:n].repeat(2))
+        assert all(ds.dok.get((int(a), int(b)), 0.0) == 0 for a, b in zip(bu[n:], bi[n:]))
+    for bu, bp, bn in ds.uij_iter(batch_size=9, neg_sampling="popularity"):
+        assert all(ds.dok.get((int(a), int(c)), 0.0) < ds.dok[(int(a), int(b))] for a, b, c in zip(bu, bp, bn))
+    with pytest.raises(ValueError):
+        next(ds.uij_iter(neg_sampling="bla"))
+    assert sorted(np.concatenate(list(ds.user_iter(4))).tolist()) == list(range(ds.num_users))
+    assert sorted(np.concatenate(list(ds.item_iter(4, shuffle=True))).tolist()) == list(range(ds.num_items))
+    # per-user / per-item views
+    assert ds.user_data[0][0][0] == 0 and ds.user_data[0][1][0] == data[0][2]
+    assert sum(len(v[0]) for v in ds.item_data.values()) == ds.num_ratings
+    with pytest.raises(ValueError):
+        ds.chrono_user_data
+    dt = Dataset.from_uirt(_tuples(with_time=True))
+    assert len(dt.timestamps) == dt.num_ratings
+    for items, ratings, times in dt.chrono_user_data.values():
+        assert times == sorted(times) and len(items) == len(ratings) == len(times)
+    with pytest.raises(ValueError):      # everything is unknown without global id maps
+        Dataset.build(data, exclude_unknowns=True)
+    # pickle round trip
+    path = os.path.join(str(tmp_path), "sub", "ds.pkl")
+    ds.save(path)
+    back = Dataset.load(path)
+    assert back.load_from == path and all(np.array_equal(a, b) for a, b in zip(back.uir_tuple, ds.uir_tuple))
+
+
+def test_dataset_matches_the_reference_dataset_draw_for_draw():
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    RefDataset = ref_loader.load().Dataset
+    for with_time in (False, True):
+        data = _tuples(with_time=with_time, seed=8)
+        make = (lambda cls: cls.from_uirt(data, seed=5)) if with_time else (lambda cls: cls.from_uir(data, seed=5))
+        ref, mine = make(RefDataset), make(Dataset)
+        for a, b in zip(ref.uir_tuple, mine.uir_tuple):
+            assert np.array_equal(a, b) and a.dtype == b.dtype
+        assert list(ref.uid_map.items()) == list(mine.uid_map.items())
+        assert (ref.min_rating, ref.max_rating, ref.global_mean) == (mine.min_rating, mine.max_rating, mine.global_mean)
+        assert (ref.csr_matrix != mine.csr_matrix).nnz == 0 and (ref.csc_matrix != mine.csc_matrix).nnz == 0
+        assert dict(ref.dok_matrix.items()) == dict(mine.dok_matrix.items())
+
+        def same(x, y):
+            x, y = list(x), list(y)
+            assert len(x) == len(y)
+            for bx, by in zip(x, y):
+                bx, by = (bx, by) if isinstance(bx, tuple) else ((bx,), (by,))
+                for p, q in zip(bx, by):
+                    assert np.array_equal(p, q) and np.asarray(p).dtype == np.asarray(q).dtype
+
+        for kw in (dict(batch_size=16), dict(batch_size=7, shuffle=True), dict(batch_size=9, shuffle=True, binary=True),
+                   dict(batch_size=11, shuffle=True, num_zeros=3), dict(batch_size=5, num_zeros=1, binary=True)):
+            same(ref.reset().uir_iter(**kw), mine.reset().uir_iter(**kw))
+        for kw in (dict(batch_size=13, shuffle=True), dict(batch_size=6, neg_sampling="popularity"),
+                   dict(batch_size=50, shuffle=True, neg_sampling="popularity")):
+            same(ref.reset().uij_iter(**kw), mine.reset().uij_iter(**kw))
+        for kw in (dict(batch_size=4), dict(batch_size=3, shuffle=True)):
+            same(ref.reset().user_iter(**kw), mine.reset().user_iter(**kw))
+            same(ref.reset().item_iter(**kw), mine.reset().item_iter(**kw))
+        same(ref.reset().idx_iter(37, 5, True), mine.reset().idx_iter(37, 5, True))
+        for name in ("user_data", "item_data") + (("chrono_user_data", "chrono_item_data") if with_time else ()):
+            r, m = getattr(ref, name), getattr(mine, name)
+            assert [int(k) for k in r.keys()] == list(m.keys())
+            for k in m:
+                assert tuple(list(map(float, col)) for col in r[k]) == tuple(list(map(float, col)) for col in m[k]), (name, k)
+        if with_time:
+            assert np.array_equal(ref.timestamps, mine.timestamps)
