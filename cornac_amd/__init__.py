@@ -12,8 +12,8 @@ from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
 from .vbpr import VBPR
 from .wmf import WMF
-from .experiment import BaseMethod, Experiment, RatioSplit, Result
+from .experiment import BaseMethod, CrossValidation, CVResult, Experiment, RatioSplit, Result, StratifiedSplit
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "RatioSplit", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "RatioSplit", "StratifiedSplit", "CrossValidation", "CVResult", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
 __version__ = "0.1.0"

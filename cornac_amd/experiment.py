@@ -1,6 +1,7 @@
-"""The callers of the hot path: split, fit, evaluate, report — `RatioSplit` / `BaseMethod` / `Experiment` / `Result`
-with the reference's interface (cornac/eval_methods/base_method.py:229-845, ratio_split.py:24-126,
-cornac/experiment/experiment.py:24-167, result.py:49-76), so that the reference's example scripts
+"""The callers of the hot path: split, fit, evaluate, report — `RatioSplit` / `StratifiedSplit` / `CrossValidation` /
+`BaseMethod` / `Experiment` / `Result` / `CVResult` with the reference's interface (cornac/eval_methods/base_method.py:229-845,
+ratio_split.py:24-126, stratified_split.py:24-145, cross_validation.py:25-143, cornac/experiment/experiment.py:24-167,
+result.py:49-116), so that the reference's example scripts
 (examples/first_example.py, examples/bpr_netflix.py, ...) run against this backend by changing the import.
 
 What is kept exactly: the split protocol (`RandomState(seed).permutation(len(data))`: train = head, test = tail,
@@ -202,6 +203,106 @@ class RatioSplit(BaseMethod):
                    val_data=pick(val_idx) if len(val_idx) > 0 else None)
 
 
+class StratifiedSplit(BaseMethod):
+    """per-user (or per-item) ratio split, optionally chronological: the newest ratings of every group are held out
+    (cornac/eval_methods/stratified_split.py:24-145; same per-group `validate_size` and `rng.permutation` protocol)"""
+
+    def __init__(self, data, group_by="user", chrono=False, fmt="UIRT", test_size=0.2, val_size=0.0, rating_threshold=1.0,
+                 seed=None, exclude_unknowns=True, verbose=False, **kwargs):
+        super().__init__(data=data, fmt=fmt, rating_threshold=rating_threshold, seed=seed,
+                         exclude_unknowns=exclude_unknowns, verbose=verbose, **kwargs)
+        if group_by not in ("user", "item"):
+            raise ValueError("group_by option must be either 'user' or 'item' but {}".format(group_by))
+        if chrono and (fmt != "UIRT" or len(self.data[0]) != 4):
+            raise ValueError('Input data must be in "UIRT" format for sorting chronologically.')
+        self.chrono, self.group_by, self.val_size, self.test_size = chrono, group_by, val_size, test_size
+        self._split()
+
+    def _split(self):
+        data = sorted(self.data, key=lambda t: t[3]) if self.chrono else self.data
+        groups = OrderedDict()
+        col = 0 if self.group_by == "user" else 1
+        for idx, rec in enumerate(data):
+            groups.setdefault(rec[col], []).append(idx)
+        parts = {"train": [], "val": [], "test": []}
+        for members in groups.values():
+            n_train, _, n_test = RatioSplit.validate_size(self.val_size, self.test_size, len(members))
+            if self.chrono:   # the oldest n_train stay in place, only the held-out tail is shuffled
+                members = members[:n_train] + self.rng.permutation(members[n_train:]).tolist()
+            else:
+                members = self.rng.permutation(members).tolist()
+            parts["train"] += members[:n_train]
+            parts["test"] += members[-n_test:]
+            parts["val"] += members[n_train:-n_test]
+        pick = lambda idx: [data[i] for i in idx]   # noqa: E731
+        self.build(train_data=pick(parts["train"]), test_data=pick(parts["test"]),
+                   val_data=pick(parts["val"]) if parts["val"] else None)
+
+
+class CVResult(list):
+    """the per-fold Results of one model + their mean / standard deviation per metric (result.py:79-116)"""
+
+    def __init__(self, model_name):
+        super().__init__()
+        self.model_name = model_name
+        self.metric_mean, self.metric_std = OrderedDict(), OrderedDict()
+        self.table = ""
+
+    def organize(self):
+        headers = list(self[0].metric_avg_results.keys())
+        values = np.asarray([[r.metric_avg_results[h] for h in headers] for r in self], dtype=float)
+        for h, mean, std in zip(headers, values.mean(axis=0), values.std(axis=0)):
+            self.metric_mean[h], self.metric_std[h] = mean, std
+        rows = [Result("Fold %d" % f, r.metric_avg_results, None) for f, r in enumerate(self)]
+        rows += [Result("Mean", self.metric_mean, None), Result("Std", self.metric_std, None)]
+        self.table = format_table(rows)
+
+    def __str__(self):
+        return "[{}]\n{}".format(self.model_name, self.table)
+
+
+class CrossValidation(BaseMethod):
+    """n-fold cross validation (cornac/eval_methods/cross_validation.py:25-143): the fold label of every rating is
+    drawn once (`rng.shuffle` of equal-sized labels + `rng.choice` for the remainder) or given as `partition`; every
+    fold trains a `clone()` of the model on the other folds"""
+
+    def __init__(self, data, n_folds=5, rating_threshold=1.0, partition=None, seed=None, exclude_unknowns=True,
+                 verbose=False, **kwargs):
+        super().__init__(data=data, rating_threshold=rating_threshold, seed=seed, exclude_unknowns=exclude_unknowns,
+                         verbose=verbose, **kwargs)
+        self.n_folds, self.n_ratings, self.current_fold = n_folds, len(self.data), 0
+        if partition is None:
+            per_fold = self.n_ratings // n_folds
+            partition = np.repeat(np.arange(n_folds), per_fold)
+            self.rng.shuffle(partition)
+            rest = self.n_ratings - per_fold * n_folds
+            if rest > 0:
+                partition = np.concatenate((partition, self.rng.choice(n_folds, size=rest, replace=True, p=None)))
+        elif len(partition) != self.n_ratings:
+            raise ValueError("The partition length must be equal to the number of ratings")
+        elif len(set(partition)) != n_folds:
+            raise ValueError("Number of folds in given partition different from %s" % n_folds)
+        self._partition = np.asarray(partition)
+
+    def _get_train_test(self):
+        if self.verbose:
+            print("Fold: {}".format(self.current_fold + 1))
+        held_out = self._partition == self.current_fold
+        train = [self.data[i] for i in np.flatnonzero(~held_out)]
+        test = [self.data[i] for i in np.flatnonzero(held_out)]
+        self.build(train_data=train, test_data=test, val_data=test)
+
+    def evaluate(self, model, metrics, user_based, show_validation=False):
+        result = CVResult(model.name)
+        for _ in range(self.n_folds):
+            self._get_train_test()
+            fold_result, _ = BaseMethod.evaluate(self, model.clone(), metrics, user_based, show_validation=False)
+            result.append(fold_result)
+            self.current_fold = (self.current_fold + 1) % self.n_folds
+        result.organize()
+        return result, None
+
+
 class Experiment:
     """fit and evaluate every model with one evaluation method; `.result` / `.val_result` hold the Result rows"""
 
@@ -224,6 +325,10 @@ class Experiment:
         output = ""
         if self.val_result:
             output += "\nVALIDATION:\n...\n" + format_table(self.val_result)
-        output += "\nTEST:\n...\n" + format_table(self.result)
+        if self.result and isinstance(self.result[0], CVResult):   # one table of folds per model, then the means
+            output += "\nTEST:\n...\n" + "\n".join(str(r) for r in self.result)
+            output += "\n" + format_table([Result(r.model_name, r.metric_mean, None) for r in self.result])
+        else:
+            output += "\nTEST:\n...\n" + format_table(self.result)
         print(output)
         return self

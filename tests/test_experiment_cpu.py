@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from cornac_amd import BaseMethod, Experiment, RatioSplit
+from cornac_amd import BaseMethod, CrossValidation, Experiment, RatioSplit, StratifiedSplit
 from cornac_amd import metrics as mm
 
 
@@ -27,6 +27,9 @@ class TableModel:
 
     def transform(self, test_set):
         pass
+
+    def clone(self, new_params=None):
+        return TableModel(self.seed)
 
     def score(self, user_idx, item_idx=None):
         return self.S[user_idx] if item_idx is None else self.S[user_idx, item_idx]
@@ -128,3 +131,75 @@ def test_split_and_evaluation_match_the_reference_classes():
                     if "(s)" not in name:
                         assert m.metric_avg_results[name] == pytest.approx(v, rel=1e-9), (kw, name)
                         assert r.metric_user_results[name].keys() == m.metric_user_results[name].keys()
+
+
+def _uirt(n_users=30, n_items=25, n=500, seed=4):
+    rs = np.random.RandomState(seed)
+    keys = rs.permutation(n_users * n_items)[:n]
+    return [("u%d" % (k // n_items), "i%d" % (k % n_items), float(rs.randint(1, 6)), int(rs.randint(0, 10000))) for k in keys]
+
+
+def test_cross_validation_and_stratified_split_on_their_own(capsys):
+    data = _grid()
+    cv = CrossValidation(data, n_folds=4, rating_threshold=3.0, seed=2)
+    assert np.bincount(cv._partition).tolist() == [27, 27, 27, 27]
+    res, none = cv.evaluate(TableModel(), [mm.MAE(), mm.Recall(k=3)], user_based=True)
+    assert none is None and len(res) == 4 and set(res.metric_mean) == {"MAE", "Recall@3", "Train (s)", "Test (s)"}
+    assert res.metric_mean["MAE"] == pytest.approx(np.mean([r.metric_avg_results["MAE"] for r in res]))
+    assert "Fold 3" in str(res) and "Mean" in str(res) and "Std" in str(res)
+    with pytest.raises(ValueError):
+        CrossValidation(data, n_folds=4, partition=[0, 1, 2])
+    with pytest.raises(ValueError):
+        CrossValidation(data, n_folds=4, partition=np.zeros(len(data), int))
+    Experiment(CrossValidation(data, n_folds=3, seed=1), [TableModel()], [mm.RMSE()]).run()
+    assert "Fold 2" in capsys.readouterr().out
+    uirt = _uirt()
+    st = StratifiedSplit(uirt, group_by="user", chrono=True, test_size=0.25, seed=6, exclude_unknowns=False)
+    newest_train = {}
+    for u, t in zip(st.train_set.uir_tuple[0], st.train_set.timestamps):
+        newest_train[u] = max(newest_train.get(u, -1), t)
+    for u, t in zip(st.test_set.uir_tuple[0], st.test_set.timestamps):     # held-out ratings are the user's newest
+        assert t >= newest_train[u]
+    with pytest.raises(ValueError):
+        StratifiedSplit(uirt, group_by="basket")
+    with pytest.raises(ValueError):
+        StratifiedSplit(_grid(), chrono=True, fmt="UIR")
+
+
+def test_cross_validation_and_stratified_split_match_the_reference_classes():
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ns = ref_loader.load()
+    import importlib
+
+    RefCV = importlib.import_module("cornac.eval_methods").CrossValidation
+    RefStrat = importlib.import_module("cornac.eval_methods").StratifiedSplit
+    rm = ns.metrics
+    data = _grid()
+    for n_folds, seed in ((5, 3), (4, 8), (7, 1)):
+        ref, mine = RefCV(data, n_folds=n_folds, rating_threshold=3.0, seed=seed), \
+            CrossValidation(data, n_folds=n_folds, rating_threshold=3.0, seed=seed)
+        assert np.array_equal(ref._partition, mine._partition)
+        r, _ = ref.evaluate(TableModel(2), [rm.MAE(), rm.Recall(k=3), rm.AUC()], user_based=True, show_validation=False)
+        m, _ = mine.evaluate(TableModel(2), [mm.MAE(), mm.Recall(k=3), mm.AUC()], user_based=True)
+        assert len(r) == len(m) == n_folds
+        for name in ("MAE", "Recall@3", "AUC"):
+            assert m.metric_mean[name] == pytest.approx(r.metric_mean[name], rel=1e-9)
+            assert m.metric_std[name] == pytest.approx(r.metric_std[name], rel=1e-9, abs=1e-15)
+            for fr, fm in zip(r, m):
+                assert fm.metric_avg_results[name] == pytest.approx(fr.metric_avg_results[name], rel=1e-9)
+    uirt = _uirt()
+    for kw in (dict(group_by="user", chrono=True, test_size=0.2, seed=3), dict(group_by="item", chrono=False, test_size=0.3, seed=5),
+               dict(group_by="user", chrono=True, test_size=0.2, val_size=0.1, seed=7, exclude_unknowns=False),
+               dict(group_by="item", chrono=True, test_size=2, seed=2)):
+        ref, mine = RefStrat(uirt, **kw), StratifiedSplit(uirt, **kw)
+        for part in ("train_set", "test_set", "val_set"):
+            a, b = getattr(ref, part), getattr(mine, part)
+            assert (a is None) == (b is None)
+            if a is not None:
+                for x, y in zip(a.uir_tuple, b.uir_tuple):
+                    assert np.array_equal(x, y)
+                assert np.array_equal(a.timestamps, b.timestamps)
+                assert list(a.uid_map.items()) == list(b.uid_map.items())
