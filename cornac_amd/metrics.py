@@ -270,6 +270,7 @@ class MAP(RankingMetric):
 class _RatingMetric:
     """rating metrics take optional per-rating weights like the reference's (cornac/metrics/rating.py:40-140)"""
     type = "rating"
+    higher_better = False
 
     @staticmethod
     def _diff(gt_ratings, pd_ratings):

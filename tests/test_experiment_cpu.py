@@ -20,7 +20,8 @@ class TableModel:
 
     def fit(self, train_set, val_set=None):
         self.num_users, self.num_items = train_set.num_users, train_set.num_items
-        self.total_items = len(train_set.iid_map)
+        if not isinstance(getattr(type(self), "total_items", None), property):   # a property on the reference's base class
+            self.total_items = len(train_set.iid_map)
         self.min_rating, self.max_rating = train_set.min_rating, train_set.max_rating
         self.S = np.random.RandomState(self.seed).uniform(0.5, 5.5, (train_set.num_users, train_set.num_items))
         return self
