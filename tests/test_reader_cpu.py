@@ -1,7 +1,6 @@
 """cornac_amd.Reader: the reference's text formats for this path (UI / UIR / UIRT) and its filters."""
 import os
 
-import numpy as np
 import pytest
 
 from cornac_amd import Dataset, Reader

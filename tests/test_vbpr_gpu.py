@@ -3,8 +3,6 @@ import numpy as np
 import pytest
 
 from cornac_amd import VBPR, _lib
-from cornac_amd.data import Dataset, ImageFeatures
-from conftest import load_golden
 from test_oracle_golden import _vbpr_case
 
 pytestmark = pytest.mark.gpu
