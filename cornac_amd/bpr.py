@@ -136,8 +136,8 @@ class BPR(Recommender):
     def _scoring_tables(self):
         return self.u_factors, self.i_factors, self.i_biases, None
 
-    def _scorer_row(self, user_idx):
-        return int(user_idx) if user_idx is not None and 0 <= user_idx < len(self.u_factors) else None
+    def _scorer_row_count(self):
+        return len(self.u_factors)
 
     def score(self, user_idx, item_idx=None):
         """recom_bpr.pyx:272-297: scores over len(i_biases) items, or one scalar."""
@@ -256,8 +256,8 @@ class VEBPR(Recommender):
     def _scoring_tables(self):
         return self.u_factor, self.i_factor, None, None
 
-    def _scorer_row(self, user_idx):
-        return int(user_idx) if user_idx is not None and 0 <= user_idx < len(self.u_factor) else None
+    def _scorer_row_count(self):
+        return len(self.u_factor)
 
     def score(self, user_idx, item_idx=None):
         if item_idx is None:

@@ -27,12 +27,20 @@ def _pos_items(csr, user_idx, threshold):
 
 
 def _bool_csr(mat, threshold, shape):
-    """entries >= threshold of a CSR matrix as a boolean CSR of the given (larger or equal) shape"""
+    """entries >= threshold of a CSR matrix as a boolean CSR of the given (larger or equal) shape — filtered in
+    place of the stored order (row pointers from a running count of the kept entries), no COO round trip"""
     from scipy.sparse import csr_matrix
 
+    if not mat.has_sorted_indices:
+        mat = mat.sorted_indices()
     keep = mat.data >= threshold
-    rows = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr))[keep]
-    return csr_matrix((np.ones(int(keep.sum()), dtype=bool), (rows, mat.indices[keep])), shape=shape)
+    kept_before = np.concatenate(([0], np.cumsum(keep, dtype=np.int64)))
+    indptr = np.empty(shape[0] + 1, dtype=np.int64)
+    indptr[: mat.shape[0] + 1] = kept_before[mat.indptr]
+    indptr[mat.shape[0] + 1:] = indptr[mat.shape[0]]
+    out = csr_matrix((np.ones(int(kept_before[-1]), dtype=bool), mat.indices[keep], indptr), shape=shape)
+    out.has_sorted_indices = True
+    return out
 
 
 def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):

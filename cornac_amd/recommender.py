@@ -195,7 +195,7 @@ class Recommender:
         u = np.asarray(user_indices, dtype=np.int64)
         i = np.asarray(item_indices, dtype=np.int64)
         sc = self._get_scorer()
-        rows = np.array([-1 if (r := self._scorer_row(int(x))) is None else r for x in u], dtype=np.int64)
+        rows = self._scorer_rows(u)
         known = (rows >= 0) & (i >= 0) & (i < sc.n_items) & (i < self.num_items)
         out = np.full(len(u), float(self.default_score()), dtype=np.float64)
         if clipping:
@@ -274,8 +274,8 @@ class Recommender:
         exclude: optional CSR `(indptr int64[n+1], indices int32)` of items to drop per listed user
         (e.g. training positives).  Returns `(items [n, k] int32, scores [n, k] float32)`, padded
         with (-1, -inf) when a user has fewer than k candidates."""
-        rows = np.asarray([self._scorer_row(int(u)) for u in user_indices])
-        if (rows == None).any():  # noqa: E711
+        rows = self._scorer_rows(user_indices)
+        if (rows < 0).any():
             raise ScoreException("rank_batch needs users known to the model")
         sc = self._get_scorer()
         topk = sc.n_items if k == -1 else min(int(k), sc.n_items)
@@ -286,14 +286,23 @@ class Recommender:
         `exclude` are CSR `(indptr int64[n+1], indices int32)` per listed user (test positives / training
         positives in `ranking_eval`).  Returns per target `(greater, pos, ge, score)` — candidates scored strictly
         higher, 0-based position in the order `rank()` gives, candidates scored at least as high, its score."""
-        rows = np.asarray([self._scorer_row(int(u)) for u in user_indices])
-        if (rows == None).any():  # noqa: E711
+        rows = self._scorer_rows(user_indices)
+        if (rows < 0).any():
             raise ScoreException("rank_positions_batch needs users known to the model")
         return self._get_scorer().rank_positions(rows.astype(np.int32), targets, exclude=exclude)
 
+    def _scorer_row_count(self):
+        """users 0 .. count-1 are rows of the device user table (models trained over `total_users` override this)"""
+        return self.num_users
+
     def _scorer_row(self, user_idx):
         """Row of the device user table for user_idx, or None if its score is not table-driven."""
-        return int(user_idx) if self.knows_user(user_idx) else None
+        return int(user_idx) if user_idx is not None and 0 <= user_idx < self._scorer_row_count() else None
+
+    def _scorer_rows(self, user_indices):
+        """`_scorer_row` for an array of users: int64 rows, -1 where there is none"""
+        u = np.asarray(user_indices, dtype=np.int64)
+        return np.where((u >= 0) & (u < self._scorer_row_count()), u, -1)
 
     def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
         """Top-k raw item ids for a raw user id (recommender.py:532-580)."""

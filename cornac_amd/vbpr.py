@@ -90,8 +90,8 @@ class VBPR(Recommender):
             self._cat_src = self.gamma_user
         return self._cat_u, self._cat_i, self._cat_b, None
 
-    def _scorer_row(self, user_idx):
-        return int(user_idx) if user_idx is not None and 0 <= user_idx < len(self.gamma_user) else None
+    def _scorer_row_count(self):
+        return len(self.gamma_user)
 
     def score(self, user_idx, item_idx=None):
         if item_idx is None:
