@@ -331,4 +331,12 @@ class Experiment:
         else:
             output += "\nTEST:\n...\n" + format_table(self.result)
         print(output)
+        if self.save_dir is not None:   # the report next to the saved models (experiment.py:160-167; the reference also
+            import os                   # writes it to the working directory when no save_dir is given — not done here)
+            from datetime import datetime
+
+            os.makedirs(self.save_dir, exist_ok=True)
+            name = "CornacExp-{}.log".format(datetime.now().strftime("%Y-%m-%d_%H-%M-%S-%f"))
+            with open(os.path.join(self.save_dir, name), "w") as f:
+                f.write(output)
         return self

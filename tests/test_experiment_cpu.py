@@ -2,6 +2,7 @@
 (tests/cornac/eval_methods/test_ratio_split.py:31-104, test_base_method.py) and a live comparison with the reference's
 classes where /root/reference is present.  Host stand-in models only — no GPU."""
 import itertools
+import os
 import random
 
 import numpy as np
@@ -78,7 +79,7 @@ def test_split_sizes_and_reproducibility():
         RatioSplit([("a", "x", 1.0), ("b", "y", 2.0), ("c", "z", 3.0)], test_size=1, seed=1)
 
 
-def test_evaluate_and_experiment_run(capsys):
+def test_evaluate_and_experiment_run(capsys, tmp_path):
     method = RatioSplit(_grid(), test_size=0.2, val_size=0.1, rating_threshold=3.0, seed=7, exclude_unknowns=True)
     metrics = [mm.MAE(), mm.RMSE(), mm.Recall(k=[3, 5]), mm.NDCG(k=-1), mm.AUC()]
     test_res, val_res = method.evaluate(TableModel(), metrics, user_based=True)
@@ -90,6 +91,13 @@ def test_evaluate_and_experiment_run(capsys):
     out = capsys.readouterr().out
     assert "TEST:" in out and "VALIDATION:" in out and out.count("table") == 4
     assert len(exp.result) == 2 and exp.result[0].metric_avg_results["MAE"] != exp.result[1].metric_avg_results["MAE"]
+    class Saveable(TableModel):
+        def save(self, save_dir):
+            open(os.path.join(save_dir, "saved_%d" % self.seed), "w").close()
+
+    Experiment(method, [Saveable(5)], [mm.MAE()], save_dir=str(tmp_path / "out")).run()
+    written = sorted(os.listdir(str(tmp_path / "out")))
+    assert written[0].startswith("CornacExp-") and written[0].endswith(".log") and written[1] == "saved_5"
     fs = BaseMethod.from_splits(_grid()[:80], _grid()[80:], rating_threshold=3.0, exclude_unknowns=True, seed=3)
     res, none = fs.evaluate(TableModel(), [mm.Precision(k=2)], user_based=True)
     assert none is None and "Precision@2" in res.metric_avg_results
