@@ -313,6 +313,10 @@ class Experiment:
 
     def run(self):
         self.result, self.val_result = [], []
+        if self.save_dir is not None:
+            import os
+
+            os.makedirs(self.save_dir, exist_ok=True)
         for model in self.models:
             test_result, val_result = self.eval_method.evaluate(model=model, metrics=self.metrics,
                                                                 user_based=self.user_based,
@@ -332,10 +336,8 @@ class Experiment:
             output += "\nTEST:\n...\n" + format_table(self.result)
         print(output)
         if self.save_dir is not None:   # the report next to the saved models (experiment.py:160-167; the reference also
-            import os                   # writes it to the working directory when no save_dir is given — not done here)
-            from datetime import datetime
+            from datetime import datetime   # writes it to the working directory when no save_dir is given — not done here)
 
-            os.makedirs(self.save_dir, exist_ok=True)
             name = "CornacExp-{}.log".format(datetime.now().strftime("%Y-%m-%d_%H-%M-%S-%f"))
             with open(os.path.join(self.save_dir, name), "w") as f:
                 f.write(output)
