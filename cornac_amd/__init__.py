@@ -5,7 +5,7 @@ reference's `Recommender.fit/score/rank/recommend/save/load/clone` interface), `
 All compute runs in libcornac_hip.so (hand-written HIP for gfx950, C ABI in include/cornac_hip.h);
 there is no CPU fallback.
 """
-from .data import Dataset, PurchaseViewDataset
+from .data import Dataset, FeatureModality, ImageModality, PurchaseViewDataset
 from .reader import Reader
 from .recommender import Recommender, ScoreException
 from .bpr import BPR, WBPR, VEBPR
@@ -15,5 +15,5 @@ from .wmf import WMF
 from .experiment import BaseMethod, CrossValidation, CVResult, Experiment, RatioSplit, Result, StratifiedSplit
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "RatioSplit", "StratifiedSplit", "CrossValidation", "CVResult", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "FeatureModality", "ImageModality", "RatioSplit", "StratifiedSplit", "CrossValidation", "CVResult", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
 __version__ = "0.1.0"

@@ -268,11 +268,71 @@ class Dataset:
             yield batch_users, batch_pos_items, batch_neg_items
 
 
-class ImageFeatures:
-    """Minimal stand-in for cornac.data.ImageModality: item visual features [n_items, d]."""
+class FeatureModality:
+    """Per-user / per-item feature rows (cornac/data/modality.py:41-113): `features` [n, d] aligned with the raw ids
+    `ids`; `build(id_map)` moves each known id's row to its mapped index (rows of unknown ids stay where they were)
+    and, if `normalized`, min-max scales the whole matrix — the order the reference does it in."""
+
+    def __init__(self, features=None, ids=None, normalized=False, **kwargs):
+        self.features = features
+        self.ids = ids
+        self.normalized = normalized
+
+    @property
+    def features(self):
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        if value is not None:
+            assert len(value.shape) == 2
+        self._features = value
+
+    @property
+    def feature_dim(self):
+        return self.features.shape[1]
+
+    def build(self, id_map=None, **kwargs):
+        if self.features is None:
+            return
+        if self.ids is not None and id_map is not None:
+            placed = [(id_map.get(raw), old) for old, raw in enumerate(self.ids)]
+            new_rows = np.array([n for n, _ in placed if n is not None], dtype=np.int64)
+            old_rows = np.array([o for n, o in placed if n is not None], dtype=np.int64)
+            assert len(new_rows) == 0 or new_rows.max() < self.features.shape[0]
+            moved, ids = np.copy(self.features), list(self.ids)
+            moved[new_rows] = self.features[old_rows]
+            for n, o in zip(new_rows.tolist(), old_rows.tolist()):
+                ids[n] = self.ids[o]
+            self.features, self.ids = moved, ids
+        if self.normalized:
+            self.features = self.features - np.min(self.features)
+            self.features = self.features / (np.max(self.features) + 1e-10)
+        return self
+
+    def batch_feature(self, batch_ids):
+        assert self.features is not None
+        return self.features[batch_ids]
+
+
+class ImageModality(FeatureModality):
+    """item (or user) visual features, optionally with the raw images / their paths (cornac/data/image.py:20-83);
+    VBPR reads `train_set.item_image.features`"""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.images = kwargs.get("images", None)
+        self.paths = kwargs.get("paths", None)
+
+    def batch_image(self, batch_ids, target_size=(256, 256), color_mode="rgb", interpolation="nearest"):
+        raise NotImplementedError
+
+
+class ImageFeatures(ImageModality):
+    """features already in item-index order: `ImageFeatures(F)` == `ImageModality(features=F)`"""
 
     def __init__(self, features):
-        self.features = np.asarray(features)
+        super().__init__(features=np.asarray(features))
 
 
 class _RangeMap:

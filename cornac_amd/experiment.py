@@ -107,9 +107,12 @@ class BaseMethod:
         self.val_set = None
         if val_data is not None and len(val_data) > 0:
             self.val_set = Dataset.build(val_data, exclude_unknowns=self.exclude_unknowns, **maps)
-        for ds in (self.train_set, self.test_set, self.val_set):
-            if ds is not None and self.item_image is not None:
-                ds.item_image = self.item_image
+        if self.item_image is not None:
+            if hasattr(self.item_image, "build"):   # rows into global item-index order (base_method.py:555-606)
+                self.item_image.build(id_map=self.global_iid_map)
+            for ds in (self.train_set, self.test_set, self.val_set):
+                if ds is not None:
+                    ds.item_image = self.item_image
         if self.verbose:
             print("---\nTraining data:\nNumber of users = {}\nNumber of items = {}\nNumber of ratings = {}".format(
                 self.train_set.num_users, self.train_set.num_items, self.train_set.num_ratings))

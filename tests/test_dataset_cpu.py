@@ -103,3 +103,51 @@ def test_dataset_matches_the_reference_dataset_draw_for_draw():
                 assert tuple(list(map(float, col)) for col in r[k]) == tuple(list(map(float, col)) for col in m[k]), (name, k)
         if with_time:
             assert np.array_equal(ref.timestamps, mine.timestamps)
+
+
+def test_image_modality_build_places_rows_by_the_global_item_map():
+    from collections import OrderedDict
+
+    from cornac_amd import ImageModality, RatioSplit
+
+    rs = np.random.RandomState(4)
+    ids = ["i%d" % j for j in rs.permutation(18)]
+    F = rs.uniform(-2, 5, (18, 6)).astype(np.float32)
+    id_map = OrderedDict(("i%d" % j, n) for n, j in enumerate(rs.permutation(18)[:12]))     # 12 of the 18 items are known
+    mod = ImageModality(features=F.copy(), ids=list(ids), normalized=True).build(id_map=id_map)
+    lo, hi = F.min(), F.max()
+    for raw, new in id_map.items():
+        want = (F[ids.index(raw)] - lo) / ((hi - lo) + 1e-10)
+        assert np.allclose(mod.features[new], want, rtol=1e-6) and mod.ids[new] == raw
+    assert mod.feature_dim == 6 and mod.batch_feature([0, 3]).shape == (2, 6)
+    # through the evaluation method: every dataset of the split carries the built modality
+    data = _tuples()
+    item_ids = sorted({t[1] for t in data})
+    feats = rs.normal(size=(len(item_ids), 4)).astype(np.float32)
+    split = RatioSplit(data, test_size=0.2, seed=1, item_image=ImageModality(features=feats.copy(), ids=item_ids))
+    assert split.test_set.item_image is split.train_set.item_image
+    for raw, idx in split.train_set.iid_map.items():
+        assert np.array_equal(split.train_set.item_image.features[idx], feats[item_ids.index(raw)])
+
+
+def test_image_modality_matches_the_reference_modality():
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ref_loader.load()
+    import importlib
+    from collections import OrderedDict
+
+    from cornac_amd import ImageModality
+
+    RefImage = importlib.import_module("cornac.data").ImageModality
+    rs = np.random.RandomState(7)
+    for normalized, n_known in ((True, 9), (False, 14), (True, 14)):
+        ids = ["x%d" % j for j in rs.permutation(14)]
+        F = rs.uniform(-1, 3, (14, 5)).astype(np.float32)
+        id_map = OrderedDict(("x%d" % j, n) for n, j in enumerate(rs.permutation(14)[:n_known]))
+        ref = RefImage(features=F.copy(), ids=list(ids), normalized=normalized).build(id_map=id_map)
+        mine = ImageModality(features=F.copy(), ids=list(ids), normalized=normalized).build(id_map=id_map)
+        assert np.array_equal(ref.features, mine.features) and ref.features.dtype == mine.features.dtype
+        assert list(ref.ids) == list(mine.ids)
