@@ -191,18 +191,18 @@ class Recommender:
     def rate_batch(self, user_indices, item_indices, clipping=True):
         """Batched rate(): predictions for many (user, item) pairs in one kernel — what
         `rating_eval` (cornac/eval_methods/base_method.py:35-105) computes one Python call at a
-        time.  Unknown users/items get `default_score()` like rate() does after a ScoreException."""
+        time.  Pairs with an unknown user or item go through `rate()` itself."""
         u = np.asarray(user_indices, dtype=np.int64)
         i = np.asarray(item_indices, dtype=np.int64)
         sc = self._get_scorer()
         rows = self._scorer_rows(u)
         known = (rows >= 0) & (i >= 0) & (i < sc.n_items) & (i < self.num_items)
-        out = np.full(len(u), float(self.default_score()), dtype=np.float64)
-        if clipping:
-            out = np.clip(out, self.min_rating, self.max_rating)
+        out = np.empty(len(u), dtype=np.float64)
         if known.any():
             clip_rng = (self.min_rating, self.max_rating) if clipping else None
             out[known] = sc.score_pairs(rows[known], i[known], clip=clip_rng)
+        for p in np.flatnonzero(~known):   # pairs outside the device tables keep the model's own rule (e.g. MF scores an
+            out[p] = self.rate(int(u[p]), int(i[p]), clipping)   # unknown user with the item's bias, recom_mf.py:281-286)
         return out
 
     # device scorer -------------------------------------------------------------------------------

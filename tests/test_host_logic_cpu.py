@@ -1,0 +1,160 @@
+"""Host logic of the model classes on the CPU, with the device layer replaced by the oracle-backed doubles of
+tests/fake_device.py: what `BPR / WBPR / MF .fit()` hand to the device (initial factors, the derived mt19937 seeds and
+their order, mode selection) reproduces the REAL reference's learned parameters (golden vectors made by the compiled
+reference, tests/golden/), and the Recommender / evaluation / experiment layers behave like the reference's around
+those parameters.  The HIP kernels themselves are covered by the `-m gpu` tests through the real C ABI."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+
+import fake_device
+from conftest import golden_dataset, load_golden
+from test_oracle_golden import CASES, _kw, assert_close
+
+
+@pytest.fixture()
+def device_double(monkeypatch):
+    fake_device.install(monkeypatch)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_seeded_fit_through_the_host_classes_reproduces_the_reference_goldens(device_double, name):
+    from cornac_amd import BPR, MF, WBPR
+
+    fx = load_golden(name)
+    ds = golden_dataset(fx)
+    for use_bias, sfx in ((True, ""), (False, "_nobias")):
+        m = BPR(use_bias=use_bias, **_kw(fx)).fit(ds)
+        assert m.effective_mode == "deterministic"
+        for attr, key in (("u_factors", "_U"), ("i_factors", "_V"), ("i_biases", "_B")):
+            assert_close(getattr(m, attr), fx["bpr" + sfx + key])
+    w = WBPR(**_kw(fx)).fit(ds)
+    for attr, key in (("u_factors", "wbpr_U"), ("i_factors", "wbpr_V"), ("i_biases", "wbpr_B")):
+        assert_close(getattr(w, attr), fx[key])
+    kw = _kw(fx)
+    kw["lambda_reg"] *= 2
+    mf = MF(use_bias=True, **kw).fit(ds)
+    for attr, key in (("u_factors", "mf_U"), ("i_factors", "mf_V"), ("u_biases", "mf_Bu"), ("i_biases", "mf_Bi")):
+        assert_close(getattr(mf, attr), fx[key])
+    assert abs(float(mf.global_mean) - float(fx["mf_mu"])) < 1e-7
+    mf = MF(use_bias=False, **kw).fit(ds)
+    assert_close(mf.u_factors, fx["mf_nobias_U"])
+    assert_close(mf.i_factors, fx["mf_nobias_V"])
+
+
+def test_mode_selection_seed_protocol_and_warm_start(device_double):
+    from cornac_amd import BPR, _lib
+
+    fx = load_golden("small")
+    ds = golden_dataset(fx)
+    seen = []
+    real = fake_device.FakeBprTrainer.fit_epochs
+
+    def spy(self, n, lr, reg, use_bias, neg, mode, flags=0):
+        seen.append((mode, list(self.calls)))
+        return real(self, n, lr, reg, use_bias, neg, mode, flags)
+
+    fake_device.FakeBprTrainer.fit_epochs = spy
+    try:
+        m = BPR(k=4, max_iter=2, seed=5).fit(ds)
+        assert seen[-1][0] == _lib.MODE_DETERMINISTIC and seen[-1][1][0][0] == "mt19937"
+        # recom_bpr.pyx:190-191 + :55-59: two draws from the model's generator AFTER the factor init, each turned into
+        # thread 0's engine seed by RandomState(draw).randint(2**31)
+        rng = np.random.RandomState(5)
+        rng.uniform(0, 1, (len(ds.uid_map), 4))
+        rng.uniform(0, 1, (len(ds.iid_map), 4))
+        want = [int(np.random.RandomState(rng.randint(2 ** 31)).randint(2 ** 31)) for _ in range(2)]
+        assert list(seen[-1][1][0][1:3]) == want and seen[-1][1][0][3] is False
+        h = BPR(k=4, max_iter=2).fit(ds)               # no seed -> throughput mode
+        assert seen[-1][0] == _lib.MODE_HOGWILD and seen[-1][1][0][0] == "hogwild" and np.isfinite(h.u_factors).all()
+        assert BPR(k=4, max_iter=1, seed=5, mode="hogwild").fit(ds).effective_mode == "hogwild"
+        # a second fit() continues from the trained factors and the advanced generator (the reference's warm start)
+        first = m.u_factors.copy()
+        with pytest.warns(UserWarning):
+            m.fit(ds)
+        assert not np.array_equal(first, m.u_factors) and len(seen[-1][1]) == 1
+        fresh = m.clone().fit(ds)
+        assert np.array_equal(fresh.u_factors, first)
+        fixed = BPR(k=4, max_iter=3, seed=5, trainable=False, init_params={"U": first.copy()}).fit(ds)
+        assert np.array_equal(fixed.u_factors, first)   # trainable=False: nothing is sent to the device
+        with pytest.raises(ValueError):
+            BPR(k=4, seed=1, init_params={"U": first.astype(np.float64)}).fit(ds)
+    finally:
+        fake_device.FakeBprTrainer.fit_epochs = real
+
+
+def test_recommender_surface_around_fitted_parameters(device_double, tmp_path):
+    from cornac_amd import MF, ScoreException
+
+    fx = load_golden("small")
+    ds = golden_dataset(fx)
+    m = MF(k=6, max_iter=5, seed=3).fit(ds)
+    s = m.score(2)
+    assert s.dtype == np.float32 and len(s) == ds.num_items and m.score(2, 4) == pytest.approx(float(s[4]), abs=1e-6)
+    with pytest.raises(ScoreException):
+        m.score(2, ds.num_items + 3)
+    cand = np.arange(3, 30)
+    ranked, scores = m.rank(2, item_indices=cand, k=5)
+    assert np.array_equal(scores, s[cand]) and list(ranked) == list(cand[np.argsort(s[cand], kind="stable")[::-1]][:5])
+    full, _ = m.rank(2)
+    assert sorted(full.tolist()) == list(range(ds.num_items)) and np.all(np.diff(s[full]) <= 0)
+    assert ds.min_rating <= m.rate(2, 4) <= ds.max_rating
+    # recom_mf.py:281-286: an unknown user still gets the item's bias; an unknown item is a ScoreException -> global mean
+    assert m.rate(ds.num_users + 1, 0) == pytest.approx(ds.global_mean + m.i_biases[0], abs=1e-6)
+    assert m.rate(2, ds.num_items + 5) == pytest.approx(ds.global_mean)
+    pairs_u, pairs_i = np.array([0, 2, 2, ds.num_users + 4]), np.array([1, 4, ds.num_items + 2, 0])
+    got = m.rate_batch(pairs_u, pairs_i)
+    want = [float(m.rate(int(u), int(i))) for u, i in zip(pairs_u, pairs_i)]
+    assert np.allclose(got, want, atol=1e-6)
+    uid = ds.user_ids[2]
+    seen_items = {ds.item_ids[i] for i in ds.matrix[2].indices}
+    assert not seen_items & set(m.recommend(uid, k=8, remove_seen=True, train_set=ds))
+    assert m.recommend(uid, k=3) == [ds.item_ids[i] for i in full[:3]]
+    with pytest.raises(ValueError):
+        m.recommend("nobody")
+    # persistence: the parameters travel, the device objects do not
+    again = pickle.loads(pickle.dumps(copy.deepcopy(m)))
+    assert np.array_equal(again.u_factors, m.u_factors) and np.array_equal(again.score(2), s)
+    loaded = MF.load(m.save(str(tmp_path)))
+    assert np.array_equal(loaded.rank(2, k=7)[0], m.rank(2, k=7)[0])
+    c = m.clone({"k": 9})
+    assert c.k == 9 and c.max_iter == 5 and c.u_factors is None
+
+
+def test_first_example_flow_equals_the_reference_flow(device_double):
+    """examples/first_example.py end to end on the CPU: the reference's RatioSplit + Experiment over MF and BPR against
+    cornac_amd's with the device double — same splits, same learned parameters (to the oracle's ulp-level agreement
+    with the compiled reference), hence the same report"""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ns = ref_loader.load()
+    import importlib
+
+    from cornac_amd import BPR, MF, Experiment, RatioSplit
+    from cornac_amd import metrics as mm
+
+    RefExperiment = importlib.import_module("cornac.experiment").Experiment
+    rm = ns.metrics
+    rs = np.random.RandomState(12)
+    keys = rs.permutation(300 * 120)[:6000]
+    data = [("u%d" % (k // 120), "i%d" % (k % 120), float(rs.randint(1, 6))) for k in keys]
+    split_kw = dict(test_size=0.2, rating_threshold=4.0, seed=123)
+    mf_kw = dict(k=10, max_iter=25, learning_rate=0.01, lambda_reg=0.02, use_bias=True, seed=123)
+    bpr_kw = dict(k=10, max_iter=60, learning_rate=0.01, lambda_reg=0.01, seed=123)
+    ref = RefExperiment(ns.eval_methods.RatioSplit(data, **split_kw), [ns.MF(**mf_kw), ns.BPR(**bpr_kw)],
+                        [rm.MAE(), rm.RMSE(), rm.Recall(k=20), rm.Precision(k=20), rm.AUC(), rm.MAP()], user_based=True)
+    ref.run()
+    mine = Experiment(RatioSplit(data, **split_kw), [MF(**mf_kw), BPR(**bpr_kw)],
+                      [mm.MAE(), mm.RMSE(), mm.Recall(k=20), mm.Precision(k=20), mm.AUC(), mm.MAP()], user_based=True).run()
+    for r, m in zip(ref.result, mine.result):
+        assert r.model_name == m.model_name and list(r.metric_avg_results) == list(m.metric_avg_results)
+        for name, v in r.metric_avg_results.items():
+            if "(s)" not in name:   # rank-based values move by one swap when two scores differ in the last ulp
+                assert m.metric_avg_results[name] == pytest.approx(v, rel=2e-3, abs=2e-4), (r.model_name, name)
+    for ref_model, my_model in zip(ref.models, mine.models):
+        assert_close(my_model.u_factors, ref_model.u_factors)
+        assert_close(my_model.i_factors, ref_model.i_factors)
