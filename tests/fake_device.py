@@ -22,7 +22,8 @@ class FakeBprTrainer:
         self.calls = []
 
     def set_factors(self, U, V, B):
-        self.U, self.V, self.B = (np.array(x, dtype=np.float32, order="C") for x in (U, V, B))
+        self.U, self.V = (np.array(x, dtype=np.float32, order="C") for x in (U, V))
+        self.B = None if B is None else np.array(B, dtype=np.float32, order="C")
 
     def seed_mt19937(self, seed_pos, seed_neg, shared_stream=False):
         self.calls.append(("mt19937", int(seed_pos), int(seed_neg), bool(shared_stream)))
@@ -54,11 +55,33 @@ class FakeBprTrainer:
                                                       n_epochs, fast=False)
         return correct, skipped
 
+    # VEBPR (recom_vebpr.pyx): view CSR + a third stream
+    def set_views(self, view_indptr, view_indices):
+        self.v_indptr = np.ascontiguousarray(view_indptr, np.int32)
+        self.v_indices = np.ascontiguousarray(view_indices, np.int32)
+        if len(self.v_indices) == 0:
+            self.v_indices = np.zeros(1, np.int32)
+
+    def seed_view_stream(self, seed_view):
+        self.calls.append(("view", int(seed_view)))
+        self.gv = orc.MT19937(seed_view)
+
+    def fit_epochs_vebpr(self, n_epochs, lr, reg, alpha, mode=_lib.MODE_HOGWILD):
+        assert mode == _lib.MODE_DETERMINISTIC, "the double runs VEBPR's seeded path only"
+        correct = skipped = 0
+        for _ in range(n_epochs):
+            c, s = C.c_int64(), C.c_int64()
+            orc.lib().oracle_vebpr_epoch_seq(self.gp.ptr, self.gv.ptr, self.gn.ptr, len(self.user_ids), self.n_items,
+                                             self.user_ids, self.indices, self.indptr, self.v_indices, self.v_indptr,
+                                             self.U, self.V, self.k, lr, reg, alpha, C.byref(c), C.byref(s))
+            correct, skipped = correct + c.value, skipped + s.value
+        return correct, skipped
+
     def last_timing(self):
         return {}
 
     def get_factors(self):
-        return self.U.copy(), self.V.copy(), self.B.copy()
+        return self.U.copy(), self.V.copy(), None if self.B is None else self.B.copy()
 
     def close(self):
         pass
@@ -83,6 +106,24 @@ class FakeMfTrainer:
                                          lr, reg, float(mu), max_iter, threads, int(use_bias), int(early_stop),
                                          loss.ctypes.data)
         return loss[:epochs], epochs
+
+    def reset_optimizer(self):
+        self.steps = []
+
+    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True):
+        """the double re-runs the torch optimiser from the initial parameters over every batch seen so far (optimiser
+        state has no other home here); returns the last epoch's sum of squared errors like the device call"""
+        from oracle import mf_minibatch_oracle
+
+        if not self.steps:
+            self.start = (self.U.copy(), self.V.copy(), self.Bu.copy(), self.Bi.copy())
+        order = np.asarray(order)
+        batches = [order[b:b + batch_size] for b in range(0, len(order), batch_size)]
+        self.steps += batches
+        U, V, Bu, Bi, losses = mf_minibatch_oracle.fit(*self.start, mu, self.rid, self.cid, self.val, self.steps, optimizer,
+                                                       lr, reg, use_bias)
+        self.U, self.V, self.Bu, self.Bi = U, V, Bu, Bi
+        return float(np.sum(losses[-len(batches):]))
 
     def last_timing(self):
         return {}
@@ -152,9 +193,85 @@ class FakeScorer:
         return tuple(np.array(o, d) for o, d in zip(out, (np.int32, np.int32, np.int32, np.float32)))
 
 
+class FakeWmfTrainer:
+    def __init__(self, csc, k, device=0):
+        self.csc, self.k = csc, int(k)
+
+    def set_factors(self, U, V):
+        self.U0, self.V0 = np.array(U, np.float32), np.array(V, np.float32)
+        self.oracle = None
+
+    def fit_batches(self, batches, lambda_u, lambda_v, a, b, lr):
+        from oracle.wmf_oracle import WmfOracle
+
+        if self.oracle is None:   # Adam moments live in the oracle object across epochs, as they do on the device
+            self.oracle = WmfOracle(self.U0, self.V0, self.csc, lambda_u, lambda_v, a, b, lr)
+        return np.array(self.oracle.fit_batches(batches))
+
+    def get_factors(self):
+        return self.oracle.U.copy(), self.oracle.V.copy()
+
+    def close(self):
+        pass
+
+
+class FakeVbprTrainer:
+    """the reference's torch minibatch body (recom_vbpr.py:228-262, restated in oracle/vbpr_oracle.py) with the
+    optimiser state kept across calls, one call per epoch of batches like the device entry point"""
+    NAMES = _lib.VbprTrainer.NAMES
+
+    def __init__(self, features, n_users, n_items, k, k2, device=0):
+        import torch
+
+        self.F = torch.tensor(np.asarray(features, np.float32))
+        self.P, self.opt = None, None
+
+    def set_params(self, **params):
+        import torch
+
+        self.P = {n: torch.tensor(np.asarray(params[n], np.float32).reshape(-1, 1) if n == "Bp" else
+                                  np.asarray(params[n], np.float32), requires_grad=True) for n in self.NAMES}
+
+    def fit_batches(self, u, i, j, batch_size, lr, lambda_w, lambda_b, lambda_e):
+        import torch
+
+        P = self.P
+        if self.opt is None:
+            self.opt = torch.optim.Adam([P[n] for n in self.NAMES], lr=lr)
+        l2 = lambda *ts: sum(t.pow(2).sum() for t in ts) / 2   # noqa: E731
+        total = 0.0
+        for b in range(0, len(u), batch_size):
+            bu, bi, bj = (torch.as_tensor(np.asarray(x[b:b + batch_size], np.int64)) for x in (u, i, j))
+            gu, tu, gi, gj = P["Gu"][bu], P["Tu"][bu], P["Gi"][bi], P["Gi"][bj]
+            beta_i, beta_j = P["Bi"][bi], P["Bi"][bj]
+            fd = self.F[bi] - self.F[bj]
+            X = beta_i - beta_j + (gu * (gi - gj)).sum(dim=1) + (tu * fd.mm(P["E"])).sum(dim=1) + fd.mm(P["Bp"])
+            ll = torch.nn.functional.logsigmoid(X).sum()
+            reg = (l2(gu, gi, gj, tu) * lambda_w + l2(beta_i) * lambda_b + l2(beta_j) * lambda_b / 10
+                   + l2(P["E"], P["Bp"]) * lambda_e)
+            loss = -ll + reg
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            total += float(loss.data.item())
+        return total
+
+    def get_params(self):
+        return {n: self.P[n].data.numpy().copy().reshape(-1) if n == "Bp" else self.P[n].data.numpy().copy()
+                for n in self.NAMES}
+
+    def item_tables(self):
+        return self.F.mm(self.P["E"]).data.numpy(), self.F.mm(self.P["Bp"]).data.numpy().ravel()
+
+    def close(self):
+        pass
+
+
 def install(monkeypatch):
     """route the model classes' device calls to the doubles for the duration of one test"""
     orc.build()
     monkeypatch.setattr(_lib, "BprTrainer", FakeBprTrainer)
     monkeypatch.setattr(_lib, "MfTrainer", FakeMfTrainer)
+    monkeypatch.setattr(_lib, "WmfTrainer", FakeWmfTrainer)
+    monkeypatch.setattr(_lib, "VbprTrainer", FakeVbprTrainer)
     monkeypatch.setattr(_lib, "Scorer", FakeScorer)
