@@ -141,14 +141,13 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             key = rows * int(n_eval_items) + pos
             cum_end = np.searchsorted(key, rows * int(n_eval_items) + end, side="right") - starts[rows]
             runs = (rows, pos, end, cum_end, starts)
-            width = max(topk_k, max_k, 1)
-            hits = np.zeros((nb, width), bool)                    # what the @k metrics (and MRR over pd_rank[:max_k]) see
+            width = max(topk_k, 1)
+            hits = np.zeros((nb, width), bool)                    # what the @k metrics see
             head = pos < width
             hits[rows[head], pos[head]] = True
             for i, mt in enumerate(metrics):
                 if mt.k <= 0:
-                    vals = mt.compute_full_batch(hits, None, n_cand, n_gt, rank_len=max_k if max_k > 0 else None,
-                                                 runs=runs)
+                    vals = mt.compute_full_batch(hits, None, n_cand, n_gt, runs=runs)
                 elif getattr(mt, "name", "").startswith("NCRR"):
                     vals = mt.compute_batch(hits[:, :topk_k], n_gt, n_pred=n_cand)
                 else:
@@ -175,9 +174,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             runs = positive_runs(hits, scores, n_cand)
             for i, mt in enumerate(metrics):
                 if mt.k <= 0:
-                    # the per-user flow hands every metric pd_rank[:max_k] (base_method.py:208-210), full-list ones too
-                    vals = mt.compute_full_batch(hits, scores, n_cand, n_gt, rank_len=max_k if max_k > 0 else None,
-                                                 runs=runs)
+                    vals = mt.compute_full_batch(hits, scores, n_cand, n_gt, runs=runs)
                 elif getattr(mt, "name", "").startswith("NCRR"):
                     vals = mt.compute_batch(hits[:, :topk_k], n_gt, n_pred=n_cand)
                 else:
@@ -189,7 +186,11 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             user_idx, gp = int(user_idx), gt_of(r)
             item_indices = np.setdiff1d(all_items, ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
             gt_neg = np.setdiff1d(item_indices, gp)
-            rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=max_k)
+            # the reference asks for k = max_k (base_method.py:208-210), but its rank() returns ALL candidates with only
+            # the first max_k in order, and the metrics over the whole list (k = -1) read past them: hand those the
+            # exact full ranking, which agrees with the reference wherever its result does not hinge on that
+            # unspecified tail order
+            rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=-1 if need_full else max_k)
             for i, mt in enumerate(metrics):
                 user_results[i][user_idx] = mt.compute(gt_pos=gp, gt_neg=gt_neg, pd_rank=rank_, pd_scores=scores_,
                                                        item_indices=item_indices)

@@ -46,8 +46,7 @@ class TableModel:
         sc = self.S[user_idx]
         item_indices = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
         sc = sc[item_indices]
-        r = item_indices[np.argsort(sc, kind="stable")[::-1]]
-        return (r if k == -1 else r[:k]), sc
+        return item_indices[np.argsort(sc, kind="stable")[::-1]], sc   # every candidate, like Recommender.rank
 
 
 def _grid():

@@ -230,3 +230,48 @@ def test_vbpr_host_class_reproduces_the_reference_golden(device_double):
     ds.item_image = None
     with pytest.raises(CornacException):
         VBPR(verbose=False, **kw).fit(ds)
+
+
+@pytest.mark.parametrize("split_kw", [dict(test_size=0.2, val_size=0.1, rating_threshold=3.0, seed=5, exclude_unknowns=False),
+                                      dict(test_size=0.3, rating_threshold=1.0, seed=9, exclude_unknowns=True)])
+def test_experiment_reports_equal_the_reference_reports(device_double, split_kw):
+    """the reference's Experiment over MF / BPR / WBPR with ten metrics (rating, @k, full-list, mixed in one list — the
+    case where the reference asks rank() for max_k items but its metrics over the whole list read past them), test and
+    validation tables, unknown users / items kept or dropped, against cornac_amd's with the device double"""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ns = ref_loader.load()
+    import importlib
+
+    import cornac_amd
+    from cornac_amd import Experiment, RatioSplit
+    from cornac_amd import metrics as mm
+
+    RefExperiment = importlib.import_module("cornac.experiment").Experiment
+    rs = np.random.RandomState(3)
+    keys = rs.permutation(250 * 100)[:4000]
+    data = [("u%d" % (k // 100), "i%d" % (k % 100), float(rs.randint(1, 6))) for k in keys]
+
+    def models(N):
+        return [N.MF(k=8, max_iter=15, learning_rate=0.01, lambda_reg=0.02, use_bias=True, seed=1),
+                N.BPR(k=8, max_iter=30, learning_rate=0.01, lambda_reg=0.01, seed=2),
+                N.WBPR(k=8, max_iter=30, learning_rate=0.01, lambda_reg=0.01, seed=3)]
+
+    def metrics(M):
+        return [M.MAE(), M.RMSE(), M.Recall(k=10), M.NDCG(k=10), M.NCRR(k=5), M.AUC(), M.MAP(), M.MRR(), M.HitRatio(k=3),
+                M.FMeasure(k=5)]
+
+    ref = RefExperiment(ns.eval_methods.RatioSplit(data, **split_kw), models(ns), metrics(ns.metrics), user_based=True)
+    ref.run()
+    mine = Experiment(RatioSplit(data, **split_kw), models(cornac_amd), metrics(mm), user_based=True).run()
+    compared = 0
+    for which in ("result", "val_result"):
+        for r, m in zip(getattr(ref, which) or [], getattr(mine, which) or []):
+            assert r.model_name == m.model_name and list(r.metric_avg_results) == list(m.metric_avg_results)
+            for name, v in r.metric_avg_results.items():
+                if "(s)" not in name:
+                    assert m.metric_avg_results[name] == pytest.approx(v, rel=2e-3, abs=2e-4), (which, r.model_name, name)
+                    compared += 1
+    assert compared >= 30

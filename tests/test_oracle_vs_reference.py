@@ -122,8 +122,7 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
             item_indices = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
             sc = s[item_indices]
             order = np.argsort(sc, kind="stable")[::-1]
-            r = item_indices[order]
-            return (r if k == -1 else r[:k]), sc
+            return item_indices[order], sc      # like Recommender.rank: every candidate, the first k (here all) in order
 
         def rank_batch(self, users, k=10, exclude=None):
             width = self.num_items if k == -1 else k
@@ -132,7 +131,7 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
             for r, u in enumerate(users):
                 ex = exclude[1][exclude[0][r]:exclude[0][r + 1]]
                 cand = np.setdiff1d(np.arange(self.num_items), ex)
-                rr, _ = self.rank(u, cand, k)
+                rr = self.rank(u, cand, k)[0][:width]
                 out[r, :len(rr)] = rr
                 out_s[r, :len(rr)] = self.S[u][rr]
             return out, out_s
@@ -176,7 +175,7 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
     names = ("NDCG", "Recall", "Precision", "NCRR", "FMeasure", "HitRatio")
     sets = (([rm.AUC(), rm.MAP(), rm.MRR()], [mm.AUC(), mm.MAP(), mm.MRR()]),
             ([getattr(rm, n)(k=-1) for n in names] + [rm.AUC()], [getattr(mm, n)(k=-1) for n in names] + [mm.AUC()]),
-            ([getattr(rm, n)(k=-1) for n in names] + [rm.Recall(k=10)],          # k = -1 metrics see pd_rank[:10] here
+            ([getattr(rm, n)(k=-1) for n in names] + [rm.Recall(k=10)],          # mixed: rank() is asked for 10 items
              [getattr(mm, n)(k=-1) for n in names] + [mm.Recall(k=10)]),
             ([rm.AUC(), rm.MAP(), rm.NCRR(k=10), rm.FMeasure(k=5), rm.Recall(k=10), rm.NDCG(k=3)],
              [mm.AUC(), mm.MAP(), mm.NCRR(k=10), mm.FMeasure(k=5), mm.Recall(k=10), mm.NDCG(k=3)]))
@@ -189,13 +188,11 @@ def test_metric_mirrors_and_batched_eval_logic_match_reference():
                 assert mine_u.keys() == ref_u.keys()
                 assert np.allclose([mine_u[u] for u in ref_u], [ref_u[u] for u in ref_u], rtol=1e-9)
     assert PositionsModel.calls >= 24   # every metric list above went through the counting interface
-    # mixed with an @k metric the reference ranks only max_k items, and MRR over that prefix finds users without a hit
-    with pytest.raises(ValueError):
-        ns.eval_methods.base_method.ranking_eval(model, [rm.MRR(), rm.Recall(k=3)], train, test)
-    with pytest.raises(ValueError):
-        ev.ranking_eval(model, [mm.MRR(), mm.Recall(k=3)], train, test)
-    with pytest.raises(ValueError):
-        ev.ranking_eval(PositionsModel(S, train.num_items), [mm.MRR(), mm.Recall(k=3)], train, test)
+    # mixed with @k metrics the reference asks rank() for max_k items but receives every candidate: MRR still sees the list
+    for mdl in (model, PositionsModel(S, train.num_items)):
+        ref_avg4, _ = ns.eval_methods.base_method.ranking_eval(mdl, [rm.MRR(), rm.Recall(k=3)], train, test)
+        avg4, _ = ev.ranking_eval(mdl, [mm.MRR(), mm.Recall(k=3)], train, test)
+        assert np.allclose(avg4, ref_avg4, rtol=1e-9)
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])
