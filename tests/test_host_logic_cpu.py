@@ -275,3 +275,66 @@ def test_experiment_reports_equal_the_reference_reports(device_double, split_kw)
                     assert m.metric_avg_results[name] == pytest.approx(v, rel=2e-3, abs=2e-4), (which, r.model_name, name)
                     compared += 1
     assert compared >= 30
+
+
+def _same_rows(R, M, min_rows=1):
+    n = 0
+    for r, m in zip(R, M):
+        assert list(r.metric_avg_results) == list(m.metric_avg_results)
+        for name, v in r.metric_avg_results.items():
+            if "(s)" not in name:
+                assert m.metric_avg_results[name] == pytest.approx(v, rel=2e-3, abs=2e-4), (r.model_name, name)
+                n += 1
+    assert n >= min_rows
+
+
+def test_search_cross_validation_and_modalities_equal_the_reference(device_double):
+    """three more caller flows against the live reference: GridSearch around BPR (same best point and score), 3-fold
+    CrossValidation of MF (same per-fold rows), VBPR fed by an ImageModality that the evaluation method builds"""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ns = ref_loader.load()
+    import importlib
+
+    from cornac_amd import BPR, MF, VBPR, CrossValidation, ImageModality, RatioSplit
+    from cornac_amd import hyperopt as my_h
+    from cornac_amd import metrics as mm
+
+    ref_h, rm = importlib.import_module("cornac.hyperopt"), ns.metrics
+    rs = np.random.RandomState(3)
+    keys = rs.permutation(200 * 80)[:3000]
+    data = [("u%d" % (k // 80), "i%d" % (k % 80), float(rs.randint(1, 6))) for k in keys]
+    skw = dict(test_size=0.2, val_size=0.15, rating_threshold=3.0, seed=4)
+    rmeth, mmeth = ns.eval_methods.RatioSplit(data, **skw), RatioSplit(data, **skw)
+    space = lambda h: [h.Discrete("learning_rate", [0.05, 0.005]), h.Discrete("k", [4, 8])]   # noqa: E731
+    rgs = ref_h.GridSearch(ns.BPR(k=4, max_iter=20, seed=1), space(ref_h), rm.AUC(), rmeth)
+    mgs = my_h.GridSearch(BPR(k=4, max_iter=20, seed=1), space(my_h), mm.AUC(), mmeth)
+    rr, _ = rmeth.evaluate(rgs, [rm.AUC(), rm.Recall(k=10)], user_based=True)
+    mr, _ = mmeth.evaluate(mgs, [mm.AUC(), mm.Recall(k=10)], user_based=True)
+    assert rgs.best_params == mgs.best_params and mgs.best_score == pytest.approx(rgs.best_score, rel=1e-6)
+    _same_rows([rr], [mr], 2)
+
+    RefCV = importlib.import_module("cornac.eval_methods").CrossValidation
+    r, _ = RefCV(data, n_folds=3, rating_threshold=3.0, seed=6).evaluate(
+        ns.MF(k=6, max_iter=10, seed=2), [rm.RMSE(), rm.NDCG(k=10)], user_based=True, show_validation=False)
+    m, _ = CrossValidation(data, n_folds=3, rating_threshold=3.0, seed=6).evaluate(
+        MF(k=6, max_iter=10, seed=2), [mm.RMSE(), mm.NDCG(k=10)], user_based=True)
+    _same_rows(list(r), list(m), 6)
+
+    RefImage = importlib.import_module("cornac.data").ImageModality
+    RefVBPR = importlib.import_module("cornac.models.vbpr").VBPR
+    item_ids = sorted({t[1] for t in data})
+    F = np.random.RandomState(1).uniform(0, 1, (len(item_ids), 12)).astype(np.float32)
+    kw = dict(test_size=0.2, rating_threshold=1.0, seed=8, exclude_unknowns=True)
+    rsp = ns.eval_methods.RatioSplit(data, item_image=RefImage(features=F.copy(), ids=list(item_ids), normalized=True), **kw)
+    msp = RatioSplit(data, item_image=ImageModality(features=F.copy(), ids=list(item_ids), normalized=True), **kw)
+    vkw = dict(k=4, k2=4, n_epochs=3, batch_size=64, learning_rate=0.005, lambda_w=0.01, lambda_b=0.01, lambda_e=0.0, seed=3,
+               verbose=False)
+    ref_model, my_model = RefVBPR(use_gpu=False, **vkw), VBPR(**vkw)
+    rres, _ = rsp.evaluate(ref_model, [rm.AUC(), rm.Recall(k=10)], user_based=True)
+    mres, _ = msp.evaluate(my_model, [mm.AUC(), mm.Recall(k=10)], user_based=True)
+    _same_rows([rres], [mres], 2)
+    assert np.abs(my_model.gamma_user - ref_model.gamma_user).max() < 1e-6
+    assert np.abs(my_model.theta_item - ref_model.theta_item).max() < 1e-5
