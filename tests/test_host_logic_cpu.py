@@ -338,3 +338,62 @@ def test_search_cross_validation_and_modalities_equal_the_reference(device_doubl
     _same_rows([rres], [mres], 2)
     assert np.abs(my_model.gamma_user - ref_model.gamma_user).max() < 1e-6
     assert np.abs(my_model.theta_item - ref_model.theta_item).max() < 1e-5
+
+
+@pytest.mark.parametrize("n_ratings", [2500, 260])
+def test_recommender_surface_equals_the_reference_recommender(device_double, n_ratings):
+    """rank / score / rate / recommend of fitted BPR, MF, WBPR against the live reference's, call by call — known and
+    unknown users and items (the sparse case leaves test-only users and items in the global id maps), candidate
+    lists, exceptions.  Scores agree to the BLAS-order tolerance; orders are compared where the reference defines them
+    (its tie order and the tail behind the first k are unspecified)."""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ns = ref_loader.load()
+    from cornac_amd import BPR, MF, WBPR, RatioSplit
+
+    rs = np.random.RandomState(5)
+    keys = rs.permutation(120 * 70)[:n_ratings]
+    data = [("u%d" % (k // 70), "i%d" % (k % 70), float(rs.randint(1, 6))) for k in keys]
+    kw = dict(test_size=0.4, seed=2, exclude_unknowns=False)
+    rsp, msp = ns.eval_methods.RatioSplit(data, **kw), RatioSplit(data, **kw)
+    n_train_users, n_train_items = rsp.train_set.num_users, rsp.train_set.num_items
+    if n_ratings < 1000:
+        assert rsp.total_items > n_train_items and rsp.total_users > n_train_users
+
+    def outcome(fn, *a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:   # noqa: BLE001 - the exception type is what is compared
+            return type(e).__name__
+
+    for R, M, mk in ((ns.BPR, BPR, dict(k=6, max_iter=20, seed=1)), (ns.MF, MF, dict(k=6, max_iter=15, seed=1, use_bias=True)),
+                     (ns.WBPR, WBPR, dict(k=6, max_iter=10, seed=4))):
+        r, m = R(**mk).fit(rsp.train_set), M(**mk).fit(msp.train_set)
+        for u in (0, 5, n_train_users - 1, rsp.total_users - 1):
+            for cand in (None, np.arange(3, 40), np.array([rsp.total_items - 1, 2, 7, 30])):
+                for k in (-1, 3):
+                    a, b = outcome(r.rank, u, item_indices=cand, k=k), outcome(m.rank, u, item_indices=cand, k=k)
+                    assert isinstance(a, str) == isinstance(b, str) and (not isinstance(a, str) or a == b)
+                    if isinstance(a, str):
+                        continue
+                    assert np.allclose(a[1], b[1], atol=3e-5)
+                    n = len(a[1]) if k == -1 else k
+                    gaps = np.abs(np.diff(np.sort(a[1]))) if len(a[1]) > 1 else np.array([1.0])
+                    if gaps.min() > 1e-4:            # no (near-)ties: the order is defined
+                        assert list(a[0][:n]) == list(b[0][:n]), (R.__name__, u, k)
+            for it in (0, 3, n_train_items - 1, rsp.total_items - 1, rsp.total_items + 5):
+                for uu in (u, rsp.total_users + 3):
+                    for fn in ("score", "rate"):
+                        a, b = outcome(getattr(r, fn), uu, it), outcome(getattr(m, fn), uu, it)
+                        if isinstance(a, str) or isinstance(b, str):
+                            assert a == b, (R.__name__, fn, uu, it, a, b)
+                        else:
+                            assert abs(float(a) - float(b)) <= 3e-5, (R.__name__, fn, uu, it)
+        uid = rsp.train_set.user_ids[5]
+        assert list(r.recommend(uid, k=5)) == list(m.recommend(uid, k=5))
+        unseen_ref = r.recommend(uid, k=7, remove_seen=True, train_set=rsp.train_set)
+        assert list(unseen_ref) == list(m.recommend(uid, k=7, remove_seen=True, train_set=msp.train_set))
+        for args in (("nobody",), (uid, 10 ** 6)):
+            assert outcome(r.recommend, *args) == outcome(m.recommend, *args)
