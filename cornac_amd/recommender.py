@@ -236,7 +236,8 @@ class Recommender:
         Ties are ordered by descending item index (the reference leaves tie order unspecified,
         tests/cornac/models/test_recommender.py:89-93).  With k != -1 the result holds exactly the
         ranked top-k; the reference appends the remaining candidates in unspecified argpartition
-        order, which no caller may rely on."""
+        order, which no caller may rely on.  A k larger than the number of candidates returns all of them (the
+        reference fails inside np.argpartition there)."""
         try:
             known_item_scores = self.score(user_idx, **kwargs)
         except ScoreException:
