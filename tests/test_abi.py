@@ -54,3 +54,26 @@ def test_error_reporting_without_a_device():
         assert b"no CPU fallback" in L.cornac_hip_last_error()
         with pytest.raises(_lib.HipError):
             _lib.BprTrainer(indptr, indices, 1, 1, 1, 1, 4)
+
+
+def test_product_never_imports_the_oracle_or_the_test_doubles():
+    """the oracle is the checker: nothing under cornac_amd/ (nor bench.py outside its cpu_baseline leg) may route through it"""
+    import ast
+
+    pkg = os.path.join(ROOT, "cornac_amd")
+    for name in sorted(os.listdir(pkg)):
+        if not name.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, name)).read())
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                mods = [node.module or ""]
+            for m in mods:
+                assert not m.split(".")[0] in ("oracle", "fake_device", "tests"), (name, m)
+    bench = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    users = {fn.name for fn in ast.walk(bench) if isinstance(fn, ast.FunctionDef)
+             for node in ast.walk(fn) if isinstance(node, ast.ImportFrom) and (node.module or "").startswith("oracle")}
+    assert users <= {"cpu_baseline", "cpu_baseline_reference", "cpu_rank_baseline"}, users
