@@ -15,8 +15,9 @@ from test_oracle_golden import CASES, _kw, assert_close
 
 
 @pytest.fixture()
-def device_double(monkeypatch):
+def device_double(monkeypatch, tmp_path):
     fake_device.install(monkeypatch)
+    monkeypatch.chdir(tmp_path)     # the reference's Experiment drops its CornacExp-*.log report into the working directory
 
 
 @pytest.mark.parametrize("name", CASES)
