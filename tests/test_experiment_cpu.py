@@ -211,3 +211,29 @@ def test_cross_validation_and_stratified_split_match_the_reference_classes():
                     assert np.array_equal(x, y)
                 assert np.array_equal(a.timestamps, b.timestamps)
                 assert list(a.uid_map.items()) == list(b.uid_map.items())
+
+
+def test_base_method_expectations_of_the_reference_tests():
+    # tests/cornac/eval_methods/test_base_method.py:33-84
+    bm = BaseMethod(None, verbose=False)
+    assert bm.exclude_unknowns and bm.rating_threshold == 1.0
+    with pytest.raises(ValueError):
+        bm.evaluate(None, {}, False)                    # no training set
+    from cornac_amd import Dataset
+
+    data = _grid()[:40]
+    bm.train_set = Dataset.from_uir(data)
+    with pytest.raises(ValueError):
+        bm.evaluate(None, {}, False)                    # no test set
+    for train, test in ((None, None), (data, None), (data, [])):
+        with pytest.raises(ValueError):
+            BaseMethod.from_splits(train_data=train, test_data=test, exclude_unknowns=True)
+    n_users, n_items = len({t[0] for t in data}), len({t[1] for t in data})
+    bm = BaseMethod.from_splits(train_data=data[:-1], test_data=data[-1:])
+    assert (bm.total_users, bm.total_items) == (n_users, n_items) and bm.val_set is None
+    bm = BaseMethod.from_splits(train_data=data[:-1], test_data=data[-1:], val_data=[(data[0][0], data[1][1], 5.0)])
+    assert (bm.total_users, bm.total_items) == (n_users, n_items) and bm.val_set.num_ratings == 1
+    with pytest.raises(ValueError):
+        BaseMethod.organize_metrics("MAE")
+    rating, ranking = BaseMethod.organize_metrics({"rating": [mm.MAE()], "ranking": [mm.AUC()]})
+    assert [m.name for m in rating + ranking] == ["MAE", "AUC"]
