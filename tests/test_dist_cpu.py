@@ -212,3 +212,103 @@ def test_row_sharded_table_world2():
     assert [len(b[0]) for b in seen0] == [20, 20, 10] == [len(b[0]) for b in seen1]
     assert n0 + n1 == n_valid
     assert np.allclose(V20, want) and np.allclose(B20, wb)
+
+
+class _OracleTrainer:
+    """stands in for _lib.BprTrainer with real BPR arithmetic: the oracle's sequential epoch function runs `n` draws
+    per enqueue IN PLACE on the replica's item table (what the bound device table is on a GPU)"""
+
+    def __init__(self, table, indptr, indices, n_items, k, seed):
+        import ctypes as C
+
+        from oracle import oracle as orc
+
+        self.C, self.orc = C, orc
+        self.indptr, self.indices = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
+        self.user_ids = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr)).astype(np.int32)
+        self.neg_ids = np.arange(n_items, dtype=np.int32)
+        self.V, self.B = table.V.numpy(), table.B.numpy()          # views of the replica's flat buffer
+        self.U = ((np.random.RandomState(seed).uniform(0, 1, (len(indptr) - 1, k)).astype(np.float32) - 0.5) / k)
+        self.gp, self.gn = orc.MT19937(seed), orc.MT19937(seed + 1)
+        self.k, self.n_items, self.correct, self.skipped = k, n_items, 0, 0
+
+    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
+        c, s = self.C.c_int64(), self.C.c_int64()
+        nnz = len(self.user_ids)
+        rc = self.orc.lib().oracle_bpr_epoch_seq(self.gp.ptr, self.gn.ptr, nnz - 1, self.n_items - 1, int(n), self.user_ids,
+                                                 self.indices, self.neg_ids, self.indptr, self.U, self.V, self.B, self.k, lr,
+                                                 reg, int(use_bias), self.C.byref(c), self.C.byref(s), None, None, None)
+        assert rc == 0
+        self.correct, self.skipped = self.correct + c.value, self.skipped + s.value
+
+    def sync(self):
+        return (self.correct, self.skipped)
+
+
+def _popularity_data(rank, n_users=250, n_items=90, per_user=24):
+    """every rank has its own users; all draw from one Zipf item popularity, so the item side is shared knowledge"""
+    rs = np.random.RandomState(100 + rank)
+    p = 1.0 / np.arange(1, n_items + 1) ** 1.1
+    rows = [np.sort(rs.choice(n_items, per_user, replace=False, p=p / p.sum())) for _ in range(n_users)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return indptr, np.concatenate(rows).astype(np.int32), n_items
+
+
+def _pairwise_accuracy(U, V, B, indptr, indices, n_items, seed=0):
+    rs = np.random.RandomState(seed)
+    hit = n = 0
+    for u in range(len(indptr) - 1):
+        pos = indices[indptr[u]:indptr[u + 1]]
+        neg = np.setdiff1d(np.arange(n_items), pos)
+        i, j = rs.choice(pos, 8), rs.choice(neg, 8)
+        s = B + V @ U[u]
+        hit, n = hit + int((s[i] > s[j]).sum()), n + 8
+    return hit / n
+
+
+def _learn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        indptr, indices, n_items = _popularity_data(rank)
+        k, nnz = 8, len(indices)
+        sh = ShardedBprTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"), sync_every=(nnz + 7) // 8)
+        init = np.random.RandomState(7)                                  # identical item table on every rank
+        sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
+        sh.trainer = _OracleTrainer(sh.table, indptr, indices, n_items, k, seed=11 + rank)
+        before = _pairwise_accuracy(sh.trainer.U, sh.table.V.numpy(), sh.table.B.numpy(), indptr, indices, n_items)
+        for _ in range(6):
+            sh.run(nnz, lr=0.05, reg=0.01)                               # 8 overlapped exchanges per epoch
+        correct, skipped = sh.finish()
+        after = _pairwise_accuracy(sh.trainer.U, sh.table.V.numpy(), sh.table.B.numpy(), indptr, indices, n_items)
+        out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), before, after, correct, skipped, nnz,
+                     sh.table.base.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_learn_one_consolidated_item_table():
+    """the whole regime-1 driver (ShardedBprTrainer.run / finish: chunked training, overlapped delta exchange, sqrt
+    rule) with REAL BPR arithmetic on two gloo ranks: both end with the same item table, the consolidated model
+    ranks each rank's own positives about as well as a single process training on one rank's data alone"""
+    out = mp.Manager().dict()
+    port = _free_port()
+    mp.spawn(_learn_worker, args=(2, port, out), nprocs=2, join=True)
+    (V0, B0, before0, after0, c0, s0, nnz0, base0), (V1, B1, before1, after1, _, _, _, base1) = out[0], out[1]
+    # one consolidated table after finish(): the rebased copies are bit-identical (same all-reduce result on every rank),
+    # the live copies agree to the rounding of  (base + d) + (R - d)  and equal the base (nothing trained since)
+    assert np.array_equal(base0, base1)
+    assert np.allclose(V0, V1, rtol=0, atol=1e-7) and np.allclose(B0, B1, rtol=0, atol=1e-6)
+    assert np.allclose(np.concatenate([V0.ravel(), B0]), base0, rtol=0, atol=1e-6)
+    assert np.isfinite(V0).all() and c0 + s0 <= 6 * nnz0 and c0 > 0
+    assert before0 < 0.6 and before1 < 0.6 and after0 > 0.75 and after1 > 0.75
+    # single process, same work on rank 0's data, no exchange
+    indptr, indices, n_items = _popularity_data(0)
+    table = ItemTableReplica(n_items, 8, torch.device("cpu"))
+    init = np.random.RandomState(7)
+    table.load((init.uniform(0, 1, (n_items, 8)).astype(np.float32) - 0.5) / 8, np.zeros(n_items, np.float32))
+    solo = _OracleTrainer(table, indptr, indices, n_items, 8, seed=11)
+    for _ in range(6):
+        solo.hogwild_enqueue(len(indices), 0.05, 0.01, True, 0, 0)
+    alone = _pairwise_accuracy(solo.U, table.V.numpy(), table.B.numpy(), indptr, indices, n_items)
+    assert after0 > alone - 0.03, (after0, alone)
