@@ -312,3 +312,69 @@ def test_two_ranks_learn_one_consolidated_item_table():
         solo.hogwild_enqueue(len(indices), 0.05, 0.01, True, 0, 0)
     alone = _pairwise_accuracy(solo.U, table.V.numpy(), table.B.numpy(), indptr, indices, n_items)
     assert after0 > alone - 0.03, (after0, alone)
+
+
+def _bpr_apply(U, u, si, sj, rows, bias_pad, lr, reg, use_bias):
+    """sequential BPR updates (recom_bpr.pyx:240-267) of a micro-batch on the rank's user rows and the STAGED item rows"""
+    R, Bp = rows.numpy(), bias_pad.numpy()
+    for t in range(len(u)):
+        a, p, q = int(u[t]), int(si[t]), int(sj[t])
+        uu, vi, vj = U[a].copy(), R[p].copy(), R[q].copy()
+        z = 1.0 / (1.0 + np.exp(Bp[p, 0] - Bp[q, 0] + uu @ (vi - vj)))
+        U[a] += lr * (z * (vi - vj) - reg * uu)
+        R[p] += lr * (z * uu - reg * vi)
+        R[q] += lr * (-z * uu - reg * vj)
+        if use_bias:
+            Bp[p, 0] += lr * (z - reg * Bp[p, 0])
+            Bp[q, 0] += lr * (-z - reg * Bp[q, 0])
+
+
+def _sharded_learn_worker(rank, world, port, out):
+    from cornac_amd.dist import RowShardedBprTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        indptr, indices, n_items = _popularity_data(rank)
+        k, nnz = 8, len(indices)
+        user_ids = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+        rs = np.random.RandomState(50 + rank)
+        U = ((np.random.RandomState(11 + rank).uniform(0, 1, (len(indptr) - 1, k)).astype(np.float32) - 0.5) / k)
+        positives = [set(indices[indptr[a]:indptr[a + 1]].tolist()) for a in range(len(indptr) - 1)]
+        sh = RowShardedBprTrainer(_FakeShardTrainer(rank, n_items), n_items, k, torch.device("cpu"), micro_batch=1500,
+                                  ops=_HostRowOps())
+        init = np.random.RandomState(7)
+        sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
+
+        def sample(n):            # uniform positive interaction, uniform negative item, -1 where the draw is a positive
+            ii = rs.randint(0, nnz, n)
+            u, i, j = user_ids[ii].astype(np.int32), indices[ii].astype(np.int32), rs.randint(0, n_items, n).astype(np.int32)
+            skip = np.array([int(b) in positives[a] for a, b in zip(u, j)])
+            u, i, j = u.copy(), i.copy(), j.copy()
+            u[skip] = i[skip] = j[skip] = -1
+            return torch.tensor(u), torch.tensor(i), torch.tensor(j)
+
+        sh._sample = sample
+        sh._apply = lambda u, si, sj, rows, bias_pad, lr, reg, use_bias: _bpr_apply(U, u.numpy(), si.numpy(), sj.numpy(), rows,
+                                                                                  bias_pad, lr, reg, use_bias)
+        V, B = sh.table.gather_full()
+        before = _pairwise_accuracy(U, V.numpy(), B.numpy(), indptr, indices, n_items)
+        for _ in range(6):
+            sh.run(nnz, 0.05, 0.01)       # 4 micro-batches per epoch: fetch -> local updates on staged rows -> push deltas
+        V, B = sh.table.gather_full()
+        out[rank] = (V.numpy().copy(), B.numpy().copy(), before,
+                     _pairwise_accuracy(U, V.numpy(), B.numpy(), indptr, indices, n_items), sh.rows_fetched, sh.triplets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_learn_over_a_row_sharded_item_table():
+    """regime 2 end to end on two gloo ranks with real BPR arithmetic on the staged rows: items live on their owner
+    rank, every micro-batch fetches the touched rows, updates them locally and pushes the deltas back; the assembled
+    table is the same on both ranks and ranks each rank's own positives well"""
+    out = mp.Manager().dict()
+    mp.spawn(_sharded_learn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (V0, B0, before0, after0, fetched0, n0), (V1, B1, before1, after1, _, _) = out[0], out[1]
+    assert np.array_equal(V0, V1) and np.array_equal(B0, B1) and np.isfinite(V0).all()
+    assert before0 < 0.6 and before1 < 0.6 and after0 > 0.75 and after1 > 0.75
+    assert 0 < fetched0 <= 24 * 90 and n0 > 0          # de-duplicated requests: at most every item once per micro-batch
