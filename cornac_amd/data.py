@@ -42,6 +42,15 @@ class Dataset:
             raise ValueError("fmt should be in ['UIR', 'UIRT']")
         gu = OrderedDict() if global_uid_map is None else global_uid_map
         gi = OrderedDict() if global_iid_map is None else global_iid_map
+        if len(data) >= cls.VECTORISED_BUILD_FROM:
+            built = cls._build_columns(data, fmt, gu, gi, exclude_unknowns)
+            if built is not None:
+                uir, ts, dups = built
+                if dups:
+                    warnings.warn("%d duplicated observations are removed!" % dups)
+                if len(uir[0]) == 0:
+                    raise ValueError("data is empty after being filtered!")
+                return cls(len(gu), len(gi), gu, gi, uir, timestamps=ts, seed=seed)
         seen = set()
         us, its, rs, ts = [], [], [], []
         dups = 0
@@ -65,6 +74,49 @@ class Dataset:
         uir = (np.asarray(us, dtype="int"), np.asarray(its, dtype="int"), np.asarray(rs, dtype="float"))
         return cls(len(gu), len(gi), gu, gi, uir, timestamps=np.asarray(ts, dtype="int") if fmt == "UIRT" else None,
                    seed=seed)
+
+    VECTORISED_BUILD_FROM = 20000   # records; below that the record-by-record loop above is as fast
+
+    @staticmethod
+    def _build_columns(data, fmt, gu, gi, exclude_unknowns):
+        """the loop of `build` column-wise, for large inputs (the reference's loop takes about a minute on 20 M tuples):
+        ids are factorised in order of first appearance — the order the loop assigns them in, since a skipped duplicate
+        never introduces a new id — mapped through / appended to the global maps, and the first record of every
+        (user, item) pair is kept.  Returns None when the ids cannot be factorised faithfully (then the loop runs)."""
+        try:
+            import pandas as pd
+        except ImportError:
+            return None
+        from operator import itemgetter
+
+        width = 4 if fmt == "UIRT" else 3
+        if len(data[0]) < width:
+            return None
+        cols = [list(map(itemgetter(c), data)) for c in range(width)]
+        idx = []
+        for raw, gmap in ((cols[0], gu), (cols[1], gi)):
+            values = np.empty(len(raw), dtype=object)
+            values[:] = raw
+            codes, uniques = pd.factorize(values)
+            if (codes < 0).any():        # NaN-like ids: pandas treats them as missing, a dict would not
+                return None
+            mapped = np.empty(len(uniques), dtype=np.int64)
+            for n, key in enumerate(uniques):
+                known = gmap.get(key)
+                if known is None:
+                    known = -1 if exclude_unknowns else gmap.setdefault(key, len(gmap))
+                mapped[n] = known
+            idx.append(mapped[codes])
+        u_idx, i_idx = idx
+        kept = np.flatnonzero((u_idx >= 0) & (i_idx >= 0))
+        pair = u_idx[kept] * np.int64(max(len(gi), 1)) + i_idx[kept]
+        _, first = np.unique(pair, return_index=True)
+        first = np.sort(first)
+        rows = kept[first]
+        ratings = np.asarray(cols[2], dtype="float")[rows]
+        ts = np.asarray(cols[3], dtype="int")[rows] if fmt == "UIRT" else None
+        uir = (u_idx[rows].astype("int"), i_idx[rows].astype("int"), ratings)
+        return uir, ts, len(kept) - len(first)
 
     @classmethod
     def from_uirt(cls, data, seed=None):

@@ -151,3 +151,69 @@ def test_image_modality_matches_the_reference_modality():
         mine = ImageModality(features=F.copy(), ids=list(ids), normalized=normalized).build(id_map=id_map)
         assert np.array_equal(ref.features, mine.features) and ref.features.dtype == mine.features.dtype
         assert list(ref.ids) == list(mine.ids)
+
+
+@pytest.mark.parametrize("exclude_unknowns,with_time", [(False, False), (True, False), (False, True), (True, True)])
+def test_column_wise_build_equals_the_record_loop(monkeypatch, exclude_unknowns, with_time):
+    """large inputs are built column-wise; same arrays, same id maps (content and order), same duplicate count as the
+    record-by-record loop, with global maps, unknown ids, duplicate pairs and mixed id types in the data"""
+    import warnings
+    from collections import OrderedDict
+
+    rs = np.random.RandomState(3)
+    n = 6000
+    users = [("u%d" % a) if a % 3 else int(a) for a in rs.randint(0, 400, n)]          # strings and ints as raw ids
+    items = ["i%d" % b for b in rs.randint(0, 150, n)]
+    data = [(u, i, float(r)) + ((int(t),) if with_time else ()) for u, i, r, t in
+            zip(users, items, rs.randint(1, 6, n), rs.randint(0, 10 ** 6, n))]
+
+    def run(threshold):
+        monkeypatch.setattr(Dataset, "VECTORISED_BUILD_FROM", threshold)
+        gu = OrderedDict(("u%d" % a, n) for n, a in enumerate((5, 7, 1, 301, 44)))    # some ids known beforehand
+        gi = OrderedDict(("i%d" % b, n) for n, b in enumerate(range(0, 150, 2)))
+        if exclude_unknowns:
+            gu.update((int(a), len(gu) + n) for n, a in enumerate(range(0, 400, 6)))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ds = Dataset.build(data, fmt="UIRT" if with_time else "UIR", global_uid_map=gu, global_iid_map=gi, seed=1,
+                               exclude_unknowns=exclude_unknowns)
+        return ds, [str(x.message) for x in w]
+
+    loop, w_loop = run(10 ** 9)
+    fast, w_fast = run(1)
+    for a, b in zip(loop.uir_tuple, fast.uir_tuple):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert list(loop.uid_map.items()) == list(fast.uid_map.items()) and list(loop.iid_map.items()) == list(fast.iid_map.items())
+    assert (loop.num_users, loop.num_items, loop.num_ratings) == (fast.num_users, fast.num_items, fast.num_ratings)
+    assert w_loop == w_fast and len(w_loop) == 1 and "duplicated" in w_loop[0]
+    if with_time:
+        assert np.array_equal(loop.timestamps, fast.timestamps)
+    monkeypatch.setattr(Dataset, "VECTORISED_BUILD_FROM", 1)
+    with pytest.raises(ValueError):
+        Dataset.build(data, exclude_unknowns=True)     # nothing is known without global maps
+
+
+def test_column_wise_build_equals_the_reference_build():
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    RefDataset = ref_loader.load().Dataset
+    rs = np.random.RandomState(9)
+    n = 30000
+    assert n >= Dataset.VECTORISED_BUILD_FROM
+    data = [("u%d" % a, "i%d" % b, float(r)) for a, b, r in zip(rs.randint(0, 3000, n), rs.randint(0, 800, n), rs.randint(1, 6, n))]
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_train, my_train = RefDataset.build(data[:20000]), Dataset.build(data[:20000])
+        ref_test = RefDataset.build(data[20000:], global_uid_map=ref_train.uid_map, global_iid_map=ref_train.iid_map,
+                                    exclude_unknowns=True)
+        my_test = Dataset.build(data[20000:] + data[20000:], global_uid_map=my_train.uid_map, global_iid_map=my_train.iid_map,
+                                exclude_unknowns=True)     # doubled: column-wise path, every pair duplicated once
+    for ref, mine in ((ref_train, my_train), (ref_test, my_test)):
+        for a, b in zip(ref.uir_tuple, mine.uir_tuple):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert list(ref.uid_map.items()) == list(mine.uid_map.items()) and list(ref.iid_map.items()) == list(mine.iid_map.items())
+        assert (ref.csr_matrix != mine.csr_matrix).nnz == 0
