@@ -398,3 +398,41 @@ def test_recommender_surface_equals_the_reference_recommender(device_double, n_r
         assert list(unseen_ref) == list(m.recommend(uid, k=7, remove_seen=True, train_set=msp.train_set))
         for args in (("nobody",), (uid, 10 ** 6)):
             assert outcome(r.recommend, *args) == outcome(m.recommend, *args)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_purchase_view_dataset_and_vebpr_equal_the_live_reference(device_double, seed):
+    """views with users and items the purchases never mention, duplicated view records and views of purchased pairs:
+    the same purchase / view matrices as the reference's PurchaseViewDataset, and through cornac_amd.VEBPR (device
+    double) the same factors, scores and ranking as the reference's compiled VEBPR"""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ref_loader.load()
+    import importlib
+    import warnings
+
+    from cornac_amd import VEBPR, PurchaseViewDataset
+
+    RefPV = importlib.import_module("cornac.data").PurchaseViewDataset
+    RefVEBPR = importlib.import_module("cornac.models.bpr.recom_vebpr").VEBPR
+    rs = np.random.RandomState(seed)
+
+    def pairs(nu, ni, n, dup=False):
+        keys = rs.randint(0, nu * ni, n) if dup else rs.permutation(nu * ni)[:n]
+        return [("u%d" % (k // ni), "i%d" % (k % ni), 1.0) for k in keys]
+
+    purchase = pairs(40, 30, 300)
+    views = pairs(55, 36, 500, dup=True) + purchase[:40]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r, m = RefPV.build(purchase, views, seed=4), PurchaseViewDataset.build(purchase, views, seed=4)
+    assert (r.matrix != m.matrix).nnz == 0 and r.view_matrix.shape == m.view_matrix.shape
+    assert (r.view_matrix != m.view_matrix).nnz == 0 and (r.num_users, r.num_items) == (m.num_users, m.num_items)
+    kw = dict(k=5, max_iter=8, learning_rate=0.05, lambda_reg=0.01, alpha=0.4, seed=7)
+    a, b = RefVEBPR(**kw).fit(r), VEBPR(**kw).fit(m)
+    assert_close(b.u_factor, a.u_factor)
+    assert_close(b.i_factor, a.i_factor)
+    assert np.abs(a.score(3) - b.score(3)).max() < 1e-6
+    assert list(a.rank(3, k=5)[0][:5]) == list(b.rank(3, k=5)[0][:5])
