@@ -116,7 +116,11 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         pos = np.minimum(np.searchsorted(gt_keys, pred_keys), len(gt_keys) - 1)
         return gt_keys[pos] == pred_keys
 
-    batchable = hasattr(model, "rank_batch") and getattr(model, "total_items", n_eval_items) == n_eval_items
+    # the batched entry points rank over the rows of the model's device item table; they stand in for the per-user flow
+    # only when that is exactly the evaluated item range (with exclude_unknowns=False the test set may bring items a
+    # model such as MF has no row for — the reference pads those with the minimum score, recommender.py:510-517)
+    ranked_items = getattr(model, "batch_num_items", getattr(model, "total_items", n_eval_items))
+    batchable = hasattr(model, "rank_batch") and ranked_items == n_eval_items
     full_ok = batchable and need_full and all(
         hasattr(m, "compute_full_batch") if m.k <= 0 else hasattr(m, "compute_batch") for m in metrics)
     if full_ok and hasattr(model, "rank_positions_batch"):

@@ -94,6 +94,10 @@ class BaseSearch(Recommender):
     # batched entry points exist on the searcher exactly when the best model has them (the evaluation loops probe
     # with hasattr): an AttributeError from the best model propagates through these properties
     @property
+    def batch_num_items(self):
+        return self.best_model.batch_num_items
+
+    @property
     def rank_batch(self):
         return self.best_model.rank_batch
 

@@ -268,6 +268,11 @@ class Recommender:
             ranked_items = item_indices[order][:topk]
         return ranked_items, item_scores
 
+    @property
+    def batch_num_items(self):
+        """number of items `rank_batch` / `rank_positions_batch` rank over: the rows of the device item table"""
+        return len(self._scoring_tables()[1])
+
     def rank_batch(self, user_indices, k=10, exclude=None):
         """Batched top-k for many users in one scoring-GEMM + top-k pass (what the evaluation loop
         cornac/eval_methods/base_method.py:176-220 does one user at a time).

@@ -1,0 +1,113 @@
+"""Differential fuzz of cornac_amd.eval.ranking_eval against the reference's ranking_eval (live, this container only):
+random small data sets, tied scores, thresholds, validation sets, unknown users / items kept or dropped, random mixes of
+@k / whole-list metrics, and all three evaluation flows (per-user `rank`, `rank_batch`, `rank_positions_batch`) through
+host stand-in models.  Found the cases fixed in eval.py (mixed metric lists; item ranges a model has no rows for)."""
+import numpy as np
+import pytest
+
+from oracle import ref_loader
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference not available / oracle/_ref not built")
+
+
+class PerUserModel:
+    """scores from a table over the TRAIN items; like a model without rows for test-only items (MF), `rank` pads those
+    with the minimum score as Recommender.rank does"""
+
+    def __init__(self, S, n_items, total):
+        self.S, self.num_items, self.total_items, self.batch_num_items = S, n_items, total, n_items
+
+    def rank(self, user_idx, item_indices=None, k=-1, **kw):
+        s = self.S[user_idx]
+        item_indices = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
+        full = np.ones(self.total_items) * s.min()
+        full[: self.num_items] = s
+        sc = full[item_indices]
+        return item_indices[np.argsort(sc, kind="stable")[::-1]], sc
+
+    def _cand(self, exclude, r):
+        return np.setdiff1d(np.arange(self.num_items), exclude[1][exclude[0][r]:exclude[0][r + 1]])
+
+
+class BatchModel(PerUserModel):
+    def rank_batch(self, users, k=10, exclude=None):
+        width = self.num_items if k == -1 else k
+        items = np.full((len(users), width), -1, np.int32)
+        scores = np.full((len(users), width), -np.inf, np.float32)
+        for r, u in enumerate(users):
+            top = self.rank(u, self._cand(exclude, r), k)[0][:width]
+            items[r, :len(top)], scores[r, :len(top)] = top, self.S[u][top]
+        return items, scores
+
+
+class PositionsModel(BatchModel):
+    def rank_positions_batch(self, users, targets, exclude=None):
+        out = [[], [], [], []]
+        for r, u in enumerate(users):
+            cand = self._cand(exclude, r)
+            sc = self.S[u][cand]
+            for t in targets[1][targets[0][r]:targets[0][r + 1]]:
+                s = self.S[u][t]
+                out[0].append((sc > s).sum())
+                out[1].append((sc > s).sum() + ((sc == s) & (cand > t)).sum())
+                out[2].append((sc >= s).sum())
+                out[3].append(s)
+        return tuple(np.array(o, d) for o, d in zip(out, (np.int32, np.int32, np.int32, np.float32)))
+
+
+AT_K = ["NDCG", "NCRR", "Recall", "Precision", "FMeasure", "HitRatio"]
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_ranking_eval_equals_the_reference_on_random_cases(block):
+    import warnings
+
+    import cornac_amd.eval as ev
+    import cornac_amd.metrics as mm
+
+    ns = ref_loader.load()
+    rm, ref_eval = ns.metrics, ns.eval_methods.base_method.ranking_eval
+    compared = 0
+    for seed in range(block * 12, block * 12 + 12):
+        rs = np.random.RandomState(seed)
+        nu, ni = rs.randint(15, 50), rs.randint(12, 40)
+        keys = rs.permutation(nu * ni)[: min(rs.randint(150, 500), nu * ni - 1)]
+        data = [(int(k // ni), int(k % ni), float(rs.randint(1, 6))) for k in keys]
+        a, b = int(len(data) * 0.6), int(len(data) * 0.8)
+        keep_unknowns = not bool(rs.randint(2))
+        train = ns.Dataset.build(data[:a])
+        maps = dict(global_uid_map=train.uid_map, global_iid_map=train.iid_map, exclude_unknowns=not keep_unknowns)
+        try:
+            test = ns.Dataset.build(data[a:b], **maps)
+            val = ns.Dataset.build(data[b:], **maps) if rs.randint(2) else None
+        except ValueError:
+            continue
+        S = rs.normal(size=(len(train.uid_map), train.num_items)).astype(np.float32)
+        if rs.randint(2):
+            S = (np.round(S * 2) / 2).astype(np.float32)                    # heavy ties
+        thr = float(rs.choice([1.0, 3.0, 4.0]))
+        picks = [(rs.choice(AT_K), int(k)) for k in rs.choice([-1, 1, 3, 5, 10], size=rs.randint(1, 5))]
+        picks += [(x, None) for x in rs.choice(["AUC", "MAP", "MRR"], size=rs.randint(0, 4), replace=False)]
+
+        def metrics(M):
+            return [getattr(M, n)() if k is None else getattr(M, n)(k=k) for n, k in picks]
+
+        for cls in (PerUserModel, BatchModel, PositionsModel):
+            model = cls(S, train.num_items, len(train.iid_map))
+            kw = dict(val_set=val, rating_threshold=thr, exclude_unknowns=not keep_unknowns)
+            outcome = []
+            for fn, M, extra in ((ref_eval, rm, {}), (ev.ranking_eval, mm, dict(batch_users=7, batch_users_full=5))):
+                try:
+                    with warnings.catch_warnings(), np.errstate(all="ignore"):
+                        warnings.simplefilter("ignore")
+                        outcome.append(fn(model, metrics(M), train, test, **kw, **extra))
+                except Exception as e:   # noqa: BLE001 - the exception type is compared
+                    outcome.append(type(e).__name__)
+            ref, mine = outcome
+            if isinstance(ref, str) or isinstance(mine, str):
+                assert ref == mine, (seed, cls.__name__, picks, ref, mine)
+                continue
+            assert np.allclose(ref[0], mine[0], rtol=1e-9, atol=1e-12, equal_nan=True), (seed, cls.__name__, picks, ref[0], mine[0])
+            assert all(x.keys() == y.keys() for x, y in zip(ref[1], mine[1]))
+            compared += 1
+    assert compared >= 20

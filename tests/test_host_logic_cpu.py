@@ -233,9 +233,11 @@ def test_vbpr_host_class_reproduces_the_reference_golden(device_double):
         VBPR(verbose=False, **kw).fit(ds)
 
 
-@pytest.mark.parametrize("split_kw", [dict(test_size=0.2, val_size=0.1, rating_threshold=3.0, seed=5, exclude_unknowns=False),
-                                      dict(test_size=0.3, rating_threshold=1.0, seed=9, exclude_unknowns=True)])
-def test_experiment_reports_equal_the_reference_reports(device_double, split_kw):
+@pytest.mark.parametrize("n_ratings,split_kw", [
+    (4000, dict(test_size=0.2, val_size=0.1, rating_threshold=3.0, seed=5, exclude_unknowns=False)),
+    (4000, dict(test_size=0.3, rating_threshold=1.0, seed=9, exclude_unknowns=True)),
+    (500, dict(test_size=0.3, val_size=0.1, rating_threshold=3.0, seed=5, exclude_unknowns=False))])   # sparse: test-only items
+def test_experiment_reports_equal_the_reference_reports(device_double, n_ratings, split_kw):
     """the reference's Experiment over MF / BPR / WBPR with ten metrics (rating, @k, full-list, mixed in one list — the
     case where the reference asks rank() for max_k items but its metrics over the whole list read past them), test and
     validation tables, unknown users / items kept or dropped, against cornac_amd's with the device double"""
@@ -252,7 +254,7 @@ def test_experiment_reports_equal_the_reference_reports(device_double, split_kw)
 
     RefExperiment = importlib.import_module("cornac.experiment").Experiment
     rs = np.random.RandomState(3)
-    keys = rs.permutation(250 * 100)[:4000]
+    keys = rs.permutation(250 * 100)[:n_ratings]
     data = [("u%d" % (k // 100), "i%d" % (k % 100), float(rs.randint(1, 6))) for k in keys]
 
     def models(N):
