@@ -167,9 +167,6 @@ struct HogArgs {
     int64_t nnz;
     int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
     int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
-    // experiment (hogwild_flags bit 4): one replica of V / padded B per XCD, plain read-modify-write inside the
-    // XCD's L2, replicas reconciled between launches (element strides of the replicas; 0 = off)
-    int64_t rep_stride_v, rep_stride_b;
 };
 
 // per-lane: draw one (u, i, j) and test membership; returns validity
@@ -308,12 +305,11 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
 // positives only from their interactions, so a user row is read and written by exactly one wave:
 // plain load/store instead of 2 atomic line-requests per triplet, and no lost or stale U update.
 // Heavy users (more interactions than half a wave's share) are split over all waves and keep atomics.
-template <int G, int R, int UNR, bool ATOMIC, bool OWNED, bool REPL = false>
+template <int G, int R, int UNR, bool ATOMIC, bool OWNED>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
     static_assert(!OWNED || G == kWave, "ownership needs one triplet per wave step");
-    static_assert(!REPL || OWNED, "the replica experiment builds on the ownership kernel");
-    float *const Vt = REPL ? a.V + (size_t)(__builtin_amdgcn_s_getreg(6164) & 7) * a.rep_stride_v : a.V;  // HW_REG_XCC_ID
-    float *const Bt = REPL ? a.B + (size_t)(__builtin_amdgcn_s_getreg(6164) & 7) * a.rep_stride_b : a.B;
+    float *const Vt = a.V;
+    float *const Bt = a.B;
     __shared__ int32_t stage[kWavesPerBlock][3][kWave];
     constexpr int TPW = kWave / G;
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -413,11 +409,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                             const float du = du_all[q][r];
                             const float dvi = a.lr * (z * u[q][r] - a.reg * vi[q][r]);
                             const float dvj = a.lr * (-z * u[q][r] - a.reg * vj[q][r]);
-                            if (REPL) {
-                                if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
-                                pi[q][G * r] = vi[q][r] + dvi;  // XCD-private replica: plain RMW in this XCD's L2
-                                pj[q][G * r] = vj[q][r] + dvj;
-                            } else if (OWNED) {
+                            if (OWNED) {
                                 if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
                                 atomic_add_f32(pi[q] + G * r, dvi);
                                 atomic_add_f32(pj[q] + G * r, dvj);
@@ -435,10 +427,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                     if (lg == 0) {
                         if (a.use_bias && !(a.ablate & 8)) {
                             const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
-                            if (REPL) {
-                                Bt[(size_t)ti[q] * a.bstride] = bi[q] + dbi;
-                                Bt[(size_t)tj[q] * a.bstride] = bj[q] + dbj;
-                            } else if (ATOMIC || OWNED) {
+                            if (ATOMIC || OWNED) {
                                 atomic_add_f32(a.B + (size_t)ti[q] * a.bstride, dbi);
                                 atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, dbj);
                             } else {
@@ -568,6 +557,10 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
     }
 }
 
+}  // namespace chip
+#include "bpr_binned.inc"
+namespace chip {
+
 static int pow2_group(int k) {  // lanes per triplet for scalar-per-lane kernels
     int g = 4;
     while (g < k && g < 64) g <<= 1;
@@ -589,7 +582,6 @@ struct cornac_hip_bpr {
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
-    DevBuf<float> Vrep, Brep;  // XCD-replica experiment
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped
     // deterministic sampler state
     DevBuf<uint32_t> mt_state;  // 2 x 624
@@ -620,6 +612,14 @@ struct cornac_hip_bpr {
     std::vector<int32_t> h_own_u, h_own_i;
     std::vector<int64_t> h_wave_ptr;
     int64_t own_tmax = 0;
+    // binned item updates (bpr_binned.inc): item -> (bucket, local row), bucket -> items, message segments
+    int bin_buckets = 0, bin_neg_population = -1, bin_max_rows = 0, bin_wg_per_cu = 0, bin_n_hot = 0;
+    int bin_hot_threshold = 0;
+    int64_t bin_chunk = 0;
+    bool bin_attr_set = false;
+    DevBuf<int32_t> bin_item_slot, bin_bucket_ptr, bin_bucket_items, bin_seg_count, bin_hot_items;
+    DevBuf<uint4> bin_seg;
+    DevBuf<float> bin_snap, bin_hot_bias;
     // VEBPR: view CSR + third sampler stream
     bool has_views = false, view_seeded = false;
     DevBuf<int32_t> v_indptr, v_indices, view_rank;
@@ -913,30 +913,6 @@ static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int
     }
 }
 
-// ---- XCD-replica experiment (hogwild_flags bit 4): broadcast / reconcile of the item-side tables ----------
-namespace chip {
-constexpr int kXcds = 8;
-__global__ __launch_bounds__(kBlock) void replicate_kernel(const float *__restrict__ src, float *__restrict__ rep,
-                                                           int64_t n, int64_t stride) {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
-        const float v = src[e];
-#pragma unroll
-        for (int x = 0; x < kXcds; ++x) rep[x * stride + e] = v;
-    }
-}
-// base += sum_x (rep_x - base): every XCD's updates since the broadcast are applied once
-__global__ __launch_bounds__(kBlock) void reconcile_kernel(float *__restrict__ base, const float *__restrict__ rep,
-                                                           int64_t n, int64_t stride) {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
-        const float b = base[e];
-        float acc = b;
-#pragma unroll
-        for (int x = 0; x < kXcds; ++x) acc += rep[x * stride + e] - b;
-        base[e] = acc;
-    }
-}
-}  // namespace chip
-
 // ---- hogwild launch -------------------------------------------------------------------------------
 typedef void (*HogKernel)(const HogArgs);
 
@@ -949,10 +925,6 @@ static HogKernel pick_hogwild_kernel(int k, int flags) {
         if (k <= 8) return bpr_hogwild_rowwise_kernel<8, 1, 2, ATOMIC, false>;
         if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC, false>;
         if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC, false>;
-        if (owned && (flags & 16)) {  // experiment: XCD-private replicas (see hogwild_enqueue)
-            if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true, true>;
-            if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true, true>;
-        }
         if (owned) {
             if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true>;
             if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true>;
@@ -1096,72 +1068,254 @@ static void launch_hogwild(cornac_hip_bpr_t h, HogArgs a, int flags) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- binned (segmented) item updates: bucket tables and launch -----------------------------------------------
+// Expected messages per epoch of item i: one per positive draw (its degree) plus its share of the negative draws.
+// Items whose expectation per CHUNK exceeds hot_threshold are "hot": they keep device-scope atomics (their rows
+// must not see hundreds of updates computed from one stale copy).  The cold items are dealt to n_buckets buckets by
+// LPT on that weight, so the apply kernel's workgroups carry equal loads whatever the popularity skew.
+static void build_item_buckets(cornac_hip_bpr_t h, int n_buckets, int neg_population, int64_t chunk, int hot_threshold) {
+    if (h->bin_buckets == n_buckets && h->bin_neg_population == neg_population && h->bin_chunk == chunk &&
+        h->bin_hot_threshold == hot_threshold)
+        return;
+    const int64_t ni = h->n_items;
+    std::vector<double> w((size_t)ni, 0.0);
+    for (int64_t p = 0; p < h->nnz; ++p) w[(size_t)h->h_indices[(size_t)p]] += 1.0;
+    const double uni = (double)h->nnz / (double)ni;
+    for (int64_t i = 0; i < ni; ++i) w[(size_t)i] += neg_population == CORNAC_HIP_NEG_POPULARITY ? w[(size_t)i] : uni;
+    const double per_chunk = (double)chunk / (double)h->nnz;
+    std::vector<int32_t> order, hot;
+    order.reserve((size_t)ni);
+    for (int64_t i = 0; i < ni; ++i) {
+        if (w[(size_t)i] * per_chunk > (double)hot_threshold) hot.push_back((int32_t)i);
+        else order.push_back((int32_t)i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return w[(size_t)x] > w[(size_t)y]; });
+    typedef std::pair<double, int> LB;  // (load, bucket)
+    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
+    for (int b = 0; b < n_buckets; ++b) heap.push(LB(0.0, b));
+    std::vector<int32_t> bucket_of((size_t)ni, -1), rows((size_t)n_buckets, 0);
+    for (int32_t i : order) {
+        LB t = heap.top();
+        heap.pop();
+        bucket_of[(size_t)i] = t.second;
+        ++rows[(size_t)t.second];
+        t.first += w[(size_t)i];
+        heap.push(t);
+    }
+    std::vector<int32_t> ptr((size_t)n_buckets + 1, 0), items(order.size()), slot((size_t)ni);
+    for (int b = 0; b < n_buckets; ++b) ptr[(size_t)b + 1] = ptr[(size_t)b] + rows[(size_t)b];
+    std::vector<int32_t> cur(ptr.begin(), ptr.end() - 1);
+    h->bin_max_rows = 1;
+    for (int32_t i : order) {
+        const int b = bucket_of[(size_t)i];
+        const int32_t local = cur[(size_t)b] - ptr[(size_t)b];
+        REQUIRE(local < 65536, "item bucket too large for the 16-bit local row index");
+        items[(size_t)cur[(size_t)b]++] = i;
+        slot[(size_t)i] = (int32_t)((uint32_t)b << 16 | (uint32_t)local);
+    }
+    for (size_t t = 0; t < hot.size(); ++t) slot[(size_t)hot[t]] = -(int32_t)t - 1;
+    for (int b = 0; b < n_buckets; ++b) h->bin_max_rows = std::max(h->bin_max_rows, rows[(size_t)b]);
+    h->bin_n_hot = (int)hot.size();
+    h->bin_item_slot.ensure((size_t)ni);
+    h->bin_bucket_ptr.ensure((size_t)n_buckets + 1);
+    h->bin_bucket_items.ensure(std::max<size_t>(1, items.size()));
+    h->bin_hot_items.ensure(std::max<size_t>(1, hot.size()));
+    h->bin_hot_bias.ensure(std::max<size_t>(1, hot.size()) * kBiasStride);
+    h->bin_item_slot.upload(slot.data(), (size_t)ni, h->stream);
+    h->bin_bucket_ptr.upload(ptr.data(), (size_t)n_buckets + 1, h->stream);
+    if (!items.empty()) h->bin_bucket_items.upload(items.data(), items.size(), h->stream);
+    if (!hot.empty()) h->bin_hot_items.upload(hot.data(), hot.size(), h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->bin_buckets = n_buckets;
+    h->bin_neg_population = neg_population;
+    h->bin_chunk = chunk;
+    h->bin_hot_threshold = hot_threshold;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+typedef void (*BinTripletKernel)(const HogArgs, const BinArgs);
+typedef void (*BinApplyKernel)(const BinApplyArgs);
+static void pick_binned_kernels(int k, int occ, BinTripletKernel *ka, BinApplyKernel *kb) {
+    if (k <= 64) { *ka = occ >= 2 ? bpr_binned_triplet_kernel<1, 4, 2> : env_int("CORNAC_HIP_BIN_UNRA", 4) >= 8 ? bpr_binned_triplet_kernel<1, 8, 1> : bpr_binned_triplet_kernel<1, 4, 1>; *kb = env_int("CORNAC_HIP_BIN_UNRB", 4) >= 4 ? bpr_binned_apply_kernel<1, 4> : bpr_binned_apply_kernel<1, 2>; }
+    else if (k <= 128) { *ka = occ >= 2 ? bpr_binned_triplet_kernel<2, 2, 2> : bpr_binned_triplet_kernel<2, 2, 1>; *kb = bpr_binned_apply_kernel<2, 2>; }
+    else if (k <= 192) { *ka = bpr_binned_triplet_kernel<3, 2, 1>; *kb = bpr_binned_apply_kernel<3, 1>; }
+    else { *ka = bpr_binned_triplet_kernel<4, 1, 1>; *kb = bpr_binned_apply_kernel<4, 1>; }
+}
+
+
+// Plan of the binned path for this handle (grid of the triplet kernel, LDS sizes, chunk length); ok == false when
+// the shape does not qualify: k outside (32, 256], too few interactions for one tile per wave, an item bucket that
+// does not fit a workgroup's LDS, or an experiment switch of the fused kernel is set.
+static constexpr size_t kBinMaxLds = 156 * 1024;  // of the 160 KiB per CU
+struct BinPlan {
+    bool ok = false;
+    int grid_a = 0, n_buckets = 0;
+    size_t lds_a = 0;
+    int64_t chunk = 0;
+    int cap = 0;  // messages per segment (a multiple of 64)
+    int hot_threshold = 0;
+};
+static BinPlan plan_binned(cornac_hip_bpr_t h, int flags, float lr) {
+    BinPlan pl;
+    // opt-in (hogwild_flags bit 6): measured slower than the fused atomic kernel at the ML-20M shape
+    if ((flags & 0xff) != 64 || h->k <= 32 || h->k > 256) return pl;
+    const DeviceInfo &di = device_info(h->device);
+    pl.n_buckets = di.cus;
+    const int R = (h->k + kWave - 1) / kWave;
+    const int64_t max_rows = (h->n_items + pl.n_buckets - 1) / pl.n_buckets + 1;  // LPT keeps row counts close to even
+    pl.lds_a = ((size_t)pl.n_buckets + (size_t)kBinWaves * 5 * kWave) * sizeof(int32_t);
+    if ((size_t)max_rows * (size_t)(2 * (kWave * R + 4) + 1) * sizeof(float) > kBinMaxLds || max_rows >= 65536) return pl;
+    BinTripletKernel ka;
+    BinApplyKernel kb;
+    if (h->bin_wg_per_cu == 0) {
+        const int want = std::max(1, std::min(2, env_int("CORNAC_HIP_BIN_WG_PER_CU", 1)));
+        pick_binned_kernels(h->k, want, &ka, &kb);
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ka, kBinBlock, pl.lds_a));
+        h->bin_wg_per_cu = std::max(1, std::min(per_cu, want));
+    }
+    pl.grid_a = di.cus * h->bin_wg_per_cu;
+    if (pl.grid_a > 1024) return pl;  // the apply kernel keeps one segment count per lane and wave
+    if (h->nnz < 8 * (int64_t)pl.grid_a * kBinWaves * kWave) return pl;  // too few tiles per wave and chunk to fill the pipeline
+    // Chunk length: every launch pays a pipeline fill/drain of about one tile per wave (measured ~0.16 ms), so chunks
+    // should be few; every cold row receives up to hot_threshold updates computed from the chunk's start, so they
+    // must not be long.  2 M triplets (a tenth of an ML-20M epoch) by default, never more than a quarter of an epoch.
+    const int64_t want = env_int("CORNAC_HIP_BIN_CHUNK", 0) > 0 ? env_int("CORNAC_HIP_BIN_CHUNK", 0) : (int64_t(1) << 21);
+    pl.chunk = std::max<int64_t>((int64_t)pl.grid_a * kBinWaves * kWave, std::min<int64_t>(want, h->nnz / 4));
+    // a segment (bucket x producing workgroup) receives 2 chunk / (buckets x workgroups) messages on average: size
+    // it for twice the mean (the surplus of an overflowing segment falls back to atomics)
+    const int64_t mean = 2 * pl.chunk / ((int64_t)pl.n_buckets * pl.grid_a) + 1;
+    pl.cap = (int)std::min<int64_t>(1024, (2 * mean + kWave - 1) / kWave * kWave);
+    // rows with more than hot_threshold messages per chunk keep device-scope atomics: the apply kernel serialises the
+    // messages of one row (~250 cycles each under its lock), which must stay well below the kernel's duration
+    pl.hot_threshold = env_int("CORNAC_HIP_BIN_HOT", 0) > 0 ? env_int("CORNAC_HIP_BIN_HOT", 0) : 4096;
+    pl.ok = true;
+    return pl;
+}
+
+static void fill_hog_args(cornac_hip_bpr_t h, HogArgs &a, int64_t n, float lr, float reg, int use_bias,
+                          int neg_population, int flags) {
+    a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
+    a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
+    a.bstride = 1;
+    a.counters = h->counters.p;
+    a.n = n;
+    a.s_begin = (uint64_t)h->hog_offset;
+    a.seed = h->hog_seed;
+    a.epoch = h->hog_epoch;
+    a.n_pos = (uint32_t)h->nnz;
+    a.n_neg = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint32_t)h->nnz : (uint32_t)h->n_items;
+    a.th_pos = lemire_thresh(a.n_pos);
+    a.th_neg = lemire_thresh(a.n_neg);
+    a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
+    a.lr = lr; a.reg = reg;
+    a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr; a.own_tmax = 0;
+    a.nnz = h->nnz;
+    a.ablate = (flags >> 8) & 0xff;
+}
+
+static void advance_hog_offset(cornac_hip_bpr_t h, int64_t n) {
+    h->hog_offset += n;
+    if (h->hog_offset >= h->nnz) {
+        h->hog_offset = 0;
+        ++h->hog_epoch;
+    }
+}
+
+static void binned_enqueue(cornac_hip_bpr_t h, const BinPlan &pl, int64_t n_samples, float lr, float reg, int use_bias,
+                           int neg_population, int flags) {
+    BinTripletKernel ka;
+    BinApplyKernel kb;
+    pick_binned_kernels(h->k, h->bin_wg_per_cu, &ka, &kb);
+    if (!h->bin_attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinMaxLds));
+        h->bin_attr_set = true;
+    }
+    const int64_t W = (int64_t)pl.grid_a * kBinWaves;
+    build_ownership(h, W);
+    build_item_buckets(h, pl.n_buckets, neg_population, pl.chunk, pl.hot_threshold);
+    const int R = (h->k + kWave - 1) / kWave;
+    const size_t lds_b = (size_t)h->bin_max_rows * (size_t)(2 * (kWave * R + 4) + 1) * sizeof(float);
+    REQUIRE(lds_b <= kBinMaxLds, "item bucket does not fit the LDS");
+    // tiles of 64 samples per wave in one launch: ceil(own_tmax * chunk / nnz) + 1 covers every [lo_tile, hi_tile)
+    const int64_t snap_tiles = std::min<int64_t>(h->own_tmax, (h->own_tmax * pl.chunk + h->nnz - 1) / h->nnz + 1);
+    REQUIRE(W * snap_tiles * kWave < (int64_t(1) << 32), "snapshot index exceeds 32 bits");
+    h->bin_seg.ensure((size_t)pl.n_buckets * pl.grid_a * pl.cap);
+    h->bin_seg_count.ensure((size_t)pl.n_buckets * pl.grid_a);
+    h->bin_snap.ensure((size_t)W * snap_tiles * kWave * h->k);
+    const unsigned hgrid = (unsigned)((h->bin_n_hot + kBlock - 1) / kBlock);
+    int64_t left = n_samples;
+    while (left > 0) {
+        const int64_t n = std::min(std::min(left, h->nnz - h->hog_offset), pl.chunk);
+        HogArgs a;
+        fill_hog_args(h, a, n, lr, reg, use_bias, neg_population, flags);
+        a.own_u = h->own_u.p; a.own_i = h->own_i.p; a.wave_ptr = h->wave_ptr.p; a.own_tmax = h->own_tmax;
+        BinArgs g;
+        g.item_slot = h->bin_item_slot.p;
+        g.seg = reinterpret_cast<v4u *>(h->bin_seg.p);
+        g.seg_count = h->bin_seg_count.p;
+        g.snap = h->bin_snap.p;
+        g.hot_bias = h->bin_hot_bias.p;
+        g.n_buckets = pl.n_buckets;
+        g.cap = pl.cap;
+        g.snap_tiles = (int)snap_tiles;
+        BinApplyArgs p;
+        p.bucket_ptr = h->bin_bucket_ptr.p; p.bucket_items = h->bin_bucket_items.p;
+        p.seg = reinterpret_cast<const v4u *>(h->bin_seg.p); p.seg_count = h->bin_seg_count.p;
+        p.snap = h->bin_snap.p; p.V = h->V.p; p.B = h->B.p;
+        p.n_seg = pl.grid_a; p.cap = pl.cap; p.k = h->k; p.use_bias = use_bias; p.max_rows = h->bin_max_rows; p.lr = lr; p.reg = reg;
+        p.ablate = a.ablate;
+        if (h->bin_n_hot)
+            hipLaunchKernelGGL(hot_bias_pad_kernel, dim3(hgrid), dim3(kBlock), 0, h->stream, h->B.p, h->bin_hot_items.p,
+                               h->bin_hot_bias.p, h->bin_n_hot);
+        h->ktimer.before(h->stream);
+        hipLaunchKernelGGL(ka, dim3(pl.grid_a), dim3(kBinBlock), pl.lds_a, h->stream, a, g);
+        if (!(a.ablate & 16))
+            hipLaunchKernelGGL(kb, dim3(pl.n_buckets), dim3(kBinBlock), lds_b, h->stream, p);
+        h->ktimer.after(h->stream);
+        if (h->bin_n_hot)
+            hipLaunchKernelGGL(hot_bias_unpad_kernel, dim3(hgrid), dim3(kBlock), 0, h->stream, h->bin_hot_bias.p,
+                               h->bin_hot_items.p, h->B.p, h->bin_n_hot);
+        HIP_CHECK(hipGetLastError());
+        advance_hog_offset(h, n);
+        left -= n;
+    }
+}
+
 static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
-    if ((flags & 8) == 0) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
-    const bool repl = (flags & 16) != 0 && (flags & 8) == 0 && hogwild_uses_ownership(h, flags) && h->k <= 128;
-    static const int repl_syncs = getenv("CORNAC_HIP_REPL_SYNCS") ? std::max(1, atoi(getenv("CORNAC_HIP_REPL_SYNCS"))) : 16;
-    const int64_t repl_chunk = (h->nnz + repl_syncs - 1) / repl_syncs;
-    const int64_t nv = h->total_items * h->k, nb = h->total_items * kBiasStride;
-    if (repl) {
-        h->Vrep.ensure((size_t)nv * kXcds);
-        h->Brep.ensure((size_t)nb * kXcds);
-    } else {
-        flags &= ~16;
+    const BinPlan pl = plan_binned(h, flags, lr);
+    if (pl.ok) {
+        binned_enqueue(h, pl, n_samples, lr, reg, use_bias, neg_population, flags);
+        return;
     }
+    flags &= ~(32 | 64);
+    if ((flags & 8) == 0) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
     int64_t left = n_samples;
     while (left > 0) {
-        int64_t n = std::min(left, h->nnz - h->hog_offset);
-        if (repl) n = std::min(n, repl_chunk);
+        const int64_t n = std::min(left, h->nnz - h->hog_offset);
         HogArgs a;
-        a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
+        fill_hog_args(h, a, n, lr, reg, use_bias, neg_population, flags);
         const bool pad_bias = (flags & 8) == 0;  // bit3: experiment switch, dense bias table
-        a.U = h->U.p; a.V = h->V.p;
         a.B = pad_bias ? h->Bpad.p : h->B.p;
         a.bstride = pad_bias ? kBiasStride : 1;
-        a.counters = h->counters.p;
-        a.n = n;
-        a.s_begin = (uint64_t)h->hog_offset;
-        a.seed = h->hog_seed;
-        a.epoch = h->hog_epoch;
-        a.n_pos = (uint32_t)h->nnz;
-        a.n_neg = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint32_t)h->nnz : (uint32_t)h->n_items;
-        a.th_pos = lemire_thresh(a.n_pos);
-        a.th_neg = lemire_thresh(a.n_neg);
-        a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
-        a.lr = lr; a.reg = reg;
-        a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr; a.own_tmax = 0;
-        a.nnz = h->nnz;
-        a.ablate = (flags >> 8) & 0xff;
         const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
         if (pad_bias)
             hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p,
                                h->total_items);
-        a.rep_stride_v = 0; a.rep_stride_b = 0;
         h->ktimer.before(h->stream);
-        if (repl) {
-            const unsigned gv = (unsigned)std::min<int64_t>((nv + kBlock - 1) / kBlock, 4096), gb = (unsigned)std::min<int64_t>((nb + kBlock - 1) / kBlock, 4096);
-            hipLaunchKernelGGL(replicate_kernel, dim3(gv), dim3(kBlock), 0, h->stream, h->V.p, h->Vrep.p, nv, nv);
-            hipLaunchKernelGGL(replicate_kernel, dim3(gb), dim3(kBlock), 0, h->stream, h->Bpad.p, h->Brep.p, nb, nb);
-            HogArgs ar = a;
-            ar.V = h->Vrep.p; ar.B = h->Brep.p; ar.rep_stride_v = nv; ar.rep_stride_b = nb;
-            launch_hogwild(h, ar, flags);
-            hipLaunchKernelGGL(reconcile_kernel, dim3(gv), dim3(kBlock), 0, h->stream, h->V.p, h->Vrep.p, nv, nv);
-            hipLaunchKernelGGL(reconcile_kernel, dim3(gb), dim3(kBlock), 0, h->stream, h->Bpad.p, h->Brep.p, nb, nb);
-        } else {
-            launch_hogwild(h, a, flags);
-        }
+        launch_hogwild(h, a, flags);
         h->ktimer.after(h->stream);
         if (pad_bias)
             hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p,
                                h->total_items);
-        h->hog_offset += n;
+        advance_hog_offset(h, n);
         left -= n;
-        if (h->hog_offset >= h->nnz) {
-            h->hog_offset = 0;
-            ++h->hog_epoch;
-        }
     }
 }
 

@@ -130,10 +130,18 @@ class MF(Recommender):
 
     # ---- prediction -------------------------------------------------------------------------------
     def _scoring_tables(self):
-        if self.__dict__.get("_item_base") is None or self._item_base_src is not self.i_biases:
+        if (self.__dict__.get("_item_base") is None or self._item_base_src is not self.i_biases
+                or self._item_base_mean != float(self.global_mean)):
             self._item_base = (self.global_mean + self.i_biases).astype(DTYPE)
             self._item_base_src = self.i_biases
+            self._item_base_mean = float(self.global_mean)
         return self.u_factors, self.i_factors, self._item_base, self.u_biases
+
+    def _drop_scorer(self):
+        # the biases are refreshed IN PLACE by a refit: the derived item_base table must go with the device scorer
+        for name in ("_item_base", "_item_base_src", "_item_base_mean"):
+            self.__dict__.pop(name, None)
+        super()._drop_scorer()
 
     def score(self, user_idx, item_idx=None):
         """recom_mf.py:254-286"""

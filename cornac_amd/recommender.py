@@ -46,7 +46,8 @@ class Recommender:
         self.verbose = verbose
         self.is_fitted = False
         # not pickled / deep-copied: datasets and device-side state
-        self.ignored_attrs = ["train_set", "val_set", "test_set", "_scorer", "_scorer_key", "_trainer"]
+        self.ignored_attrs = ["train_set", "val_set", "test_set", "_scorer", "_scorer_key", "_trainer", "_item_base",
+                              "_item_base_src", "_item_base_mean", "_cat_u", "_cat_i", "_cat_b", "_cat_src"]
         for attr in self._DATASET_FACTS:
             setattr(self, attr, None)
         self._item_ids = None
@@ -216,6 +217,12 @@ class Recommender:
         if sc is not None:
             sc.close()
 
+    def invalidate_scorer(self):
+        """Call after editing learned parameters IN PLACE (warm-start tweaks, loading values into the existing
+        arrays): the device copy of the scoring tables is keyed on the identity of the host arrays and would
+        otherwise go stale.  `fit()` calls it itself."""
+        self._drop_scorer()
+
     def _get_scorer(self):
         from . import _lib
 
@@ -234,10 +241,11 @@ class Recommender:
 
         Scores (score_user kernel) and the ordering (top-k / sort kernels) run on the device.
         Ties are ordered by descending item index (the reference leaves tie order unspecified,
-        tests/cornac/models/test_recommender.py:89-93).  With k != -1 the result holds exactly the
-        ranked top-k; the reference appends the remaining candidates in unspecified argpartition
-        order, which no caller may rely on.  A k larger than the number of candidates returns all of them (the
-        reference fails inside np.argpartition there)."""
+        tests/cornac/models/test_recommender.py:89-93).  With k != -1 the result holds, like the reference's
+        (recommender.py:521-528), EVERY candidate: the first k are the ranked top-k, the remaining ones follow in
+        candidate order (the reference leaves them in argpartition order) — callers such as the reference's
+        `ranking_eval` hand the whole array to metrics that read past k.  A k larger than the number of candidates
+        ranks all of them (the reference fails inside np.argpartition there)."""
         try:
             known_item_scores = self.score(user_idx, **kwargs)
         except ScoreException:
@@ -261,11 +269,15 @@ class Recommender:
             items, _ = sc.rank_topk(np.array([row], np.int32), topk,
                                     exclude=(np.array([0, len(excl)], np.int64), excl) if len(excl) else None)
             ranked_items = items[0].astype(item_indices.dtype)
+            if topk < n_cand:  # the candidates outside the top-k follow, unranked (recommender.py:521-528)
+                in_top = np.zeros(sc.n_items, dtype=bool)
+                in_top[ranked_items] = True
+                ranked_items = np.concatenate([ranked_items, item_indices[~in_top[item_indices]]])
         else:
             # user unknown to the device tables (constant scores) or candidates beyond the scored
             # items (all tied at the row minimum): only the pinned tie rule is left to apply.
             order = np.argsort(item_scores, kind="stable")[::-1]
-            ranked_items = item_indices[order][:topk]
+            ranked_items = item_indices[order]
         return ranked_items, item_scores
 
     @property

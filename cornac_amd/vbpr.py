@@ -90,6 +90,11 @@ class VBPR(Recommender):
             self._cat_src = self.gamma_user
         return self._cat_u, self._cat_i, self._cat_b, None
 
+    def _drop_scorer(self):
+        for name in ("_cat_u", "_cat_i", "_cat_b", "_cat_src"):  # derived tables follow the parameters they copy
+            self.__dict__.pop(name, None)
+        super()._drop_scorer()
+
     def _scorer_row_count(self):
         return len(self.gamma_user)
 

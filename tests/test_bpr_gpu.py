@@ -383,26 +383,36 @@ def test_sharded_trainer_single_rank_stream_ordering():
     assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
 
 
-def test_xcd_replica_experiment_learns_like_the_atomic_kernel():
-    """hogwild_flags bit 4 (experiment, off by default): one replica of V/B per XCD with plain read-modify-write,
-    reconciled between launches.  Same sampler, so the skip count is identical; training must stay close."""
+def test_binned_item_updates_learn_like_the_fused_atomic_kernel():
+    """hogwild_flags bit 6 (opt-in experiment): the item-side updates go through message segments +
+    LDS-resident item buckets with the own-drift correction (bpr_binned.inc) instead of the fused kernel's device-scope
+    atomics.  Different wave count, hence different sample streams (skip counts are compared statistically), same
+    optimisation problem: training must stay close to the fused kernel."""
     from cornac_amd import synth
 
-    n_users, n_items, k = 6000, 3000, 64
-    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
+    n_users, n_items, k = 20000, 3000, 64
+    users, items = synth.zipf_interactions(n_users, n_items, 2_500_000, 0.8, 3)
     indptr, indices = synth.csr_from_sorted(users, items, n_users)
     rs = np.random.RandomState(0)
     U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
     V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
     out = {}
-    for flags in (0, 16):
+    for flags in (64, 0):
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
         tr.set_factors(U, V, np.zeros(n_items, np.float32))
         tr.seed_hogwild(9)
-        tr.fit_epochs(6, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
-        c, s = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        tr.fit_epochs(6, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
         out[flags] = (c / (len(indices) - s), s, tr.get_factors())
         tr.close()
-    assert out[0][1] == out[16][1]
-    assert abs(out[0][0] - out[16][0]) < 0.02, (out[0][0], out[16][0])
-    assert np.isfinite(out[16][2][1]).all() and np.abs(out[16][2][1] - V).max() > 1e-3
+    assert abs(out[64][1] - out[0][1]) < 0.05 * out[0][1] + 50
+    assert abs(out[64][0] - out[0][0]) < 0.01, (out[64][0], out[0][0])
+    for f in (64, 0):
+        V2, B2 = out[f][2][1], out[f][2][2]
+        assert np.isfinite(V2).all() and np.abs(V2 - V).max() > 1e-3
+    # the fused kernel's atomics conserve the column sums exactly (dV_i = -dV_j); the binned path re-evaluates z per
+    # item row (own-drift correction), so its two updates of a triplet only cancel to first order
+    V2, B2 = out[0][2][1], out[0][2][2]
+    moved = np.abs(V2.astype(np.float64) - V).sum(0)
+    assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+    assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
