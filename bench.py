@@ -10,6 +10,13 @@ matrix.  For N > 1 the driver launches this file under torch.distributed.run, on
 every rank owns a disjoint ML-20M-shaped user population (weak scaling) and the replicated item
 table is reconciled by RCCL all-reduce of its deltas (cornac_amd/dist.py).
 
+A plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1, so the one command works with and without an external launcher.
+
+At N = 1 the line also carries `legs`: the other single-GPU configurations of BASELINE.json, each with its own
+`roofline` and reference `cpu_baseline` — `mf_netflix` (configs[2]: biased MF k = 128 at the Netflix Prize shape),
+`vbpr_tradesy` (configs[3]) and `bpr_k128_scale` (one GPU's user slice of configs[4], k = 128).
+
 Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement" for every field).
 """
 import argparse
@@ -189,6 +196,295 @@ def cpu_baseline(indptr, indices, n_items, k, lr, reg, budget_s):
                       "%d threads (best of %s on a %d-thread host), %.1f s" % (n, n / nnz, k, threads, cands, max_threads, dt)}
 
 
+# ======================================================================================================================
+# extra single-GPU legs (N = 1): BASELINE.json configs[2], [3] and one GPU's slice of [4]
+# ======================================================================================================================
+def synth_ratings(n_users, n_items, nnz, zipf_a, seed):
+    """COO ratings sorted by user at a dataset's SHAPE, generated in O(nnz) without a global de-duplication (100 M
+    entries in seconds): per-user counts ~ multinomial(log-normal activity), items ~ Zipf over a random permutation,
+    ratings 1..5 around user + item offsets.  (MF trains on the COO list as given; duplicates are harmless.)"""
+    rs = np.random.RandomState(seed)
+    act = rs.lognormal(0.0, 1.0, n_users)
+    counts = rs.multinomial(nnz, act / act.sum())
+    users = np.repeat(np.arange(n_users, dtype=np.int64), counts)
+    p_item = 1.0 / np.arange(1, n_items + 1) ** zipf_a
+    cdf = np.cumsum(p_item / p_item.sum())
+    perm = rs.permutation(n_items).astype(np.int64)
+    items = np.empty(nnz, np.int64)
+    step = 1 << 24
+    for a in range(0, nnz, step):   # chunked: bounds the float64 temporaries
+        b = min(a + step, nnz)
+        items[a:b] = perm[np.searchsorted(cdf, rs.random_sample(b - a)).clip(0, n_items - 1)]
+    bu, bi = rs.normal(0, 0.5, n_users).astype(np.float32), rs.normal(0, 0.5, n_items).astype(np.float32)
+    val = np.empty(nnz, np.float32)
+    for a in range(0, nnz, step):
+        b = min(a + step, nnz)
+        val[a:b] = np.clip(np.rint(3.5 + bu[users[a:b]] + bi[items[a:b]] + rs.normal(0, 0.7, b - a)), 1, 5)
+    return users, items, val
+
+
+def leg_mf_netflix(args, _lib):
+    """configs[2]: biased MF, k = 128, Netflix Prize shape (480 189 x 17 770, 100 480 507 ratings), hogwild mode.
+    Algorithmic bytes per rating: U and V rows read + written (16 k), the two biases R+W (16), the COO
+    record (int64 rid, int64 cid, f32 val = 20)."""
+    from cornac_amd import synth
+
+    n_users, n_items, nnz, zipf_a, seed = synth.CONFIGS["netflix"]
+    k, lr, reg = 128, 0.01, 0.02
+    t0 = time.time()
+    users, items, val = synth_ratings(n_users, n_items, nnz, zipf_a, seed)
+    t_gen = time.time() - t0
+    rs = np.random.RandomState(1)
+    mu = float(val.mean())
+    t0 = time.time()
+    tr = _lib.MfTrainer(users, items, val, n_users, n_items, k)
+    U = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    tr.set_factors(U, V, np.zeros(n_users, np.float32), np.zeros(n_items, np.float32))
+    tr.fit(1, lr, reg, mu, True, False, _lib.MODE_HOGWILD)  # warm-up: builds the ownership tables
+    t_setup = time.time() - t0
+    epochs = 3
+    tr.kernel_timing(True)
+    t0 = time.perf_counter()
+    loss, _ = tr.fit(epochs, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
+    dt = time.perf_counter() - t0
+    kms, launches = tr.kernel_timing(False)
+    tr.close()
+    b = 16 * k + 16 + 20
+    out = {"metric": "mf_ratings_per_sec", "value": nnz * epochs / dt, "unit": "ratings/s", "steps": epochs,
+           "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "biased MF k=%d, Netflix-Prize-shaped synthetic ratings (%d users x %d items, %d "
+                                  "ratings, int64 COO as the reference's uir_tuple), hogwild mode" % (k, n_users, n_items, nnz),
+                      "lr": lr, "reg": reg},
+           "roofline": {"bound": "hbm", "achieved": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "mf_hogwild_rowwise_kernel (one launch = one epoch)",
+                        "launches": launches, "avg_launch_ms": kms / max(launches, 1),
+                        "algorithmic_bytes_per_rating": b},
+           "train_stats": {"mse_per_epoch": [float(x) / nnz for x in loss]},
+           "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
+    if args.cpu_baseline_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline_mf(users, items, val, n_users, n_items, k, lr, reg, mu,
+                                              args.cpu_baseline_seconds)
+        if out["cpu_baseline"]:
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def cpu_baseline_mf(users, items, val, n_users, n_items, k, lr, reg, mu, budget_s):
+    """The reference's `backend_cpu.fit_sgd` (cornac/models/mf/backend_cpu.pyx:35-97, compiled in oracle/_ref) on a
+    bounded sample of the same ratings: one epoch = one pass over the sample's COO list."""
+    try:
+        from oracle import ref_loader
+
+        ref_fit = ref_loader.load_mf_kernel()
+        kind = "reference"
+
+        def fit_sgd(rid, cid, v, U, V, Bu, Bi, iters, threads):
+            ref_fit(rid, cid, v, U, V, Bu, Bi, lr, reg, mu, iters, threads, True, False, False)
+    except Exception as e:
+        print("[bench] reference MF kernel unavailable (%r): timing the port" % (e,), file=sys.stderr)
+        try:
+            from oracle import oracle as orc
+
+            L, kind = orc.lib(), "port"
+
+            def fit_sgd(rid, cid, v, U, V, Bu, Bi, iters, threads):
+                loss = np.zeros(iters, np.float32)
+                L.oracle_mf_fit(rid, cid, v, len(v), U, V, Bu, Bi, k, lr, reg, mu, iters, threads, 1, 0, loss)
+        except Exception as e2:
+            print("[bench] mf cpu_baseline failed: %r" % (e2,), file=sys.stderr)
+            return None
+    n = min(len(val), 20_000_000)
+    rs = np.random.RandomState(3)
+    rid, cid, v = np.ascontiguousarray(users[:n]), np.ascontiguousarray(items[:n]), np.ascontiguousarray(val[:n])
+    nu = int(rid.max()) + 1
+    U = rs.normal(0, 0.01, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    Bu, Bi = np.zeros(nu, np.float32), np.zeros(n_items, np.float32)
+    max_threads = os.cpu_count() or 1
+
+    def run(threads, iters):
+        t0 = time.time()
+        fit_sgd(rid, cid, v, U, V, Bu, Bi, iters, threads)
+        return time.time() - t0
+
+    run(max_threads, 1)  # page in
+    cands = sorted({t for t in (16, 32, 64, max_threads) if t <= max_threads})
+    best = min((run(t, 1), t) for t in cands)
+    iters = int(max(1, min(6, round(budget_s / max(best[0], 1e-3)))))
+    dt = run(best[1], iters)
+    return {"value": n * iters / dt, "unit": "ratings/s", "cores": best[1], "kind": kind,
+            "sample": "%d epochs over the first %d ratings (%d users) of the same COO list through the reference's compiled "
+                      "backend_cpu.fit_sgd (Cython/OpenMP, k=%d), %d threads (best of %s on a %d-thread host), %.1f s"
+                      % (iters, n, nu, k, best[1], cands, max_threads, dt)}
+
+
+def leg_vbpr_tradesy(args, _lib):
+    """configs[3]: VBPR k = k2 = 64 with 4096-d visual features at the Tradesy shape (19 243 users x 165 906 items,
+    394 421 feedback), batch 100 as the reference's default.  The step is bound by torch.optim.Adam's dense sweep
+    over every table (recom_vbpr.py:228-262): 7 passes x 4 bytes over all parameters + the 2 B feature rows gathered."""
+    nu, ni, nnz, nf, k, k2, B = 19243, 165906, 394421, 4096, 64, 64, 100
+    rs = np.random.RandomState(44)
+    t0 = time.time()
+    F = rs.random_sample((ni, nf)).astype(np.float32)
+    u = rs.randint(0, nu, nnz).astype(np.int32)
+    i = rs.randint(0, ni, nnz).astype(np.int32)
+    j = rs.randint(0, ni, nnz).astype(np.int32)
+    t_gen = time.time() - t0
+    tr = _lib.VbprTrainer(F, nu, ni, k, k2)
+    lim = np.sqrt(3.0) * np.sqrt(2.0 / (nu + k))
+    params = dict(Bi=np.zeros(ni, np.float32), Gu=rs.uniform(-lim, lim, (nu, k)), Gi=rs.uniform(-lim, lim, (ni, k)),
+                  Tu=rs.uniform(-lim, lim, (nu, k2)), E=rs.uniform(-0.03, 0.03, (nf, k2)), Bp=rs.uniform(-0.03, 0.03, nf))
+    tr.set_params(**params)
+    tr.fit_batches(u[:2000], i[:2000], j[:2000], B, 0.005, 0.01, 0.01, 0.0)  # warm-up
+    t0 = time.perf_counter()
+    nll = tr.fit_batches(u, i, j, B, 0.005, 0.01, 0.01, 0.0)
+    dt = time.perf_counter() - t0
+    tr.close()
+    steps = (nnz + B - 1) // B
+    n_par = ni + nu * k + ni * k + nu * k2 + nf * k2 + nf
+    bytes_step = 28.0 * n_par + 2.0 * B * nf * 4
+    out = {"metric": "vbpr_triplets_per_sec", "value": nnz / dt, "unit": "triplets/s", "steps": steps,
+           "ms_per_step": 1e3 * dt / steps, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "VBPR k=k2=%d, %d-d features, Tradesy-shaped synthetic (%d users x %d items, %d "
+                                  "feedback), batch %d, one epoch on pre-sampled batches" % (k, nf, nu, ni, nnz, B)},
+           "roofline": {"bound": "hbm", "achieved": bytes_step * steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_step * steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "whole minibatch step (featdiff gather, projection GEMM, pair gradient, scatter, dense "
+                                  "Adam sweep): bytes / wall time of the epoch, no per-kernel events",
+                        "algorithmic_bytes_per_step": bytes_step},
+           "train_stats": {"mean_nll_per_pair": nll / (steps * B * B)}, "host_s": {"generate": t_gen}}
+    if args.cpu_baseline_seconds > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline_vbpr(F, u, i, j, params, nu, ni, k, k2, B, args.cpu_baseline_seconds)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            print("[bench] vbpr cpu_baseline failed: %r" % (e,), file=sys.stderr)
+            out["cpu_baseline"] = None
+    return out
+
+
+def cpu_baseline_vbpr(F, u, i, j, params, nu, ni, k, k2, B, budget_s):
+    """The reference's VBPR step is PyTorch on the host (recom_vbpr.py:228-262); oracle/vbpr_oracle.py restates it
+    line by line (bit-identical to the live reference, tests/test_oracle_vs_reference.py) — timed over a few batches."""
+    import torch
+
+    from oracle import vbpr_oracle
+
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    n_steps, dt = vbpr_oracle.timed_steps(F, params, u, i, j, B, budget_s=min(budget_s, 8.0))
+    return {"value": n_steps * B / dt, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d minibatch steps of %d triplets of the same tables through the torch restatement of the "
+                      "reference's VBPR step (oracle/vbpr_oracle.py; the reference itself is torch on the host), "
+                      "%d threads, %.1f s" % (n_steps, B, torch.get_num_threads(), dt)}
+
+
+def leg_bpr_k128_scale(args, _lib):
+    """One GPU's share of configs[4] (100 M users x 10 M items, k = 128, 8 GPUs): users are partitioned, so a rank
+    owns 12.5 M users; the item table (10 M x 128 fp32 = 5.1 GB) is held whole.  5 distinct items per user."""
+    nu, ni, d, k = 12_500_000, 10_000_000, 5, 128
+    rs = np.random.RandomState(45)
+    t0 = time.time()
+    base = rs.randint(0, ni, size=nu, dtype=np.int64)
+    step = rs.randint(1, ni // (2 * d), size=nu, dtype=np.int64)
+    items = (base[:, None] + step[:, None] * np.arange(d, dtype=np.int64)[None, :]) % ni
+    items.sort(axis=1)
+    indices = items.astype(np.int32).ravel()
+    indptr = (np.arange(nu + 1, dtype=np.int64) * d).astype(np.int32)
+    del items, base, step
+    t_gen = time.time() - t0
+    nnz = len(indices)
+    t0 = time.time()
+    tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+    r2 = np.random.RandomState(2)
+    V = ((r2.uniform(0, 1, (ni, k)).astype(np.float32) - 0.5) / k)
+    U = ((r2.uniform(0, 1, (nu, k)).astype(np.float32) - 0.5) / k)
+    tr.set_factors(U, V, np.zeros(ni, np.float32))
+    tr.seed_hogwild(7)
+    tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)  # warm-up: builds ownership tables
+    t_setup = time.time() - t0
+    epochs = 2
+    tr.kernel_timing(True)
+    t0 = time.perf_counter()
+    c, sk = tr.fit_epochs(epochs, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    dt = time.perf_counter() - t0
+    kms, launches = tr.kernel_timing(False)
+    tr.close()
+    b_full, b_skip = algorithmic_bytes_per_triplet(k, d)
+    skip = sk / float(nnz * epochs)
+    bytes_launch = nnz * ((1 - skip) * b_full + skip * b_skip)
+    out = {"metric": "bpr_triplets_per_sec", "value": nnz * epochs / dt, "unit": "triplets/s", "steps": epochs,
+           "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BPR k=%d on one GPU's user slice of the 100 M x 10 M synthetic (%d users x %d items, "
+                                  "%d interactions, U %.1f GB, V %.1f GB: beyond the Infinity Cache), hogwild mode"
+                                  % (k, nu, ni, nnz, nu * k * 4 / 1e9, ni * k * 4 / 1e9)},
+           "roofline": {"bound": "hbm", "achieved": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>", "launches": launches,
+                        "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
+           "train_stats": {"correct_frac": c / max(nnz * epochs - sk, 1), "skipped_frac": skip},
+           "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
+    if args.cpu_baseline_seconds > 0:
+        try:
+            # the reference kernel on the first 1 M users of the same matrix (its U slice is 0.5 GB instead of 6.4 GB)
+            sub = 1_000_000
+            cb = cpu_baseline(indptr[:sub + 1], indices[:sub * d], ni, k, 0.05, 0.01, min(args.cpu_baseline_seconds, 8.0))
+            cb["sample"] = "first %d users of the same matrix; " % sub + cb["sample"].replace("ML-20M-shaped", "scale-leg")
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        except Exception as e:
+            print("[bench] scale cpu_baseline failed: %r" % (e,), file=sys.stderr)
+            out["cpu_baseline"] = None
+    return out
+
+
+LEGS = {"mf_netflix": leg_mf_netflix, "vbpr_tradesy": leg_vbpr_tradesy, "bpr_k128_scale": leg_bpr_k128_scale}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    port = os.environ.get("MASTER_PORT", str(29400 + os.getpid() % 500))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """The launcher / rendezvous / timing / JSON scaffolding with a stand-in step and the gloo backend: what the CPU
+    test of `--gpus N` exercises (tests/test_bench_launcher_cpu.py).  No HIP code runs."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))  # uneven ranks: the reported time must be the slowest one's
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "bpr_triplets_per_sec", "value": 1000.0 * args.steps * world / elapsed,
+                          "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run",
+                          "config": {"workload": "dry run of the launcher (no GPU work)", "parallelism": "dp%d" % world}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +507,15 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=2_000_000, help="draws per exchange with --sharded-items")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
+    ap.add_argument("--legs", default="mf_netflix,vbpr_tradesy,bpr_k128_scale",
+                    help="extra single-GPU legs reported under `legs` at N = 1 (comma list; empty = none)")
+    ap.add_argument("--no-legs", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="launcher / timing scaffolding only, gloo, no GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
+    if args.dry_run_cpu:
+        return dry_run(args)
 
     import torch
 

@@ -336,6 +336,8 @@ class Recommender:
             X = train_set.csr_matrix
             if user_idx < X.shape[0]:
                 candidates = np.setdiff1d(candidates, X.indices[X.indptr[user_idx]:X.indptr[user_idx + 1]])
-        ranked, _ = self.rank(user_idx, candidates, k=k)
+        ranked, _ = self.rank(user_idx, candidates, k=k)   # device top-k (the reference sorts everything, then cuts)
+        if k != -1:
+            ranked = ranked[:k]
         names = self.item_ids
         return [names[i] for i in ranked]

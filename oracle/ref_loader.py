@@ -112,3 +112,23 @@ def load_kernel_only():
         _loaded = True
     m = importlib.import_module("cornac.models.bpr.recom_bpr")
     return m.RNGVector, m.BPR
+
+
+def load_mf_kernel():
+    """`fit_sgd` of the REAL compiled reference extension cornac/models/mf/backend_cpu (oracle/_ref).  The extension
+    only imports numpy / multiprocessing / tqdm, so on the GPU box it loads over an empty stand-in package."""
+    global _loaded
+    import importlib
+
+    if available():
+        return load().backend_cpu.fit_sgd
+    if not os.path.exists(build_ref.so_path("cornac/models/mf/backend_cpu")):
+        raise RuntimeError("oracle/_ref is not built")
+    if not _loaded:
+        if "cornac" in sys.modules:
+            raise RuntimeError("a `cornac` package is already imported")
+        stubs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs")
+        sys.meta_path.insert(0, _RefExtFinder())
+        sys.path.insert(0, stubs)
+        _loaded = True
+    return importlib.import_module("cornac.models.mf.backend_cpu").fit_sgd

@@ -82,3 +82,41 @@ class VBPROracle:
         self.theta_item = F.mm(E).data.numpy()
         self.visual_bias = F.mm(Bp).data.numpy().ravel()
         return self
+
+
+def timed_steps(features, params, u, i, j, batch_size, lr=0.005, lambda_w=0.01, lambda_b=0.01, lambda_e=0.0,
+                budget_s=5.0):
+    """The same minibatch step as VBPROracle.fit (recom_vbpr.py:228-262), run over consecutive slices of pre-sampled
+    (u, i, j) until `budget_s` seconds have passed — bench.py's CPU baseline for the VBPR leg.  `params` maps
+    Bi, Gu, Gi, Tu, E, Bp to arrays.  Returns (steps done, seconds)."""
+    import time
+
+    import torch
+
+    dt = torch.float
+    F = torch.tensor(np.asarray(features, np.float32), dtype=dt)
+    P = {n: torch.tensor(np.asarray(params[n], np.float32).reshape(-1, 1) if n == "Bp" else
+                         np.asarray(params[n], np.float32), dtype=dt, requires_grad=True)
+         for n in ("Bi", "Gu", "Gi", "Tu", "E", "Bp")}
+    Bi, Gu, Gi, Tu, E, Bp = (P[n] for n in ("Bi", "Gu", "Gi", "Tu", "E", "Bp"))
+    opt = torch.optim.Adam([Bi, Gu, Gi, Tu, E, Bp], lr=lr)
+
+    def l2(*ts):
+        return sum(t.pow(2).sum() for t in ts) / 2
+
+    n, t0 = 0, time.time()
+    while (n + 1) * batch_size <= len(u) and time.time() - t0 < budget_s:
+        a = n * batch_size
+        bu, bi, bj = (torch.as_tensor(np.asarray(x[a:a + batch_size], np.int64)) for x in (u, i, j))
+        gu, tu = Gu[bu], Tu[bu]
+        beta_i, beta_j = Bi[bi], Bi[bj]
+        gi, gj = Gi[bi], Gi[bj]
+        feat_diff = F[bi] - F[bj]
+        X = (beta_i - beta_j + (gu * (gi - gj)).sum(dim=1) + (tu * feat_diff.mm(E)).sum(dim=1) + feat_diff.mm(Bp))
+        loss = -torch.nn.functional.logsigmoid(X).sum() + (l2(gu, gi, gj, tu) * lambda_w + l2(beta_i) * lambda_b
+                                                         + l2(beta_j) * lambda_b / 10 + l2(E, Bp) * lambda_e)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        n += 1
+    return n, time.time() - t0

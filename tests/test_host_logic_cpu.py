@@ -98,7 +98,8 @@ def test_recommender_surface_around_fitted_parameters(device_double, tmp_path):
         m.score(2, ds.num_items + 3)
     cand = np.arange(3, 30)
     ranked, scores = m.rank(2, item_indices=cand, k=5)
-    assert np.array_equal(scores, s[cand]) and list(ranked) == list(cand[np.argsort(s[cand], kind="stable")[::-1]][:5])
+    assert np.array_equal(scores, s[cand]) and list(ranked[:5]) == list(cand[np.argsort(s[cand], kind="stable")[::-1]][:5])
+    assert len(ranked) == len(cand) and sorted(ranked.tolist()) == sorted(cand.tolist())  # recommender.py:521-528
     full, _ = m.rank(2)
     assert sorted(full.tolist()) == list(range(ds.num_items)) and np.all(np.diff(s[full]) <= 0)
     assert ds.min_rating <= m.rate(2, 4) <= ds.max_rating

@@ -53,7 +53,7 @@ def test_fixture_and_model_surface():
     s = m.score(0)
     assert np.abs(s - m.V @ m.U[0]).max() < 1e-5
     ranked, scores = m.rank(0, k=5)
-    assert len(ranked) == 5 and scores[ranked[0]] == scores.max()
+    assert len(ranked) == len(scores) and scores[ranked[0]] == scores.max() and np.all(np.diff(scores[ranked[:5]]) <= 0)
     # explicit zeros and empty columns: the weights fall back to b and nothing breaks
     R = sp.csc_matrix((np.array([0.0, 2.0], np.float32), (np.array([0, 1]), np.array([0, 0]))), shape=(4, 3))
     U = np.full((4, 2), 0.1, np.float32); V = np.full((3, 2), 0.2, np.float32)
