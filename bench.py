@@ -586,8 +586,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     correct = skipped = 0
+    step_ms = []
     for _ in range(args.steps):
-        c, s = step()
+        ts = time.perf_counter()
+        c, s = step()   # (single GPU: returns after the epoch's counters have been fetched, i.e. after the kernel)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         correct += c
         skipped += s
     if sharded is not None:
@@ -610,12 +613,17 @@ def main():
         "config": {"workload": "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
                                "GPU), hogwild mode, fp32 tables resident in HBM" % (k, n_users, n_items, nnz),
                    "k": k, "lr": args.lr, "reg": args.reg, "hogwild_flags": args.flags,
+                   "sampling": "stratified by user ownership: every wave of the persistent grid draws its positives i.i.d. "
+                               "from its own users' interactions (len(slice) draws per epoch), negatives uniform over all "
+                               "items - not the reference's single global draw stream",
                    "parallelism": "1 gpu" if world == 1 and not distributed else
                                   ("user-partitioned dp%d, item table sharded by row, all-to-all every %d draws"
                                    % (world, args.micro_batch)) if args.sharded_items else
                                   ("user-partitioned dp%d, item table all-reduce x%d/epoch"
                                    % (world, args.sync_per_epoch))},
     }
+    if rank == 0 and sharded is None:
+        out["step_ms"] = {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)), "max": float(np.max(step_ms))}
     if rank == 0:
         mean_deg = nnz / n_users
         b_full, b_skip = algorithmic_bytes_per_triplet(k, mean_deg)
@@ -625,18 +633,26 @@ def main():
         bytes_per_launch = draws_per_launch * ((1.0 - skip_frac) * b_full + skip_frac * b_skip)
         avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else None
+        kernel_name = ("bpr_hogwild_rowwise_kernel<64,1,4,atomic,owned>" if not args.sharded_items
+                       else "sample/apply kernels of the row-sharded path (no fused SGD kernel)")
+        # counter-measured traffic is only quoted for the kernel + workload it was taken on (profiles/traffic.json
+        # names both); any other launch configuration reports null rather than a stale number
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bpr_hogwild_bytes_per_launch")
+                tj = json.load(open(tpath))
+                same = (tj.get("kernel") == kernel_name and tj.get("hogwild_flags") == args.flags and
+                        tj.get("k") == k and tj.get("config") == args.config and tj.get("draws_per_launch") == int(draws_per_launch))
+                traffic = tj.get("bpr_hogwild_bytes_per_launch") if same else None
+                if not same:
+                    print("[bench] profiles/traffic.json was measured on another kernel / workload: traffic = null",
+                          file=sys.stderr)
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                           "kernel": "bpr_hogwild_rowwise_kernel<64,1,4,atomic,owned>" if not args.sharded_items
-                                     else "sample/apply kernels of the row-sharded path (no fused SGD kernel)",
-                           "launches": launches,
+                           "kernel": kernel_name, "launches": launches,
                            "avg_launch_ms": 1e3 * avg_launch_s, "algorithmic_bytes_per_triplet": b_full,
                            "skip_fraction": skip_frac}
         out["train_stats"] = {"correct_frac": correct / max(n_draws - skipped, 1.0), "skipped_frac": skip_frac}
@@ -653,8 +669,21 @@ def main():
             U2, V2, B2 = trainer.get_factors()
         sc = _lib.Scorer(U2, V2, B2, None, device=local_rank)
         n_rank = n_users if args.rank_users <= 0 else min(args.rank_users, n_users)
-        sc.rank_topk_device_ms(0, min(n_rank, 4096), 10, 1)  # warm-up
-        ms = sc.rank_topk_device_ms(0, n_rank, 10, 1)
+        # The evaluation protocol's ranking (cornac/eval_methods/base_method.py:176-220): every user's top-10 with the
+        # TRAINING POSITIVES EXCLUDED, results copied back to the host.  The exclusion lists (the training CSR) are
+        # registered once and stay on the device, as they do across the epochs / models evaluated on one split.
+        sc.set_exclusions(indptr.astype(np.int64), indices)
+        sc.rank_topk_resident((0, min(n_rank, 4096)), 10)  # warm-up
+        t0 = time.perf_counter()
+        items, _, ms_dev = sc.rank_topk_resident((0, n_rank), 10, fetch=True, timed=True)
+        ms = 1e3 * (time.perf_counter() - t0)
+        assert items.shape == (n_rank, 10)
+        # the same ranking with the lists handed over per call (H2D of the 80 MB CSR included) and without exclusions
+        t0 = time.perf_counter()
+        sc.rank_topk(np.arange(n_rank, dtype=np.int32), 10, exclude=(indptr[:n_rank + 1].astype(np.int64), indices[:indptr[n_rank]]))
+        ms_percall = 1e3 * (time.perf_counter() - t0)
+        sc.rank_topk_device_ms(0, min(n_rank, 4096), 10, 1)
+        ms_plain = sc.rank_topk_device_ms(0, n_rank, 10, 1)
         # full ranking (rank(k=-1)): materialised score tile + per-row sort, 10 000 users
         n_full = min(args.rank_full_users, n_users)
         ms_full = None
@@ -664,9 +693,15 @@ def main():
         pairs = float(n_rank) * n_items
         out["rank"] = {"metric": "rank_items_scored_per_sec", "value": pairs / (ms / 1e3), "unit": "items/s",
                        "users": n_rank, "items": n_items, "topk": 10, "ms": ms,
+                       "what": "top-10 of every user with the user's training positives excluded (resident lists), "
+                               "results copied to the host: wall time of the call",
+                       "device_ms": ms_dev, "ms_lists_passed_per_call": ms_percall,
+                       "ms_no_exclusions_device_only": ms_plain,
                        "roofline": {"bound": "mfma", "achieved": 2.0 * k * pairs / (ms / 1e3) / 1e12,
                                     "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                    "frac": 2.0 * k * pairs / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF}}
+                                    "frac": 2.0 * k * pairs / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                    "frac_device_only": 2.0 * k * pairs / (ms_dev / 1e3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                    "frac_no_exclusions_device_only": 2.0 * k * pairs / (ms_plain / 1e3) / 1e12 / FP32_MFMA_PEAK_TF}}
         if ms_full is not None:
             out["rank"]["full_ranking"] = {"topk": -1, "users": n_full, "ms": ms_full,
                                            "value": float(n_full) * n_items / (ms_full / 1e3), "unit": "items/s",
@@ -679,6 +714,18 @@ def main():
                 print("[bench] rank cpu_baseline failed: %r" % (e,), file=sys.stderr)
                 out["rank"]["cpu_baseline"] = None
     trainer.close()
+
+    # ---- extra single-GPU legs (rank 0, N = 1 only) -------------------------------------------------------------
+    if rank == 0 and world == 1 and not distributed and not args.no_legs and args.legs:
+        out["legs"] = {}
+        for name in [x for x in args.legs.split(",") if x]:
+            t_leg = time.time()
+            try:
+                out["legs"][name] = LEGS[name](args, _lib)
+                out["legs"][name]["leg_wall_s"] = time.time() - t_leg
+            except Exception as e:  # a leg must not take the headline line down with it
+                print("[bench] leg %s failed: %r" % (name, e), file=sys.stderr)
+                out["legs"][name] = {"error": repr(e)}
 
     # ---- CPU baseline leg (rank 0, N = 1 only) ------------------------------------------------------------------
     if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:

@@ -40,6 +40,7 @@ SYMBOLS = [
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
+    "cornac_hip_scorer_set_exclusions", "cornac_hip_rank_topk_resident",
     "cornac_hip_rank_positions",
 ]
 
@@ -181,6 +182,8 @@ def lib():
         L.cornac_hip_rank_topk.argtypes = [_vp, _i32, C.c_int64, C.c_int, _vp, _vp, _i32, _f32]
         L.cornac_hip_rank_positions.argtypes = [_vp, _i32, C.c_int64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32]
         L.cornac_hip_rank_topk_device.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.cornac_hip_scorer_set_exclusions.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_rank_topk_resident.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]
         _lib = L
     return _lib
 
@@ -490,6 +493,31 @@ class Scorer:
         check(lib().cornac_hip_rank_positions(self.h, users, len(users), _ptr(ip), _ptr(ix), _ptr(tp), _ptr(tx), greater,
                                               pos, ge, scores))
         return greater, pos, ge, scores
+
+    def set_exclusions(self, indptr=None, indices=None):
+        """Keep per-USER exclusion lists on the device: CSR (indptr int64[n_users + 1], indices int32); None drops them."""
+        if indptr is None:
+            check(lib().cornac_hip_scorer_set_exclusions(self.h, None, None))
+            return
+        ip = np.ascontiguousarray(indptr, np.int64)
+        ix = np.ascontiguousarray(indices, np.int32)
+        assert len(ip) == self.n_users + 1
+        check(lib().cornac_hip_scorer_set_exclusions(self.h, ip.ctypes.data, _ptr(ix) if len(ix) else None))
+
+    def rank_topk_resident(self, users, topk, fetch=True, timed=False):
+        """top-k with the resident exclusion lists.  users: array of user ids, or (u0, n) for a contiguous range.
+        fetch=False leaves the results on the device; timed=True also returns the HIP-event milliseconds."""
+        if isinstance(users, tuple):
+            up, u0, n = None, int(users[0]), int(users[1])
+        else:
+            ua = np.ascontiguousarray(users, np.int32)
+            up, u0, n = ua.ctypes.data, 0, len(ua)
+        items = np.empty((n, topk), np.int32) if fetch else None
+        scores = np.empty((n, topk), np.float32) if fetch else None
+        ms = C.c_double()
+        check(lib().cornac_hip_rank_topk_resident(self.h, up, u0, n, topk, _ptr(items), _ptr(scores),
+                                                  C.cast(C.byref(ms), _vp) if timed else None))
+        return (items, scores, ms.value) if timed else (items, scores)
 
     def rank_topk_device_ms(self, u0, n, topk, repeats=1):
         ms = C.c_double()

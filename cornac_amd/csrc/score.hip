@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                                                           int64_t n_rows, int64_t n_items, int64_t work_per_wg,
                                                           int topk, const int64_t *__restrict__ excl_indptr,
                                                           const int32_t *__restrict__ excl_indices, int64_t excl_row0,
+                                                          const uint32_t *__restrict__ excl_bits,
                                                           const int32_t *__restrict__ perm, float *tau_pub,
                                                           unsigned long long *__restrict__ part, int ablate) {
     // V / item_base are the scorer's RANK-ORDER copies: row p is item perm[p] (items sorted by a cheap upper
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     // (coalesced 16-byte global loads, double-buffered) instead of gathered 4x through the TA
     __shared__ float btile[2][32][KP + 2];  // row stride == 2 (mod 64): the 64 lanes of a fragment read hit 64 banks
     __shared__ float ibase[2][32];
+    // exclusion bitmap words of the tile being compared: wmask[t % 3][wave][row] has bit c set when the c-th item of
+    // tile t is excluded for that row (see excl_bitmap_kernel).  Three buffers: tile t's words are read in the
+    // survivor path of step t while faster waves already stage tile t+2.
+    __shared__ uint32_t wmask[3][kBlk / 64][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
     const int64_t n_item_tiles = (n_items + 31) / 32;
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     const int64_t work_total = n_row_blocks * n_item_tiles;
     int64_t pos = (int64_t)blockIdx.x * work_per_wg;
     const int64_t work_end = min(work_total, pos + work_per_wg);
+    int64_t cur_rb = 0;  // row block of the segment being walked (stage_load reads its exclusion words)
     float bcur[KT];
     // staging: 32 items x KP floats = 8*KP float4; thread i moves float4 #i, #i+256, ...
     constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
@@ -202,9 +208,12 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             const int64_t item = it * 32 + threadIdx.x;
             stg_ib = item < n_items ? (item_base ? item_base[item] : 0.f) : __builtin_nanf("");
             stg_id = item < n_items ? (perm ? perm[item] : (int32_t)item) : 0;
+        } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
+            const int w = (threadIdx.x - 32) >> 5, rl = (threadIdx.x - 32) & 31;
+            stg_id = (int32_t)excl_bits[((cur_rb * (kBlk / 64) + w) * n_item_tiles + it) * 32 + rl];
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int wbuf) {
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
             const int idx = threadIdx.x + q * kBlk;
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
         if (threadIdx.x < 32) {
             ibase[buf][threadIdx.x] = stg_ib;
             ipos[buf][threadIdx.x] = stg_id;
+        } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
+            wmask[wbuf][(threadIdx.x - 32) >> 5][(threadIdx.x - 32) & 31] = (uint32_t)stg_id;
         }
     };
     // B fragments of one tile: issued in groups of FG so that the loads of group g+1 are in flight while the
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     int64_t pos_hi = work_end;
     while (pos_hi > pos) {
         const int64_t rb = (pos_hi - 1) / n_item_tiles;
+        cur_rb = rb;
         const int64_t seg_lo = max(pos, rb * n_item_tiles);
         const int64_t t_begin = seg_lo - rb * n_item_tiles;
         const int64_t t_end = pos_hi - rb * n_item_tiles;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                 const int c = cnt[wave][rl];
                 unsigned long long *krow = keys[wave][rl];
                 unsigned long long mine = lane < c ? krow[lane] : 0ull;
-                if (excl_indptr) {  // drop excluded items before they can raise the threshold
+                if (excl_indptr && !excl_bits) {  // no bitmap (huge catalogue): drop excluded items before they can raise the threshold
                     bool dropped = false;
                     if (mine != 0ull) {
                         const int32_t item = (int32_t)(uint32_t)mine;
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
         float ib_a = 0.f, ib_b = 0.f;
         int32_t id_a = 0, id_b = 0;
         stage_load(t_begin);
-        stage_store(0);
+        stage_store(0, 0);
         __syncthreads();
         if (t_begin + 1 < t_end) stage_load(t_begin + 1);
         {
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
 #pragma unroll
             for (int t = 0; t < KT; ++t) acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_a, 0, 0, 0);
         }
-        if (t_begin + 1 < t_end) stage_store(1);
+        if (t_begin + 1 < t_end) stage_store(1, 1);
         __syncthreads();
         auto step = [&](int64_t it, f32x16 &acc_cur, f32x16 &acc_nxt, float &ib_cur, float &ib_nxt, int32_t &id_cur,
                         int32_t &id_nxt) __attribute__((always_inline)) {
@@ -411,6 +423,24 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
 #pragma unroll
             for (int r = 0; r < 16; ++r) any |= hm[r];
             if (ablate & 1) any = 0ull;
+            // excluded items are removed from the survivor masks with scalar operations: one LDS read brings the 32
+            // bitmap words of this wave's rows for tile `it`, two v_readlane per register that has survivors at all
+            auto drop_excluded = [&]() __attribute__((always_inline)) {
+                const uint32_t wv = wmask[(int)((unsigned)(it - t_begin) % 3u)][wave][col];
+                unsigned long long left = 0ull;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (hm[r] != 0ull) {  // wave-uniform
+                        const int rl = (r & 3) + 8 * (r >> 2);
+                        const unsigned long long m = (unsigned long long)__builtin_amdgcn_readlane(wv, rl) |
+                                                     ((unsigned long long)__builtin_amdgcn_readlane(wv, rl + 4) << 32);
+                        hm[r] &= ~m;
+                        left |= hm[r];
+                    }
+                }
+                return left;
+            };
+            if (any != 0ull && excl_bits) any = drop_excluded();
             // ---- rare path: append the survivors of tile it ---------------------------------------------------
             if (any != 0ull) {
                 // rows whose buffer cannot take this tile's survivors are compacted first (their thresholds rise,
@@ -429,6 +459,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                     compact(over_l);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hm[r] = __ballot(sc[r] >= thr[r]);
+                    if (excl_bits) (void)drop_excluded();
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -445,7 +476,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                     }
                 }
             }
-            if (it + 2 < t_end && !(ablate & 8)) stage_store((int)((it + 2 - t_begin) & 1));
+            if (it + 2 < t_end && !(ablate & 8)) stage_store((int)((it + 2 - t_begin) & 1), (int)((unsigned)(it + 2 - t_begin) % 3u));
             if (!(ablate & 4)) __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
         };
         for (int64_t it = t_begin; it < t_end; it += 2) {
@@ -463,6 +494,47 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             __hip_atomic_store(tau_pub + row_tile * 32 + lane, tau[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Exclusion bitmap of the fused top-k kernel.  For every tile of 32 rows (users of this call, in call order) and every
+// tile of 32 items (in the scorer's RANK ORDER, position p = inv_perm[item]) one word per row:
+//     bits[((row_tile * n_item_tiles) + item_tile) * 32 + row_in_tile]  bit c  <=>  item at position item_tile*32 + c
+// is excluded for that row.  One workgroup per row tile gathers the rows' exclusion lists into an LDS bitmap
+// (LDS integer atomics: ~2.4 cycles per set bit) over chunks of `chunk_tiles` item tiles and writes it out transposed,
+// coalesced.  The lists come either per ROW of this call (indptr[r], by_user = 0) or per USER id from the resident
+// CSR registered with cornac_hip_scorer_set_exclusions (by_user = 1: row r is user users[r] or u0 + r).
+__global__ __launch_bounds__(kBlk) void excl_bitmap_kernel(const int64_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const int32_t *__restrict__ users, int64_t u0, int by_user,
+                                                          const int32_t *__restrict__ inv_perm, int64_t n_rows,
+                                                          int64_t n_item_tiles, int chunk_tiles,
+                                                          uint32_t *__restrict__ bits) {
+    extern __shared__ uint32_t bm[];  // [32][chunk_tiles + 1]
+    const int ld = chunk_tiles + 1;
+    const int64_t rt = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t c0 = 0; c0 < n_item_tiles; c0 += chunk_tiles) {
+        const int nt = (int)min((int64_t)chunk_tiles, n_item_tiles - c0);
+        for (int i = threadIdx.x; i < 32 * ld; i += kBlk) bm[i] = 0u;
+        __syncthreads();
+        for (int rl = wave; rl < 32; rl += kBlk / 64) {
+            const int64_t row = rt * 32 + rl;
+            if (row >= n_rows) break;
+            const int64_t key = by_user ? (users ? (int64_t)users[row] : u0 + row) : row;
+            const int64_t lo = indptr[key], hi = indptr[key + 1];
+            for (int64_t p = lo + lane; p < hi; p += 64) {
+                const int32_t pos = inv_perm[indices[p]];
+                const int t = (pos >> 5) - (int)c0;
+                if (t >= 0 && t < nt) atomicOr(&bm[rl * ld + t], 1u << (pos & 31));
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * nt; i += kBlk) {
+            const int t = i >> 5, rl = i & 31;
+            bits[((rt * n_item_tiles) + c0 + t) * 32 + rl] = bm[rl * ld + t];
+        }
+        __syncthreads();
     }
 }
 
@@ -768,7 +840,12 @@ struct cornac_hip_scorer {
     DevBuf<float> U, V, item_base, user_base;
     // rank-order copies for the fused top-k kernel: row p = item perm[p] (build_rank_order)
     DevBuf<float> Vr, ibr;
-    DevBuf<int32_t> perm;
+    DevBuf<int32_t> perm, inv_perm;
+    DevBuf<uint32_t> excl_bits;  // exclusion bitmap of the current fused launch (excl_bitmap_kernel)
+    // exclusion lists per USER id, resident on the device (cornac_hip_scorer_set_exclusions)
+    DevBuf<int64_t> res_excl_indptr;
+    DevBuf<int32_t> res_excl_indices;
+    bool has_res_excl = false;
     DevBuf<float> tau_pub;  // per row: threshold published by the head segment of its row block
     bool has_user_base = false, is_set = false;
     DevBuf<float> scores;  // workspace [rows_cap, n_items]
@@ -858,11 +935,30 @@ static void build_rank_order(cornac_hip_scorer_t h, const float *U, const float 
     h->Vr.ensure((size_t)ni * h->ld);
     h->ibr.ensure((size_t)ni);
     h->perm.upload(order.data(), (size_t)ni, h->stream);
+    std::vector<int32_t> inv_order((size_t)ni);
+    for (int64_t p = 0; p < ni; ++p) inv_order[(size_t)order[(size_t)p]] = (int32_t)p;
+    h->inv_perm.ensure((size_t)ni);
+    h->inv_perm.upload(inv_order.data(), (size_t)ni, h->stream);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ni * 16 + 255) / 256, 8192));
     hipLaunchKernelGGL(permute_rows_kernel, dim3(grid), dim3(256), 0, h->stream, h->V.p, h->item_base.p, h->perm.p, ni, h->ld,
                        h->Vr.p, h->ibr.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(h->stream));  // `order` is pageable host memory
+}
+
+// a CSR handed over the C ABI: indptr non-decreasing from 0, every index a valid item (the kernels index tables
+// with them); the length of `indices` is taken to be indptr[n], as in scipy
+static void validate_csr(const int64_t *indptr, const int32_t *indices, int64_t n, int64_t n_items, const char *what) {
+    REQUIRE(indptr[0] == 0, "%s_indptr must start at 0", what);
+    for (int64_t r = 0; r < n; ++r)
+        REQUIRE(indptr[r + 1] >= indptr[r], "%s_indptr decreases at row %lld", what, (long long)r);
+    const int64_t ne = indptr[n];
+    int32_t lo = 0, hi = 0;
+    for (int64_t p = 0; p < ne; ++p) {
+        lo = std::min(lo, indices[p]);
+        hi = std::max(hi, indices[p]);
+    }
+    REQUIRE(lo >= 0 && hi < n_items, "%s_indices out of range [0, %lld)", what, (long long)n_items);
 }
 
 static void sc_check(cornac_hip_scorer_t h, bool need_set = true) {
@@ -929,9 +1025,12 @@ constexpr int kFusedMaxTopk = 32;
 static bool can_fuse(cornac_hip_scorer_t h, int topk) { return topk <= kFusedMaxTopk && h->k <= 128; }
 
 // fused GEMM + top-k for rows [0, n): users from d_users (or u0 + row); optional exclusion CSR on the device
+constexpr int64_t kMaxBitmapTiles = 8192;  // item tiles (x32 items) up to which the exclusion bitmap is used
+
+// excl_by_user: d_excl_indptr is indexed by user id (resident lists) instead of by row of this call
 static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int64_t u0, int64_t n, int topk,
                               const int64_t *d_excl_indptr, const int32_t *d_excl_indices, int64_t excl_row0,
-                              int32_t *items_out, float *scores_out) {
+                              int32_t *items_out, float *scores_out, bool excl_by_user = false) {
     const float *ub = h->has_user_base ? h->user_base.p : nullptr;
     const DeviceInfo &di = device_info(h->device);
     static const int ablate = getenv("CORNAC_HIP_RANK_ABLATE") ? atoi(getenv("CORNAC_HIP_RANK_ABLATE")) : 0;  // profiling only
@@ -949,6 +1048,28 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     HIP_CHECK(hipMemsetAsync(h->part.p, 0, (size_t)(max_segs * n * topk) * sizeof(unsigned long long), h->stream));
     h->tau_pub.ensure((size_t)n);
     HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->tau_pub.p, 0xff800000u /* -inf */, (size_t)n, h->stream));
+    // exclusion lists -> bitmap in rank order (the kernel then masks excluded items out of its survivor masks with
+    // scalar operations; without it they flood the candidate buffers — a trained model scores a user's training
+    // positives highest — and are only dropped at compaction)
+    const uint32_t *d_bits = nullptr;
+    if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles) {
+        const int64_t row_tiles = wg_rows * (kBlk / 64);  // padded to whole workgroups: the kernel reads every wave's words
+        h->excl_bits.ensure((size_t)(row_tiles * n_item_tiles * 32));
+        const int chunk = (int)std::min<int64_t>(n_item_tiles, 1152);  // 32 x 1153 words = 147.6 KB of LDS
+        const size_t lds = (size_t)32 * (chunk + 1) * sizeof(uint32_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)excl_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(32 * 1153 * sizeof(uint32_t))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(excl_bitmap_kernel, dim3((unsigned)row_tiles), dim3(kBlk), lds, h->stream,
+                           d_excl_indptr + (excl_by_user ? 0 : excl_row0), d_excl_indices, d_users, u0, excl_by_user ? 1 : 0,
+                           h->inv_perm.p, n, n_item_tiles, chunk, h->excl_bits.p);
+        d_bits = h->excl_bits.p;
+    } else if (d_excl_indptr) {
+        REQUIRE(!excl_by_user, "resident exclusion lists need the bitmap path (catalogue too large)");
+    }
     dim3 grid((unsigned)n_wgs), block(kBlk);
 #define FUSED(KT_, CAP_) do {                                                                                    \
     if (getenv("CORNAC_HIP_RANK_ABLATE")) {                                                                       \
@@ -959,12 +1080,12 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     }                                                                                                             \
     if (ub)                                                                                                       \
         hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, true>), grid, block, 0, h->stream, h->U.p, h->Vr.p,       \
-                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
-                           d_excl_indices, excl_row0, h->perm.p, h->tau_pub.p, h->part.p, ablate);              \
+                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_bits ? nullptr : d_excl_indptr, \
+                           d_excl_indices, excl_row0, d_bits, h->perm.p, h->tau_pub.p, h->part.p, ablate);       \
     else                                                                                                          \
         hipLaunchKernelGGL((rank_fused_kernel<KT_, CAP_, false>), grid, block, 0, h->stream, h->U.p, h->Vr.p,      \
-                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_excl_indptr,            \
-                           d_excl_indices, excl_row0, h->perm.p, h->tau_pub.p, h->part.p, ablate); } while (0)
+                           h->ibr.p, ub, d_users, u0, n, h->n_items, work_per_wg, topk, d_bits ? nullptr : d_excl_indptr, \
+                           d_excl_indices, excl_row0, d_bits, h->perm.p, h->tau_pub.p, h->part.p, ablate); } while (0)
     if (topk <= 10 && h->ld == 128) {
         FUSED(64, 42);  // k = 128: the smallest buffer (topk + 32) lets two workgroups share a CU's LDS
     } else if (topk <= 24) {  // CAP = 56: 24 slots of slack above the 32 a tile can add
@@ -1082,7 +1203,7 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
             REQUIRE(users[b] >= 0 && users[b] < h->n_users, "user %d out of range", users[b]);
         const bool have_excl = excl_indptr != nullptr && excl_indices != nullptr;
         if (have_excl) {
-            REQUIRE(excl_indptr[0] == 0, "excl_indptr must start at 0");
+            validate_csr(excl_indptr, excl_indices, n, h->n_items, "excl");
             h->d_excl_indptr.ensure((size_t)n + 1);
             h->d_excl_indptr.upload(excl_indptr, (size_t)n + 1, h->stream);
             const int64_t ne = excl_indptr[n];
@@ -1090,8 +1211,9 @@ int cornac_hip_rank_topk(cornac_hip_scorer_t h, const int32_t *users, int64_t n,
             if (ne > 0) h->d_excl_indices.upload(excl_indices, (size_t)ne, h->stream);
         }
         if (can_fuse(h, topk)) {
-            // fused path: no score workspace, all users in one launch; the exclusion rows must be sorted
-            if (have_excl)
+            // fused path: no score workspace, all users in one launch.  Catalogues too large for the exclusion bitmap
+            // binary-search the lists at compaction: the rows must then be sorted
+            if (have_excl && (h->n_items + 31) / 32 > kMaxBitmapTiles)
                 for (int64_t b = 0; b < n; ++b)
                     for (int64_t p = excl_indptr[b] + 1; p < excl_indptr[b + 1]; ++p)
                         REQUIRE(excl_indices[p] > excl_indices[p - 1], "exclusion row %lld is not strictly sorted",
@@ -1148,7 +1270,7 @@ int cornac_hip_rank_positions(cornac_hip_scorer_t h, const int32_t *users, int64
         REQUIRE(tgt_indices && greater_out && pos_out && ge_out && tgt_scores_out, "bad arguments");
         const bool have_excl = excl_indptr != nullptr && excl_indices != nullptr;
         if (have_excl) {
-            REQUIRE(excl_indptr[0] == 0, "excl_indptr must start at 0");
+            validate_csr(excl_indptr, excl_indices, n, h->n_items, "excl");
             h->d_excl_indptr.ensure((size_t)n + 1);
             h->d_excl_indptr.upload(excl_indptr, (size_t)n + 1, h->stream);
             const int64_t ne = excl_indptr[n];
@@ -1211,6 +1333,64 @@ int cornac_hip_score_pairs(cornac_hip_scorer_t h, const int32_t *users, const in
         HIP_CHECK(hipGetLastError());
         dout.download(out, (size_t)n, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_scorer_set_exclusions(cornac_hip_scorer_t h, const int64_t *indptr, const int32_t *indices) {
+    return guarded([&] {
+        sc_check(h, false);
+        if (!indptr) {
+            h->has_res_excl = false;
+            return;
+        }
+        REQUIRE(indices != nullptr || indptr[h->n_users] == 0, "indices is NULL");
+        validate_csr(indptr, indices, h->n_users, h->n_items, "excl");
+        const int64_t ne = indptr[h->n_users];
+        h->res_excl_indptr.ensure((size_t)h->n_users + 1);
+        h->res_excl_indices.ensure((size_t)std::max<int64_t>(ne, 1));
+        h->res_excl_indptr.upload(indptr, (size_t)h->n_users + 1, h->stream);
+        if (ne > 0) h->res_excl_indices.upload(indices, (size_t)ne, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->has_res_excl = true;
+    });
+}
+
+int cornac_hip_rank_topk_resident(cornac_hip_scorer_t h, const int32_t *users, int64_t u0, int64_t n, int topk,
+                                  int32_t *items_out, float *scores_out, double *device_ms) {
+    return guarded([&] {
+        sc_check(h);
+        REQUIRE(h->has_res_excl, "cornac_hip_scorer_set_exclusions has not been called");
+        REQUIRE(n > 0 && topk >= 1 && topk <= h->n_items, "bad arguments");
+        REQUIRE(can_fuse(h, topk) && (h->n_items + 31) / 32 <= kMaxBitmapTiles,
+                "resident exclusion lists serve the fused top-k path (topk <= 32, k <= 128, <= 262144 items)");
+        if (users) {
+            for (int64_t b = 0; b < n; ++b) REQUIRE(users[b] >= 0 && users[b] < h->n_users, "user %d out of range", users[b]);
+            h->d_users.ensure((size_t)n);
+            h->d_users.upload(users, (size_t)n, h->stream);
+        } else {
+            REQUIRE(u0 >= 0 && u0 + n <= h->n_users, "user range out of bounds");
+        }
+        h->d_items_out.ensure((size_t)(n * topk));
+        h->d_scores_out.ensure((size_t)(n * topk));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (device_ms) {
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, h->stream));
+        }
+        launch_rank_fused(h, users ? h->d_users.p : nullptr, u0, n, topk, h->res_excl_indptr.p, h->res_excl_indices.p, 0,
+                          h->d_items_out.p, h->d_scores_out.p, true);
+        if (device_ms) HIP_CHECK(hipEventRecord(e1, h->stream));
+        if (items_out) h->d_items_out.download(items_out, (size_t)(n * topk), h->stream);
+        if (scores_out) h->d_scores_out.download(scores_out, (size_t)(n * topk), h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (device_ms) {
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *device_ms = (double)t;
+        }
     });
 }
 

@@ -88,7 +88,7 @@ def eval_lists_loop(train_mat, test_mat, val_mat, rating_threshold, n_eval_items
 
 
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
-                 verbose=False, batch_users=16384, batch_users_full=1024):
+                 verbose=False, batch_users=16384, batch_users_full=1024, batch_users_topk=65536):
     if len(metrics) == 0:
         return [], []
     max_k = max(m.k for m in metrics)
@@ -102,6 +102,41 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
 
     def gt_of(r):
         return gt_idx[gt_ptr[r]:gt_ptr[r + 1]]
+
+    def per_user(r):
+        """the reference's flow for one user (base_method.py:176-220) through model.rank()"""
+        user_idx, gp = int(users[r]), gt_of(r)
+        item_indices = np.setdiff1d(np.arange(n_eval_items), ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
+        gt_neg = np.setdiff1d(item_indices, gp)
+        # the reference asks for k = max_k (base_method.py:208-210), but its rank() returns ALL candidates with only
+        # the first max_k in order, and the metrics over the whole list (k = -1) read past them: hand those the
+        # exact full ranking, which agrees with the reference wherever its result does not hinge on that
+        # unspecified tail order
+        rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=-1 if need_full else max_k)
+        for i, mt in enumerate(metrics):
+            user_results[i][user_idx] = mt.compute(gt_pos=gp, gt_neg=gt_neg, pd_rank=rank_, pd_scores=scores_,
+                                                   item_indices=item_indices)
+
+    # Users the model has no device row for (test-only users of a model trained over num_users, e.g. MF with
+    # exclude_unknowns=False: the reference still evaluates them — MF.score falls back to global_mean + i_biases,
+    # recom_mf.py:281-286) cannot go through the batched entry points: they take the per-user flow, the rest is
+    # re-indexed so that the batched paths below see only users with a row.
+    if hasattr(model, "rank_batch") and hasattr(model, "_scorer_rows") and len(users):
+        has_row = np.asarray(model._scorer_rows(users)) >= 0
+        if not has_row.all():
+            for r in np.flatnonzero(~has_row):
+                per_user(int(r))
+            keep = np.flatnonzero(has_row)
+
+            def take(ptr, idx):
+                cnt = np.diff(ptr)[keep]
+                newptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+                pos = np.repeat(ptr[keep] - newptr[:-1], cnt) + np.arange(newptr[-1])
+                return newptr, idx[pos]
+
+            gt_ptr, gt_idx = take(gt_ptr, gt_idx)
+            ex_ptr, ex_idx = take(ex_ptr, ex_idx)
+            users = users[keep]
 
     def batch_hits(items, b0, b1):
         """hits[r, p]: the p-th ranked item of batch row r is one of its test positives — one sorted-key lookup for
@@ -185,22 +220,11 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
                     vals = mt.compute_batch(hits[:, :topk_k], n_gt)
                 user_results[i].update(zip(ub, np.asarray(vals, dtype=float).tolist()))
     elif need_full or not batchable:
-        all_items = np.arange(n_eval_items)
-        for r, user_idx in enumerate(users):
-            user_idx, gp = int(user_idx), gt_of(r)
-            item_indices = np.setdiff1d(all_items, ex_idx[ex_ptr[r]:ex_ptr[r + 1]])
-            gt_neg = np.setdiff1d(item_indices, gp)
-            # the reference asks for k = max_k (base_method.py:208-210), but its rank() returns ALL candidates with only
-            # the first max_k in order, and the metrics over the whole list (k = -1) read past them: hand those the
-            # exact full ranking, which agrees with the reference wherever its result does not hinge on that
-            # unspecified tail order
-            rank_, scores_ = model.rank(user_idx=user_idx, item_indices=item_indices, k=-1 if need_full else max_k)
-            for i, mt in enumerate(metrics):
-                user_results[i][user_idx] = mt.compute(gt_pos=gp, gt_neg=gt_neg, pd_rank=rank_, pd_scores=scores_,
-                                                       item_indices=item_indices)
+        for r in range(len(users)):
+            per_user(r)
     else:
-        for b0 in range(0, len(users), batch_users):
-            b1 = min(b0 + batch_users, len(users))
+        for b0 in range(0, len(users), batch_users_topk):
+            b1 = min(b0 + batch_users_topk, len(users))
             ub = [int(u) for u in users[b0:b1]]
             indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
             indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)

@@ -281,6 +281,17 @@ int cornac_hip_wmf_last_timing(cornac_hip_wmf_t h, double *device_ms);
  * ------------------------------------------------------------------------- */
 typedef struct cornac_hip_scorer *cornac_hip_scorer_t;
 
+/* Exclusion lists per USER id, kept on the device: CSR (indptr int64[n_users + 1], indices int32) of the items
+ * ranking must skip for each user — in the evaluation loop the user's training (+ validation) positives
+ * (cornac/eval_methods/base_method.py:176-205 builds the same list per user with numpy set operations).  NULL indptr
+ * drops them.  cornac_hip_rank_topk_resident ranks `n` users (users[0..n), or u0 .. u0+n-1 when users is NULL) with
+ * those lists applied, like cornac_hip_rank_topk with per-call lists but without moving the lists again; items_out /
+ * scores_out may be NULL (results stay on the device), device_ms (optional) receives the HIP-event time of the
+ * bitmap build + fused top-k + merge kernels. */
+int cornac_hip_scorer_set_exclusions(cornac_hip_scorer_t h, const int64_t *indptr, const int32_t *indices);
+int cornac_hip_rank_topk_resident(cornac_hip_scorer_t h, const int32_t *users, int64_t u0, int64_t n, int topk,
+                                  int32_t *items_out, float *scores_out, double *device_ms);
+
 int cornac_hip_scorer_create(cornac_hip_scorer_t *out, int device, int64_t n_users, int64_t n_items, int k);
 int cornac_hip_scorer_destroy(cornac_hip_scorer_t h);
 /* item_base: BPR -> i_biases; MF -> global_mean + i_biases.  user_base: MF -> u_biases; NULL = 0. */

@@ -1,0 +1,126 @@
+"""Drop-in checks from the REFERENCE's side (this container only: the reference tree + oracle/_ref): a cornac_amd model
+object is handed to the reference's OWN `ranking_eval` / `rating_eval` / `Experiment` — unmodified reference code
+calling `fit / score / rank / rate` on our class — next to the reference's own model; both reports must agree.  The
+device layer is the oracle-backed double of tests/fake_device.py (host logic on CPU); tests/test_dropin_gpu.py repeats
+the model-inside-the-reference-evaluator check on the real kernels against golden reports.
+
+Also here: a model refitted on other data must not serve scores from the previous fit's derived tables, and the batched
+evaluation must cope with test users the model has no row for."""
+import numpy as np
+import pytest
+
+import fake_device
+from oracle import ref_loader
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference not available / oracle/_ref not built")
+
+
+@pytest.fixture()
+def device_double(monkeypatch, tmp_path):
+    fake_device.install(monkeypatch)
+    monkeypatch.chdir(tmp_path)
+
+
+def _data(seed, nu=60, ni=45, n=1400):
+    rs = np.random.RandomState(seed)
+    keys = rs.permutation(nu * ni)[:n]
+    return [("u%d" % (k // ni), "i%d" % (k % ni), float(rs.randint(1, 6))) for k in keys]
+
+
+def test_reference_evaluators_accept_our_models(device_double):
+    """the reference's ranking_eval (base_method.py:108-226) and rating_eval (:35-105) driving cornac_amd.BPR / MF"""
+    import cornac_amd as ca
+
+    ns = ref_loader.load()
+    rm = ns.metrics
+    ref_rank_eval = ns.eval_methods.base_method.ranking_eval
+    ref_rate_eval = ns.eval_methods.base_method.rating_eval
+    data = _data(3)
+    train = ns.Dataset.build(data[:1000])
+    test = ns.Dataset.build(data[1000:], global_uid_map=train.uid_map, global_iid_map=train.iid_map, exclude_unknowns=True)
+    kw = dict(k=8, max_iter=12, learning_rate=0.05, lambda_reg=0.01, seed=11)
+    # @k metrics mixed with whole-list metrics: the reference asks rank() for max_k items and hands the array to AUC /
+    # MAP / MRR too, so rank(k != -1) must return every candidate (recommender.py:521-528)
+    metrics = lambda: [rm.Recall(k=5), rm.NDCG(k=10), rm.Precision(k=3), rm.AUC(), rm.MAP(), rm.MRR()]  # noqa: E731
+    for ours, theirs in ((ca.BPR(**kw), ns.BPR(**kw)), (ca.MF(**kw), ns.MF(**kw))):
+        ours.fit(train)      # our class consumes the REFERENCE's Dataset object as is
+        theirs.fit(train)
+        a = ref_rank_eval(ours, metrics(), train, test)
+        b = ref_rank_eval(theirs, metrics(), train, test)
+        # identical learned parameters (seeded, deterministic) -> reports differ only through summation order in
+        # score() (fp32 fma chain vs BLAS) at near-ties
+        assert np.allclose(a[0], b[0], atol=2e-3), (type(ours).__name__, a[0], b[0])
+        assert a[1][0].keys() == b[1][0].keys()
+    ours, theirs = ca.MF(**kw).fit(train), ns.MF(**kw).fit(train)
+    a = ref_rate_eval(ours, [rm.RMSE(), rm.MAE()], test)
+    b = ref_rate_eval(theirs, [rm.RMSE(), rm.MAE()], test)
+    assert np.allclose(a[0], b[0], atol=1e-5)
+
+
+def test_reference_eval_method_runs_our_models(device_double):
+    """examples/first_example.py's flow: the reference's RatioSplit.evaluate — what its Experiment.run calls per model
+    (experiment.py:139-145: fit on the split's train set, rating + ranking evaluation, Result) — with OUR model classes
+    inside.  (Experiment itself filters its model list with isinstance(model, cornac.models.Recommender),
+    experiment.py:95-99, so inside the reference our classes are used through the patched recom_*.py of INTEGRATION.md.)"""
+    import cornac_amd as ca
+
+    ns = ref_loader.load()
+    rm = ns.metrics
+    RatioSplit = ns.eval_methods.RatioSplit
+    data = _data(5, nu=80, ni=50, n=2200)
+    kw = dict(k=6, max_iter=10, learning_rate=0.03, lambda_reg=0.01, seed=5)
+    reports = []
+    for models in ([ca.MF(**kw), ca.BPR(**kw)], [ns.MF(**kw), ns.BPR(**kw)]):
+        rs = RatioSplit(data=data, test_size=0.2, rating_threshold=3.0, exclude_unknowns=True, seed=9, verbose=False)
+        rows = []
+        for model in models:
+            test_result, _ = rs.evaluate(model=model, metrics=[rm.MAE(), rm.RMSE(), rm.Recall(k=10), rm.AUC()],
+                                         user_based=True, show_validation=False)
+            rows.append([test_result.metric_avg_results[m] for m in ("MAE", "RMSE", "Recall@10", "AUC")])
+        reports.append(rows)
+    assert np.allclose(reports[0], reports[1], atol=3e-3), reports
+
+
+def test_refit_does_not_serve_the_previous_fit(device_double):
+    """MF caches item_base = global_mean + i_biases; a second fit() refreshes the biases in place, so the
+    cache (and the device scorer built from it) must be dropped — BaseMethod.evaluate refits without cloning."""
+    import cornac_amd as ca
+
+    a = ca.Dataset.from_uir([(u, i, 1.0 + (u * 7 + i) % 5) for u in range(20) for i in range(15) if (u + 2 * i) % 3], seed=1)
+    b = ca.Dataset.from_uir([(u, i, 5.0 - (u + i) % 3) for u in range(20) for i in range(15) if (u * i) % 4 != 1], seed=1)
+    m = ca.MF(k=4, max_iter=8, learning_rate=0.05, lambda_reg=0.02, seed=3)
+    for ds in (a, b, a):
+        m.fit(ds)
+        want = m.global_mean + m.i_biases + m.u_biases[2] + m.i_factors @ m.u_factors[2]
+        assert np.abs(m.score(2) - want).max() < 1e-5
+        ranked, scores = m.rank(2)
+        assert np.array_equal(np.sort(ranked), np.arange(ds.num_items)) and np.all(np.diff(want[ranked]) <= 1e-6)
+        assert abs(m.rate_batch([2], [3])[0] - np.clip(want[3], ds.min_rating, ds.max_rating)) < 1e-5
+    # in-place edits need an explicit invalidation (documented): after it the device tables follow
+    m.i_biases[...] += 1.0
+    m.invalidate_scorer()
+    assert np.abs(m.score(2) - (want + 1.0)).max() < 1e-5
+
+
+def test_batched_ranking_eval_with_users_the_model_has_no_row_for(device_double):
+    """exclude_unknowns=False brings test-only USERS; MF has num_users rows, so rank_batch cannot serve
+    them — the reference evaluates them through MF.score's fallback (global_mean + i_biases, recom_mf.py:281-286)."""
+    import cornac_amd as ca
+    import cornac_amd.eval as ev
+    import cornac_amd.metrics as mm
+
+    ns = ref_loader.load()
+    rs = np.random.RandomState(0)
+    train_rows = [("u%d" % u, "i%d" % i, float(rs.randint(1, 6))) for u in range(25) for i in range(20) if rs.rand() < 0.4]
+    test_rows = [("u%d" % u, "i%d" % i, float(rs.randint(3, 6))) for u in range(20, 32) for i in range(20) if rs.rand() < 0.25]
+    train = ns.Dataset.build(train_rows)
+    test = ns.Dataset.build(test_rows, global_uid_map=train.uid_map, global_iid_map=train.iid_map, exclude_unknowns=False)
+    assert test.num_users > train.num_users, "the case needs test-only users"
+    m = ca.MF(k=5, max_iter=10, learning_rate=0.05, lambda_reg=0.02, seed=2).fit(train)
+    ref_eval = ns.eval_methods.base_method.ranking_eval
+    rm = ns.metrics
+    for picks in (lambda M: [M.Recall(k=5), M.NDCG(k=5)], lambda M: [M.AUC(), M.MAP()], lambda M: [M.Recall(k=3), M.MRR()]):
+        mine = ev.ranking_eval(m, picks(mm), train, test, exclude_unknowns=False)
+        ref = ref_eval(m, picks(rm), train, test, exclude_unknowns=False)
+        assert np.allclose(mine[0], ref[0], atol=1e-9), (mine[0], ref[0])
+        assert all(x.keys() == y.keys() for x, y in zip(mine[1], ref[1]))
