@@ -187,3 +187,49 @@ def test_mf_full_size_deterministic_and_hogwild(oracle, ml20m):
     loss_h, _ = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_HOGWILD)
     tr.close()
     assert abs(loss_h[0] - loss_d[0]) <= 0.02 * loss_d[0], (loss_h, loss_d)
+
+
+@pytest.mark.timeout(900)
+def test_mf_netflix_shape_deterministic_and_hogwild(oracle):
+    """BASELINE configs[2] at its TRUE shape: 480 189 users x 17 770 items, 100 480 507 ratings (int64 COO, the
+    reference's uir_tuple dtypes), k = 128.  One deterministic epoch against the sequential oracle (the reference's
+    seeded loop, backend_cpu.pyx:35-97), then the hogwild kernel's epoch loss against the same oracle state."""
+    from bench import synth_ratings
+    from cornac_amd import synth
+
+    n_users, n_items, nnz, zipf_a, seed = synth.CONFIGS["netflix"]
+    rid, cid, val = synth_ratings(n_users, n_items, nnz, zipf_a, seed)
+    assert len(val) == 100_480_507 and rid.dtype == np.int64 and cid.dtype == np.int64
+    # insertion order != sorted order in a real uir_tuple: shuffle blocks of the list (a full permutation of 100 M
+    # entries costs more host time than the test needs)
+    rs = np.random.RandomState(11)
+    blocks = rs.permutation(1024)
+    cuts = np.linspace(0, nnz, 1025).astype(np.int64)
+    order = np.concatenate([np.arange(cuts[b], cuts[b + 1]) for b in blocks])
+    rid, cid, val = rid[order], cid[order], val[order]
+    k, lr, reg = 128, 0.01, 0.02
+    mu = np.float32(val.mean(dtype=np.float64))
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    Uo, Vo, Buo, Bio = U0.copy(), V0.copy(), zu.copy(), zi.copy()
+    loss_o = np.zeros(1, np.float32)
+    assert oracle.lib().oracle_mf_fit(rid, cid, val, len(val), Uo, Vo, Buo, Bio, k, lr, reg, float(mu), 1, 1, 1, 0,
+                                      loss_o.ctypes.data) == 1
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.set_factors(U0, V0, zu, zi)
+    loss_d, _ = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_DETERMINISTIC)
+    Ud, Vd, Bud, Bid = tr.get_factors()
+    err = max(np.abs(Ud - Uo).max(), np.abs(Vd - Vo).max(), np.abs(Bud - Buo).max(), np.abs(Bid - Bio).max())
+    print("Netflix-shape MF deterministic epoch: max |err| = %.3g, timing %s" % (err, tr.last_timing()))
+    assert err <= 1e-4 and np.mean(Ud == Uo) > 0.99
+    # fp32 sequential accumulation of 1e8 squared errors in the reference's loss vs fp64 on the device
+    assert abs(loss_d[0] - loss_o[0]) <= 0.25 * loss_o[0]
+    tr.set_factors(U0, V0, zu, zi)
+    loss_h, _ = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_HOGWILD)
+    Uh, Vh, _, _ = tr.get_factors()
+    tr.close()
+    assert abs(loss_h[0] - loss_d[0]) <= 0.02 * loss_d[0], (loss_h, loss_d)
+    assert np.isfinite(Uh).all() and np.isfinite(Vh).all()
+    # same optimisation step from the same start: the tables moved by the same amount
+    assert abs(np.linalg.norm(Vh - V0) / np.linalg.norm(Vd - V0) - 1) < 0.05
