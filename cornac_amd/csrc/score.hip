@@ -756,7 +756,10 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
 // full ranking, so neither the sort nor the [users, items] ranking ever has to exist.  One workgroup per row; the
 // row's targets go through registers kPosT at a time while the row's scores stream from the score tile (one row
 // is ~100 KB: L2-resident after the first pass).  Integer compares on the order-preserving score bits: exact.
-constexpr int kPosT = 4;
+constexpr int kPosT = 8;
+// The counts are kept per WAVE in scalar registers: every compare is one v_cmp whose lane mask is popcounted and
+// added on the scalar unit (three v_cmp per (item, target) pair, no per-lane accumulators), the row is read with
+// 16-byte loads (4 items per lane) wherever its alignment allows, eight targets per pass over the row.
 __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__restrict__ scores,
                                                               const uint8_t *__restrict__ excl_mask, int64_t n_items,
                                                               const int64_t *__restrict__ tgt_indptr,
@@ -770,46 +773,64 @@ __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__res
     const uint8_t *erow = excl_mask ? excl_mask + row * n_items : nullptr;
     const int64_t lo = tgt_indptr[row0 + row], hi = tgt_indptr[row0 + row + 1];
     __shared__ int cnt[kPosT * 3];
+    // items [head, body_end) are read four at a time from 16-byte aligned addresses; the rest one by one
+    const int64_t mis = (int64_t)((reinterpret_cast<uintptr_t>(srow) >> 2) & 3);
+    const int64_t head = min(n_items, (4 - mis) & 3);
+    const int64_t body_end = head + ((n_items - head) & ~int64_t(3));
+    const bool vec_mask = !erow || ((reinterpret_cast<uintptr_t>(erow) + head) & 3) == 0;
     for (int64_t t0 = lo; t0 < hi; t0 += kPosT) {
-        uint32_t ts[kPosT], ti[kPosT];
+        unsigned long long tk[kPosT];  // (order key << 32) | item: unique per candidate, ordered like rank()'s output
+        uint32_t ts[kPosT];
         bool ok[kPosT];
+        int32_t titem[kPosT];
 #pragma unroll
         for (int q = 0; q < kPosT; ++q) {
             const int64_t t = t0 + q;
             const int32_t item = t < hi ? tgt_indices[t] : -1;
             ok[q] = item >= 0 && item < n_items && !(erow && erow[item]);
             ts[q] = ok[q] ? order_key(srow[item]) : 0xFFFFFFFFu;
-            ti[q] = (uint32_t)item;
+            titem[q] = item;
+            tk[q] = ((unsigned long long)ts[q] << 32) | (uint32_t)item;
         }
-        int g[kPosT], ps[kPosT], e[kPosT];
+        int g[kPosT], ps[kPosT], e[kPosT];  // wave-uniform (scalar) partial counts
 #pragma unroll
         for (int q = 0; q < kPosT; ++q) g[q] = ps[q] = e[q] = 0;
-        for (int64_t i = threadIdx.x; i < n_items; i += kBlk) {
-            if (erow && erow[i]) continue;
-            const uint32_t oc = order_key(srow[i]);
+        // (lane 0 of a wave is active whenever any lane of the wave is — the loops below run longest for the lowest
+        // lanes — so its copy of the wave's counts is complete; ballots ignore inactive lanes)
+        auto visit = [&](bool live, float sc, int64_t i) __attribute__((always_inline)) {
+            const uint32_t oc = order_key(sc);
+            const unsigned long long key = ((unsigned long long)oc << 32) | (uint32_t)i;
 #pragma unroll
             for (int q = 0; q < kPosT; ++q) {
-                const bool gt = oc > ts[q], eq = oc == ts[q];
-                g[q] += gt;
-                e[q] += gt | eq;
-                ps[q] += gt | (eq & ((uint32_t)i > ti[q]));
+                g[q] += __popcll(__ballot(live && oc > ts[q]));
+                e[q] += __popcll(__ballot(live && oc >= ts[q]));
+                ps[q] += __popcll(__ballot(live && key > tk[q]));
             }
+        };
+        for (int64_t i = threadIdx.x; i < head; i += kBlk) visit(!(erow && erow[i]), srow[i], i);
+        for (int64_t i0 = head + 4 * (int64_t)threadIdx.x; i0 < body_end + 4 * (int64_t)(kBlk - 1); i0 += 4 * kBlk) {
+            // (the loop bound keeps whole waves together: lanes beyond the body contribute nothing)
+            const bool in = i0 < body_end;
+            const v4f32 sv = in ? *reinterpret_cast<const v4f32 *>(srow + i0) : v4f32{0.f, 0.f, 0.f, 0.f};
+            uint32_t em = 0u;
+            if (erow && in) {
+                if (vec_mask) em = *reinterpret_cast<const uint32_t *>(erow + i0);
+                else em = (uint32_t)erow[i0] | ((uint32_t)erow[i0 + 1] << 8) | ((uint32_t)erow[i0 + 2] << 16) | ((uint32_t)erow[i0 + 3] << 24);
+            }
+            visit(in && !(em & 0xffu), sv.x, i0);
+            visit(in && !(em & 0xff00u), sv.y, i0 + 1);
+            visit(in && !(em & 0xff0000u), sv.z, i0 + 2);
+            visit(in && !(em & 0xff000000u), sv.w, i0 + 3);
         }
+        for (int64_t i = body_end + threadIdx.x; i < n_items; i += kBlk) visit(!(erow && erow[i]), srow[i], i);
         if (threadIdx.x < kPosT * 3) cnt[threadIdx.x] = 0;
         __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < kPosT; ++q) {
-            int a = g[q], b = ps[q], c = e[q];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-                c += __shfl_xor(c, o, 64);
-            }
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&cnt[q * 3 + 0], a);
-                atomicAdd(&cnt[q * 3 + 1], b);
-                atomicAdd(&cnt[q * 3 + 2], c);
+            for (int q = 0; q < kPosT; ++q) {
+                atomicAdd(&cnt[q * 3 + 0], g[q]);
+                atomicAdd(&cnt[q * 3 + 1], ps[q]);
+                atomicAdd(&cnt[q * 3 + 2], e[q]);
             }
         }
         __syncthreads();
@@ -820,7 +841,7 @@ __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__res
                 greater_out[t] = ok[q] ? cnt[q * 3 + 0] : -1;
                 pos_out[t] = ok[q] ? cnt[q * 3 + 1] : -1;
                 ge_out[t] = ok[q] ? cnt[q * 3 + 2] : -1;
-                score_out[t] = ok[q] ? srow[ti[q]] : -INFINITY;
+                score_out[t] = ok[q] ? srow[titem[q]] : -INFINITY;
             }
         }
         __syncthreads();

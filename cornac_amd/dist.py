@@ -318,13 +318,25 @@ class RowShardedBprTrainer:
                                     bias_pad.data_ptr(), self.BIAS_STRIDE, lr, reg, use_bias)
 
     def run(self, n_samples, lr, reg, use_bias=True):
-        """n_samples draws on this rank, in micro-batches; every rank must call with the same micro-batch count"""
+        """n_samples draws on this rank, in micro-batches.  Every micro-batch is a collective (three all-to-alls), so
+        all ranks must go through the same number of them: the ranks agree on the maximum up front and a rank whose
+        user shard runs out of draws keeps serving the others' fetches / pushes with empty batches."""
         left = int(n_samples)
+        rounds = (left + self.micro_batch - 1) // self.micro_batch
+        if self.table.collective and self.table.world > 1:
+            r = torch.tensor([rounds], dtype=torch.int64, device=self.device)
+            with self._on_stream():
+                dist.all_reduce(r, op=dist.ReduceOp.MAX, group=self.group)
+            rounds = int(r.item())
         with self._on_stream():
-            while left > 0:
+            for _ in range(rounds):
                 n = min(left, self.micro_batch)
                 left -= n
-                u, i, j = self._sample(n)
+                if n > 0:
+                    u, i, j = self._sample(n)
+                else:   # nothing left to draw here: an empty batch (all skipped) keeps the collectives matched
+                    u = torch.full((0,), -1, dtype=torch.int32, device=self.device)
+                    i, j = u.clone(), u.clone()
                 keep = u >= 0                                       # skipped draws carry -1
                 u, i, j = u[keep], i[keep].long(), j[keep].long()
                 g = torch.cat([self.table.owner_major(i), self.table.owner_major(j)])
@@ -334,7 +346,8 @@ class RowShardedBprTrainer:
                 bias_pad = torch.zeros(len(bias), self.BIAS_STRIDE, dtype=torch.float32, device=self.device)
                 bias_pad[:, 0] = bias
                 inv = inv.to(torch.int32)
-                self._apply(u, inv[: len(u)].contiguous(), inv[len(u):].contiguous(), rows, bias_pad, lr, reg, use_bias)
+                if len(u):
+                    self._apply(u, inv[: len(u)].contiguous(), inv[len(u):].contiguous(), rows, bias_pad, lr, reg, use_bias)
                 self.table.push(plan, rows - rows0, bias_pad[:, 0] - bias0)
                 self.rows_fetched += len(uniq)
                 self.triplets += len(u)
@@ -359,3 +372,38 @@ def slice_csr(indptr, indices, u0, u1):
     indptr = np.asarray(indptr)
     a, b = int(indptr[u0]), int(indptr[u1])
     return (indptr[u0:u1 + 1] - a).astype(np.int32), np.asarray(indices[a:b], dtype=np.int32)
+
+
+def rank_users_sharded(rank_fn, users, k, device=None, group=None):
+    """Multi-GPU scoring: ranking shards by user block with no data-path collective — every
+    rank holds the (replicated or gathered) factor tables, ranks its contiguous block of `users` with
+    `rank_fn(block) -> (items [n, k] int32, scores [n, k] float32)` (e.g. `model.rank_batch`, the fused MFMA top-k
+    kernel) — followed by one all-gather of the top-k lists.  Returns the full `(items, scores)` for `users` on
+    every rank.  Without an initialised process group it is a plain call."""
+    users = np.asarray(users)
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    cuts = np.linspace(0, len(users), world + 1).astype(np.int64)
+    mine = users[cuts[rank]:cuts[rank + 1]]
+    if len(mine):
+        items, scores = rank_fn(mine)
+        items, scores = np.asarray(items, np.int32), np.asarray(scores, np.float32)
+    else:
+        items, scores = np.empty((0, k), np.int32), np.empty((0, k), np.float32)
+    if world == 1:
+        return items, scores
+    width = items.shape[1] if len(mine) else k
+    cap = int((cuts[1:] - cuts[:-1]).max())
+    dev = device if device is not None else torch.device("cpu")
+    pad_i = torch.full((cap, width), -1, dtype=torch.int32, device=dev)
+    pad_s = torch.full((cap, width), float("-inf"), dtype=torch.float32, device=dev)
+    pad_i[: len(mine)] = torch.as_tensor(items)
+    pad_s[: len(mine)] = torch.as_tensor(scores)
+    all_i = [torch.empty_like(pad_i) for _ in range(world)]
+    all_s = [torch.empty_like(pad_s) for _ in range(world)]
+    dist.all_gather(all_i, pad_i, group=group)
+    dist.all_gather(all_s, pad_s, group=group)
+    out_i = np.concatenate([all_i[r][: cuts[r + 1] - cuts[r]].cpu().numpy() for r in range(world)])
+    out_s = np.concatenate([all_s[r][: cuts[r + 1] - cuts[r]].cpu().numpy() for r in range(world)])
+    return out_i, out_s

@@ -378,3 +378,81 @@ def test_two_ranks_learn_over_a_row_sharded_item_table():
     assert np.array_equal(V0, V1) and np.array_equal(B0, B1) and np.isfinite(V0).all()
     assert before0 < 0.6 and before1 < 0.6 and after0 > 0.75 and after1 > 0.75
     assert 0 < fetched0 <= 24 * 90 and n0 > 0          # de-duplicated requests: at most every item once per micro-batch
+
+
+def _uneven_worker(rank, world, port, out):
+    from cornac_amd.dist import RowShardedBprTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_items, k = 40, 4
+        sh = RowShardedBprTrainer(_FakeShardTrainer(rank, n_items), n_items, k, torch.device("cpu"), micro_batch=100,
+                                  ops=_HostRowOps())
+        sh.load_items(np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32))
+        rs = np.random.RandomState(rank)
+        calls = []
+
+        def sample(n):
+            calls.append(n)
+            return (torch.tensor(rs.randint(0, 5, n).astype(np.int32)), torch.tensor(rs.randint(0, n_items, n).astype(np.int32)),
+                    torch.tensor(rs.randint(0, n_items, n).astype(np.int32)))
+
+        def apply(u, si, sj, rows, bias_pad, lr, reg, use_bias):
+            rows[si.long()] += 1.0     # every positive row +1, every negative row -1: the table's total stays 0
+            rows[sj.long()] -= 1.0
+
+        sh._sample, sh._apply = sample, apply
+        sh.run(350 if rank == 0 else 120, 0.05, 0.01)   # 4 micro-batches on rank 0, 2 on rank 1
+        V, _ = sh.table.gather_full()
+        out[rank] = (calls, float(V.sum()), float(V.abs().sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_ranks_with_different_draw_counts_do_not_deadlock():
+    """every micro-batch is a collective; ranks whose user shards hold different numbers of interactions
+    agree on the round count up front and the rank that runs dry serves empty rounds"""
+    out = mp.Manager().dict()
+    mp.spawn(_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (calls0, tot0, mass0), (calls1, tot1, mass1) = out[0], out[1]
+    assert calls0 == [100, 100, 100, 50] and calls1 == [100, 20]
+    assert tot0 == tot1 and mass0 == mass1 and mass0 > 0
+
+
+def _rank_worker(rank, world, port, out):
+    from cornac_amd.dist import rank_users_sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(3)                      # the same (replicated) tables on every rank
+        U, V = rs.normal(size=(37, 6)).astype(np.float32), rs.normal(size=(50, 6)).astype(np.float32)
+        seen = []
+
+        def rank_fn(users):
+            seen.append(np.asarray(users).copy())
+            S = U[users] @ V.T
+            items = np.argsort(-S, axis=1, kind="stable")[:, :5].astype(np.int32)
+            return items, np.take_along_axis(S, items, 1).astype(np.float32)
+
+        users = np.arange(37)[::-1].copy()
+        items, scores = rank_users_sharded(rank_fn, users, 5)
+        out[rank] = (items, scores, np.concatenate(seen) if seen else np.empty(0, np.int64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_user_block_sharded_ranking_gathers_the_topk_lists():
+    """scoring shards by user block, then one gather of the top-k lists — every rank ends with the
+    ranking a single process computes, each having scored only its own block"""
+    out = mp.Manager().dict()
+    mp.spawn(_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (i0, s0, seen0), (i1, s1, seen1) = out[0], out[1]
+    rs = np.random.RandomState(3)
+    U, V = rs.normal(size=(37, 6)).astype(np.float32), rs.normal(size=(50, 6)).astype(np.float32)
+    users = np.arange(37)[::-1]
+    S = U[users] @ V.T
+    want = np.argsort(-S, axis=1, kind="stable")[:, :5]
+    assert np.array_equal(i0, want) and np.array_equal(i1, want) and np.allclose(s0, np.take_along_axis(S, want, 1))
+    assert len(seen0) + len(seen1) == 37 and set(seen0.tolist()).isdisjoint(seen1.tolist())
