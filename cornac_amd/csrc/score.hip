@@ -432,8 +432,9 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                 for (int r = 0; r < 16; ++r) {
                     if (hm[r] != 0ull) {  // wave-uniform
                         const int rl = (r & 3) + 8 * (r >> 2);
-                        const unsigned long long m = (unsigned long long)__builtin_amdgcn_readlane(wv, rl) |
-                                                     ((unsigned long long)__builtin_amdgcn_readlane(wv, rl + 4) << 32);
+                        // (v_readlane returns int: widen through uint32_t, a set bit 31 must not sign-extend)
+                        const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(wv, rl) |
+                                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(wv, rl + 4) << 32);
                         hm[r] &= ~m;
                         left |= hm[r];
                     }
@@ -1073,7 +1074,8 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     // scalar operations; without it they flood the candidate buffers — a trained model scores a user's training
     // positives highest — and are only dropped at compaction)
     const uint32_t *d_bits = nullptr;
-    if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles) {
+    static const bool no_bitmap = getenv("CORNAC_HIP_RANK_NO_BITMAP") != nullptr;  // A/B switch for profiling
+    if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles && !no_bitmap) {
         const int64_t row_tiles = wg_rows * (kBlk / 64);  // padded to whole workgroups: the kernel reads every wave's words
         h->excl_bits.ensure((size_t)(row_tiles * n_item_tiles * 32));
         const int chunk = (int)std::min<int64_t>(n_item_tiles, 1152);  // 32 x 1153 words = 147.6 KB of LDS
