@@ -211,18 +211,51 @@ class RowShardedItemTable:
                                group=self.group)
         return recv
 
-    def fetch(self, uniq_g):
-        """uniq_g: sorted unique owner-major indices (int64, on `device`).  Returns (rows [n,k], bias [n], plan)."""
-        bounds = torch.arange(self.world + 1, device=uniq_g.device, dtype=uniq_g.dtype) * self.rows_per_rank
-        cuts = torch.searchsorted(uniq_g, bounds).tolist()  # host sync: the split sizes of the exchange
-        send_counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+    def dedupe(self, g, valid):
+        """De-duplicate the owner-major indices `g` (int64 [m], entries with valid == False ignored) WITHOUT sorting
+        and with ONE host synchronisation: a flag per table row, an inclusive scan of the flags (slot of a touched row
+        = scan - 1; scan order = owner-major order, so the unique list is bucketed by owner), the per-owner counts read
+        off the scan at the owner boundaries, exchanged with the peers on the device and copied to the host together
+        with the local counts.  Returns (uniq [n_unique] int64 sorted, slot [m] int32, send_counts, recv_counts)."""
+        n_rows = self.world * self.rows_per_rank
+        gg = torch.where(valid, g, torch.full_like(g, n_rows))          # ignored entries point at a spare flag
+        mark = torch.zeros(n_rows + 1, dtype=torch.int32, device=g.device)
+        mark[gg] = 1
+        mark[n_rows] = 0
+        scan = torch.cumsum(mark, 0, dtype=torch.int32)
+        slot = (scan[gg] - 1).clamp_(min=0)
+        bounds = torch.arange(1, self.world + 1, device=g.device) * self.rows_per_rank - 1
+        ends = scan[bounds].to(torch.int64)
+        sc = ends - torch.cat([ends.new_zeros(1), ends[:-1]])
         if self.collective:
-            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
             rc = torch.empty_like(sc)
             dist.all_to_all_single(rc, sc, group=self.group)
-            recv_counts = rc.tolist()
         else:
-            recv_counts = list(send_counts)
+            rc = sc
+        counts = torch.stack([sc, rc]).tolist()                           # the ONE host synchronisation
+        send_counts, recv_counts = counts[0], counts[1]
+        uniq = torch.empty(int(sum(send_counts)), dtype=torch.int64, device=g.device)
+        if len(uniq):
+            keep = torch.where(valid, slot.long(), torch.full_like(g, len(uniq)))   # ignored entries -> a spare slot
+            buf = torch.empty(len(uniq) + 1, dtype=torch.int64, device=g.device)
+            buf[keep] = gg
+            uniq = buf[:-1]
+        return uniq, slot, send_counts, recv_counts
+
+    def fetch(self, uniq_g, send_counts=None, recv_counts=None):
+        """uniq_g: sorted unique owner-major indices (int64, on `device`).  Returns (rows [n,k], bias [n], plan).
+        Without the split sizes (as `dedupe` returns them) they are derived here with two more host syncs."""
+        if send_counts is None:
+            bounds = torch.arange(self.world + 1, device=uniq_g.device, dtype=uniq_g.dtype) * self.rows_per_rank
+            cuts = torch.searchsorted(uniq_g, bounds).tolist()  # host sync: the split sizes of the exchange
+            send_counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+            if self.collective:
+                sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+                rc = torch.empty_like(sc)
+                dist.all_to_all_single(rc, sc, group=self.group)
+                recv_counts = rc.tolist()
+            else:
+                recv_counts = list(send_counts)
         local_rows = (uniq_g % self.rows_per_rank).to(torch.int32)
         wanted = self._exchange(local_rows, send_counts, recv_counts)          # rows the others want from me
         out_rows = torch.empty(len(wanted), self.k, dtype=torch.float32, device=self.device)
@@ -296,10 +329,15 @@ class RowShardedBprTrainer:
             # the handle's own (full-size) item table is not used in this mode: release it
             trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
         self.rows_fetched = 0
-        self.triplets = 0
+        self._valid_draws = torch.zeros((), dtype=torch.int64, device=device)
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    @property
+    def triplets(self):
+        """valid (not skipped) draws applied so far"""
+        return int(self._valid_draws.item())
 
     def load_items(self, V, B):
         with self._on_stream():
@@ -337,20 +375,19 @@ class RowShardedBprTrainer:
                 else:   # nothing left to draw here: an empty batch (all skipped) keeps the collectives matched
                     u = torch.full((0,), -1, dtype=torch.int32, device=self.device)
                     i, j = u.clone(), u.clone()
-                keep = u >= 0                                       # skipped draws carry -1
-                u, i, j = u[keep], i[keep].long(), j[keep].long()
-                g = torch.cat([self.table.owner_major(i), self.table.owner_major(j)])
-                uniq, inv = torch.unique(g, return_inverse=True)   # sorted -> bucketed by owner
-                rows, bias, plan = self.table.fetch(uniq)
+                valid = u >= 0                                      # skipped draws carry -1 and stay in place: the
+                nv = len(u)                                         # apply kernel ignores them (no compaction, no sync)
+                g = torch.cat([self.table.owner_major(i.long()), self.table.owner_major(j.long())])
+                uniq, slot, send_counts, recv_counts = self.table.dedupe(g, torch.cat([valid, valid]))
+                rows, bias, plan = self.table.fetch(uniq, send_counts, recv_counts)
                 rows0, bias0 = rows.clone(), bias
                 bias_pad = torch.zeros(len(bias), self.BIAS_STRIDE, dtype=torch.float32, device=self.device)
                 bias_pad[:, 0] = bias
-                inv = inv.to(torch.int32)
-                if len(u):
-                    self._apply(u, inv[: len(u)].contiguous(), inv[len(u):].contiguous(), rows, bias_pad, lr, reg, use_bias)
+                if nv and len(uniq):
+                    self._apply(u, slot[:nv].contiguous(), slot[nv:].contiguous(), rows, bias_pad, lr, reg, use_bias)
                 self.table.push(plan, rows - rows0, bias_pad[:, 0] - bias0)
                 self.rows_fetched += len(uniq)
-                self.triplets += len(u)
+                self._valid_draws = self._valid_draws + valid.sum()   # stays on the device: read through .triplets
 
     def finish(self):
         out = self.trainer.sync()

@@ -157,6 +157,8 @@ def _shard_worker(rank, world, port, out):
             return torch.tensor(u), torch.tensor(i), torch.tensor(j)
 
         def apply(u, si, sj, rows, bias_pad, lr, reg, use_bias):
+            ok = u >= 0            # skipped draws stay in the arrays (u = -1): the apply kernel ignores them
+            si, sj = si[ok], sj[ok]
             rows.index_add_(0, si.long(), torch.ones(len(si), k))
             rows.index_add_(0, sj.long(), -torch.ones(len(sj), k))
             bias_pad[:, 0].index_add_(0, si.long(), torch.full((len(si),), 0.5))
@@ -318,6 +320,8 @@ def _bpr_apply(U, u, si, sj, rows, bias_pad, lr, reg, use_bias):
     """sequential BPR updates (recom_bpr.pyx:240-267) of a micro-batch on the rank's user rows and the STAGED item rows"""
     R, Bp = rows.numpy(), bias_pad.numpy()
     for t in range(len(u)):
+        if u[t] < 0:
+            continue   # skipped draw
         a, p, q = int(u[t]), int(si[t]), int(sj[t])
         uu, vi, vj = U[a].copy(), R[p].copy(), R[q].copy()
         z = 1.0 / (1.0 + np.exp(Bp[p, 0] - Bp[q, 0] + uu @ (vi - vj)))
@@ -399,8 +403,8 @@ def _uneven_worker(rank, world, port, out):
                     torch.tensor(rs.randint(0, n_items, n).astype(np.int32)))
 
         def apply(u, si, sj, rows, bias_pad, lr, reg, use_bias):
-            rows[si.long()] += 1.0     # every positive row +1, every negative row -1: the table's total stays 0
-            rows[sj.long()] -= 1.0
+            rows.index_add_(0, si.long(), torch.ones(len(si), rows.shape[1]))    # every positive row +1, every negative
+            rows.index_add_(0, sj.long(), -torch.ones(len(sj), rows.shape[1]))   # row -1: the table's total stays 0
 
         sh._sample, sh._apply = sample, apply
         sh.run(350 if rank == 0 else 120, 0.05, 0.01)   # 4 micro-batches on rank 0, 2 on rank 1
