@@ -506,14 +506,15 @@ class Scorer:
 
     def rank_topk_resident(self, users, topk, fetch=True, timed=False):
         """top-k with the resident exclusion lists.  users: array of user ids, or (u0, n) for a contiguous range.
-        fetch=False leaves the results on the device; timed=True also returns the HIP-event milliseconds."""
+        fetch=False leaves the results on the device, fetch="items" copies only the item ids back (what the @k metrics
+        read); timed=True also returns the HIP-event milliseconds."""
         if isinstance(users, tuple):
             up, u0, n = None, int(users[0]), int(users[1])
         else:
             ua = np.ascontiguousarray(users, np.int32)
             up, u0, n = ua.ctypes.data, 0, len(ua)
         items = np.empty((n, topk), np.int32) if fetch else None
-        scores = np.empty((n, topk), np.float32) if fetch else None
+        scores = np.empty((n, topk), np.float32) if fetch and fetch != "items" else None
         ms = C.c_double()
         check(lib().cornac_hip_rank_topk_resident(self.h, up, u0, n, topk, _ptr(items), _ptr(scores),
                                                   C.cast(C.byref(ms), _vp) if timed else None))

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     __shared__ float btile[2][32][KP + 2];  // row stride == 2 (mod 64): the 64 lanes of a fragment read hit 64 banks
     __shared__ float ibase[2][32];
     // exclusion bitmap words of the tile being compared: wmask[t % 3][wave][row] has bit c set when the c-th item of
-    // tile t is excluded for that row (see excl_bitmap_kernel).  Three buffers: tile t's words are read in the
+    // tile t is excluded for that row (see excl_bitmap_kernel; 128 four-byte loads per workgroup and tile, L2-served).  Three buffers: tile t's words are read in the
     // survivor path of step t while faster waves already stage tile t+2.
     __shared__ uint32_t wmask[3][kBlk / 64][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             stg_id = item < n_items ? (perm ? perm[item] : (int32_t)item) : 0;
         } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
             const int w = (threadIdx.x - 32) >> 5, rl = (threadIdx.x - 32) & 31;
-            stg_id = (int32_t)excl_bits[((cur_rb * (kBlk / 64) + w) * n_item_tiles + it) * 32 + rl];
+            stg_id = (int32_t)excl_bits[((cur_rb * (kBlk / 64) + w) * 32 + rl) * n_item_tiles + it];
         }
     };
     auto stage_store = [&](int buf, int wbuf) {
@@ -498,44 +498,46 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     }
 }
 
-// Exclusion bitmap of the fused top-k kernel.  For every tile of 32 rows (users of this call, in call order) and every
-// tile of 32 items (in the scorer's RANK ORDER, position p = inv_perm[item]) one word per row:
-//     bits[((row_tile * n_item_tiles) + item_tile) * 32 + row_in_tile]  bit c  <=>  item at position item_tile*32 + c
-// is excluded for that row.  One workgroup per row tile gathers the rows' exclusion lists into an LDS bitmap
-// (LDS integer atomics: ~2.4 cycles per set bit) over chunks of `chunk_tiles` item tiles and writes it out transposed,
-// coalesced.  The lists come either per ROW of this call (indptr[r], by_user = 0) or per USER id from the resident
-// CSR registered with cornac_hip_scorer_set_exclusions (by_user = 1: row r is user users[r] or u0 + r).
+// Exclusion bitmap of the fused top-k kernel: one word per (row, tile of 32 items in the scorer's RANK ORDER),
+//     bits[row * n_item_tiles + item_tile]  bit c  <=>  the item at position item_tile*32 + c is excluded for that row
+// (row = position in this call's user list, position p = inv_perm[item]).  One WAVE per row gathers the row's exclusion
+// list into a private LDS bitmap (LDS integer atomics: ~2.4 cycles per set bit) in chunks of `chunk_tiles` words and
+// writes it out contiguously.  The lists come either per ROW of this call (indptr[r], by_user = 0) or per USER id from
+// the resident CSR registered with cornac_hip_scorer_set_exclusions (by_user = 1: row r is user users[r] or u0 + r).
+// Rows beyond n_rows (the padding of the last workgroup of the top-k kernel) get all-zero words.
+constexpr int kBitmapChunk = 1024;  // words per wave and pass (4 KB of LDS per wave)
 __global__ __launch_bounds__(kBlk) void excl_bitmap_kernel(const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices,
                                                           const int32_t *__restrict__ users, int64_t u0, int by_user,
                                                           const int32_t *__restrict__ inv_perm, int64_t n_rows,
-                                                          int64_t n_item_tiles, int chunk_tiles,
+                                                          int64_t n_rows_padded, int64_t n_item_tiles,
                                                           uint32_t *__restrict__ bits) {
-    extern __shared__ uint32_t bm[];  // [32][chunk_tiles + 1]
-    const int ld = chunk_tiles + 1;
-    const int64_t rt = blockIdx.x;
+    __shared__ uint32_t bm_all[kBlk / 64][kBitmapChunk];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t c0 = 0; c0 < n_item_tiles; c0 += chunk_tiles) {
-        const int nt = (int)min((int64_t)chunk_tiles, n_item_tiles - c0);
-        for (int i = threadIdx.x; i < 32 * ld; i += kBlk) bm[i] = 0u;
-        __syncthreads();
-        for (int rl = wave; rl < 32; rl += kBlk / 64) {
-            const int64_t row = rt * 32 + rl;
-            if (row >= n_rows) break;
-            const int64_t key = by_user ? (users ? (int64_t)users[row] : u0 + row) : row;
-            const int64_t lo = indptr[key], hi = indptr[key + 1];
-            for (int64_t p = lo + lane; p < hi; p += 64) {
-                const int32_t pos = inv_perm[indices[p]];
-                const int t = (pos >> 5) - (int)c0;
-                if (t >= 0 && t < nt) atomicOr(&bm[rl * ld + t], 1u << (pos & 31));
-            }
+    uint32_t *bm = bm_all[wave];
+    const int64_t row = (int64_t)blockIdx.x * (kBlk / 64) + wave;
+    if (row >= n_rows_padded) return;
+    int64_t lo = 0, hi = 0;
+    if (row < n_rows) {
+        const int64_t key = by_user ? (users ? (int64_t)users[row] : u0 + row) : row;
+        lo = indptr[key];
+        hi = indptr[key + 1];
+    }
+    for (int64_t c0 = 0; c0 < n_item_tiles; c0 += kBitmapChunk) {
+        const int nt = (int)min((int64_t)kBitmapChunk, n_item_tiles - c0);
+        for (int i = lane; i < nt; i += 64) bm[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t p = lo + lane; p < hi; p += 64) {
+            const int32_t pos = inv_perm[indices[p]];
+            const int t = (pos >> 5) - (int)c0;
+            if (t >= 0 && t < nt) atomicOr(&bm[t], 1u << (pos & 31));
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * nt; i += kBlk) {
-            const int t = i >> 5, rl = i & 31;
-            bits[((rt * n_item_tiles) + c0 + t) * 32 + rl] = bm[rl * ld + t];
-        }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nt; i += 64) bits[row * n_item_tiles + c0 + i] = bm[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1076,19 +1078,11 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     const uint32_t *d_bits = nullptr;
     static const bool no_bitmap = getenv("CORNAC_HIP_RANK_NO_BITMAP") != nullptr;  // A/B switch for profiling
     if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles && !no_bitmap) {
-        const int64_t row_tiles = wg_rows * (kBlk / 64);  // padded to whole workgroups: the kernel reads every wave's words
-        h->excl_bits.ensure((size_t)(row_tiles * n_item_tiles * 32));
-        const int chunk = (int)std::min<int64_t>(n_item_tiles, 1152);  // 32 x 1153 words = 147.6 KB of LDS
-        const size_t lds = (size_t)32 * (chunk + 1) * sizeof(uint32_t);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)excl_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(32 * 1153 * sizeof(uint32_t))));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(excl_bitmap_kernel, dim3((unsigned)row_tiles), dim3(kBlk), lds, h->stream,
-                           d_excl_indptr + (excl_by_user ? 0 : excl_row0), d_excl_indices, d_users, u0, excl_by_user ? 1 : 0,
-                           h->inv_perm.p, n, n_item_tiles, chunk, h->excl_bits.p);
+        const int64_t rows_padded = wg_rows * 128;  // whole workgroups of the top-k kernel: it reads every wave's words
+        h->excl_bits.ensure((size_t)(rows_padded * n_item_tiles));
+        hipLaunchKernelGGL(excl_bitmap_kernel, dim3((unsigned)((rows_padded + kBlk / 64 - 1) / (kBlk / 64))), dim3(kBlk), 0,
+                           h->stream, d_excl_indptr + (excl_by_user ? 0 : excl_row0), d_excl_indices, d_users, u0,
+                           excl_by_user ? 1 : 0, h->inv_perm.p, n, rows_padded, n_item_tiles, h->excl_bits.p);
         d_bits = h->excl_bits.p;
     } else if (d_excl_indptr) {
         REQUIRE(!excl_by_user, "resident exclusion lists need the bitmap path (catalogue too large)");
@@ -1427,6 +1421,11 @@ int cornac_hip_rank_topk_device(cornac_hip_scorer_t h, int64_t u0, int64_t n, in
         const int64_t cap = fused ? n : rows_per_batch(h);
         const int64_t nb_max = std::min(cap, n);
         if (!fused) h->scores.ensure((size_t)(nb_max * h->n_items));
+        if (!fused && topk > TOPK_MAX) {  // the sort scratch is (re)allocated here, not between the timing events
+            int64_t pad = 1;
+            while (pad < h->n_items) pad <<= 1;
+            h->sort_scratch.ensure((size_t)(nb_max * pad));
+        }
         h->d_items_out.ensure((size_t)(nb_max * topk));
         h->d_scores_out.ensure((size_t)(nb_max * topk));
         hipEvent_t e0, e1;

@@ -24,5 +24,15 @@ def pmc(path):
         print('"%s",%s,%d,%.1f,%.1f,%.1f,%.0f' % r)
 
 
+def dispatches(path, pattern="%"):
+    """every dispatch of the kernels whose name matches the SQL LIKE pattern, in launch order"""
+    cur = sqlite3.connect(path).cursor()
+    print("kernel,grid_x,workgroup_x,lds_bytes,vgprs,duration_us")
+    for name, gx, wx, lds, slds, vg, dur in cur.execute(
+            "select name, grid_x, workgroup_x, lds_size, static_lds_size, vgpr_count, duration from kernels "
+            "where name like ? order by start", (pattern,)):
+        print('"%s",%d,%d,%d,%d,%.1f' % (name[:90], gx, wx, lds + slds, vg, dur / 1e3))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "dispatches": dispatches}[sys.argv[1]](*sys.argv[2:])
