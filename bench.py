@@ -14,7 +14,8 @@ A plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) re-execute
 torch.distributed.run with N ranks on 127.0.0.1, so the one command works with and without an external launcher.
 
 At N = 1 the line also carries `legs`: the other single-GPU configurations of BASELINE.json, each with its own
-`roofline` and reference `cpu_baseline` — `mf_netflix` (configs[2]: biased MF k = 128 at the Netflix Prize shape),
+`roofline` and reference `cpu_baseline` — `mf_netflix` / `wmf_netflix` (configs[2]: biased MF and WMF, k = 128, at the
+Netflix Prize shape),
 `vbpr_tradesy` (configs[3]) and `bpr_k128_scale` (one GPU's user slice of configs[4], k = 128).
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement" for every field).
@@ -440,7 +441,66 @@ def leg_bpr_k128_scale(args, _lib):
     return out
 
 
-LEGS = {"mf_netflix": leg_mf_netflix, "vbpr_tradesy": leg_vbpr_tradesy, "bpr_k128_scale": leg_bpr_k128_scale}
+def leg_wmf_netflix(args, _lib):
+    """configs[2], the WMF half: one Adam step = one batch of 128 items against ALL 480 189 users (wmf.py:34-55), k = 128.
+    Bound: fp32 MFMA — three GEMM-shaped pieces of 2 n_users B k flops each per step."""
+    import scipy.sparse as sp
+
+    n_users, n_items, k, B = 480_189, 17_770, 128, 128
+    nnz = 20_000_000  # the step cost depends on n_users, B, k and the batch's non-zeros only: a fifth of the ratings
+    rs = np.random.RandomState(0)
+    t0 = time.time()
+    keys = np.unique(rs.randint(0, n_users * n_items, size=int(nnz * 1.05), dtype=np.int64))[:nnz]
+    users, items = keys // n_items, keys % n_items
+    R = sp.csc_matrix((rs.randint(1, 6, len(users)).astype(np.float32), (users, items)), shape=(n_users, n_items))
+    t_gen = time.time() - t0
+    tr = _lib.WmfTrainer(R, k)
+    lim = np.sqrt(6.0 / (n_users + k))
+    U0 = rs.uniform(-lim, lim, (n_users, k)).astype(np.float32)
+    V0 = rs.uniform(-lim, lim, (n_items, k)).astype(np.float32)
+    tr.set_factors(U0, V0)
+    perm = rs.permutation(n_items)
+    batches = [perm[a:a + B] for a in range(0, n_items - B + 1, B)][:60]
+    tr.fit_batches(batches[:3], 0.01, 0.01, 1.0, 0.01, 0.001)  # warm-up
+    tr.kernel_timing(True)
+    t0 = time.perf_counter()
+    loss = tr.fit_batches(batches, 0.01, 0.01, 1.0, 0.01, 0.001)
+    dt = time.perf_counter() - t0
+    dev_ms = tr.last_device_ms()
+    tr.close()
+    steps = len(batches)
+    flops = 6.0 * n_users * B * k
+    out = {"metric": "wmf_steps_per_sec", "value": steps / dt, "unit": "Adam steps/s (128 items x all users each)",
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "WMF k=%d, %d users x %d items, batches of %d items, a=1 b=0.01 (one epoch = %d steps)"
+                                  % (k, n_users, n_items, B, (n_items + B - 1) // B)},
+           "roofline": {"bound": "mfma", "achieved": flops * steps / (dev_ms / 1e3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": flops * steps / (dev_ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF,
+                        "kernel": "wmf_user_step_kernel (+ gather / reduce / scatter / item-side Adam): HIP events around "
+                                  "the whole batch loop", "flops_per_step": flops, "device_ms_per_step": dev_ms / steps},
+           "train_stats": {"loss_first_last": [float(loss[0]), float(loss[-1])]}, "host_s": {"generate": t_gen},
+           "parity": "oracle unpinned (no TensorFlow in the image): oracle/wmf_oracle.py restates the published graph"}
+    if args.cpu_baseline_seconds > 0:
+        try:
+            from oracle import wmf_oracle
+
+            o = wmf_oracle.WmfOracle(U0, V0, R, 0.01, 0.01, 1.0, 0.01, 0.001)
+            n, t0 = 0, time.time()
+            while time.time() - t0 < min(args.cpu_baseline_seconds, 8.0) and n < len(batches):
+                o.step(batches[n])
+                n += 1
+            dtc = time.time() - t0
+            out["cpu_baseline"] = {"value": n / dtc, "unit": out["unit"], "cores": os.cpu_count() or 1, "kind": "port",
+                                   "sample": "%d steps of the same batches through the numpy restatement of the reference's "
+                                             "TensorFlow graph (oracle/wmf_oracle.py, BLAS threads as configured), %.1f s" % (n, dtc)}
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            print("[bench] wmf cpu_baseline failed: %r" % (e,), file=sys.stderr)
+            out["cpu_baseline"] = None
+    return out
+
+
+LEGS = {"mf_netflix": leg_mf_netflix, "wmf_netflix": leg_wmf_netflix, "vbpr_tradesy": leg_vbpr_tradesy, "bpr_k128_scale": leg_bpr_k128_scale}
 
 
 def self_launch(args):
@@ -507,7 +567,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=2_000_000, help="draws per exchange with --sharded-items")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
-    ap.add_argument("--legs", default="mf_netflix,vbpr_tradesy,bpr_k128_scale",
+    ap.add_argument("--legs", default="mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale",
                     help="extra single-GPU legs reported under `legs` at N = 1 (comma list; empty = none)")
     ap.add_argument("--no-legs", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launcher / timing scaffolding only, gloo, no GPU")

@@ -24,7 +24,9 @@ struct GemmSmem {
 //   A_KC: a_sk == 1 (k contiguous) else a_sm == 1;   B_NC: b_sn == 1 (n contiguous) else b_sk == 1.
 // Out-of-range rows/cols/k read as zero.  acc[i][j] is the 32 x 32 block (i, j) of this wave's 64 x 64 part:
 // register r of lane l holds C[row = wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][col = wn*64 + j*32 + (l&31)].
-template <bool A_KC, bool B_NC>
+//   ZERO = false accumulates into acc instead of starting from zero; A_NT reads A with L1-bypassing (nt) loads —
+//   for an A operand the same workgroup has just written to global memory.
+template <bool A_KC, bool B_NC, bool ZERO = true, bool A_NT = false>
 __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t a_sm, int64_t a_sk,
                                            const float *__restrict__ B, int64_t b_sk, int64_t b_sn, int64_t M,
                                            int64_t N, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
@@ -32,14 +34,20 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
+    if (ZERO) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     f32x4 ra[2], rb[2];
+    auto ld4 = [](const float *p) {
+        return A_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p)) : *reinterpret_cast<const f32x4 *>(p);
+    };
+    auto ld1 = [](const float *p) { return A_NT ? __builtin_nontemporal_load(p) : *p; };
     auto load_tile = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -49,11 +57,11 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
                 if (m < M) {
                     const float *p = A + m * a_sm + kk;
                     if (kk + 3 < k_end && ((a_sm | kk) & 3) == 0) {
-                        v = *reinterpret_cast<const f32x4 *>(p);
+                        v = ld4(p);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (kk + q < k_end) v[q] = p[q];
+                            if (kk + q < k_end) v[q] = ld1(p + q);
                     }
                 }
                 ra[i] = v;
@@ -63,11 +71,11 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
                 if (kk < k_end) {
                     const float *p = A + kk * a_sk + m;
                     if (m + 3 < M && ((a_sk | m) & 3) == 0) {
-                        v = *reinterpret_cast<const f32x4 *>(p);
+                        v = ld4(p);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (m + q < M) v[q] = p[q];
+                            if (m + q < M) v[q] = ld1(p + q);
                     }
                 }
                 ra[i] = v;
@@ -166,4 +174,48 @@ __device__ __forceinline__ void for_each_acc(f32x16 (&acc)[2][2], int64_t m0, in
             }
 }
 
+// the same visit in four 16-element blocks the scheduler may not interleave: an epilogue that loads several values per
+// element (Adam: U, m, v) otherwise has all 64 x 3 loads hoisted and spills
+template <class F>
+__device__ __forceinline__ void for_each_acc_blocked(f32x16 (&acc)[2][2], int64_t m0, int64_t n0, F &&f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t col = n0 + wn * 64 + j * 32 + l31;
+                f(row, col, acc[i][j][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+}  // namespace chip
+
+namespace chip {
+// Visit for epilogues inside a PERSISTENT tile loop: f(offset, row, col, value) with offset = row * stride + col as a
+// 32-bit element offset rebuilt from a per-lane base the optimiser cannot see through.  Without the opaque base the 64
+// per-element addresses are loop-invariant, get hoisted out of the tile loop and stay live in 128+ registers.
+template <class F>
+__device__ __forceinline__ void for_each_acc_local(f32x16 (&acc)[2][2], int stride, F &&f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    int row_base = wm * 64 + 4 * half, col_base = wn * 64 + l31;
+    asm volatile("" : "+v"(row_base), "+v"(col_base));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2), col = col_base + j * 32;
+                f(row * stride + col, row, col, acc[i][j][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
 }  // namespace chip

@@ -36,8 +36,8 @@ __device__ __forceinline__ double block_sum_f64(double v, double *scratch) {
 
 // V_b = V[ids]  (contiguous [B x ld]);  also lambda_v/2 * |V_b|^2 into the loss
 __global__ __launch_bounds__(kWb) void wmf_gather_kernel(const float *__restrict__ V, const int32_t *__restrict__ ids,
-                                                         int B, int ld, float *__restrict__ Vb, float half_lambda_v,
-                                                         double *loss) {
+                                                         int B, int ld, float *__restrict__ Vb,
+                                                         float *__restrict__ VbT, float half_lambda_v, double *loss) {
     __shared__ double scratch[kWb / 64];
     double part = 0;
     const int64_t n = (int64_t)B * ld;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kWb) void wmf_gather_kernel(const float *__restrict
         const int c = (int)(e / ld), f = (int)(e % ld);
         const float v = V[(int64_t)ids[c] * ld + f];
         Vb[e] = v;
+        if (VbT) VbT[(int64_t)f * kMaxBatch + c] = v;  // [ld][128]: the n-contiguous B operand of P = U V_b^T
         part += (double)v * v;
     }
     const double s = block_sum_f64(part, scratch);
@@ -157,6 +158,172 @@ __global__ __launch_bounds__(kWb) void wmf_update_u_kernel(const float *__restri
     if (threadIdx.x == 0) atomicAdd(loss, 0.5 * (double)lambda_u * s);
 }
 
+// ---- the user side of one step in ONE kernel (k <= 128) ---------------------------------------------------------
+// Per 128-user tile, in a persistent workgroup: P = U_t V_b^T (MFMA) -> G = 2 b P written to a 64 KB scratch tile of
+// the workgroup (L2-resident: written and re-read by the same workgroup, never by another) -> the batch's non-zeros
+// of this tile patched in place (CSC columns are sorted by row and a workgroup walks consecutive tiles: a cursor
+// per column) -> dV += G_t^T U_t accumulated in registers ACROSS the workgroup's tiles -> dU = G_t V_b with the clipped
+// TF1-Adam update of U, m_U, v_U as the epilogue.  The n_users x 128 matrix G of the unfused path (written once,
+// patched, read twice: 4 x 246 MB per step at the Netflix user count) never exists, U is read once for the three
+// products.  Each workgroup leaves its dV partial in `dv_part`; wmf_reduce_dv_kernel sums them.
+__global__ __launch_bounds__(kWb, 2) void wmf_user_step_kernel(const float *__restrict__ Vb, const float *__restrict__ VbT,
+                                                            int64_t n_users, int B, int k,
+                                                            int ld, float *U, float *mU, float *vU, float *g_scratch,
+                                                            const int64_t *__restrict__ indptr,
+                                                            const int32_t *__restrict__ rows,
+                                                            const float *__restrict__ vals,
+                                                            const int32_t *__restrict__ ids, float a, float b,
+                                                            float lambda_u, const TfAdam ad,
+                                                            float *__restrict__ dv_part, double *loss, int ablate) {
+    __shared__ GemmSmem sm;
+    __shared__ double scratch[kWb / 64];
+    float *Gs = g_scratch + (size_t)blockIdx.x * kBM * kMaxBatch;  // [128 users][128 batch columns]
+    f32x16 acc[2][2], accv[2][2];  // accv: this workgroup's dV partial, accumulated across its tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[i][j][r] = 0.f;
+    double part = 0;  // loss terms of this thread
+    const float two_b = 2.f * b;
+    const int64_t n_tiles = (n_users + kBM - 1) / kBM;
+    // a workgroup walks a CONTIGUOUS range of user tiles, so that a thread's cursor into its (row-sorted) CSC column
+    // only ever moves forward by the few non-zeros of the current tile: one binary search per column and kernel
+    const int64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_lo = (int64_t)blockIdx.x * per_wg, tile_hi = min(n_tiles, tile_lo + per_wg);
+    int64_t cur = 0, col_end = 0;
+    if ((int)threadIdx.x < B && tile_lo < tile_hi) {
+        const int32_t item = ids[threadIdx.x];
+        int64_t lo = indptr[item], hi = indptr[item + 1];
+        col_end = hi;
+        const int64_t key = tile_lo * kBM;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)rows[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const int64_t m0 = tile * kBM;
+        const int64_t rows_here = min((int64_t)kBM, n_users - m0);
+        // (a) P = U_t V_b^T
+        gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);  // (columns >= B of V_b^T are zero)
+        // (b) G = 2 b P into the scratch tile (zero outside the live rows / columns); loss += b sum P^2
+        float sq = 0.f;  // (64 squares of |P| <= a few units per thread and tile: fp32 partial, fp64 across tiles)
+        const int nrow = (int)rows_here;
+        if (!(ablate & 32)) for_each_acc_local(acc, kMaxBatch, [&](int off, int rl, int cl, float pv) {
+            const bool live = rl < nrow && cl < B;
+            Gs[off] = live ? two_b * pv : 0.f;
+            if (live) sq += pv * pv;
+        });
+        part += (double)b * (double)sq;
+        __syncthreads();
+        // (c) the batch's non-zeros whose user is in this tile: G = 2 a (p - r), loss += a (r - p)^2 - b p^2
+        if ((int)threadIdx.x < B && !(ablate & 4)) {
+            const int c = threadIdx.x;
+            const float *vrow = Vb + (int64_t)c * ld;
+            const int64_t m1 = m0 + rows_here;
+            while (cur < col_end) {
+                const int64_t u = rows[cur];
+                if (u >= m1) break;
+                const float r = vals[cur];
+                ++cur;
+                if (r == 0.f) continue;  // explicit zeros stay "unobserved" (batch_R.nonzero(), recom_wmf.py:186)
+                float *gp = Gs + (u - m0) * kMaxBatch + c;
+                float pv;
+                if (two_b != 0.f) {
+                    pv = __builtin_nontemporal_load(gp) / two_b;  // the prediction the MFMA pass just produced
+                } else {                                           // b == 0: G carries nothing to recover p from
+                    const float *urow = U + u * ld;
+                    pv = 0.f;
+                    for (int f = 0; f < k; f += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4 *>(urow + f), y = *reinterpret_cast<const f32x4 *>(vrow + f);
+                        pv += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                    }
+                }
+                *gp = 2.f * a * (pv - r);
+                part += (double)a * (double)(r - pv) * (double)(r - pv) - (double)b * (double)pv * (double)pv;
+            }
+        }
+        __syncthreads();
+        // (e) dV += G_t^T U_t  (U before its update): M = batch columns, N = ld, K = the tile's users
+        if (!(ablate & 1)) gemm_block<false, true, false, true>(Gs, 1, kMaxBatch, U + m0 * ld, ld, 1, B, ld, 0, 0, 0, rows_here, sm, accv);
+        // (d) dU = G_t V_b, then g = clip(dU + lambda_u U), TF1 Adam on U, m_U, v_U; loss += lambda_u/2 |U|^2 (pre-update)
+        if (!(ablate & 8)) gemm_block<true, true, true, true>(Gs, kMaxBatch, 1, Vb, ld, 1, rows_here, ld, 0, 0, 0, B, sm, acc);
+        // The accumulators hold 32 consecutive columns per half-wave and row: staged through LDS (64 rows at a time,
+        // the GEMM tiles' 33 KB are free here) so that every thread updates float4s of U, m_U, v_U — 16-byte
+        // accesses, whole 512-byte rows per half-wave — instead of 3 x 64 dword loads and stores
+        if (!(ablate & 16)) {
+            float *stg = &sm.a[0][0][0];  // [64][128]
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int wm = wave >> 1;
+            (void)lane;
+            float usq = 0.f;
+            for (int h = 0; h < 2; ++h) {
+                if (wm == h) for_each_acc_local(acc, kBN, [&](int off, int, int, float v) { stg[off - h * 64 * kBN] = v; });
+                __syncthreads();
+                const int c4 = (threadIdx.x & 31) * 4;
+                if (c4 < ld) {
+#pragma unroll 1
+                    for (int q = 0; q < 8; ++q) {
+                        const int row = (threadIdx.x >> 5) + 8 * q;
+                        const int64_t gr = m0 + h * 64 + row;
+                        if (gr < n_users) {
+                            const f32x4 du = *reinterpret_cast<const f32x4 *>(stg + row * kBN + c4);
+                            f32x4 *pu = reinterpret_cast<f32x4 *>(U + gr * ld + c4);
+                            f32x4 *pm = reinterpret_cast<f32x4 *>(mU + gr * ld + c4);
+                            f32x4 *pv = reinterpret_cast<f32x4 *>(vU + gr * ld + c4);
+                            f32x4 u = *pu, m = *pm, v = *pv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                usq += u[e] * u[e];
+                                float g = du[e] + lambda_u * u[e];
+                                g = fminf(fmaxf(g, -5.f), 5.f);
+                                m[e] = m[e] + ad.one_minus_beta1 * (g - m[e]);
+                                v[e] = v[e] + ad.one_minus_beta2 * (g * g - v[e]);
+                                u[e] = u[e] - ad.lr_t * m[e] / (sqrtf(v[e]) + ad.eps);
+                            }
+                            *pm = m;
+                            *pv = v;
+                            *pu = u;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            part += 0.5 * (double)lambda_u * (double)usq;
+        }
+        __syncthreads();  // the scratch tile is rewritten by the next tile
+    }
+    float *mine = dv_part + (size_t)blockIdx.x * kMaxBatch * kBN;
+    for_each_acc_local(accv, kBN, [&](int off, int, int, float v) { mine[off] = v; });
+    const double s = block_sum_f64(part, scratch);
+    if (threadIdx.x == 0 && s != 0) atomicAdd(loss, s);
+}
+
+// dV[c, f] += sum over a slice of the workgroups' partials (fused path; grid.y slices, dV is zero on entry: the scatter
+// kernel re-zeroes it after every step)
+__global__ __launch_bounds__(kWb) void wmf_reduce_dv_kernel(const float *__restrict__ dv_part, int n_parts, int B, int ld,
+                                                            float *__restrict__ dV) {
+    const int64_t n = (int64_t)B * ld;
+    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = min(n_parts, w0 + per);
+    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
+        const int c = (int)(e / ld), f = (int)(e % ld);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        int w = w0;
+        for (; w + 3 < w1; w += 4) {
+            acc0 += dv_part[((size_t)w * kMaxBatch + c) * kBN + f];
+            acc1 += dv_part[((size_t)(w + 1) * kMaxBatch + c) * kBN + f];
+            acc2 += dv_part[((size_t)(w + 2) * kMaxBatch + c) * kBN + f];
+            acc3 += dv_part[((size_t)(w + 3) * kMaxBatch + c) * kBN + f];
+        }
+        for (; w < w1; ++w) acc0 += dv_part[((size_t)w * kMaxBatch + c) * kBN + f];
+        atomicAdd(dV + e, (acc0 + acc1) + (acc2 + acc3));
+    }
+}
+
 // gV rows of the batch: clip(dV + lambda_v V_b) scattered into the dense (otherwise zero) gradient; dV re-zeroed
 __global__ __launch_bounds__(kWb) void wmf_scatter_gv_kernel(float *__restrict__ dV, const float *__restrict__ Vb,
                                                              const int32_t *__restrict__ ids, int B, int k, int ld,
@@ -223,6 +390,8 @@ struct cornac_hip_wmf {
     hipStream_t stream = nullptr;
     DevBuf<float> U, V, mU, vU, mV, vV, gV;   // [rows x ld], zero padded columns
     DevBuf<float> G, Vb, dV, stage;           // [n_users x 128], [128 x ld], [128 x ld], host<->device staging
+    DevBuf<float> g_scratch, dv_part, VbT;    // fused path: per-workgroup G tile [wgs x 128 x 128], dV partials, V_b^T [ld x 128]
+    int fused_wgs = 0;
     DevBuf<int64_t> indptr;                   // CSC
     DevBuf<int32_t> rows, ids;          // ids: all batches of the current call, back to back
     DevBuf<float> vals;
@@ -261,7 +430,6 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         const size_t nu = (size_t)n_users * h->ld, ni = (size_t)n_items * h->ld;
         for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
         for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV, &h->gV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
-        h->G.alloc((size_t)n_users * kMaxBatch);
         h->Vb.alloc((size_t)kMaxBatch * h->ld);
         h->dV.alloc((size_t)kMaxBatch * h->ld);
         HIP_CHECK(hipMemsetAsync(h->dV.p, 0, h->dV.n * 4, h->stream));
@@ -271,6 +439,30 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         h->h_indptr.assign(csc_indptr, csc_indptr + n_items + 1);
         h->rows.alloc((size_t)std::max<int64_t>(nnz, 1));
         h->vals.alloc((size_t)std::max<int64_t>(nnz, 1));
+        // the fused step kernel binary-searches a column for the rows of a user tile: columns sorted by row
+        std::vector<int32_t> srows;
+        std::vector<float> svals;
+        bool sorted = true;
+        for (int64_t i = 0; i < n_items && sorted; ++i)
+            for (int64_t e = csc_indptr[i] + 1; e < csc_indptr[i + 1]; ++e)
+                if (csc_rows[e] < csc_rows[e - 1]) { sorted = false; break; }
+        if (!sorted) {
+            srows.assign(csc_rows, csc_rows + nnz);
+            svals.assign(csc_vals, csc_vals + nnz);
+            std::vector<int64_t> perm;
+            for (int64_t i = 0; i < n_items; ++i) {
+                const int64_t lo = csc_indptr[i], hi = csc_indptr[i + 1];
+                perm.resize((size_t)(hi - lo));
+                for (int64_t e = lo; e < hi; ++e) perm[(size_t)(e - lo)] = e;
+                std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return csc_rows[x] < csc_rows[y]; });
+                for (int64_t e = lo; e < hi; ++e) {
+                    srows[(size_t)e] = csc_rows[perm[(size_t)(e - lo)]];
+                    svals[(size_t)e] = csc_vals[perm[(size_t)(e - lo)]];
+                }
+            }
+            csc_rows = srows.data();
+            csc_vals = svals.data();
+        }
         if (nnz) { h->rows.upload(csc_rows, (size_t)nnz, h->stream); h->vals.upload(csc_vals, (size_t)nnz, h->stream); }
         HIP_CHECK(hipStreamSynchronize(h->stream));
         *out = h.release();
@@ -342,6 +534,20 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
         int64_t chunk = std::max<int64_t>(kBK, (nu + 511) / 512);
         chunk = (chunk + kBK - 1) / kBK * kBK;
         const int n_chunks = (int)((nu + chunk - 1) / chunk);
+        // k <= 128: the whole user side of a step is one persistent kernel (wmf_user_step_kernel)
+        static const bool no_fuse = getenv("CORNAC_HIP_WMF_UNFUSED") != nullptr;  // A/B switch for profiling
+        static const int wmf_ablate = getenv("CORNAC_HIP_WMF_ABLATE") ? atoi(getenv("CORNAC_HIP_WMF_ABLATE")) : 0;
+        const bool fused = ld <= kBN && !no_fuse;
+        if (fused && h->fused_wgs == 0) {
+            int per_cu = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_kernel, kWb, 0));
+            h->fused_wgs = (int)std::min<int64_t>(m_tiles, (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 2)));
+            h->g_scratch.alloc((size_t)h->fused_wgs * kBM * kMaxBatch);
+            h->dv_part.alloc((size_t)h->fused_wgs * kMaxBatch * kBN);
+            h->VbT.alloc((size_t)ld * kMaxBatch);
+            HIP_CHECK(hipMemsetAsync(h->VbT.p, 0, h->VbT.n * 4, h->stream));
+        }
+        if (!fused && !h->G.p) h->G.alloc((size_t)nu * kMaxBatch);
         const int64_t n_ids = batch_ptr[n_batches] - batch_ptr[0];
         h->ids.ensure((size_t)n_ids);
         h->loss.ensure((size_t)n_batches);
@@ -362,7 +568,17 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
             ad.lr_t = (float)((double)learning_rate * std::sqrt(1.0 - std::pow(beta2, (double)h->step)) /
                               (1.0 - std::pow(beta1, (double)h->step)));
             ad.eps = 1e-8f;
-            wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, 0.5f * lambda_v, d_loss);
+            wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, fused ? h->VbT.p : nullptr, 0.5f * lambda_v, d_loss);
+            if (fused) {
+                wmf_user_step_kernel<<<h->fused_wgs, kWb, 0, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, h->g_scratch.p,
+                                                                  h->indptr.p, h->rows.p, h->vals.p, d_ids, a, b, lambda_u, ad,
+                                                                  h->dv_part.p, d_loss, wmf_ablate);
+                wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, h->fused_wgs, B, ld, h->dV.p);
+                wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
+                wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
+                HIP_CHECK(hipGetLastError());
+                continue;
+            }
             wmf_pred_kernel<<<m_tiles, kWb, 0, s>>>(h->U.p, h->Vb.p, nu, B, k, ld, h->G.p, b, d_loss);
             if (max_col > 0) {
                 const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((max_col + kWb / 16 - 1) / (kWb / 16), 64));
