@@ -42,7 +42,8 @@ nnz = nu * d
 sh.run(min(nnz, args.micro_batch), 0.05, 0.01); sh.finish()  # warm-up
 dist.barrier(); torch.cuda.synchronize()
 t0 = time.perf_counter()
-sh.rows_fetched = sh.triplets = 0
+sh.rows_fetched = 0
+sh._valid_draws.zero_()
 for _ in range(args.epochs):
     sh.run(nnz, 0.05, 0.01)
 c, s = sh.finish()
