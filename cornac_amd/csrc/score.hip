@@ -760,9 +760,8 @@ __global__ __launch_bounds__(kSortBlk) void full_sort_kernel(const float *__rest
 // row's targets go through registers kPosT at a time while the row's scores stream from the score tile (one row
 // is ~100 KB: L2-resident after the first pass).  Integer compares on the order-preserving score bits: exact.
 constexpr int kPosT = 8;
-// The counts are kept per WAVE in scalar registers: every compare is one v_cmp whose lane mask is popcounted and
-// added on the scalar unit (three v_cmp per (item, target) pair, no per-lane accumulators), the row is read with
-// 16-byte loads (4 items per lane) wherever its alignment allows, eight targets per pass over the row.
+// The row is read with 16-byte loads (4 candidates per lane) wherever its alignment allows, eight targets per pass
+// over the row; counts are per-lane registers reduced across the workgroup once per pass.
 __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__restrict__ scores,
                                                               const uint8_t *__restrict__ excl_mask, int64_t n_items,
                                                               const int64_t *__restrict__ tgt_indptr,
@@ -782,7 +781,6 @@ __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__res
     const int64_t body_end = head + ((n_items - head) & ~int64_t(3));
     const bool vec_mask = !erow || ((reinterpret_cast<uintptr_t>(erow) + head) & 3) == 0;
     for (int64_t t0 = lo; t0 < hi; t0 += kPosT) {
-        unsigned long long tk[kPosT];  // (order key << 32) | item: unique per candidate, ordered like rank()'s output
         uint32_t ts[kPosT];
         bool ok[kPosT];
         int32_t titem[kPosT];
@@ -793,47 +791,89 @@ __global__ __launch_bounds__(kBlk) void rank_positions_kernel(const float *__res
             ok[q] = item >= 0 && item < n_items && !(erow && erow[item]);
             ts[q] = ok[q] ? order_key(srow[item]) : 0xFFFFFFFFu;
             titem[q] = item;
-            tk[q] = ((unsigned long long)ts[q] << 32) | (uint32_t)item;
         }
-        int g[kPosT], ps[kPosT], e[kPosT];  // wave-uniform (scalar) partial counts
+        // per-lane counts: g = candidates strictly above the target, eq = candidates with the target's score,
+        // tie = of those, the ones rank() orders first (higher item index).  The common case costs two VALU per
+        // (candidate, target) — v_cmp_gt + add-with-carry — plus one v_cmp_eq whose lane mask is OR-ed on the scalar
+        // unit; only a group of candidates in which some score EQUALS some target's (the target itself, real ties)
+        // takes the exact path below.  A dead candidate gets key 0, which is above no target.
+        int g[kPosT], eq[kPosT], tie[kPosT];
 #pragma unroll
-        for (int q = 0; q < kPosT; ++q) g[q] = ps[q] = e[q] = 0;
-        // (lane 0 of a wave is active whenever any lane of the wave is — the loops below run longest for the lowest
-        // lanes — so its copy of the wave's counts is complete; ballots ignore inactive lanes)
-        auto visit = [&](bool live, float sc, int64_t i) __attribute__((always_inline)) {
-            const uint32_t oc = order_key(sc);
-            const unsigned long long key = ((unsigned long long)oc << 32) | (uint32_t)i;
+        for (int q = 0; q < kPosT; ++q) g[q] = eq[q] = tie[q] = 0;
+        auto visit = [&](const bool *live, const float *sc, int64_t i, int n) __attribute__((always_inline)) {
+            uint32_t oc[4];
+            unsigned long long any_eq = 0;
 #pragma unroll
-            for (int q = 0; q < kPosT; ++q) {
-                g[q] += __popcll(__ballot(live && oc > ts[q]));
-                e[q] += __popcll(__ballot(live && oc >= ts[q]));
-                ps[q] += __popcll(__ballot(live && key > tk[q]));
+            for (int c = 0; c < n; ++c) {
+                oc[c] = live[c] ? order_key(sc[c]) : 0u;
+#pragma unroll
+                for (int q = 0; q < kPosT; ++q) {
+                    g[q] += oc[c] > ts[q];
+                    any_eq |= __ballot(oc[c] == ts[q]);
+                }
+            }
+            if (any_eq) {
+#pragma unroll
+                for (int c = 0; c < n; ++c) {
+                    asm volatile("" : "+v"(oc[c]));  // recompute the compares here: keeping 32 lane masks alive spills
+#pragma unroll
+                    for (int q = 0; q < kPosT; ++q) {
+                        const bool same = live[c] && oc[c] == ts[q];
+                        eq[q] += same;
+                        tie[q] += same && (uint32_t)(i + c) > (uint32_t)titem[q];
+                    }
+                }
             }
         };
-        for (int64_t i = threadIdx.x; i < head; i += kBlk) visit(!(erow && erow[i]), srow[i], i);
-        for (int64_t i0 = head + 4 * (int64_t)threadIdx.x; i0 < body_end + 4 * (int64_t)(kBlk - 1); i0 += 4 * kBlk) {
-            // (the loop bound keeps whole waves together: lanes beyond the body contribute nothing)
+        for (int64_t i = threadIdx.x; i < head; i += kBlk) {
+            const bool lv = !(erow && erow[i]);
+            const float sc = srow[i];
+            visit(&lv, &sc, i, 1);
+        }
+        // (the loop bound keeps whole waves together: lanes beyond the body contribute nothing; the next iteration's
+        // 16-byte loads are issued before the current one's compares: two loads in flight per lane)
+        auto fetch = [&](int64_t i0, v4f32 &sv, uint32_t &em) __attribute__((always_inline)) {
             const bool in = i0 < body_end;
-            const v4f32 sv = in ? *reinterpret_cast<const v4f32 *>(srow + i0) : v4f32{0.f, 0.f, 0.f, 0.f};
-            uint32_t em = 0u;
+            sv = in ? *reinterpret_cast<const v4f32 *>(srow + i0) : v4f32{0.f, 0.f, 0.f, 0.f};
+            em = 0u;
             if (erow && in) {
                 if (vec_mask) em = *reinterpret_cast<const uint32_t *>(erow + i0);
                 else em = (uint32_t)erow[i0] | ((uint32_t)erow[i0 + 1] << 8) | ((uint32_t)erow[i0 + 2] << 16) | ((uint32_t)erow[i0 + 3] << 24);
             }
-            visit(in && !(em & 0xffu), sv.x, i0);
-            visit(in && !(em & 0xff00u), sv.y, i0 + 1);
-            visit(in && !(em & 0xff0000u), sv.z, i0 + 2);
-            visit(in && !(em & 0xff000000u), sv.w, i0 + 3);
+        };
+        const int64_t i_first = head + 4 * (int64_t)threadIdx.x, i_stop = body_end + 4 * (int64_t)(kBlk - 1);
+        v4f32 sv_n = {0.f, 0.f, 0.f, 0.f};
+        uint32_t em_n = 0u;
+        if (i_first < i_stop) fetch(i_first, sv_n, em_n);
+        for (int64_t i0 = i_first; i0 < i_stop; i0 += 4 * kBlk) {
+            const v4f32 sv = sv_n;
+            const uint32_t em = em_n;
+            if (i0 + 4 * kBlk < i_stop) fetch(i0 + 4 * kBlk, sv_n, em_n);
+            const bool in = i0 < body_end;
+            const bool lv[4] = {in && !(em & 0xffu), in && !(em & 0xff00u), in && !(em & 0xff0000u), in && !(em & 0xff000000u)};
+            const float sc[4] = {sv.x, sv.y, sv.z, sv.w};
+            visit(lv, sc, i0, 4);
         }
-        for (int64_t i = body_end + threadIdx.x; i < n_items; i += kBlk) visit(!(erow && erow[i]), srow[i], i);
+        for (int64_t i = body_end + threadIdx.x; i < n_items; i += kBlk) {
+            const bool lv = !(erow && erow[i]);
+            const float sc = srow[i];
+            visit(&lv, &sc, i, 1);
+        }
+#pragma unroll
+        for (int q = 0; q < kPosT; ++q)
+            for (int o = 32; o > 0; o >>= 1) {
+                g[q] += __shfl_xor(g[q], o, 64);
+                eq[q] += __shfl_xor(eq[q], o, 64);
+                tie[q] += __shfl_xor(tie[q], o, 64);
+            }
         if (threadIdx.x < kPosT * 3) cnt[threadIdx.x] = 0;
         __syncthreads();
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
             for (int q = 0; q < kPosT; ++q) {
                 atomicAdd(&cnt[q * 3 + 0], g[q]);
-                atomicAdd(&cnt[q * 3 + 1], ps[q]);
-                atomicAdd(&cnt[q * 3 + 2], e[q]);
+                atomicAdd(&cnt[q * 3 + 1], g[q] + tie[q]);
+                atomicAdd(&cnt[q * 3 + 2], g[q] + eq[q]);
             }
         }
         __syncthreads();
