@@ -29,6 +29,9 @@ SYMBOLS = [
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
+    "cornac_hip_bpr_staged_slots", "cornac_hip_bpr_emit_triplets", "cornac_hip_bpr_apply_staged",
+    "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
+    "cornac_hip_bpr_scatter_diff_rows", "cornac_hip_bpr_switch_stream",
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
     "cornac_hip_bpr_table_delta_step",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
@@ -119,6 +122,7 @@ def lib():
         L.cornac_hip_bpr_bind_device.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_device_ptrs.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
         L.cornac_hip_bpr_set_stream.argtypes = [_vp, _vp]
+        L.cornac_hip_bpr_switch_stream.argtypes = [_vp, _vp]
         L.cornac_hip_bpr_seed_mt19937.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_int]
         L.cornac_hip_bpr_seed_hogwild.argtypes = [_vp, C.c_uint64]
         L.cornac_hip_bpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -135,6 +139,14 @@ def lib():
         L.cornac_hip_bpr_apply_triplets.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_float,
                                                     C.c_float, C.c_int]
         L.cornac_hip_bpr_gather_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
+        L.cornac_hip_bpr_staged_slots.argtypes = [_vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_emit_triplets.argtypes = [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_apply_staged.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_float, C.c_float,
+                                                  C.c_int]
+        L.cornac_hip_bpr_shard_mark.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]
+        L.cornac_hip_bpr_shard_slots.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, _vp, _vp]
+        L.cornac_hip_bpr_shard_uniq.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp]
+        L.cornac_hip_bpr_scatter_diff_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]
         L.cornac_hip_bpr_scatter_add_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
         L.cornac_hip_bpr_table_delta_begin.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
@@ -286,6 +298,10 @@ class BprTrainer:
     def set_stream(self, stream_ptr):
         check(lib().cornac_hip_bpr_set_stream(self.h, stream_ptr))
 
+    def switch_stream(self, stream_ptr):
+        """set_stream without waiting for the previous stream's queued work (the caller orders the streams)"""
+        check(lib().cornac_hip_bpr_switch_stream(self.h, stream_ptr))
+
     # ---- row-sharded item table building blocks (device pointers; see cornac_amd/dist.py) -----------
     def sample_triplets(self, n_draws, d_u, d_i, d_j, neg_population=NEG_UNIFORM):
         check(lib().cornac_hip_bpr_sample_triplets(self.h, int(n_draws), neg_population, d_u, d_i, d_j))
@@ -293,6 +309,35 @@ class BprTrainer:
     def apply_triplets(self, d_u, d_slot_i, d_slot_j, n, d_rows, d_bias, bias_stride, lr, reg, use_bias=True):
         check(lib().cornac_hip_bpr_apply_triplets(self.h, d_u, d_slot_i, d_slot_j, int(n), d_rows, d_bias,
                                                   int(bias_stride), lr, reg, int(use_bias)))
+
+    def staged_slots(self, n_draws):
+        """array length emit_triplets needs for n_draws (0: this shape has no owned kernel)"""
+        n = C.c_int64()
+        check(lib().cornac_hip_bpr_staged_slots(self.h, int(n_draws), C.byref(n)))
+        return n.value
+
+    def emit_triplets(self, n_draws, d_u, d_i, d_j, slots_cap, neg_population=NEG_UNIFORM):
+        n = C.c_int64()
+        check(lib().cornac_hip_bpr_emit_triplets(self.h, int(n_draws), neg_population, d_u, d_i, d_j, int(slots_cap),
+                                                 C.byref(n)))
+        return n.value
+
+    def apply_staged(self, d_u, d_slot_i, d_slot_j, n_slots, d_rows, d_bias, bias_stride, lr, reg, use_bias=True):
+        check(lib().cornac_hip_bpr_apply_staged(self.h, d_u, d_slot_i, d_slot_j, int(n_slots), d_rows, d_bias,
+                                                int(bias_stride), lr, reg, int(use_bias)))
+
+    def shard_mark(self, d_i, d_j, n, world, rows_per_rank, d_mark):
+        check(lib().cornac_hip_bpr_shard_mark(self.h, d_i, d_j, int(n), int(world), int(rows_per_rank), d_mark))
+
+    def shard_slots(self, d_i, d_j, n, world, rows_per_rank, d_scan, d_slot_i, d_slot_j):
+        check(lib().cornac_hip_bpr_shard_slots(self.h, d_i, d_j, int(n), int(world), int(rows_per_rank), d_scan, d_slot_i,
+                                               d_slot_j))
+
+    def shard_uniq(self, d_mark, d_scan, n_rows, rows_per_rank, d_uniq_local):
+        check(lib().cornac_hip_bpr_shard_uniq(self.h, d_mark, d_scan, int(n_rows), int(rows_per_rank), d_uniq_local))
+
+    def scatter_diff_rows(self, d_table, d_ids, n, width, d_now, d_before, d_scale=None):
+        check(lib().cornac_hip_bpr_scatter_diff_rows(self.h, d_table, d_ids, int(n), int(width), d_now, d_before, d_scale))
 
     def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local):
         check(lib().cornac_hip_bpr_table_delta_begin(self.h, d_flat, d_base, int(n_items), int(k), d_bucket, d_local))

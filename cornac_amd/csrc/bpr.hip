@@ -167,7 +167,12 @@ struct HogArgs {
     int64_t nnz;
     int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
     int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
+    // row-sharded item table (sharded.inc): the owned kernel in its EMIT / STAGED forms exchanges the triplets of
+    // tile t of wave w through trip_*[((trip_tile0 + t) * total_waves + w) * 64 + lane]
+    int32_t *trip_u, *trip_i, *trip_j;
+    int64_t trip_tile0, trip_tiles;
 };
+constexpr int32_t kTripShared = 0x40000000;  // bit 30 of an emitted user id: a shared (heavy) user, atomics on its row
 
 // per-lane: draw one (u, i, j) and test membership; returns validity
 __device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int32_t &u, int32_t &i, int32_t &j,
@@ -305,9 +310,15 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
 // positives only from their interactions, so a user row is read and written by exactly one wave:
 // plain load/store instead of 2 atomic line-requests per triplet, and no lost or stale U update.
 // Heavy users (more interactions than half a wave's share) are split over all waves and keep atomics.
-template <int G, int R, int UNR, bool ATOMIC, bool OWNED>
+//
+// MODE (OWNED only; the row-sharded item table of sharded.inc): 0 = the fused kernel; 1 = EMIT: sample only and write
+// the wave's triplets to trip_* (-1 = skipped draw), no table access; 2 = STAGED: take the triplets from trip_* — item
+// entries are SLOTS of the staging table a.V / a.B — and update.  The same grid and ownership tables in both launches
+// keep every user row with one wave, so U stays on plain loads/stores exactly as in the fused kernel.
+template <int G, int R, int UNR, bool ATOMIC, bool OWNED, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
     static_assert(!OWNED || G == kWave, "ownership needs one triplet per wave step");
+    static_assert(MODE == 0 || OWNED, "the emit / staged forms exist for the owned kernel only");
     float *const Vt = a.V;
     float *const Bt = a.B;
     __shared__ int32_t stage[kWavesPerBlock][3][kWave];
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
     int64_t n_tiles = (a.n + kWave - 1) / kWave, tile0 = wave_id, tile_step = total_waves;
     int64_t own_base = 0, own_lo = 0, own_hi = 0;
     uint32_t own_len = 1, own_th = 0;
-    if (OWNED) {
+    if (OWNED && MODE != 2) {
         own_base = a.wave_ptr[wave_id];
         own_len = (uint32_t)(a.wave_ptr[wave_id + 1] - own_base);
         // this launch covers the epoch fraction [s_begin, s_begin + n) / nnz of every wave's samples
@@ -338,6 +349,28 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         own_th = own_len ? lemire_thresh(own_len) : 0;
     }
     unsigned int n_correct = 0, n_skipped = 0;
+    if (MODE == 1) {
+        for (int64_t tile = 0; tile < a.trip_tiles; ++tile) {
+            int32_t su, si, sj;
+            const int64_t local = own_lo + tile * kWave + lane;
+            const bool in_range = local < own_hi;
+            const bool valid = hog_sample_owned(a, (uint32_t)wave_id, own_base, own_len, own_th, local, in_range, su, si, sj);
+            const int64_t pos = ((a.trip_tile0 + tile) * total_waves + wave_id) * kWave + lane;
+            a.trip_u[pos] = valid ? (su < 0 ? (~su | kTripShared) : su) : -1;
+            a.trip_i[pos] = valid ? si : -1;
+            a.trip_j[pos] = valid ? sj : -1;
+            n_skipped += (in_range && !valid) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_skipped += __shfl_xor(n_skipped, o, kWave);
+        if (lane == 0 && n_skipped) atomicAdd(&a.counters[1], (unsigned long long)n_skipped);
+        return;
+    }
+    if (MODE == 2) {
+        n_tiles = a.trip_tiles;
+        tile0 = 0;
+        tile_step = 1;
+    }
     bool inb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) inb[r] = lg + G * r < a.k;
@@ -345,7 +378,15 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         int32_t su, si, sj;
         bool in_range;
         bool valid;
-        if (OWNED) {
+        if (MODE == 2) {
+            const int64_t pos = ((a.trip_tile0 + tile) * total_waves + wave_id) * kWave + lane;
+            su = __builtin_nontemporal_load(a.trip_u + pos);
+            si = __builtin_nontemporal_load(a.trip_i + pos);
+            sj = __builtin_nontemporal_load(a.trip_j + pos);
+            valid = su >= 0;
+            in_range = valid;  // skipped draws were counted by the emit launch
+            if (valid && (su & kTripShared)) su = ~(su & ~kTripShared);
+        } else if (OWNED) {
             const int64_t local = own_lo + tile * kWave + lane;
             in_range = local < own_hi;
             valid = hog_sample_owned(a, (uint32_t)wave_id, own_base, own_len, own_th, local, in_range, su, si, sj);
@@ -385,9 +426,9 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const bool ld = inb[r] && !(a.ablate & 4);
-                    u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : 0.01f;
-                    vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : 0.02f;
-                    vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : 0.03f;
+                    u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : (inb[r] ? 0.01f : 0.f);
+                    vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : (inb[r] ? 0.02f : 0.f);
+                    vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : (inb[r] ? 0.03f : 0.f);
                 }
                 bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)ti[q] * a.bstride);
                 bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)tj[q] * a.bstride);
@@ -604,6 +645,7 @@ struct cornac_hip_bpr {
     EventTimer ktimer;  // hogwild SGD kernel launches
     void (*hog_kernel)(const chip::HogArgs) = nullptr;
     int hog_blocks_per_cu = 8;
+    int staged_blocks_per_cu = 0;  // sharded.inc: occupancy of the staged (MODE 2) kernel, 0 = not queried yet
     // user-row ownership tables of the hogwild kernel (built lazily for the persistent grid width)
     std::vector<int32_t> h_indptr, h_indices;
     int64_t own_waves = 0;
@@ -741,6 +783,13 @@ int cornac_hip_bpr_set_stream(cornac_hip_bpr_t h, void *hip_stream) {
     return guarded([&] {
         bpr_check(h);
         HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    });
+}
+
+int cornac_hip_bpr_switch_stream(cornac_hip_bpr_t h, void *hip_stream) {
+    return guarded([&] {
+        bpr_check(h);
         h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     });
 }

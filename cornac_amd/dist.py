@@ -193,6 +193,7 @@ class RowShardedItemTable:
         self.rows_per_rank = (self.total_items + self.world - 1) // self.world
         self.V = torch.zeros(self.rows_per_rank, self.k, dtype=torch.float32, device=device)
         self.B = torch.zeros(self.rows_per_rank, dtype=torch.float32, device=device)
+        self.mark = lambda label: None   # tracing hook (RowShardedBprTrainer.trace)
 
     def owner_major(self, item_ids):
         return (item_ids % self.world) * self.rows_per_rank + item_ids // self.world
@@ -203,28 +204,42 @@ class RowShardedItemTable:
         self.V[: len(mine)].copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(V, np.float32)[mine])))
         self.B[: len(mine)].copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(B, np.float32)[mine])))
 
-    def _exchange(self, send, send_counts, recv_counts):
+    def _exchange(self, send, send_counts, recv_counts, group=None):
         if not self.collective:
             return send
         recv = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
-                               group=self.group)
+                               group=group if group is not None else self.group)
         return recv
 
-    def dedupe(self, g, valid):
-        """De-duplicate the owner-major indices `g` (int64 [m], entries with valid == False ignored) WITHOUT sorting
-        and with ONE host synchronisation: a flag per table row, an inclusive scan of the flags (slot of a touched row
-        = scan - 1; scan order = owner-major order, so the unique list is bucketed by owner), the per-owner counts read
+    def dedupe_items(self, i, j):
+        """De-duplicate the items of a micro-batch (int32 device arrays `i`, `j`; entries < 0 are skipped draws)
+        WITHOUT sorting and with ONE host synchronisation: a flag per table row in owner-major order, an inclusive scan
+        of the flags (slot of a touched row = scan - 1; the scan order is bucketed by owner), the per-owner counts read
         off the scan at the owner boundaries, exchanged with the peers on the device and copied to the host together
-        with the local counts.  Returns (uniq [n_unique] int64 sorted, slot [m] int32, send_counts, recv_counts)."""
+        with the local counts.  Returns (local_rows int32 [n_unique]: the request lists, one run per owner; slot_i,
+        slot_j int32 [m]; send_counts; recv_counts).  The mark / slot / request-list passes are HIP kernels when `ops`
+        has them (DeviceRowOps), device-agnostic torch code otherwise (the gloo tests)."""
         n_rows = self.world * self.rows_per_rank
-        gg = torch.where(valid, g, torch.full_like(g, n_rows))          # ignored entries point at a spare flag
-        mark = torch.zeros(n_rows + 1, dtype=torch.int32, device=g.device)
-        mark[gg] = 1
-        mark[n_rows] = 0
-        scan = torch.cumsum(mark, 0, dtype=torch.int32)
-        slot = (scan[gg] - 1).clamp_(min=0)
-        bounds = torch.arange(1, self.world + 1, device=g.device) * self.rows_per_rank - 1
+        fast = hasattr(self.ops, "shard_mark")
+        if fast:
+            mark = torch.zeros(n_rows, dtype=torch.int32, device=i.device)
+            self.ops.shard_mark(i, j, self.world, self.rows_per_rank, mark)
+            scan = torch.cumsum(mark, 0, dtype=torch.int32)
+            slot_i, slot_j = torch.empty_like(i), torch.empty_like(j)
+            self.ops.shard_slots(i, j, self.world, self.rows_per_rank, scan, slot_i, slot_j)
+        else:
+            valid = i >= 0
+            g = torch.cat([self.owner_major(i.long()), self.owner_major(j.long())])
+            gg = torch.where(torch.cat([valid, valid]), g, torch.full_like(g, n_rows))   # skipped -> a spare flag
+            mark = torch.zeros(n_rows + 1, dtype=torch.int32, device=i.device)
+            mark[gg] = 1
+            mark[n_rows] = 0
+            scan = torch.cumsum(mark, 0, dtype=torch.int32)
+            slot = (scan[gg] - 1).clamp_(min=0)
+            slot_i, slot_j = slot[: len(i)].contiguous(), slot[len(i):].contiguous()
+        self.mark("a slots")
+        bounds = torch.arange(1, self.world + 1, device=i.device) * self.rows_per_rank - 1
         ends = scan[bounds].to(torch.int64)
         sc = ends - torch.cat([ends.new_zeros(1), ends[:-1]])
         if self.collective:
@@ -232,19 +247,22 @@ class RowShardedItemTable:
             dist.all_to_all_single(rc, sc, group=self.group)
         else:
             rc = sc
+        self.mark("a counts")
         counts = torch.stack([sc, rc]).tolist()                           # the ONE host synchronisation
+        self.mark("a synced")
         send_counts, recv_counts = counts[0], counts[1]
-        uniq = torch.empty(int(sum(send_counts)), dtype=torch.int64, device=g.device)
-        if len(uniq):
-            keep = torch.where(valid, slot.long(), torch.full_like(g, len(uniq)))   # ignored entries -> a spare slot
-            buf = torch.empty(len(uniq) + 1, dtype=torch.int64, device=g.device)
-            buf[keep] = gg
-            uniq = buf[:-1]
-        return uniq, slot, send_counts, recv_counts
+        n_unique = int(sum(send_counts))
+        if fast:
+            local_rows = torch.empty(n_unique, dtype=torch.int32, device=i.device)
+            if n_unique:
+                self.ops.shard_uniq(mark, scan, self.rows_per_rank, local_rows)
+        else:
+            local_rows = (torch.nonzero(mark[:n_rows]).view(-1) % self.rows_per_rank).to(torch.int32)
+        return local_rows, slot_i, slot_j, send_counts, recv_counts
 
     def fetch(self, uniq_g, send_counts=None, recv_counts=None):
         """uniq_g: sorted unique owner-major indices (int64, on `device`).  Returns (rows [n,k], bias [n], plan).
-        Without the split sizes (as `dedupe` returns them) they are derived here with two more host syncs."""
+        The split sizes are derived here with two host syncs (the training loop gets them from `dedupe_items`)."""
         if send_counts is None:
             bounds = torch.arange(self.world + 1, device=uniq_g.device, dtype=uniq_g.dtype) * self.rows_per_rank
             cuts = torch.searchsorted(uniq_g, bounds).tolist()  # host sync: the split sizes of the exchange
@@ -256,31 +274,63 @@ class RowShardedItemTable:
                 recv_counts = rc.tolist()
             else:
                 recv_counts = list(send_counts)
-        local_rows = (uniq_g % self.rows_per_rank).to(torch.int32)
+        return self.fetch_local((uniq_g % self.rows_per_rank).to(torch.int32), send_counts, recv_counts)
+
+    def fetch_local(self, local_rows, send_counts, recv_counts):
+        """local_rows: the request lists (`dedupe_items`).  The plan keeps the rows as the owner SENT them: a later
+        `push_updated` turns the returned rows into deltas on the owner's side."""
         wanted = self._exchange(local_rows, send_counts, recv_counts)          # rows the others want from me
+        self.mark("a ids")
         out_rows = torch.empty(len(wanted), self.k, dtype=torch.float32, device=self.device)
         out_bias = torch.empty(len(wanted), 1, dtype=torch.float32, device=self.device)
         self.ops.gather(self.V, wanted, out_rows)
         self.ops.gather(self.B.view(-1, 1), wanted, out_bias)
+        self.mark("a gathered")
         rows = self._exchange(out_rows, recv_counts, send_counts)
         bias = self._exchange(out_bias, recv_counts, send_counts).view(-1)
-        return rows, bias, (send_counts, recv_counts, wanted)
+        if not self.collective:   # no exchange: the staged rows must not alias what the owner keeps
+            rows, bias = rows.clone(), bias.clone()
+        return rows, bias, (send_counts, recv_counts, wanted, out_rows, out_bias)
+
+    def _sender_scale(self, wanted):
+        """1 / sqrt(number of ranks that requested the row), per received row (None on one rank)"""
+        if self.world == 1 or not len(wanted):
+            return None
+        idx = wanted.long()
+        senders = torch.zeros(self.rows_per_rank, dtype=torch.float32, device=self.device)
+        senders.index_add_(0, idx, torch.ones(len(idx), dtype=torch.float32, device=self.device))
+        return senders[idx].rsqrt()
 
     def push(self, plan, d_rows, d_bias):
         """owners apply  sum of the received deltas of a row / sqrt(number of ranks that sent one)  (the same
         reconciliation rule as ItemTableReplica: several ranks' stale steps on one popular row are damped)"""
-        send_counts, recv_counts, wanted = plan
+        send_counts, recv_counts, wanted = plan[:3]
         got_rows = self._exchange(d_rows.contiguous(), send_counts, recv_counts)
         got_bias = self._exchange(d_bias.contiguous().view(-1, 1), send_counts, recv_counts)
-        if self.world > 1 and len(wanted):
-            idx = wanted.long()
-            senders = torch.zeros(self.rows_per_rank, dtype=torch.float32, device=self.device)
-            senders.index_add_(0, idx, torch.ones(len(idx), dtype=torch.float32, device=self.device))
-            scale = senders[idx].rsqrt().unsqueeze(1)
-            got_rows = got_rows * scale
-            got_bias = got_bias * scale
+        scale = self._sender_scale(wanted)
+        if scale is not None:
+            got_rows = got_rows * scale.unsqueeze(1)
+            got_bias = got_bias * scale.unsqueeze(1)
         self.ops.scatter_add(self.V, wanted, got_rows)
         self.ops.scatter_add(self.B.view(-1, 1), wanted, got_bias)
+
+    def push_updated(self, plan, rows, bias, group=None):
+        """the same push from the UPDATED staged rows: they travel back as they are and the owner applies
+        (returned - sent) / sqrt(senders) in one scatter pass — no delta buffer on the requester's side"""
+        send_counts, recv_counts, wanted, out_rows, out_bias = plan
+        got_rows = self._exchange(rows.contiguous(), send_counts, recv_counts, group)
+        got_bias = self._exchange(bias.contiguous().view(-1, 1), send_counts, recv_counts, group)
+        scale = self._sender_scale(wanted)
+        if hasattr(self.ops, "scatter_diff"):
+            self.ops.scatter_diff(self.V, wanted, got_rows, out_rows, scale)
+            self.ops.scatter_diff(self.B.view(-1, 1), wanted, got_bias, out_bias, scale)
+        else:
+            d_rows, d_bias = got_rows - out_rows, got_bias - out_bias
+            if scale is not None:
+                d_rows, d_bias = d_rows * scale.unsqueeze(1), d_bias * scale.unsqueeze(1)
+            self.ops.scatter_add(self.V, wanted, d_rows)
+            self.ops.scatter_add(self.B.view(-1, 1), wanted, d_bias)
+        return got_rows, got_bias
 
     def gather_full(self):
         """(V [total_items, k], B [total_items]) assembled on every rank (for get_factors / evaluation)"""
@@ -296,7 +346,8 @@ class RowShardedItemTable:
 
 
 class DeviceRowOps:
-    """row gather / scatter-add through libcornac_hip on the trainer's stream (device tensors only)"""
+    """row gather / scatter and the de-duplication passes through libcornac_hip on the trainer's stream (device
+    tensors only)"""
 
     def __init__(self, trainer):
         self.trainer = trainer
@@ -307,32 +358,77 @@ class DeviceRowOps:
     def scatter_add(self, table, ids, delta):
         self.trainer.scatter_add_rows(table.data_ptr(), ids.data_ptr(), len(ids), table.shape[1], delta.data_ptr())
 
+    def scatter_diff(self, table, ids, now, before, scale=None):
+        self.trainer.scatter_diff_rows(table.data_ptr(), ids.data_ptr(), len(ids), table.shape[1], now.data_ptr(),
+                                       before.data_ptr(), scale.data_ptr() if scale is not None else None)
+
+    def shard_mark(self, i, j, world, rows_per_rank, mark):
+        self.trainer.shard_mark(i.data_ptr(), j.data_ptr(), len(i), world, rows_per_rank, mark.data_ptr())
+
+    def shard_slots(self, i, j, world, rows_per_rank, scan, slot_i, slot_j):
+        self.trainer.shard_slots(i.data_ptr(), j.data_ptr(), len(i), world, rows_per_rank, scan.data_ptr(),
+                                 slot_i.data_ptr(), slot_j.data_ptr())
+
+    def shard_uniq(self, mark, scan, rows_per_rank, uniq_local):
+        self.trainer.shard_uniq(mark.data_ptr(), scan.data_ptr(), len(mark), rows_per_rank, uniq_local.data_ptr())
+
 
 class RowShardedBprTrainer:
     """One rank of BPR with the item table sharded by row.  Users (CSR slice, U rows) are rank-local as in
-    regime 1; each micro-batch samples triplets, fetches the touched item rows, applies the hogwild update on
-    the staged rows and pushes the deltas back.  Between a fetch and the matching push other ranks may fetch the
-    same rows: the usual bounded-staleness asynchrony, one micro-batch deep."""
+    regime 1; each micro-batch goes through two stages:
+
+        A  draw the triplets, de-duplicate their items, fetch the touched rows from their owners into a staging table
+        B  the hogwild update on the staged rows, the updated rows back to their owners (who apply the difference)
+
+    On a GPU the fetch side, the update kernel and the push side run on three streams (two RCCL communicators, one per
+    exchanging stream): stage A of micro-batch r overlaps the update of r-1 and the push of r-2 (the update kernel
+    waits on atomics and leaves the copy / exchange bandwidth free), so a fetch may miss the pushes of the three
+    previous micro-batches — the usual bounded-staleness asynchrony.  With the handle's
+    owned kernel (k in 33..256) stage A is its EMIT launch and stage B its STAGED launch: user rows stay with one wave
+    and are updated with plain stores, as in the single-GPU kernel; otherwise the generic sample / apply kernels run."""
 
     BIAS_STRIDE = 32  # staged biases sit one per 128-byte line (see DESIGN.md "padded bias table")
 
-    def __init__(self, trainer, total_items, k, device, micro_batch, group=None, ops=None):
+    def __init__(self, trainer, total_items, k, device, micro_batch, group=None, ops=None, pipeline=None):
         self.trainer, self.device, self.micro_batch, self.group = trainer, device, int(micro_batch), group
-        self.stream = None
-        if device.type == "cuda":
+        self.stream = self.stream_b = self.stream_c = None
+        cuda = device.type == "cuda"
+        self.pipeline = cuda if pipeline is None else bool(pipeline)
+        if cuda:
             self.stream = torch.cuda.Stream(device)
+            self.stream_b = torch.cuda.Stream(device) if self.pipeline else self.stream
+            self.stream_c = torch.cuda.Stream(device) if self.pipeline else self.stream
             torch.cuda.synchronize(device)
             trainer.set_stream(self.stream.cuda_stream)
-        with self._on_stream():
+        with self._on(self.stream):
             self.table = RowShardedItemTable(total_items, k, device, ops or DeviceRowOps(trainer), group)
-        if device.type == "cuda":
+        # stage B's exchanges get their own communicator: two streams must not share one
+        self.group_b = group
+        if self.pipeline and self.table.collective:
+            self.group_b = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group))
+        if cuda:
             # the handle's own (full-size) item table is not used in this mode: release it
             trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
+        self.slots_cap = trainer.staged_slots(self.micro_batch) if cuda and hasattr(trainer, "staged_slots") else 0
+        self.owned = self.slots_cap > 0
+        self._trip, self._trip_free = [], []   # two sets of triplet arrays: stage A of r+1 writes while stage B of r reads
+        self._turn, self._last_turn = 0, None
         self.rows_fetched = 0
         self._valid_draws = torch.zeros((), dtype=torch.int64, device=device)
+        self.trace = None   # set to a list to collect (label, stream name, event) marks (tools/bench_sharded.py --trace)
+        self.table.mark = lambda label: self._mark(label, self.stream, "A")
+
+    def _mark(self, label, stream, which):
+        if self.trace is not None and stream is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.trace.append((label, which, ev))
+
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
     def _on_stream(self):
-        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        return self._on(self.stream)
 
     @property
     def triplets(self):
@@ -346,19 +442,93 @@ class RowShardedBprTrainer:
             self.stream.synchronize()
 
     def _sample(self, n):
+        """(u, i, j) int32 device arrays; skipped draws (and padding slots) carry i = j = -1 and u < 0"""
+        if self.owned:
+            if not self._trip:
+                for _ in range(2 if self.stream_b is not self.stream else 1):
+                    self._trip.append(tuple(torch.empty(self.slots_cap, dtype=torch.int32, device=self.device)
+                                            for _ in range(3)))
+                self._trip_free = [None] * len(self._trip)
+            turn = self._turn % len(self._trip)
+            self._turn += 1
+            u, i, j = self._trip[turn]
+            if self._trip_free[turn] is not None:   # the stage B that read this set two micro-batches ago
+                self.stream.wait_event(self._trip_free[turn])
+            n_slots = self.trainer.emit_triplets(n, u.data_ptr(), i.data_ptr(), j.data_ptr(), self.slots_cap)
+            self._last_turn = turn
+            return u[:n_slots], i[:n_slots], j[:n_slots]
         u = torch.empty(n, dtype=torch.int32, device=self.device)
         i, j = torch.empty_like(u), torch.empty_like(u)
         self.trainer.sample_triplets(n, u.data_ptr(), i.data_ptr(), j.data_ptr())
         return u, i, j
 
     def _apply(self, u, slot_i, slot_j, rows, bias_pad, lr, reg, use_bias):
-        self.trainer.apply_triplets(u.data_ptr(), slot_i.data_ptr(), slot_j.data_ptr(), len(u), rows.data_ptr(),
-                                    bias_pad.data_ptr(), self.BIAS_STRIDE, lr, reg, use_bias)
+        fn = self.trainer.apply_staged if self.owned else self.trainer.apply_triplets
+        fn(u.data_ptr(), slot_i.data_ptr(), slot_j.data_ptr(), len(u), rows.data_ptr(), bias_pad.data_ptr(),
+           self.BIAS_STRIDE, lr, reg, use_bias)
+
+    def _stage_a(self, n):
+        """draw, de-duplicate, fetch (stream A)"""
+        if self.stream is not None:
+            self.trainer.switch_stream(self.stream.cuda_stream)
+        with self._on(self.stream):
+            self._mark("A begin", self.stream, "A")
+            if n > 0:
+                u, i, j = self._sample(n)
+            else:   # nothing left to draw here: an empty batch keeps the collectives matched
+                u = torch.full((0,), -1, dtype=torch.int32, device=self.device)
+                i, j = u.clone(), u.clone()
+            self._mark("A emitted", self.stream, "A")
+            local_rows, slot_i, slot_j, send_counts, recv_counts = self.table.dedupe_items(i, j)
+            self._mark("A deduped", self.stream, "A")
+            rows, bias, plan = self.table.fetch_local(local_rows, send_counts, recv_counts)
+            bias_pad = torch.zeros(len(bias), self.BIAS_STRIDE, dtype=torch.float32, device=self.device)
+            bias_pad[:, 0] = bias
+            self.rows_fetched += len(local_rows)
+            self._valid_draws = self._valid_draws + (i >= 0).sum()   # stays on the device: read through .triplets
+            self._mark("A end", self.stream, "A")
+            ready = None
+            if self.stream is not None and self.stream_b is not self.stream:
+                ready = torch.cuda.Event()
+                ready.record(self.stream)
+        return dict(u=u, slot_i=slot_i, slot_j=slot_j, rows=rows, bias_pad=bias_pad, plan=plan, ready=ready,
+                    n_unique=len(local_rows), turn=self._last_turn if self.owned and n > 0 else None)
+
+    def _stage_b(self, st, lr, reg, use_bias):
+        """the update on the staged rows (stream B), then the updated rows back to their owners (stream C: the push of
+        micro-batch r runs beside the update of r+1)"""
+        split = st["ready"] is not None
+        if self.stream_b is not None:
+            self.trainer.switch_stream(self.stream_b.cuda_stream)
+        with self._on(self.stream_b):
+            if split:
+                self.stream_b.wait_event(st["ready"])
+                for t in (st["u"], st["slot_i"], st["slot_j"], st["rows"], st["bias_pad"]):
+                    t.record_stream(self.stream_b)   # allocated on stream A, used here
+            self._mark("B begin", self.stream_b, "B")
+            if len(st["u"]) and st["n_unique"]:
+                self._apply(st["u"], st["slot_i"], st["slot_j"], st["rows"], st["bias_pad"], lr, reg, use_bias)
+            self._mark("B end", self.stream_b, "B")
+            if split:
+                applied = torch.cuda.Event()
+                applied.record(self.stream_b)
+                if st["turn"] is not None:
+                    self._trip_free[st["turn"]] = applied
+        if self.stream_c is not None:
+            self.trainer.switch_stream(self.stream_c.cuda_stream)
+        with self._on(self.stream_c):
+            if split:
+                self.stream_c.wait_event(applied)
+                for t in (st["rows"], st["bias_pad"], st["plan"][2], st["plan"][3], st["plan"][4]):
+                    t.record_stream(self.stream_c)
+            self._mark("C begin", self.stream_c, "C")
+            self.table.push_updated(st["plan"], st["rows"], st["bias_pad"][:, 0], group=self.group_b)
+            self._mark("C end", self.stream_c, "C")
 
     def run(self, n_samples, lr, reg, use_bias=True):
-        """n_samples draws on this rank, in micro-batches.  Every micro-batch is a collective (three all-to-alls), so
-        all ranks must go through the same number of them: the ranks agree on the maximum up front and a rank whose
-        user shard runs out of draws keeps serving the others' fetches / pushes with empty batches."""
+        """n_samples draws on this rank, in micro-batches.  Every micro-batch is a collective (all-to-alls in both
+        stages), so all ranks must go through the same number of them: the ranks agree on the maximum up front and a
+        rank whose user shard runs out of draws keeps serving the others' fetches / pushes with empty batches."""
         left = int(n_samples)
         rounds = (left + self.micro_batch - 1) // self.micro_batch
         if self.table.collective and self.table.world > 1:
@@ -366,30 +536,27 @@ class RowShardedBprTrainer:
             with self._on_stream():
                 dist.all_reduce(r, op=dist.ReduceOp.MAX, group=self.group)
             rounds = int(r.item())
-        with self._on_stream():
-            for _ in range(rounds):
-                n = min(left, self.micro_batch)
-                left -= n
-                if n > 0:
-                    u, i, j = self._sample(n)
-                else:   # nothing left to draw here: an empty batch (all skipped) keeps the collectives matched
-                    u = torch.full((0,), -1, dtype=torch.int32, device=self.device)
-                    i, j = u.clone(), u.clone()
-                valid = u >= 0                                      # skipped draws carry -1 and stay in place: the
-                nv = len(u)                                         # apply kernel ignores them (no compaction, no sync)
-                g = torch.cat([self.table.owner_major(i.long()), self.table.owner_major(j.long())])
-                uniq, slot, send_counts, recv_counts = self.table.dedupe(g, torch.cat([valid, valid]))
-                rows, bias, plan = self.table.fetch(uniq, send_counts, recv_counts)
-                rows0, bias0 = rows.clone(), bias
-                bias_pad = torch.zeros(len(bias), self.BIAS_STRIDE, dtype=torch.float32, device=self.device)
-                bias_pad[:, 0] = bias
-                if nv and len(uniq):
-                    self._apply(u, slot[:nv].contiguous(), slot[nv:].contiguous(), rows, bias_pad, lr, reg, use_bias)
-                self.table.push(plan, rows - rows0, bias_pad[:, 0] - bias0)
-                self.rows_fetched += len(uniq)
-                self._valid_draws = self._valid_draws + valid.sum()   # stays on the device: read through .triplets
+        prev = None
+        for _ in range(rounds):
+            n = min(left, self.micro_batch)
+            left -= n
+            if self.pipeline:
+                if prev is not None:
+                    self._stage_b(prev, lr, reg, use_bias)       # enqueued first: overlaps the next stage A
+                prev = self._stage_a(n)
+            else:
+                self._stage_b(self._stage_a(n), lr, reg, use_bias)
+        if prev is not None:
+            self._stage_b(prev, lr, reg, use_bias)
+        if self.stream is not None and self.stream_b is not self.stream:
+            self.stream.wait_stream(self.stream_b)               # a following run / finish sees every update and push
+            self.stream.wait_stream(self.stream_c)
+            self.trainer.set_stream(self.stream.cuda_stream)
 
     def finish(self):
+        for st in (self.stream_b, self.stream_c):
+            if st is not None:
+                st.synchronize()
         out = self.trainer.sync()
         if self.stream is not None:
             self.stream.synchronize()

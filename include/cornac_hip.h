@@ -80,8 +80,11 @@ int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B)
 /* Use caller-owned device buffers (same shapes) instead of the library's. */
 int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB);
 int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB);
-/* run the handle's work on a caller-provided hipStream_t (NULL = the handle's own) */
+/* run the handle's work on a caller-provided hipStream_t (NULL = the handle's own); waits for the previous stream */
 int cornac_hip_bpr_set_stream(cornac_hip_bpr_t h, void *hip_stream);
+/* the same without waiting for the work already queued on the previous stream: for callers that alternate between two
+ * streams and order them with events themselves (cornac_amd/dist.py:RowShardedBprTrainer, stages A / B) */
+int cornac_hip_bpr_switch_stream(cornac_hip_bpr_t h, void *hip_stream);
 
 /* Deterministic-mode sampler state = the two boost::random::mt19937 engines of
  * RNGVector(1, ...) (recom_bpr.pyx:188-191): pass the ALREADY-DERIVED 32-bit
@@ -141,6 +144,34 @@ int cornac_hip_bpr_sample_triplets(cornac_hip_bpr_t h, int64_t n_draws, int neg_
 int cornac_hip_bpr_apply_triplets(cornac_hip_bpr_t h, const int32_t *d_u, const int32_t *d_slot_i,
                                   const int32_t *d_slot_j, int64_t n, float *d_rows, float *d_bias, int bias_stride,
                                   float lr, float reg, int use_bias);
+/* The same two steps through the hogwild kernel's user-row ownership (k in 33..256): emit_triplets runs the owned
+ * sampler of the fused kernel and writes the triplets of tile t of wave w at ((t * waves + w) * 64 + lane) — u with
+ * bit 30 set for a shared (heavy) user, u = i = j = -1 for a skipped or padding slot; *n_slots (a multiple of
+ * waves * 64, at most what staged_slots(n_draws) returns, <= slots_cap) is the array length written.  apply_staged
+ * takes the same arrays with i / j replaced by staging-table slots: every user row is again touched by one wave only
+ * (plain loads/stores, atomics only on the staged item rows), exactly the fused kernel's update.
+ * staged_slots returns 0 when the shape has no owned kernel (use sample_triplets / apply_triplets). */
+int cornac_hip_bpr_staged_slots(cornac_hip_bpr_t h, int64_t n_draws, int64_t *n_slots);
+int cornac_hip_bpr_emit_triplets(cornac_hip_bpr_t h, int64_t n_draws, int neg_population, int32_t *d_u, int32_t *d_i,
+                                 int32_t *d_j, int64_t slots_cap, int64_t *n_slots);
+int cornac_hip_bpr_apply_staged(cornac_hip_bpr_t h, const int32_t *d_u, const int32_t *d_slot_i, const int32_t *d_slot_j,
+                                int64_t n_slots, float *d_rows, float *d_bias, int bias_stride, float lr, float reg,
+                                int use_bias);
+/* De-duplication of a micro-batch's item ids without a sort.  Owner-major index of item i:
+ * g(i) = (i % world) * rows_per_rank + i / world.  shard_mark sets d_mark[g] = 1 for the items of every valid triplet
+ * (d_mark: int32 [world * rows_per_rank], zeroed by the caller); the caller scans it (inclusive); shard_slots writes
+ * slot = d_scan[g] - 1 per triplet side (-1 for skipped draws); shard_uniq writes the request lists
+ * d_uniq_local[d_scan[g] - 1] = g % rows_per_rank, one contiguous run per owner. */
+int cornac_hip_bpr_shard_mark(cornac_hip_bpr_t h, const int32_t *d_i, const int32_t *d_j, int64_t n, int world,
+                              int64_t rows_per_rank, int32_t *d_mark);
+int cornac_hip_bpr_shard_slots(cornac_hip_bpr_t h, const int32_t *d_i, const int32_t *d_j, int64_t n, int world,
+                               int64_t rows_per_rank, const int32_t *d_scan, int32_t *d_slot_i, int32_t *d_slot_j);
+int cornac_hip_bpr_shard_uniq(cornac_hip_bpr_t h, const int32_t *d_mark, const int32_t *d_scan, int64_t n_rows,
+                              int64_t rows_per_rank, int32_t *d_uniq_local);
+/* d_table[d_ids[r], :] += (d_now[r, :] - d_before[r, :]) * (d_scale ? d_scale[r] : 1)  (atomic): the owner's side of
+ * a push — d_before is the row as the owner sent it, d_now the row as the requester returned it */
+int cornac_hip_bpr_scatter_diff_rows(cornac_hip_bpr_t h, float *d_table, const int32_t *d_ids, int64_t n, int width,
+                                     const float *d_now, const float *d_before, const float *d_scale);
 /* d_out[r, :] = d_table[d_ids[r], :] and d_table[d_ids[r], :] += d_delta[r, :] (atomic), rows of `width` floats */
 int cornac_hip_bpr_gather_rows(cornac_hip_bpr_t h, const float *d_table, const int32_t *d_ids, int64_t n, int width,
                                float *d_out);

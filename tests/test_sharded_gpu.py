@@ -108,6 +108,163 @@ def test_apply_gather_scatter_kernels(k):
     tr.close()
 
 
+def _big_trainer(k, seed=3):
+    from cornac_amd import synth
+
+    n_users, n_items = 6000, 3000
+    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, seed)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    return tr, indptr, indices, n_users, n_items
+
+
+@pytest.mark.parametrize("k", [64, 100])
+def test_emit_triplets_are_valid_owned_draws(k):
+    """the EMIT launch of the owned kernel: every emitted triplet is (user, one of its positives, a non-positive),
+    emitted + skipped = draws, padding slots are -1, and a non-shared user only ever appears in ONE wave's slots"""
+    import torch
+
+    tr, indptr, indices, n_users, n_items = _big_trainer(k)
+    tr.seed_hogwild(99)
+    nnz = len(indices)
+    # a launch covers whole 64-sample tiles of every wave, so only whole epochs have an exact draw count: one third of
+    # an epoch, then the rest of it plus a whole second epoch (the second call crosses the epoch boundary)
+    n1 = nnz // 3
+    n2 = 2 * nnz - n1
+    n = n1 + n2
+    cap = tr.staged_slots(n2)
+    assert cap > 0 and cap % 64 == 0 and tr.staged_slots(n1) <= cap
+    dev = torch.device("cuda", 0)
+    parts, skipped = [], 0
+    for nn in (n1, n2):
+        u, i, j = (torch.full((cap,), 7, dtype=torch.int32, device=dev) for _ in range(3))
+        torch.cuda.synchronize()
+        n_slots = tr.emit_triplets(nn, u.data_ptr(), i.data_ptr(), j.data_ptr(), cap)
+        assert 0 <= n_slots <= cap
+        skipped += tr.sync()[1]
+        parts.append([x[:n_slots].cpu().numpy() for x in (u, i, j)])
+    u, i, j = (np.concatenate([p[q] for p in parts]) for q in range(3))
+    n_slots = len(u)
+    ok = i >= 0
+    assert np.array_equal(ok, j >= 0) and np.array_equal(ok, u >= 0)
+    assert int(ok.sum()) + skipped == n and 0 < skipped < 0.2 * n
+    shared = (u & 0x40000000) != 0
+    uu = np.where(ok, u & 0x3FFFFFFF, 0)
+    assert uu.max() < n_users and i[ok].max() < n_items and j[ok].max() < n_items
+    import scipy.sparse as sp
+
+    X = sp.csr_matrix((np.ones(nnz, np.int8), indices, indptr), shape=(n_users, n_items))
+    assert np.asarray(X[uu[ok], i[ok]]).all() and not np.asarray(X[uu[ok], j[ok]]).any()
+    # slot -> wave: slots are laid out [tile][wave][lane]
+    W = tr.staged_slots(1) // (3 * 64)
+    wave = (np.arange(n_slots) // 64) % W
+    excl = ok & ~shared
+    first = np.full(n_users, -1, np.int64)
+    first[uu[excl]] = wave[excl]                      # any one wave the user appears in ...
+    assert np.array_equal(first[uu[excl]], wave[excl])  # ... is the only one
+    deg = np.diff(indptr)
+    assert not shared[ok].any() or deg[uu[ok & shared]].min() > deg[uu[excl]].max() // 2
+    tr.close()
+
+
+@pytest.mark.parametrize("k", [64, 128, 200])
+def test_apply_staged_equals_the_sequential_update_on_a_conflict_free_batch(k):
+    import torch
+
+    rs = np.random.RandomState(k)
+    tr, indptr, indices, nu, n_items = _big_trainer(k)
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    tr.set_factors(U, np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32))
+    dev = torch.device("cuda", 0)
+    unit = tr.staged_slots(1) // 3          # waves * 64: one tile of every wave
+    assert unit > 0 and unit % 64 == 0
+    n_slots_tab, n, total = 150, 60, 2 * unit
+    rows = rs.normal(0, 0.3, (n_slots_tab, k)).astype(np.float32)
+    bias = rs.normal(0, 0.3, n_slots_tab).astype(np.float32)
+    users = rs.permutation(nu)[:n].astype(np.int32)
+    slots = rs.permutation(n_slots_tab)[: 2 * n].astype(np.int32)
+    si, sj = slots[:n].copy(), slots[n:].copy()
+    where = rs.permutation(total)[:n]
+    au, ai, aj = (np.full(total, -1, np.int32) for _ in range(3))
+    au[where], ai[where], aj[where] = users, si, sj
+    au[where[3]] |= 0x40000000            # a "shared" user: same arithmetic through the atomic path
+    t_rows = torch.tensor(rows, device=dev)
+    stride = 32
+    t_bias = torch.zeros(n_slots_tab, stride, device=dev)
+    t_bias[:, 0] = torch.tensor(bias, device=dev)
+    lr, reg = 0.05, 0.01
+    t_u, t_si, t_sj = (torch.tensor(x, device=dev) for x in (au, ai, aj))
+    torch.cuda.synchronize()
+    # apply_staged follows an emit on the handle (ownership tables of the same grid)
+    tr.seed_hogwild(1)
+    scratch = torch.empty(3, tr.staged_slots(64), dtype=torch.int32, device=dev)
+    tr.emit_triplets(64, scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(), scratch.shape[1])
+    tr.sync()
+    tr.apply_staged(t_u.data_ptr(), t_si.data_ptr(), t_sj.data_ptr(), total, t_rows.data_ptr(), t_bias.data_ptr(), stride,
+                    lr, reg, True)
+    c, _ = tr.sync()
+    U2 = tr.get_factors()[0]
+    wantU, wantR, wantB, correct = U.astype(np.float64), rows.astype(np.float64), bias.astype(np.float64), 0
+    for t in range(n):
+        u, a, b = users[t], si[t], sj[t]
+        uf, vi, vj = U[u].astype(np.float64), rows[a].astype(np.float64), rows[b].astype(np.float64)
+        z = 1.0 / (1.0 + np.exp(bias[a] - bias[b] + uf @ (vi - vj)))
+        correct += z < 0.5
+        wantU[u] += lr * (z * (vi - vj) - reg * uf)
+        wantR[a] += lr * (z * uf - reg * vi)
+        wantR[b] += lr * (-z * uf - reg * vj)
+        wantB[a] += lr * (z - reg * bias[a])
+        wantB[b] += lr * (-z - reg * bias[b])
+    assert c == correct
+    assert np.abs(U2 - wantU).max() < 2e-6 and np.abs(t_rows.cpu().numpy() - wantR).max() < 2e-6
+    assert np.abs(t_bias[:, 0].cpu().numpy() - wantB).max() < 2e-6 and float(t_bias[:, 1:].abs().max()) == 0.0
+    tr.close()
+
+
+def test_dedupe_and_scatter_diff_kernels():
+    import torch
+
+    from cornac_amd.dist import DeviceRowOps, RowShardedItemTable
+
+    rs = np.random.RandomState(4)
+    tr, *_ = _big_trainer(64)
+    dev = torch.device("cuda", 0)
+    tr.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # as RowShardedBprTrainer does: one stream for both
+    n_items, k, world = 1001, 8, 1
+    m = 5000
+    i = rs.randint(0, n_items, m).astype(np.int32)
+    j = rs.randint(0, n_items, m).astype(np.int32)
+    skip = rs.rand(m) < 0.1
+    i[skip] = j[skip] = -1
+    for ops in (DeviceRowOps(tr), None):
+        class Plain:   # the torch formulation (the gloo tests' path): gather / scatter_add only
+            def gather(self, table, ids, out): out.copy_(table[ids.long()])
+            def scatter_add(self, table, ids, delta): table.index_add_(0, ids.long(), delta)
+        t = RowShardedItemTable(n_items, k, dev, ops or Plain())
+        assert not t.collective and t.world == world
+        ti, tj = torch.tensor(i, device=dev), torch.tensor(j, device=dev)
+        torch.cuda.synchronize()
+        local_rows, slot_i, slot_j, sc, rc = t.dedupe_items(ti, tj)
+        tr.sync()
+        torch.cuda.synchronize()
+        uniq = np.unique(np.concatenate([i[~skip], j[~skip]]))
+        assert sc == [len(uniq)] == rc and np.array_equal(local_rows.cpu().numpy(), uniq)
+        assert np.array_equal(uniq[slot_i.cpu().numpy()[~skip]], i[~skip])
+        assert np.array_equal(uniq[slot_j.cpu().numpy()[~skip]], j[~skip])
+    # scatter_diff with repeated ids and a per-row scale
+    table = torch.tensor(rs.normal(0, 1, (90, k)).astype(np.float32), device=dev)
+    ids = torch.tensor(rs.randint(0, 90, 400).astype(np.int32), device=dev)
+    now = torch.tensor(rs.normal(0, 1, (400, k)).astype(np.float32), device=dev)
+    before = torch.tensor(rs.normal(0, 1, (400, k)).astype(np.float32), device=dev)
+    scale = torch.tensor(rs.uniform(0.5, 1, 400).astype(np.float32), device=dev)
+    want = table.double().index_add(0, ids.long(), (now.double() - before.double()) * scale.double().unsqueeze(1))
+    torch.cuda.synchronize()
+    tr.scatter_diff_rows(table.data_ptr(), ids.data_ptr(), 400, k, now.data_ptr(), before.data_ptr(), scale.data_ptr())
+    tr.sync()
+    assert (table.double() - want).abs().max() < 1e-5
+    tr.close()
+
+
 def test_row_sharded_trainer_single_rank_through_rccl():
     """the whole regime-2 loop on one rank with a real NCCL group (all_to_all_single through RCCL): learns like
     the fused hogwild kernel on the same data, and with reg = 0 conserves the column sums of V / the sum of B

@@ -17,6 +17,7 @@ ap.add_argument("--degree", type=int, default=20)
 ap.add_argument("--k", type=int, default=128)
 ap.add_argument("--micro-batch", type=int, default=2_000_000)
 ap.add_argument("--epochs", type=int, default=3)
+ap.add_argument("--trace", action="store_true", help="print the stage timeline (device events) of the last epoch")
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0))
@@ -44,7 +45,9 @@ dist.barrier(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 sh.rows_fetched = 0
 sh._valid_draws.zero_()
-for _ in range(args.epochs):
+for e in range(args.epochs):
+    if args.trace and e == args.epochs - 1:
+        sh.trace = []
     sh.run(nnz, 0.05, 0.01)
 c, s = sh.finish()
 dist.barrier(); torch.cuda.synchronize()
@@ -56,5 +59,9 @@ if rank == 0:
                       "micro_batch": args.micro_batch, "triplets_per_s": n / t.item(),
                       "rows_fetched_per_triplet": sh.rows_fetched / max(sh.triplets, 1),
                       "exchange_bytes_per_triplet": sh.rows_fetched / max(sh.triplets, 1) * (k + 1) * 4 * 2}))
+if args.trace and rank == 0:
+    t0e = sh.trace[0][2]
+    for label, which, ev in sh.trace:
+        print("%-10s %s %9.3f ms" % (label, {"A": "", "B": "      ", "C": "            "}[which], t0e.elapsed_time(ev)))
 tr.close()
 dist.destroy_process_group()
