@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -333,7 +334,7 @@ def _bpr_apply(U, u, si, sj, rows, bias_pad, lr, reg, use_bias):
             Bp[q, 0] += lr * (-z - reg * Bp[q, 0])
 
 
-def _sharded_learn_worker(rank, world, port, out):
+def _sharded_learn_worker(rank, world, port, out, pipeline=False):
     from cornac_amd.dist import RowShardedBprTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -346,7 +347,8 @@ def _sharded_learn_worker(rank, world, port, out):
         U = ((np.random.RandomState(11 + rank).uniform(0, 1, (len(indptr) - 1, k)).astype(np.float32) - 0.5) / k)
         positives = [set(indices[indptr[a]:indptr[a + 1]].tolist()) for a in range(len(indptr) - 1)]
         sh = RowShardedBprTrainer(_FakeShardTrainer(rank, n_items), n_items, k, torch.device("cpu"), micro_batch=1500,
-                                  ops=_HostRowOps())
+                                  ops=_HostRowOps(), pipeline=pipeline)
+        assert (sh.group_b is not sh.group) == pipeline   # the push side exchanges through its own communicator
         init = np.random.RandomState(7)
         sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
 
@@ -372,19 +374,21 @@ def _sharded_learn_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_learn_over_a_row_sharded_item_table():
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_two_ranks_learn_over_a_row_sharded_item_table(pipeline):
     """regime 2 end to end on two gloo ranks with real BPR arithmetic on the staged rows: items live on their owner
-    rank, every micro-batch fetches the touched rows, updates them locally and pushes the deltas back; the assembled
-    table is the same on both ranks and ranks each rank's own positives well"""
+    rank, every micro-batch fetches the touched rows, updates them locally and returns them (the owner applies the
+    difference); the assembled table is the same on both ranks and ranks each rank's own positives well.  pipeline=True
+    is the GPU driver's order (update / push of micro-batch r-1 enqueued before the fetch of r, second communicator)"""
     out = mp.Manager().dict()
-    mp.spawn(_sharded_learn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_sharded_learn_worker, args=(2, _free_port(), out, pipeline), nprocs=2, join=True)
     (V0, B0, before0, after0, fetched0, n0), (V1, B1, before1, after1, _, _) = out[0], out[1]
     assert np.array_equal(V0, V1) and np.array_equal(B0, B1) and np.isfinite(V0).all()
     assert before0 < 0.6 and before1 < 0.6 and after0 > 0.75 and after1 > 0.75
     assert 0 < fetched0 <= 24 * 90 and n0 > 0          # de-duplicated requests: at most every item once per micro-batch
 
 
-def _uneven_worker(rank, world, port, out):
+def _uneven_worker(rank, world, port, out, pipeline=False):
     from cornac_amd.dist import RowShardedBprTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -392,7 +396,7 @@ def _uneven_worker(rank, world, port, out):
     try:
         n_items, k = 40, 4
         sh = RowShardedBprTrainer(_FakeShardTrainer(rank, n_items), n_items, k, torch.device("cpu"), micro_batch=100,
-                                  ops=_HostRowOps())
+                                  ops=_HostRowOps(), pipeline=pipeline)
         sh.load_items(np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32))
         rs = np.random.RandomState(rank)
         calls = []
@@ -414,11 +418,12 @@ def _uneven_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_row_sharded_ranks_with_different_draw_counts_do_not_deadlock():
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_row_sharded_ranks_with_different_draw_counts_do_not_deadlock(pipeline):
     """every micro-batch is a collective; ranks whose user shards hold different numbers of interactions
     agree on the round count up front and the rank that runs dry serves empty rounds"""
     out = mp.Manager().dict()
-    mp.spawn(_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_uneven_worker, args=(2, _free_port(), out, pipeline), nprocs=2, join=True)
     (calls0, tot0, mass0), (calls1, tot1, mass1) = out[0], out[1]
     assert calls0 == [100, 100, 100, 50] and calls1 == [100, 20]
     assert tot0 == tot1 and mass0 == mass1 and mass0 > 0
