@@ -324,7 +324,8 @@ def cpu_baseline_mf(users, items, val, n_users, n_items, k, lr, reg, mu, budget_
 def leg_vbpr_tradesy(args, _lib):
     """configs[3]: VBPR k = k2 = 64 with 4096-d visual features at the Tradesy shape (19 243 users x 165 906 items,
     394 421 feedback), batch 100 as the reference's default.  The step is bound by torch.optim.Adam's dense sweep
-    over every table (recom_vbpr.py:228-262): 7 passes x 4 bytes over all parameters + the 2 B feature rows gathered."""
+    over every table (recom_vbpr.py:228-262): parameter and two moments read and written = 6 passes x 4 bytes over all
+    parameters (rows outside the batch have an exactly zero gradient, which is not read) + the 2 B feature rows."""
     nu, ni, nnz, nf, k, k2, B = 19243, 165906, 394421, 4096, 64, 64, 100
     rs = np.random.RandomState(44)
     t0 = time.time()
@@ -345,7 +346,7 @@ def leg_vbpr_tradesy(args, _lib):
     tr.close()
     steps = (nnz + B - 1) // B
     n_par = ni + nu * k + ni * k + nu * k2 + nf * k2 + nf
-    bytes_step = 28.0 * n_par + 2.0 * B * nf * 4
+    bytes_step = 24.0 * n_par + 2.0 * B * nf * 4
     out = {"metric": "vbpr_triplets_per_sec", "value": nnz / dt, "unit": "triplets/s", "steps": steps,
            "ms_per_step": 1e3 * dt / steps, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "VBPR k=k2=%d, %d-d features, Tradesy-shaped synthetic (%d users x %d items, %d "
