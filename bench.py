@@ -327,6 +327,7 @@ def leg_vbpr_tradesy(args, _lib):
     over every table (recom_vbpr.py:228-262): parameter and two moments read and written = 6 passes x 4 bytes over all
     parameters (rows outside the batch have an exactly zero gradient, which is not read) + the 2 B feature rows."""
     nu, ni, nnz, nf, k, k2, B = 19243, 165906, 394421, 4096, 64, 64, 100
+    nnz = int(os.environ.get("CORNAC_BENCH_VBPR_FEEDBACK", nnz))  # (counter-collection runs shorten the epoch: tools/pmc_legs.sh)
     rs = np.random.RandomState(44)
     t0 = time.time()
     F = rs.random_sample((ni, nf)).astype(np.float32)

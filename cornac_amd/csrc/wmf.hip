@@ -302,6 +302,226 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_kernel(const float *__re
     if (threadIdx.x == 0 && s != 0) atomicAdd(loss, s);
 }
 
+// ---- the same step with the G tile resident in the LDS ------------------------------------------------------------
+// Counters of the kernel above (profiles/r02_legs_pmc.csv): 2.98 GB of fabric traffic per step against the 1.48 GB of
+// U, m_U, v_U read + written — the 64 KB scratch tiles do not stay in the L2 beside the streamed tables (0.25 GB written,
+// 0.49 GB re-read per step) and U is fetched again for every product.  Here G lives in the LDS for the whole tile:
+//   LDS (80 KB per workgroup, two workgroups per CU):  Gl[128][128] floats, column index XOR-swizzled with the row so
+//   that BOTH products read it without bank conflicts — dV = G^T U walks it by rows (k = user), dU = G V_b by columns
+//   (k = batch column) — and a 16 KB double buffer for the other operand's k-tiles.  The P = U_t V_b^T product runs
+//   first with its two staging tiles laid over the (not yet live) G region; the Adam epilogue stages dU through it
+//   once G is dead.
+constexpr int kGl = kBM * kMaxBatch;                        // floats of the G tile
+constexpr size_t kWmfLdsBytes = (size_t)(kGl + 2 * kBK * kBN) * sizeof(float);   // 81 920 B = half of a CU's LDS
+
+__device__ __forceinline__ int gl_index(int row, int col) { return row * kMaxBatch + (col ^ (row & 31)); }
+
+// acc (+)= A B over k in [0, k_end): A comes from the LDS-resident G tile — K_IS_ROW: A(m, kk) = G[kk][m] (dV: k = user,
+// m = batch column), else A(m, kk) = G[m][kk] (dU: m = user, k = batch column); B(kk, n) = Bp[kk * b_sk + n], n < N
+// contiguous, staged through the double buffer sb[2][kBK][kBN].
+template <bool K_IS_ROW, bool ZERO>
+__device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restrict__ Bp, int64_t b_sk, int N, int k_end,
+                                           float *sb, f32x16 (&acc)[2][2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    if (ZERO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // (a second k-tile in flight in registers — 2-ahead prefetch — costs 8 spilled registers here and measured slower:
+    // 0.79 vs 0.77 ms per step)
+    f32x4 rb[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = k0 + (tid >> 5) + 8 * i, n = (tid & 31) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kk < k_end) {
+                const float *q = Bp + (int64_t)kk * b_sk + n;
+                if (n + 3 < N && ((b_sk | n) & 3) == 0) {
+                    v = *reinterpret_cast<const f32x4 *>(q);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) v[e] = q[e];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<f32x4 *>(sb + (buf * kBK + (tid >> 5) + 8 * i) * kBN + (tid & 31) * 4) = rb[i];
+    };
+    const int n_steps = (k_end + kBK - 1) / kBK;
+    if (n_steps <= 0) return;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int m_a = wm * 64 + l31;
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) load_tile((s + 1) * kBK);
+#pragma unroll
+        for (int t = 0; t < kBK / 2; ++t) {
+            const int kk = s * kBK + 2 * t + half;
+            float a0, a1;
+            if (K_IS_ROW) {
+                a0 = Gl[kk * kMaxBatch + (m_a ^ (kk & 31))];
+                a1 = Gl[kk * kMaxBatch + ((m_a + 32) ^ (kk & 31))];
+            } else {
+                a0 = Gl[m_a * kMaxBatch + (kk ^ (m_a & 31))];
+                a1 = Gl[(m_a + 32) * kMaxBatch + (kk ^ (m_a & 31))];
+            }
+            const float b0 = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + l31];
+            const float b1 = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < n_steps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *__restrict__ Vb, const float *__restrict__ VbT,
+                                                                   int64_t n_users, int B, int k, int ld, float *U, float *mU,
+                                                                   float *vU, const int64_t *__restrict__ indptr,
+                                                                   const int32_t *__restrict__ rows,
+                                                                   const float *__restrict__ vals,
+                                                                   const int32_t *__restrict__ ids, float a, float b,
+                                                                   float lambda_u, const TfAdam ad,
+                                                                   float *__restrict__ dv_part, double *loss) {
+    extern __shared__ float lds[];
+    float *Gl = lds;                  // [128][128] swizzled; also the P product's staging and the epilogue's stage
+    float *sb = lds + kGl;            // [2][kBK][kBN]
+    GemmSmem &sm = *reinterpret_cast<GemmSmem *>(lds);
+    static_assert(sizeof(GemmSmem) <= kGl * sizeof(float), "the P product's staging tiles must fit the G region");
+    f32x16 acc[2][2], accv[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[i][j][r] = 0.f;
+    double part = 0;
+    const float two_b = 2.f * b;
+    const int64_t n_tiles = (n_users + kBM - 1) / kBM;
+    const int64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_lo = (int64_t)blockIdx.x * per_wg, tile_hi = min(n_tiles, tile_lo + per_wg);
+    int64_t cur = 0, col_end = 0;
+    if ((int)threadIdx.x < B && tile_lo < tile_hi) {
+        const int32_t item = ids[threadIdx.x];
+        int64_t lo = indptr[item], hi = indptr[item + 1];
+        col_end = hi;
+        const int64_t key = tile_lo * kBM;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)rows[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const int64_t m0 = tile * kBM;
+        const int nrow = (int)min((int64_t)kBM, n_users - m0);
+        // (a) P = U_t V_b^T  (staging tiles over the G region; the trailing barrier of gemm_block separates their last
+        // read from the G stores below)
+        gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);
+        // (b) G = 2 b P (zero outside the live rows / columns); loss += b sum P^2
+        float sq = 0.f;
+        for_each_acc_local(acc, kMaxBatch, [&](int, int rl, int cl, float pv) {
+            const bool live = rl < nrow && cl < B;
+            Gl[gl_index(rl, cl)] = live ? two_b * pv : 0.f;
+            if (live) sq += pv * pv;
+        });
+        part += (double)b * (double)sq;
+        __syncthreads();
+        // (c) the batch's non-zeros whose user is in this tile: G = 2 a (p - r), loss += a (r - p)^2 - b p^2
+        if ((int)threadIdx.x < B) {
+            const int c = threadIdx.x;
+            const float *vrow = Vb + (int64_t)c * ld;
+            const int64_t m1 = m0 + nrow;
+            while (cur < col_end) {
+                const int64_t u = rows[cur];
+                if (u >= m1) break;
+                const float r = vals[cur];
+                ++cur;
+                if (r == 0.f) continue;  // explicit zeros stay "unobserved" (batch_R.nonzero(), recom_wmf.py:186)
+                float *gp = Gl + gl_index((int)(u - m0), c);
+                float pv;
+                if (two_b != 0.f) {
+                    pv = *gp / two_b;  // the prediction the MFMA pass just produced
+                } else {              // b == 0: G carries nothing to recover p from
+                    const float *urow = U + u * ld;
+                    pv = 0.f;
+                    for (int f = 0; f < k; f += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4 *>(urow + f), y = *reinterpret_cast<const f32x4 *>(vrow + f);
+                        pv += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                    }
+                }
+                *gp = 2.f * a * (pv - r);
+                part += (double)a * (double)(r - pv) * (double)(r - pv) - (double)b * (double)pv * (double)pv;
+            }
+        }
+        __syncthreads();
+        // (e) dV += G_t^T U_t  (U before its update): M = batch columns, N = ld, K = the tile's users
+        gemm_lds_a<true, false>(Gl, U + m0 * ld, ld, ld, nrow, sb, accv);
+        // (d) dU = G_t V_b
+        gemm_lds_a<false, true>(Gl, Vb, ld, ld, B, sb, acc);
+        // (the trailing barrier of the product: G is dead, its region now stages dU, 64 rows at a time) clipped TF1 Adam
+        // on float4s of U, m_U, v_U; loss += lambda_u/2 |U|^2 (pre-update).  (Parking the whole 128-row tile at once and
+        // keeping the loads of 2 or 4 row groups in flight was measured slower: 0.82 vs 0.77 ms per step.)
+        {
+            float *stg = Gl;  // [64][128]
+            const int wm = (threadIdx.x >> 6) >> 1;
+            float usq = 0.f;
+            for (int h = 0; h < 2; ++h) {
+                if (wm == h) for_each_acc_local(acc, kBN, [&](int off, int, int, float v) { stg[off - h * 64 * kBN] = v; });
+                __syncthreads();
+                const int c4 = (threadIdx.x & 31) * 4;
+                if (c4 < ld) {
+#pragma unroll 1
+                    for (int q = 0; q < 8; ++q) {
+                        const int row = (threadIdx.x >> 5) + 8 * q;
+                        const int64_t gr = m0 + h * 64 + row;
+                        if (gr < n_users) {
+                            const f32x4 du = *reinterpret_cast<const f32x4 *>(stg + row * kBN + c4);
+                            f32x4 *pu = reinterpret_cast<f32x4 *>(U + gr * ld + c4);
+                            f32x4 *pm = reinterpret_cast<f32x4 *>(mU + gr * ld + c4);
+                            f32x4 *pv = reinterpret_cast<f32x4 *>(vU + gr * ld + c4);
+                            f32x4 u = *pu, m = *pm, v = *pv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                usq += u[e] * u[e];
+                                float g = du[e] + lambda_u * u[e];
+                                g = fminf(fmaxf(g, -5.f), 5.f);
+                                m[e] = m[e] + ad.one_minus_beta1 * (g - m[e]);
+                                v[e] = v[e] + ad.one_minus_beta2 * (g * g - v[e]);
+                                u[e] = u[e] - ad.lr_t * m[e] / (sqrtf(v[e]) + ad.eps);
+                            }
+                            *pm = m;
+                            *pv = v;
+                            *pu = u;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            part += 0.5 * (double)lambda_u * (double)usq;
+        }
+    }
+    float *mine = dv_part + (size_t)blockIdx.x * kMaxBatch * kBN;
+    for_each_acc_local(accv, kBN, [&](int off, int, int, float v) { mine[off] = v; });
+    const double s = block_sum_f64(part, reinterpret_cast<double *>(sb));
+    if (threadIdx.x == 0 && s != 0) atomicAdd(loss, s);
+}
+
 // dV[c, f] += sum over a slice of the workgroups' partials (fused path; grid.y slices, dV is zero on entry: the scatter
 // kernel re-zeroes it after every step)
 __global__ __launch_bounds__(kWb) void wmf_reduce_dv_kernel(const float *__restrict__ dv_part, int n_parts, int B, int ld,
@@ -538,9 +758,17 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
         static const bool no_fuse = getenv("CORNAC_HIP_WMF_UNFUSED") != nullptr;  // A/B switch for profiling
         static const int wmf_ablate = getenv("CORNAC_HIP_WMF_ABLATE") ? atoi(getenv("CORNAC_HIP_WMF_ABLATE")) : 0;
         const bool fused = ld <= kBN && !no_fuse;
+        static const bool g_scratch = getenv("CORNAC_HIP_WMF_GSCRATCH") != nullptr;  // A/B switch: G in a global scratch tile
         if (fused && h->fused_wgs == 0) {
             int per_cu = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_kernel, kWb, 0));
+            if (g_scratch) {
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_kernel, kWb, 0));
+            } else {
+                HIP_CHECK(hipFuncSetAttribute((const void *)wmf_user_step_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)kWmfLdsBytes));
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_lds_kernel, kWb, kWmfLdsBytes));
+            }
+            if (getenv("CORNAC_HIP_WMF_DEBUG")) fprintf(stderr, "[wmf] fused kernel: %d workgroups per CU\n", per_cu);
             h->fused_wgs = (int)std::min<int64_t>(m_tiles, (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 2)));
             h->g_scratch.alloc((size_t)h->fused_wgs * kBM * kMaxBatch);
             h->dv_part.alloc((size_t)h->fused_wgs * kMaxBatch * kBN);
@@ -570,9 +798,14 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
             ad.eps = 1e-8f;
             wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, fused ? h->VbT.p : nullptr, 0.5f * lambda_v, d_loss);
             if (fused) {
-                wmf_user_step_kernel<<<h->fused_wgs, kWb, 0, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, h->g_scratch.p,
-                                                                  h->indptr.p, h->rows.p, h->vals.p, d_ids, a, b, lambda_u, ad,
-                                                                  h->dv_part.p, d_loss, wmf_ablate);
+                if (g_scratch)
+                    wmf_user_step_kernel<<<h->fused_wgs, kWb, 0, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, h->g_scratch.p,
+                                                                      h->indptr.p, h->rows.p, h->vals.p, d_ids, a, b, lambda_u, ad,
+                                                                      h->dv_part.p, d_loss, wmf_ablate);
+                else
+                    wmf_user_step_lds_kernel<<<h->fused_wgs, kWb, kWmfLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p,
+                                                                                     h->vU.p, h->indptr.p, h->rows.p, h->vals.p, d_ids,
+                                                                                     a, b, lambda_u, ad, h->dv_part.p, d_loss);
                 wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, h->fused_wgs, B, ld, h->dV.p);
                 wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
                 wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
