@@ -224,6 +224,21 @@ def synth_ratings(n_users, n_items, nnz, zipf_a, seed):
     return users, items, val
 
 
+def leg_traffic(name, **must_match):
+    """counter-measured bytes per launch of a leg's dominant kernel (profiles/traffic.json, taken by tools/pmc_legs.sh), or
+    None when the file does not describe this kernel / workload"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["legs"][name]
+    except Exception:
+        return None
+    for key, val in must_match.items():
+        if tj.get(key) != val:
+            print("[bench] profiles/traffic.json leg %s was measured with %s = %r (now %r): traffic = null"
+                  % (name, key, tj.get(key), val), file=sys.stderr)
+            return None
+    return tj.get("bytes_per_launch")
+
+
 def leg_mf_netflix(args, _lib):
     """configs[2]: biased MF, k = 128, Netflix Prize shape (480 189 x 17 770, 100 480 507 ratings), hogwild mode.
     Algorithmic bytes per rating: U and V rows read + written (16 k), the two biases R+W (16), the COO
@@ -259,7 +274,9 @@ def leg_mf_netflix(args, _lib):
                       "lr": lr, "reg": reg},
            "roofline": {"bound": "hbm", "achieved": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "mf_hogwild_rowwise_kernel (one launch = one epoch)",
+                        "traffic": leg_traffic("mf_netflix", kernel="mf_hogwild_rowwise_kernel (one launch = one epoch)",
+                                               ratings_per_launch=int(nnz), k=int(k)),
+                        "kernel": "mf_hogwild_rowwise_kernel (one launch = one epoch)",
                         "launches": launches, "avg_launch_ms": kms / max(launches, 1),
                         "algorithmic_bytes_per_rating": b},
            "train_stats": {"mse_per_epoch": [float(x) / nnz for x in loss]},

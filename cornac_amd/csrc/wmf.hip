@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_kernel(const float *__re
 }
 
 // ---- the same step with the G tile resident in the LDS ------------------------------------------------------------
-// Counters of the kernel above (profiles/r02_legs_pmc.csv): 2.98 GB of fabric traffic per step against the 1.48 GB of
+// Counters of the kernel above (profiles/r02_legs_pmc.csv): 3.05 GB of fabric traffic per step against the 1.48 GB of
 // U, m_U, v_U read + written — the 64 KB scratch tiles do not stay in the L2 beside the streamed tables (0.25 GB written,
 // 0.49 GB re-read per step) and U is fetched again for every product.  Here G lives in the LDS for the whole tile:
 //   LDS (80 KB per workgroup, two workgroups per CU):  Gl[128][128] floats, column index XOR-swizzled with the row so
