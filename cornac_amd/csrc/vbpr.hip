@@ -536,7 +536,10 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         const DeviceInfo &di = device_info(h->device);
         h->DF.ensure((size_t)batch_size * h->n_feat);
         // feature chunks of the split-K projection GEMM: a multiple of the k tile, ~2 workgroups per CU
-        int feat_chunk = std::max(kBK, (h->n_feat + 2 * di.cus - 1) / (2 * di.cus));
+        // (two k-tiles per workgroup measured best: 16 / 32 / 64 / 128 features per chunk -> 63.1 / 61.0 / 64.5 / 72.1 us per
+        // step of the small-kernel chain at n_feat = 4096)
+        int feat_chunk = std::max(2 * kBK, (h->n_feat + 2 * di.cus - 1) / (2 * di.cus));
+        if (getenv("CORNAC_HIP_VBPR_PROJ_CHUNK")) feat_chunk = atoi(getenv("CORNAC_HIP_VBPR_PROJ_CHUNK"));
         feat_chunk = (feat_chunk + kBK - 1) / kBK * kBK;
         const int n_chunks = (h->n_feat + feat_chunk - 1) / feat_chunk;
         // the dense sweep: one launch over the four row tables, 16-byte accesses where the row width allows
