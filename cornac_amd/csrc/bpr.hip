@@ -194,7 +194,7 @@ __device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int3
 // `local` indexes the wave's samples of this epoch.  u is returned encoded (negative = shared user).
 __device__ __forceinline__ bool hog_sample_owned(const HogArgs &a, uint32_t wave_id, int64_t base, uint32_t len,
                                                  uint32_t th_len, int64_t local, bool in_range, int32_t &u_enc,
-                                                 int32_t &i, int32_t &j) {
+                                                 int32_t &i, int32_t &j, bool share_neg = false) {
     const uint64_t s = (uint64_t)(in_range ? local : 0);
     uint32_t w[4];
     philox4x32_10((uint32_t)s, wave_id, a.epoch, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
@@ -204,6 +204,7 @@ __device__ __forceinline__ bool hog_sample_owned(const HogArgs &a, uint32_t wave
     i = a.own_i[base + r];
     const int32_t u = u_enc < 0 ? ~u_enc : u_enc;
     j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
+    if (share_neg) j = __shfl(j, lane_id() & ~3, kWave);  // every lane draws; groups of 4 keep their leader's
     const bool skip = (a.ablate & 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
 }
@@ -315,8 +316,9 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_vec4_kernel(const HogArgs 
 // the wave's triplets to trip_* (-1 = skipped draw), no table access; 2 = STAGED: take the triplets from trip_* — item
 // entries are SLOTS of the staging table a.V / a.B — and update.  The same grid and ownership tables in both launches
 // keep every user row with one wave, so U stays on plain loads/stores exactly as in the fused kernel.
-template <int G, int R, int UNR, bool ATOMIC, bool OWNED, int MODE = 0>
+template <int G, int R, int UNR, bool ATOMIC, bool OWNED, int MODE = 0, bool SHARE = false>
 __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogArgs a) {
+    static_assert(!SHARE || (OWNED && MODE == 0), "the shared-negative experiment exists for the fused owned kernel only");
     static_assert(!OWNED || G == kWave, "ownership needs one triplet per wave step");
     static_assert(MODE == 0 || OWNED, "the emit / staged forms exist for the owned kernel only");
     float *const Vt = a.V;
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
     bool inb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) inb[r] = lg + G * r < a.k;
+    // (lanes beyond k hold zeros: they enter the dot product; so do all lanes under the "no row loads" ablation)
     for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
         int32_t su, si, sj;
         bool in_range;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
         } else if (OWNED) {
             const int64_t local = own_lo + tile * kWave + lane;
             in_range = local < own_hi;
-            valid = hog_sample_owned(a, (uint32_t)wave_id, own_base, own_len, own_th, local, in_range, su, si, sj);
+            valid = hog_sample_owned(a, (uint32_t)wave_id, own_base, own_len, own_th, local, in_range, su, si, sj, SHARE);
         } else {
             valid = hog_sample(a, tile * kWave + lane, su, si, sj, in_range);
         }
@@ -426,14 +429,19 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const bool ld = inb[r] && !(a.ablate & 4);
-                    u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : (inb[r] ? 0.01f : 0.f);
-                    vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : (inb[r] ? 0.02f : 0.f);
-                    vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : (inb[r] ? 0.03f : 0.f);
+                    u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
+                    vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : 0.f;
+                    vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : 0.f;
                 }
                 bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)ti[q] * a.bstride);
                 bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)tj[q] * a.bstride);
             }
             float du_all[UNR][R];
+            float dvj_all[SHARE ? UNR : 1][R], dbj_all[SHARE ? UNR : 1];  // (SHARE: the negative rows' deltas, combined below)
+            if (SHARE) {
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) dbj_all[SHARE ? q : 0] = 0.f;
+            }
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 float part = 0.f;
@@ -453,7 +461,8 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                             if (OWNED) {
                                 if (tue[q] < 0) atomic_add_f32(pu[q] + G * r, du);  // shared heavy user
                                 atomic_add_f32(pi[q] + G * r, dvi);
-                                atomic_add_f32(pj[q] + G * r, dvj);
+                                if (SHARE) dvj_all[SHARE ? q : 0][r] = dvj;
+                                if (!SHARE) atomic_add_f32(pj[q] + G * r, dvj);
                             } else if (ATOMIC) {
                                 atomic_add_f32(pu[q] + G * r, du);
                                 atomic_add_f32(pi[q] + G * r, dvi);
@@ -468,9 +477,10 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                     if (lg == 0) {
                         if (a.use_bias && !(a.ablate & 8)) {
                             const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
+                            if (SHARE) dbj_all[SHARE ? q : 0] = dbj;
                             if (ATOMIC || OWNED) {
                                 atomic_add_f32(a.B + (size_t)ti[q] * a.bstride, dbi);
-                                atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, dbj);
+                                if (!SHARE) atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, dbj);
                             } else {
                                 a.B[(size_t)ti[q] * a.bstride] = bi[q] + dbi;
                                 a.B[(size_t)tj[q] * a.bstride] = bj[q] + dbj;
@@ -478,6 +488,33 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                         }
                         n_correct += z < .5f ? 1u : 0u;
                     }
+                }
+            }
+            if (SHARE) {
+                // one atomic row update per DISTINCT negative item of the batch: the first triplet naming it carries
+                // the sum of the deltas of all of them (each computed against the same loaded row)
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    if (!act[q] || (a.ablate & 2)) continue;
+                    bool lead = true;
+#pragma unroll
+                    for (int q2 = 0; q2 < q; ++q2) lead = lead && !(act[q2] && tj[q2] == tj[q]);
+                    if (!lead) continue;
+                    float tot[R], totb = dbj_all[SHARE ? q : 0];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) tot[r] = dvj_all[SHARE ? q : 0][r];
+#pragma unroll
+                    for (int q2 = q + 1; q2 < UNR; ++q2) {
+                        if (act[q2] && tj[q2] == tj[q]) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) tot[r] += dvj_all[SHARE ? q2 : 0][r];
+                            totb += dbj_all[SHARE ? q2 : 0];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (inb[r]) atomic_add_f32(pj[q] + G * r, tot[r]);
+                    if (lg == 0 && a.use_bias && !(a.ablate & 8)) atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, totb);
                 }
             }
             if (OWNED) {
@@ -975,6 +1012,7 @@ static HogKernel pick_hogwild_kernel(int k, int flags) {
         if (k <= 16) return bpr_hogwild_rowwise_kernel<16, 1, 2, ATOMIC, false>;
         if (k <= 32) return bpr_hogwild_rowwise_kernel<32, 1, 4, ATOMIC, false>;
         if (owned) {
+            if (k <= 64 && (flags & 16)) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true, 0, true>;  // experiment
             if (k <= 64) return bpr_hogwild_rowwise_kernel<64, 1, 4, true, true>;
             if (k <= 128) return bpr_hogwild_rowwise_kernel<64, 2, 2, true, true>;
             if (k <= 192) return bpr_hogwild_rowwise_kernel<64, 3, 2, true, true>;

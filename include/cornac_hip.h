@@ -101,7 +101,10 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
  * reference's per-epoch counters over the epochs run (either may be NULL).
  * hogwild_flags (experiment switches, 0 = default): bit0 = plain (racy,
  * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
- * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic). */
+ * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic);
+ * bit4 = (k in 33..64) the four sampling lanes 4g..4g+3 share one negative item and its row gets ONE combined atomic
+ * update — a different joint distribution of the draws than the reference's, kept as a measured experiment;
+ * bit6 = the segmented ("binned") item-update path. */
 int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, int use_bias, int neg_population,
                               int mode, int hogwild_flags, int64_t *correct, int64_t *skipped);
 /* Same, but only enqueues `n_samples` hogwild samples (sample counter and

@@ -167,7 +167,7 @@ def test_emit_triplets_are_valid_owned_draws(k):
     tr.close()
 
 
-@pytest.mark.parametrize("k", [64, 128, 200])
+@pytest.mark.parametrize("k", [40, 64, 128, 160, 200])
 def test_apply_staged_equals_the_sequential_update_on_a_conflict_free_batch(k):
     import torch
 

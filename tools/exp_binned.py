@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep of the binned hogwild BPR path against the fused atomic kernel at the ML-20M shape (k = 64 by default).
-An arm is a dash-separated spec: `fused` (the default kernel; every other arm sets hogwild_flags bit 6), `wgN` (workgroups per CU of the triplet kernel),
+An arm is a dash-separated spec: `fused` (the default kernel), `share` (fused + shared negatives, bit 4; every other arm sets hogwild_flags bit 6), `wgN` (workgroups per CU of the triplet kernel),
 `cNm` / `cNk` (chunk length), `hN` (hot threshold), `ablN` (profiling switches, hogwild_flags bits 8..).
 Prints one line per arm: ms/epoch (HIP events around the kernels), triplets/s, the 'correct' fraction of the last
 epoch and the pairwise loss / accuracy on a fixed probe sample after the same number of epochs."""
@@ -36,6 +36,8 @@ def parse(spec):
     for tok in spec.split("-"):
         if tok == "fused":
             flags &= ~64
+        elif tok == "share":      # fused kernel with negatives shared by groups of 4 sampling lanes (hogwild_flags bit 4)
+            flags = (flags & ~64) | 16
         elif tok.startswith("wg"):
             env["CORNAC_HIP_BIN_WG_PER_CU"] = tok[2:]
         elif tok.startswith("c"):
