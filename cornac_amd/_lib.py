@@ -43,7 +43,7 @@ SYMBOLS = [
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
-    "cornac_hip_scorer_set_exclusions", "cornac_hip_rank_topk_resident",
+    "cornac_hip_scorer_set_exclusions", "cornac_hip_rank_topk_resident", "cornac_hip_scorer_host_buffer",
     "cornac_hip_rank_positions",
 ]
 
@@ -195,6 +195,7 @@ def lib():
         L.cornac_hip_rank_positions.argtypes = [_vp, _i32, C.c_int64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32]
         L.cornac_hip_rank_topk_device.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.cornac_hip_scorer_set_exclusions.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_scorer_host_buffer.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
         L.cornac_hip_rank_topk_resident.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]
         _lib = L
     return _lib
@@ -549,17 +550,29 @@ class Scorer:
         assert len(ip) == self.n_users + 1
         check(lib().cornac_hip_scorer_set_exclusions(self.h, ip.ctypes.data, _ptr(ix) if len(ix) else None))
 
-    def rank_topk_resident(self, users, topk, fetch=True, timed=False):
+    def rank_topk_resident(self, users, topk, fetch=True, timed=False, pinned=False):
         """top-k with the resident exclusion lists.  users: array of user ids, or (u0, n) for a contiguous range.
         fetch=False leaves the results on the device, fetch="items" copies only the item ids back (what the @k metrics
-        read); timed=True also returns the HIP-event milliseconds."""
+        read); timed=True also returns the HIP-event milliseconds; pinned=True returns views of page-locked memory owned
+        by the scorer (faster device-to-host copy, overwritten by the next pinned call)."""
         if isinstance(users, tuple):
             up, u0, n = None, int(users[0]), int(users[1])
         else:
             ua = np.ascontiguousarray(users, np.int32)
             up, u0, n = ua.ctypes.data, 0, len(ua)
-        items = np.empty((n, topk), np.int32) if fetch else None
-        scores = np.empty((n, topk), np.float32) if fetch and fetch != "items" else None
+        if fetch and pinned:
+            # results land in page-locked memory owned by the scorer: the arrays returned are VIEWS of it, valid until
+            # the next pinned call or close()
+            want_scores = fetch != "items"
+            nbytes = n * topk * 4 * (2 if want_scores else 1)
+            buf = _vp()
+            check(lib().cornac_hip_scorer_host_buffer(self.h, nbytes, C.byref(buf)))
+            raw = (C.c_char * nbytes).from_address(buf.value)
+            items = np.frombuffer(raw, np.int32, n * topk).reshape(n, topk)
+            scores = np.frombuffer(raw, np.float32, n * topk, offset=n * topk * 4).reshape(n, topk) if want_scores else None
+        else:
+            items = np.empty((n, topk), np.int32) if fetch else None
+            scores = np.empty((n, topk), np.float32) if fetch and fetch != "items" else None
         ms = C.c_double()
         check(lib().cornac_hip_rank_topk_resident(self.h, up, u0, n, topk, _ptr(items), _ptr(scores),
                                                   C.cast(C.byref(ms), _vp) if timed else None))

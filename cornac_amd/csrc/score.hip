@@ -906,6 +906,8 @@ struct cornac_hip_scorer {
     DevBuf<float> Vr, ibr;
     DevBuf<int32_t> perm, inv_perm;
     DevBuf<uint32_t> excl_bits;  // exclusion bitmap of the current fused launch (excl_bitmap_kernel)
+    void *pinned_out = nullptr;  // page-locked host memory lent to the caller for result copies (cornac_hip_scorer_host_buffer)
+    size_t pinned_bytes = 0;
     // exclusion lists per USER id, resident on the device (cornac_hip_scorer_set_exclusions)
     DevBuf<int64_t> res_excl_indptr;
     DevBuf<int32_t> res_excl_indices;
@@ -1196,6 +1198,7 @@ int cornac_hip_scorer_destroy(cornac_hip_scorer_t h) {
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamDestroy(h->stream);
         }
+        if (h->pinned_out) (void)hipHostFree(h->pinned_out);
         delete h;
     });
 }
@@ -1448,6 +1451,21 @@ int cornac_hip_rank_topk_resident(cornac_hip_scorer_t h, const int32_t *users, i
             (void)hipEventDestroy(e1);
             *device_ms = (double)t;
         }
+    });
+}
+
+int cornac_hip_scorer_host_buffer(cornac_hip_scorer_t h, size_t bytes, void **out) {
+    return guarded([&] {
+        sc_check(h);
+        REQUIRE(out != nullptr, "out is NULL");
+        if (bytes > h->pinned_bytes) {
+            if (h->pinned_out) HIP_CHECK(hipHostFree(h->pinned_out));
+            h->pinned_out = nullptr;
+            h->pinned_bytes = 0;
+            HIP_CHECK(hipHostMalloc(&h->pinned_out, bytes, hipHostMallocDefault));
+            h->pinned_bytes = bytes;
+        }
+        *out = h->pinned_out;
     });
 }
 

@@ -303,3 +303,52 @@ def test_fused_rank_long_item_ranges_and_many_segments(oracle, k, topk):
         want, _ = oracle.rank(full[b], ni, ni, k=topk)
         assert np.array_equal(items[b], want[:topk]), b
         assert np.array_equal(scores[b], full[b][want[:topk]])
+
+
+@pytest.mark.parametrize("k,n_items", [(64, 5000), (100, 40000)])
+def test_resident_exclusion_lists_rank_like_per_call_lists(oracle, k, n_items):
+    """cornac_hip_scorer_set_exclusions + cornac_hip_rank_topk_resident (lists keyed by USER id, kept on the device,
+    turned into exclusion bitmaps in rank order) against the per-call form and the oracle: a user range, an arbitrary
+    user list, results in pageable and in the scorer's page-locked host memory, scores optional; heavy users whose
+    lists cover most of the catalogue, empty lists, item 0 and the last item excluded"""
+    rs = np.random.RandomState(k)
+    nu, topk = 700, 10
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (n_items, k)).astype(np.float32)
+    ib = rs.normal(0, 0.2, n_items).astype(np.float32)
+    lens = rs.randint(0, 60, nu)
+    lens[3], lens[11], lens[12] = n_items - topk, 0, n_items - topk - 5
+    rows = [np.sort(rs.choice(n_items, n, replace=False)).astype(np.int32) for n in lens]
+    rows[5] = np.array([0, n_items - 1], np.int32)
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows).astype(np.int32)
+    sc = _lib.Scorer(U, V, ib, None)
+    sc.set_exclusions(indptr, indices)
+    full = oracle.score_block(U, V, ib, None, np.arange(nu, dtype=np.int32))
+
+    def check(users, items, scores):
+        for b, u in enumerate(users):
+            s = full[u].copy()
+            keep = np.ones(n_items, bool)
+            keep[rows[u]] = False
+            cand = np.flatnonzero(keep)
+            want, _ = oracle.rank(s, n_items, n_items, k=-1, item_indices=cand)
+            assert np.array_equal(items[b], want[:topk]), (b, u)
+            if scores is not None:
+                assert np.array_equal(scores[b], s[want[:topk]])
+
+    items, scores = sc.rank_topk_resident((0, nu), topk)
+    check(range(nu), items, scores)
+    users = rs.permutation(nu)[:333].astype(np.int32)
+    items2, none, ms = sc.rank_topk_resident(users, topk, fetch="items", timed=True, pinned=True)
+    assert none is None and ms > 0
+    check(users, items2.copy(), None)
+    items3, scores3 = sc.rank_topk_resident(users, topk, pinned=True)   # re-uses (and outgrows) the pinned buffer
+    check(users, items3, scores3)
+    # the per-call form with the same lists
+    sel_ptr = np.concatenate([[0], np.cumsum([len(rows[u]) for u in users])]).astype(np.int64)
+    sel_idx = np.concatenate([rows[u] for u in users]).astype(np.int32)
+    items4, scores4 = sc.rank_topk(users, topk, exclude=(sel_ptr, sel_idx))
+    assert np.array_equal(items4, items3) and np.array_equal(scores4, scores3)
+    assert sc.rank_topk_resident((5, 1), topk, fetch=False) == (None, None)
+    sc.close()
