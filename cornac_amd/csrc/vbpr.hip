@@ -599,9 +599,14 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
                                h->gV.p, h->loss.p);
             hipLaunchKernelGGL(vbpr_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
                                h->bj.p + b0, n, h->gS.p, h->gV.p, h->proj.p, lambda_w, lambda_b, h->W.p, ldw);
+            // the batch rows' own Adam step: a latency chain (index -> claim -> row) that took 27 us beside the sweep and
+            // 7 us alone, so it runs before the sweep starts (W keeps the Tu rows the E / beta' step still needs)
+            hipLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
+                               h->bj.p + b0, step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p, h->mTu.p,
+                               h->vTu.p, a);
             // The sweep of this step starts here — behind the latency-bound score / gradient kernels, which a
-            // bandwidth-saturating neighbour slows several-fold — and runs beside the E / beta' step, the batch rows'
-            // Adam step and the next step's feature gather and projection.
+            // bandwidth-saturating neighbour slows several-fold — and runs beside the E / beta' step and the next step's
+            // feature gather and projection.
             sw.step = step;
             for (int q = 0; q < 4; ++q) sw.tab[q].stamp = (sw_user[q] ? t.stamp_u : t.stamp_i);
             if (one_stream) {
@@ -616,10 +621,6 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             hipLaunchKernelGGL(vbpr_feat_adam_kernel, dim3((h->n_feat + fpb - 1) / fpb), dim3(kVb),
                                ((size_t)n * ldw + (size_t)fpb * n) * sizeof(float), h->stream, h->DF.p, h->W.p, n,
                                h->n_feat, h->k2, ldw, fpb, h->E.p, h->mE.p, h->vE.p, h->Bp.p, h->mBp.p, h->vBp.p, lambda_e, a);
-            // (W holds the batch's Tu rows as they were at the start of the step, so the order of these two is free)
-            hipLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p, h->mTu.p,
-                               h->vTu.p, a);
         }
         // everything the caller does next runs on the main stream: it must see the last sweep
         if (h->sweep_pending) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept, 0));
