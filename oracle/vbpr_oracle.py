@@ -85,10 +85,11 @@ class VBPROracle:
 
 
 def timed_steps(features, params, u, i, j, batch_size, lr=0.005, lambda_w=0.01, lambda_b=0.01, lambda_e=0.0,
-                budget_s=5.0):
+                budget_s=5.0, max_steps=None, return_params=False):
     """The same minibatch step as VBPROracle.fit (recom_vbpr.py:228-262), run over consecutive slices of pre-sampled
-    (u, i, j) until `budget_s` seconds have passed — bench.py's CPU baseline for the VBPR leg.  `params` maps
-    Bi, Gu, Gi, Tu, E, Bp to arrays.  Returns (steps done, seconds)."""
+    (u, i, j) until `budget_s` seconds have passed (or `max_steps` steps are done) — bench.py's CPU baseline for the
+    VBPR leg and the full-size parity test's checker.  `params` maps Bi, Gu, Gi, Tu, E, Bp to arrays.  Returns
+    (steps done, seconds[, the updated tables])."""
     import time
 
     import torch
@@ -105,7 +106,7 @@ def timed_steps(features, params, u, i, j, batch_size, lr=0.005, lambda_w=0.01, 
         return sum(t.pow(2).sum() for t in ts) / 2
 
     n, t0 = 0, time.time()
-    while (n + 1) * batch_size <= len(u) and time.time() - t0 < budget_s:
+    while (n + 1) * batch_size <= len(u) and time.time() - t0 < budget_s and (max_steps is None or n < max_steps):
         a = n * batch_size
         bu, bi, bj = (torch.as_tensor(np.asarray(x[a:a + batch_size], np.int64)) for x in (u, i, j))
         gu, tu = Gu[bu], Tu[bu]
@@ -119,4 +120,6 @@ def timed_steps(features, params, u, i, j, batch_size, lr=0.005, lambda_w=0.01, 
         loss.backward()
         opt.step()
         n += 1
+    if return_params:
+        return n, time.time() - t0, {name: t.detach().numpy().copy() for name, t in P.items()}
     return n, time.time() - t0

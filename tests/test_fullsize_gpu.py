@@ -250,3 +250,43 @@ def test_mf_netflix_shape_deterministic_and_hogwild(oracle):
     # same optimisation problem as the sequential pass on the subsample: item rows moved in the same direction
     dv_h, dv_d = (Vh - V0).ravel(), (Vd - V0).ravel()
     assert float(dv_h @ dv_d) / (np.linalg.norm(dv_h) * np.linalg.norm(dv_d)) > 0.5
+
+
+@pytest.mark.timeout(900)
+def test_vbpr_tradesy_shape_matches_the_torch_oracle():
+    """configs[3] at its real size (19 243 users x 165 906 items, 4096-d features, k = k2 = 64, batch 100): 40 minibatch
+    steps on the device — stamped batch rows, gradient-free dense sweep on the second stream, E / beta' step — against
+    torch autograd + torch.optim.Adam over the same pre-sampled batches (oracle/vbpr_oracle.py, bit-identical to the
+    live reference at toy size): every table within 1e-4, the tolerance north_star states for learned factors."""
+    from oracle import vbpr_oracle
+
+    nu, ni, nf, k, k2, B, steps = 19243, 165906, 4096, 64, 64, 100, 40
+    rs = np.random.RandomState(44)
+    F = rs.random_sample((ni, nf)).astype(np.float32)
+    n = steps * B
+    u = rs.randint(0, nu, n).astype(np.int32)
+    i = rs.randint(0, ni, n).astype(np.int32)
+    j = rs.randint(0, ni, n).astype(np.int32)
+    u[B:B + 40] = u[B]                      # a batch with a heavily repeated user ...
+    i[2 * B:2 * B + 30] = i[2 * B]          # ... a repeated positive item ...
+    j[3 * B + 5] = i[3 * B + 6]             # ... and an item that is positive in one triplet and negative in another
+    lim = np.sqrt(3.0) * np.sqrt(2.0 / (nu + k))
+    params = dict(Bi=np.zeros(ni, np.float32), Gu=rs.uniform(-lim, lim, (nu, k)).astype(np.float32),
+                  Gi=rs.uniform(-lim, lim, (ni, k)).astype(np.float32), Tu=rs.uniform(-lim, lim, (nu, k2)).astype(np.float32),
+                  E=rs.uniform(-0.03, 0.03, (nf, k2)).astype(np.float32), Bp=rs.uniform(-0.03, 0.03, nf).astype(np.float32))
+    lr, lw, lb, le = 0.005, 0.01, 0.01, 0.002
+    tr = _lib.VbprTrainer(F, nu, ni, k, k2)
+    tr.set_params(**params)
+    nll = tr.fit_batches(u, i, j, B, lr, lw, lb, le)
+    got = tr.get_params()
+    tr.close()
+    done, _, want = vbpr_oracle.timed_steps(F, params, u, i, j, B, lr=lr, lambda_w=lw, lambda_b=lb, lambda_e=le,
+                                             budget_s=1e9, max_steps=steps, return_params=True)
+    assert done == steps and np.isfinite(nll)
+    for name in ("Bi", "Gu", "Gi", "Tu", "E", "Bp"):
+        a, b = np.asarray(got[name], np.float64).ravel(), np.asarray(want[name], np.float64).ravel()
+        assert a.shape == b.shape
+        err = np.abs(a - b).max()
+        moved = np.abs(b - np.asarray(params[name], np.float64).ravel()).max()
+        assert err <= 1e-4, (name, err)
+        assert moved > 1e-3, (name, moved)   # the comparison is not between two untouched tables
