@@ -290,3 +290,38 @@ def test_vbpr_tradesy_shape_matches_the_torch_oracle():
         moved = np.abs(b - np.asarray(params[name], np.float64).ravel()).max()
         assert err <= 1e-4, (name, err)
         assert moved > 1e-3, (name, moved)   # the comparison is not between two untouched tables
+
+
+@pytest.mark.timeout(900)
+def test_wmf_netflix_user_count_matches_the_oracle():
+    """configs[2]'s user count (480 189 users, k = 128, 128-item batches): every workgroup of the fused user-step kernel
+    walks 7-8 consecutive user tiles (column cursors carried from tile to tile, the LDS-resident G tile and the dV
+    accumulators re-used across them, a ragged last tile) — none of which the small parity cases reach — against the
+    numpy restatement of the reference's graph (oracle/wmf_oracle.py; parity unpinned: no TensorFlow here)."""
+    import scipy.sparse as sp
+
+    from oracle.wmf_oracle import WmfOracle
+
+    nu, ni, k, nnz = 480189, 600, 128, 2_000_000
+    rs = np.random.RandomState(12)
+    keys = np.unique(rs.randint(0, nu * ni, size=int(nnz * 1.02), dtype=np.int64))[:nnz]
+    u, i = keys // ni, keys % ni
+    vals = rs.randint(1, 6, len(keys)).astype(np.float32)
+    vals[::97] = 0.0                         # explicit zeros stay "unobserved"
+    R = sp.csc_matrix((vals, (u, i)), shape=(nu, ni))
+    U = rs.normal(0, 0.1, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.1, (ni, k)).astype(np.float32)
+    perm = rs.permutation(ni)
+    batches = [perm[0:128], perm[128:256], perm[256:293]]    # two full batches and a ragged one
+    lu, lv, a, b, lr = 0.02, 0.03, 1.0, 0.01, 0.001
+    o = WmfOracle(U, V, R, lu, lv, a, b, lr)
+    lo = np.array(o.fit_batches(batches))
+    tr = _lib.WmfTrainer(R, k)
+    tr.set_factors(U, V)
+    lg = np.array(tr.fit_batches(batches, lu, lv, a, b, lr))
+    Ug, Vg = tr.get_factors()
+    tr.close()
+    assert np.abs(Ug - o.U).max() <= 1e-4, np.abs(Ug - o.U).max()
+    assert np.abs(Vg - o.V).max() <= 1e-4, np.abs(Vg - o.V).max()
+    assert np.allclose(lg, lo, rtol=1e-4), np.abs(lg / lo - 1).max()
+    assert np.abs(o.U - U).max() > 1e-3 and np.abs(o.V - V).max() > 1e-3
