@@ -168,27 +168,30 @@ def test_rate_batch_matches_per_pair_rate(oracle):
     assert np.array_equal(sc.score_pairs(u[known], i[known]), full[np.arange(known.sum()), i[known]])
 
 
-@pytest.mark.parametrize("k,with_excl", [(16, True), (64, False), (100, True)])
-def test_rank_positions_equal_counts_over_the_score_block(k, with_excl):
+@pytest.mark.parametrize("k,with_excl,ni", [(16, True, 3000), (64, False, 3000), (100, True, 3000), (64, True, 3001),
+                                             (32, False, 2998), (64, True, 2999), (16, True, 3)])
+def test_rank_positions_equal_counts_over_the_score_block(k, with_excl, ni):
     """cornac_hip_rank_positions vs NumPy counts over the same (bit-identical) device scores: tied scores, targets
     at the extremes of a row, rows without targets, more targets per row than one register pass, excluded and
-    out-of-range targets"""
-    rs = np.random.RandomState(k)
-    nu, ni = 70, 3000
+    out-of-range targets; item counts that leave the rows of the score tile at every 16-byte misalignment (scalar head
+    and tail around the 16-byte body, byte-wise exclusion flags) and a catalogue shorter than one vector"""
+    rs = np.random.RandomState(k + ni)
+    nu = 70
     U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
     V = rs.normal(0, 0.3, (ni, k)).astype(np.float32)
-    V[100:160] = V[200:260]                       # runs of exactly tied scores
+    if ni > 300:
+        V[100:160] = V[200:260]                   # runs of exactly tied scores
     ib = np.zeros(ni, np.float32)
     sc = _lib.Scorer(U, V, ib, None)
     users = rs.permutation(nu)[:50].astype(np.int32)
     S = sc.score_block(users)
-    excl = [np.sort(rs.choice(ni, rs.randint(0, 40), replace=False)).astype(np.int32) if with_excl else
+    excl = [np.sort(rs.choice(ni, rs.randint(0, min(40, ni)), replace=False)).astype(np.int32) if with_excl else
             np.empty(0, np.int32) for _ in users]
     tgts = []
     for r in range(len(users)):
-        n_t = [0, 1, 3, 4, 5, 9, 33][r % 7]
+        n_t = min([0, 1, 3, 4, 5, 9, 33][r % 7], ni)
         t = rs.choice(ni, n_t, replace=False).astype(np.int32)
-        if n_t >= 3:
+        if n_t >= 3 and ni > 300:
             t[0], t[1] = 120, 220                 # two members of one tie run
             t[2] = int(np.argmax(S[r]))           # the row's best item
         if n_t >= 9:
