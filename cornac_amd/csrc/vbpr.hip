@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "mfma_gemm.h"
 
@@ -568,6 +570,7 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         static const int sweep_wg_per_cu = getenv("CORNAC_HIP_VBPR_SWEEP_WGS") ? atoi(getenv("CORNAC_HIP_VBPR_SWEEP_WGS")) : 7;
         const int sweep_grid = (int)std::min<int64_t>((sw.total + kVb - 1) / kVb, (int64_t)di.cus * sweep_wg_per_cu);
         static const bool one_stream = getenv("CORNAC_HIP_VBPR_ONE_STREAM") != nullptr;  // A/B switch: everything in stream order
+        static const bool ext_events = getenv("CORNAC_HIP_VBPR_PLAIN_EVENTS") == nullptr;  // A/B switch: hipEventRecord hand-overs
         for (int64_t b0 = 0; b0 < n_total; b0 += batch_size) {
             const int n = (int)std::min<int64_t>(batch_size, n_total - b0);
             ++h->step;
@@ -601,9 +604,17 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
                                h->bj.p + b0, n, h->gS.p, h->gV.p, h->proj.p, lambda_w, lambda_b, h->W.p, ldw);
             // the batch rows' own Adam step: a latency chain (index -> claim -> row) that took 27 us beside the sweep and
             // 7 us alone, so it runs before the sweep starts (W keeps the Tu rows the E / beta' step still needs)
-            hipLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p, h->mTu.p,
-                               h->vTu.p, a);
+            // (hipExtLaunchKernelGGL attaches the hand-over event to the kernel's own completion signal: a separate
+            // hipEventRecord costs a barrier packet and ~7 us of idle stream per hand-over)
+            if (one_stream || !ext_events)
+                hipLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
+                                   h->bj.p + b0, step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p,
+                                   h->mTu.p, h->vTu.p, a);
+            else
+                hipExtLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, nullptr, h->ev_stamped, 0,
+                                      t, (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
+                                      (const int32_t *)(h->bj.p + b0), step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p,
+                                      h->vGi.p, h->mTu.p, h->vTu.p, a);
             // The sweep of this step starts here — behind the latency-bound score / gradient kernels, which a
             // bandwidth-saturating neighbour slows several-fold — and runs beside the E / beta' step and the next step's
             // feature gather and projection.
@@ -612,10 +623,15 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             if (one_stream) {
                 hipLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->stream, sw, a);
             } else {
-                HIP_CHECK(hipEventRecord(h->ev_stamped, h->stream));
+                if (!ext_events) HIP_CHECK(hipEventRecord(h->ev_stamped, h->stream));
                 HIP_CHECK(hipStreamWaitEvent(h->sweep_stream, h->ev_stamped, 0));
-                hipLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, sw, a);
-                HIP_CHECK(hipEventRecord(h->ev_swept, h->sweep_stream));
+                if (ext_events) {
+                    hipExtLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, nullptr,
+                                          h->ev_swept, 0, sw, a);
+                } else {
+                    hipLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, sw, a);
+                    HIP_CHECK(hipEventRecord(h->ev_swept, h->sweep_stream));
+                }
                 h->sweep_pending = true;
             }
             hipLaunchKernelGGL(vbpr_feat_adam_kernel, dim3((h->n_feat + fpb - 1) / fpb), dim3(kVb),
