@@ -734,6 +734,14 @@ def main():
                            "kernel": kernel_name, "launches": launches,
                            "avg_launch_ms": 1e3 * avg_launch_s, "algorithmic_bytes_per_triplet": b_full,
                            "skip_fraction": skip_frac}
+        if achieved and not args.sharded_items and k == 64 and args.flags == 0:
+            # what actually bounds the kernel: every processed triplet issues 10.04 64-byte fp32 atomic
+            # requests (TCC_ATOMIC counters, profiles/r02_sgd_pmc.csv: all forwarded to the memory side); the chip
+            # retires ~10 G 128-byte atomic line-touches/s = ~20 G such requests/s in tools/atomic_probe.hip
+            req = (n_draws - skipped) / max(launches, 1) * 10.04 / avg_launch_s / 1e9
+            out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules)", "requests_per_triplet": 10.04,
+                                          "achieved_G_per_s": req, "probe_ceiling_G_per_s": 20.0, "frac_of_probe_ceiling": req / 20.0,
+                                          "evidence": "profiles/r02_sgd_pmc.csv, profiles/r01_pmc_calibration.txt"}
         out["train_stats"] = {"correct_frac": correct / max(n_draws - skipped, 1.0), "skipped_frac": skip_frac}
 
     # ---- scoring leg: batched rank() over users with fused top-10 --------------------------------------------
