@@ -561,8 +561,8 @@ class Scorer:
             ua = np.ascontiguousarray(users, np.int32)
             up, u0, n = ua.ctypes.data, 0, len(ua)
         if fetch and pinned:
-            # results land in page-locked memory owned by the scorer: the arrays returned are VIEWS of it, valid until
-            # the next pinned call or close()
+            # results land in page-locked memory owned by the scorer: the arrays returned are VIEWS of it, overwritten by
+            # the next pinned call and valid until close()
             want_scores = fetch != "items"
             nbytes = n * topk * 4 * (2 if want_scores else 1)
             buf = _vp()

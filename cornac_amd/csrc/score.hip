@@ -908,6 +908,7 @@ struct cornac_hip_scorer {
     DevBuf<uint32_t> excl_bits;  // exclusion bitmap of the current fused launch (excl_bitmap_kernel)
     void *pinned_out = nullptr;  // page-locked host memory lent to the caller for result copies (cornac_hip_scorer_host_buffer)
     size_t pinned_bytes = 0;
+    std::vector<void *> pinned_retired;
     // exclusion lists per USER id, resident on the device (cornac_hip_scorer_set_exclusions)
     DevBuf<int64_t> res_excl_indptr;
     DevBuf<int32_t> res_excl_indices;
@@ -1199,6 +1200,7 @@ int cornac_hip_scorer_destroy(cornac_hip_scorer_t h) {
             (void)hipStreamDestroy(h->stream);
         }
         if (h->pinned_out) (void)hipHostFree(h->pinned_out);
+        for (void *q : h->pinned_retired) (void)hipHostFree(q);
         delete h;
     });
 }
@@ -1459,11 +1461,14 @@ int cornac_hip_scorer_host_buffer(cornac_hip_scorer_t h, size_t bytes, void **ou
         sc_check(h);
         REQUIRE(out != nullptr, "out is NULL");
         if (bytes > h->pinned_bytes) {
-            if (h->pinned_out) HIP_CHECK(hipHostFree(h->pinned_out));
+            // an outgrown buffer may still be referenced by the caller (arrays viewing it): it is kept until the scorer
+            // is destroyed; growth at least doubles, so the retired ones add up to less than the live one
+            if (h->pinned_out) h->pinned_retired.push_back(h->pinned_out);
             h->pinned_out = nullptr;
+            const size_t want = std::max(bytes, 2 * h->pinned_bytes);
             h->pinned_bytes = 0;
-            HIP_CHECK(hipHostMalloc(&h->pinned_out, bytes, hipHostMallocDefault));
-            h->pinned_bytes = bytes;
+            HIP_CHECK(hipHostMalloc(&h->pinned_out, want, hipHostMallocDefault));
+            h->pinned_bytes = want;
         }
         *out = h->pinned_out;
     });

@@ -325,7 +325,8 @@ typedef struct cornac_hip_scorer *cornac_hip_scorer_t;
 int cornac_hip_scorer_set_exclusions(cornac_hip_scorer_t h, const int64_t *indptr, const int32_t *indices);
 /* Page-locked host memory of at least `bytes` bytes owned by the scorer (re-used across calls, freed with it): a caller
  * that passes it as items_out / scores_out gets its results at the full PCIe rate instead of through the pageable-copy
- * staging path (5.5 MB of top-10 ids for 138 493 users: 0.2 instead of 0.5 ms).  A later, larger request replaces it. */
+ * staging path (5.5 MB of top-10 ids for 138 493 users: 0.2 instead of 0.5 ms).  A later, larger request returns a new
+ * buffer; outgrown ones stay valid (and allocated) until the scorer is destroyed. */
 int cornac_hip_scorer_host_buffer(cornac_hip_scorer_t h, size_t bytes, void **out);
 int cornac_hip_rank_topk_resident(cornac_hip_scorer_t h, const int32_t *users, int64_t u0, int64_t n, int topk,
                                   int32_t *items_out, float *scores_out, double *device_ms);
