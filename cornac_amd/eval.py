@@ -34,16 +34,46 @@ def _bool_csr(mat, threshold, shape):
     if not mat.has_sorted_indices:
         mat = mat.sorted_indices()
     keep = mat.data >= threshold
-    kept_before = np.concatenate(([0], np.cumsum(keep, dtype=np.int64)))
     indptr = np.empty(shape[0] + 1, dtype=np.int64)
-    indptr[: mat.shape[0] + 1] = kept_before[mat.indptr]
+    if keep.all():   # implicit feedback / every rating at or above the threshold: the stored structure as it is
+        indptr[: mat.shape[0] + 1] = mat.indptr
+        indices, n_kept = mat.indices, mat.nnz
+    else:
+        kept_before = np.concatenate(([0], np.cumsum(keep, dtype=np.int64)))
+        indptr[: mat.shape[0] + 1] = kept_before[mat.indptr]
+        indices, n_kept = mat.indices[keep], int(kept_before[-1])
     indptr[mat.shape[0] + 1:] = indptr[mat.shape[0]]
-    out = csr_matrix((np.ones(int(kept_before[-1]), dtype=bool), mat.indices[keep], indptr), shape=shape)
+    out = csr_matrix((np.ones(n_kept, dtype=bool), indices, indptr), shape=shape)
     out.has_sorted_indices = True
     return out
 
 
+_LISTS_CACHE = []   # [(weakrefs of the three matrices, threshold, n_eval_items, result)], most recent first
+
+
 def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
+    """`_eval_lists` memoised on the IDENTITY of the matrices: an experiment evaluates every model (and both the test
+    and the validation pass) on the same split, and the lists depend on nothing else.  (The matrices are the cached
+    `Dataset.csr_matrix` objects; a dataset that is modified builds new ones.)"""
+    import weakref
+
+    mats = (train_mat, test_mat, val_mat)
+    for entry in _LISTS_CACHE:
+        refs, thr, n_items, result = entry
+        if thr == rating_threshold and n_items == n_eval_items and all(
+                (m is None and r is None) or (r is not None and m is not None and r() is m) for m, r in zip(mats, refs)):
+            return result
+    result = _eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items)
+    try:
+        refs = tuple(None if m is None else weakref.ref(m) for m in mats)
+    except TypeError:
+        return result
+    _LISTS_CACHE.insert(0, (refs, rating_threshold, n_eval_items, result))
+    del _LISTS_CACHE[4:]
+    return result
+
+
+def _eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
     """Vectorised form of the per-user mask building of the reference's ranking_eval
     (cornac/eval_methods/base_method.py:176-206), for all test users at once:
 
@@ -62,8 +92,15 @@ def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
     users = np.flatnonzero(np.diff(T.indptr) > 0)
     E = (P - P.multiply(T)).tocsr()
     E.eliminate_zeros()
-    E = E[users][:, :n_eval_items].tocsr()
-    G = T[users][:, :n_eval_items].tocsr()
+    def cut(M):   # rows of the test users, columns below n_eval_items — without copying when nothing is cut
+        if len(users) != M.shape[0]:
+            M = M[users]
+        if n_eval_items < M.shape[1]:
+            M = M[:, :n_eval_items]
+        return M.tocsr()
+
+    E = cut(E)
+    G = cut(T)
     E.sort_indices()
     G.sort_indices()
     return (users.astype(np.int64), G.indptr.astype(np.int64), G.indices.astype(np.int64), E.indptr.astype(np.int64),
