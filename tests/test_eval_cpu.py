@@ -108,3 +108,35 @@ def test_full_list_metric_batch_forms_equal_per_user_with_ties(levels):
             want = np.array([mt.compute(gt_pos=kw["gt_pos"], pd_rank=kw["pd_rank"][:rank_len]) for kw in per_user],
                             dtype=float)
             assert np.allclose(got, want, rtol=1e-12, atol=1e-15), (cls.__name__, rank_len)
+
+
+def test_eval_lists_shortcuts_and_memo():
+    """implicit feedback (every stored rating passes the threshold), square shapes where nothing is cut, and the
+    per-split memo: the same matrix OBJECTS give the cached lists, equal-valued new objects are recomputed, and the
+    result never aliases the caller's matrices"""
+    from cornac_amd import eval as ev
+
+    rs = np.random.RandomState(5)
+    nu, ni = 90, 60
+
+    def ones_csr(nnz):
+        keys = np.unique(rs.randint(0, nu * ni, nnz))
+        return sp.csr_matrix((np.ones(len(keys)), (keys // ni, keys % ni)), shape=(nu, ni))
+
+    train, test = ones_csr(1200), ones_csr(2500)     # dense enough for every user to have a test positive
+    test_users = np.repeat(np.arange(nu), np.diff(test.indptr))
+    first = eval_lists(train, test, None, 1.0, ni)
+    users_l, gt_l, ex_l = eval_lists_loop(train, test, None, 1.0, ni, test_users)
+    users, gp, gi, ep, ei = first
+    assert users.tolist() == users_l == list(range(nu))
+    for r in range(nu):
+        assert np.array_equal(gi[gp[r]:gp[r + 1]], gt_l[r]) and np.array_equal(ei[ep[r]:ep[r + 1]], ex_l[r])
+    assert eval_lists(train, test, None, 1.0, ni) is first                 # memo hit: same objects, same arguments
+    assert eval_lists(train, test, None, 2.0, ni) is not first             # another threshold
+    again = eval_lists(train.copy(), test, None, 1.0, ni)                   # another object with the same values
+    assert again is not first and all(np.array_equal(a, b) for a, b in zip(again, first))
+    test2 = test.copy()
+    test2.data[:] = 1.0
+    before = test2.indices.copy()
+    eval_lists(train, test2, None, 1.0, ni)
+    assert np.array_equal(test2.indices, before) and len(ev._LISTS_CACHE) <= 4
