@@ -10,7 +10,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcornac_hip.so")
+# CORNAC_HIP_PROFILE=1 loads the -DCORNAC_PROFILE build of the same sources (A/B switches and ablation bits compiled
+# in; `make -C cornac_amd/csrc PROFILE=1`): tools/ only — the tests, bench.py and smoke() use the shipped library
+PROFILE = os.environ.get("CORNAC_HIP_PROFILE", "") == "1"
+LIB_PATH = os.path.join(_HERE, "lib", "libcornac_hip_profile.so" if PROFILE else "libcornac_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MODE_DETERMINISTIC = 0
@@ -28,6 +31,7 @@ SYMBOLS = [
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs",
+    "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
     "cornac_hip_bpr_staged_slots", "cornac_hip_bpr_emit_triplets", "cornac_hip_bpr_apply_staged",
     "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
@@ -58,7 +62,7 @@ class HipError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile libcornac_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j", "4"] + (["-B"] if force else [])
+    cmd = ["make", "-C", CSRC, "-j", "4"] + (["-B"] if force else []) + (["PROFILE=1"] if PROFILE else [])
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
@@ -152,6 +156,9 @@ def lib():
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
         L.cornac_hip_bpr_table_delta_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
+        L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+        L.cornac_hip_bpr_strata_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_debug_strata.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_vbpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _f32]
@@ -236,6 +243,7 @@ class BprTrainer:
         self.indices = np.ascontiguousarray(indices, np.int32)
         self.shape = (int(total_users), int(total_items), int(k))
         self.nnz = len(self.indices)
+        self.n_items = int(n_items)
         self.h = _vp()
         check(lib().cornac_hip_bpr_create(C.byref(self.h), device, n_users, n_items, total_users, total_items, k,
                                           self.indptr, self.indices, self.nnz))
@@ -387,6 +395,26 @@ class BprTrainer:
         check(lib().cornac_hip_bpr_debug_ownership(self.h, C.byref(w), wp.ctypes.data, ou.ctypes.data,
                                                    oi.ctypes.data))
         return wp, ou, oi
+
+    def strata_config(self, hot_permille=120, hot_min_mult_x100=200, rehash_period=1):
+        check(lib().cornac_hip_bpr_strata_config(self.h, int(hot_permille), int(hot_min_mult_x100), int(rehash_period)))
+
+    def strata_stats(self):
+        o = (C.c_int64 * 4)()
+        check(lib().cornac_hip_bpr_strata_stats(self.h, o))
+        return {"n_hot": o[0], "misplaced_workgroups": o[1], "bucket_builds": o[2], "waves": o[3]}
+
+    def debug_strata(self, epoch):
+        """(sptr, rec_u, rec_i, rank_item, key): the partition buckets the strata form uses in `epoch`"""
+        wp = self.debug_ownership()[0]
+        W = len(wp) - 1
+        sptr = np.empty(8 * W + 1, np.int64)
+        ru, ri = np.empty(self.nnz, np.int32), np.empty(self.nnz, np.int32)
+        rank_item = np.empty(self.n_items, np.int32)
+        key = C.c_uint32()
+        check(lib().cornac_hip_bpr_debug_strata(self.h, int(epoch), sptr.ctypes.data, ru.ctypes.data, ri.ctypes.data,
+                                                rank_item.ctypes.data, C.byref(key)))
+        return sptr, ru, ri, rank_item, key.value
 
     def kernel_timing(self, enable=True):
         """(total_ms, launches) of the hogwild kernel launches recorded since the last call (HIP events)."""

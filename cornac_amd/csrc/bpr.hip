@@ -171,6 +171,11 @@ struct HogArgs {
     // tile t of wave w through trip_*[((trip_tile0 + t) * total_waves + w) * 64 + lane]
     int32_t *trip_u, *trip_i, *trip_j;
     int64_t trip_tile0, trip_tiles;
+    // XCD strata (bpr_strata.inc): per-wave partition buckets of the ownership slices, rank -> item, epoch key
+    const int32_t *rec_u, *rec_i, *rank_item;
+    const int64_t *sptr;
+    uint32_t strata_key, n_hot;
+    int phase;
 };
 constexpr int32_t kTripShared = 0x40000000;  // bit 30 of an emitted user id: a shared (heavy) user, atomics on its row
 
@@ -637,6 +642,8 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
 
 }  // namespace chip
 #include "bpr_binned.inc"
+#include "bpr_strata.inc"
+
 namespace chip {
 
 static int pow2_group(int k) {  // lanes per triplet for scalar-per-lane kernels
@@ -660,7 +667,7 @@ struct cornac_hip_bpr {
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
-    DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped
+    DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped, [2] strata workgroups placed off their logical XCD
     // deterministic sampler state
     DevBuf<uint32_t> mt_state;  // 2 x 624
     DevBuf<int32_t> mt_idx;     // 2
@@ -691,6 +698,17 @@ struct cornac_hip_bpr {
     std::vector<int32_t> h_own_u, h_own_i;
     std::vector<int64_t> h_wave_ptr;
     int64_t own_tmax = 0;
+    // XCD strata (bpr_strata.inc): popularity ranks, per-epoch partition buckets of the ownership slices
+    bool strata_ranked = false;
+    DevBuf<int32_t> item_rank, rank_item, rec_u, rec_i;
+    DevBuf<int64_t> sptr;
+    std::vector<int32_t> h_rank_item;
+    uint32_t strata_n_hot = 0, strata_key_built = 0;
+    bool strata_built = false;
+    int strata_hot_permille = 120, strata_hot_min_mult_x100 = 200, strata_rehash_period = 1;
+    int64_t strata_misplaced = 0, strata_builds = 0;
+    void (*strata_kernel)(const chip::HogArgs) = nullptr;
+    int strata_blocks_per_cu = 0;
     // binned item updates (bpr_binned.inc): item -> (bucket, local row), bucket -> items, message segments
     int bin_buckets = 0, bin_neg_population = -1, bin_max_rows = 0, bin_wg_per_cu = 0, bin_n_hot = 0;
     int bin_hot_threshold = 0;
@@ -758,8 +776,8 @@ int cornac_hip_bpr_create(cornac_hip_bpr_t *out, int device, int64_t n_users, in
         HIP_CHECK(hipMemsetAsync(h->U.p, 0, h->U.n * sizeof(float), h->stream));
         HIP_CHECK(hipMemsetAsync(h->V.p, 0, h->V.n * sizeof(float), h->stream));
         HIP_CHECK(hipMemsetAsync(h->B.p, 0, h->B.n * sizeof(float), h->stream));
-        h->counters.alloc(2);
-        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        h->counters.alloc(4);
+        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 4 * sizeof(unsigned long long), h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         *out = h.release();
     });
@@ -1373,9 +1391,138 @@ static void binned_enqueue(cornac_hip_bpr_t h, const BinPlan &pl, int64_t n_samp
     }
 }
 
+// ---- XCD strata (bpr_strata.inc) ------------------------------------------------------------------------------
+typedef void (*StrataKernel)(const HogArgs);
+static StrataKernel pick_strata_kernel(int k) {
+#ifdef CORNAC_PROFILE
+    switch (k <= 64 ? prof_env_int("CORNAC_HIP_STRATA_VARIANT", 0) : 0) {  // A/B forms
+        case 1: return bpr_strata_kernel<1, 4, 1>;
+        case 2: return bpr_strata_kernel<1, 4, 2>;
+        case 3: return bpr_strata_kernel<1, 2, 0>;
+        case 4: return bpr_strata_kernel<1, 2, 1>;
+        case 5: return bpr_strata_kernel<1, 8, 0>;
+        default: break;
+    }
+#endif
+    if (k <= 64) return bpr_strata_kernel<1, 4>;
+    if (k <= 128) return bpr_strata_kernel<2, 2>;
+    if (k <= 192) return bpr_strata_kernel<3, 2>;
+    return bpr_strata_kernel<4, 1>;
+}
+
+// popularity ranks of the items (expected row touches per epoch = degree + the uniform share of the negative draws;
+// the second term is the same for every item, so the order is by degree, ties by id) and the hot set: the leading
+// ranks that (a) are touched at least hot_min_mult times as often as the average row and (b) together receive at most
+// hot_permille / 1000 of all item-row touches.  Those rows keep device-scope atomics.
+static void build_item_ranks(cornac_hip_bpr_t h) {
+    if (h->strata_ranked) return;
+    const int64_t ni = h->n_items, nnz = h->nnz;
+    std::vector<int64_t> deg((size_t)ni, 0);
+    for (int64_t t = 0; t < nnz; ++t) ++deg[(size_t)h->h_indices[(size_t)t]];
+    h->h_rank_item.resize((size_t)ni);
+    for (int64_t i = 0; i < ni; ++i) h->h_rank_item[(size_t)i] = (int32_t)i;
+    std::stable_sort(h->h_rank_item.begin(), h->h_rank_item.end(),
+                     [&](int32_t x, int32_t y) { return deg[(size_t)x] > deg[(size_t)y]; });
+    std::vector<int32_t> item_rank((size_t)ni);
+    for (int64_t r = 0; r < ni; ++r) item_rank[(size_t)h->h_rank_item[(size_t)r]] = (int32_t)r;
+    const double neg_share = (double)nnz / (double)ni, mean_touch = 2.0 * neg_share;
+    const double cap = 2.0 * (double)nnz * h->strata_hot_permille / 1000.0;
+    double cum = 0;
+    int64_t n_hot = 0;
+    for (int64_t r = 0; r < ni; ++r) {
+        const double touch = (double)deg[(size_t)h->h_rank_item[(size_t)r]] + neg_share;
+        if (touch * 100.0 < mean_touch * h->strata_hot_min_mult_x100 || cum + touch > cap) break;
+        cum += touch;
+        n_hot = r + 1;
+    }
+    h->strata_n_hot = (uint32_t)n_hot;
+    h->item_rank.ensure((size_t)ni);
+    h->rank_item.ensure((size_t)ni);
+    h->item_rank.upload(item_rank.data(), (size_t)ni, h->stream);
+    h->rank_item.upload(h->h_rank_item.data(), (size_t)ni, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->strata_ranked = true;
+    h->strata_built = false;
+}
+
+static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_population, int flags) {
+#ifdef CORNAC_PROFILE
+    flags &= 0xff;  // (profile builds: the ablation bits 8.. are honoured by the strata kernel too)
+#endif
+    return flags == 0 && neg_population == CORNAC_HIP_NEG_UNIFORM && hogwild_uses_ownership(h, 0) &&
+           h->n_items >= 64 && h->hog_offset == 0 && n_samples > 0 && n_samples % h->nnz == 0 &&
+           device_info(h->device).xcds == 8;
+}
+
+// grid / ownership / rank tables of the strata kernel; returns the grid width
+static int strata_prepare(cornac_hip_bpr_t h) {
+    const DeviceInfo &di = device_info(h->device);
+    StrataKernel kern = pick_strata_kernel(h->k);
+    if (h->strata_kernel != kern) {
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+        h->strata_kernel = kern;
+        h->strata_blocks_per_cu = std::max(1, std::min(per_cu, 8));
+    }
+    const int grid = di.cus * h->strata_blocks_per_cu;
+    const int64_t W = (int64_t)grid * kWavesPerBlock;
+    if (h->own_waves != W) h->strata_built = false;
+    build_ownership(h, W);
+    build_item_ranks(h);
+    h->rec_u.ensure((size_t)h->nnz);
+    h->rec_i.ensure((size_t)h->nnz);
+    h->sptr.ensure((size_t)W * 8 + 1);
+    return grid;
+}
+
+static void strata_build_buckets(cornac_hip_bpr_t h, int grid, uint32_t key) {
+    if (h->strata_built && h->strata_key_built == key) return;
+    StrataArgs s;
+    s.own_u = h->own_u.p; s.own_i = h->own_i.p; s.wave_ptr = h->wave_ptr.p; s.item_rank = h->item_rank.p;
+    s.rec_u = h->rec_u.p; s.rec_i = h->rec_i.p; s.sptr = h->sptr.p;
+    s.key = key; s.n_hot = h->strata_n_hot; s.n_waves = (int64_t)grid * kWavesPerBlock;
+    hipLaunchKernelGGL(strata_bucket_kernel, dim3(grid), dim3(kBlock), 0, h->stream, s);
+    HIP_CHECK(hipGetLastError());
+    h->strata_built = true;
+    h->strata_key_built = key;
+    ++h->strata_builds;
+}
+
+// whole epochs only: 8 phase launches per epoch, buckets re-dealt when the epoch key changes
+static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_epochs, float lr, float reg, int use_bias, int flags) {
+    const int grid = strata_prepare(h);
+    h->Bpad.ensure((size_t)h->total_items * kBiasStride);
+    const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
+    for (int64_t e = 0; e < n_epochs; ++e) {
+        const uint32_t key = strata_key(h->hog_seed, h->hog_epoch / (uint32_t)std::max(1, h->strata_rehash_period));
+        strata_build_buckets(h, grid, key);
+        HogArgs a;
+        fill_hog_args(h, a, h->nnz, lr, reg, use_bias, CORNAC_HIP_NEG_UNIFORM, flags);
+        a.B = h->Bpad.p;
+        a.bstride = kBiasStride;
+        a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
+        a.strata_key = key; a.n_hot = h->strata_n_hot;
+        hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
+        for (int ph = 0; ph < 8; ++ph) {
+            a.phase = ph;
+            h->ktimer.before(h->stream);
+            hipLaunchKernelGGL(h->strata_kernel, dim3(grid), dim3(kBlock), 0, h->stream, a);
+            h->ktimer.after(h->stream);
+        }
+        hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
+        HIP_CHECK(hipGetLastError());
+        advance_hog_offset(h, h->nnz);
+    }
+}
+
 static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+    if (hogwild_uses_strata(h, n_samples, neg_population, flags)) {
+        strata_enqueue(h, n_samples / h->nnz, lr, reg, use_bias, flags);
+        return;
+    }
+    flags &= ~128;  // bit7 only opts out of the strata form
     const BinPlan pl = plan_binned(h, flags, lr);
     if (pl.ok) {
         binned_enqueue(h, pl, n_samples, lr, reg, use_bias, neg_population, flags);
@@ -1407,12 +1554,13 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
 }
 
 static void fetch_counters(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped) {
-    unsigned long long c[2];
+    unsigned long long c[4];
     HIP_CHECK(hipMemcpyAsync(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemsetAsync(h->counters.p, 0, sizeof c, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (correct) *correct += (int64_t)c[0];
     if (skipped) *skipped += (int64_t)c[1];
+    h->strata_misplaced += (int64_t)c[2];
 }
 
 extern "C" {
@@ -1429,7 +1577,7 @@ int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float 
         if (skipped) *skipped = 0;
         for (double &t : h->timing) t = 0;
         Timer total;
-        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 4 * sizeof(unsigned long long), h->stream));
         for (int e = 0; e < n_epochs; ++e) {
             if (mode == CORNAC_HIP_MODE_DETERMINISTIC) {
                 bpr_epoch_deterministic(h, lr, reg, use_bias, neg_population);
@@ -1489,12 +1637,19 @@ int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t
         REQUIRE(n_waves != nullptr, "n_waves is NULL");
         *n_waves = 0;
         if (!hogwild_uses_ownership(h, 0)) return;
-        // same kernel/grid choice as launch_hogwild with flags == 0
-        HogKernel kern = pick_hogwild_kernel<true>(h->k, 0);
-        int per_cu = 0;
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
-        const int64_t W = (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 8)) * kWavesPerBlock;
-        build_ownership(h, W);
+        // the tables of the default throughput path (flags == 0): the strata kernel's grid where that form applies,
+        // else the fused kernel's; tables already built for a launch are returned as they are
+        if (h->own_waves == 0) {
+            if (hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0)) {
+                strata_prepare(h);
+            } else {
+                HogKernel kern = pick_hogwild_kernel<true>(h->k, 0);
+                int per_cu = 0;
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+                build_ownership(h, (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 8)) * kWavesPerBlock);
+            }
+        }
+        const int64_t W = h->own_waves;
         *n_waves = W;
         if (wave_ptr) std::copy(h->h_wave_ptr.begin(), h->h_wave_ptr.end(), wave_ptr);
         if (own_u) std::copy(h->h_own_u.begin(), h->h_own_u.end(), own_u);
@@ -1508,6 +1663,51 @@ int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_m
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->ktimer.collect(total_ms, launches);
         h->ktimer.enabled = enable != 0;
+    });
+}
+
+int cornac_hip_bpr_strata_config(cornac_hip_bpr_t h, int hot_permille, int hot_min_mult_x100, int rehash_period) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(hot_permille >= 0 && hot_permille <= 1000, "hot_permille must be in [0, 1000]");
+        REQUIRE(hot_min_mult_x100 >= 0, "hot_min_mult_x100 must be >= 0");
+        REQUIRE(rehash_period >= 1, "rehash_period must be >= 1");
+        h->strata_hot_permille = hot_permille;
+        h->strata_hot_min_mult_x100 = hot_min_mult_x100;
+        h->strata_rehash_period = rehash_period;
+        h->strata_ranked = false;  // the hot set is re-derived (and the buckets re-dealt) at the next launch
+        h->strata_built = false;
+    });
+}
+
+int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(out4 != nullptr, "out4 is NULL");
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        out4[0] = h->strata_ranked ? (int64_t)h->strata_n_hot : -1;
+        out4[1] = h->strata_misplaced;
+        out4[2] = h->strata_builds;
+        out4[3] = h->strata_kernel ? h->own_waves : 0;
+    });
+}
+
+int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
+                                int32_t *rank_item, uint32_t *key) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->hog_seeded, "seed the hogwild sampler first");
+        REQUIRE(hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0), "this handle does not use the strata form");
+        const int grid = strata_prepare(h);
+        const uint32_t kk = strata_key(h->hog_seed, epoch / (uint32_t)std::max(1, h->strata_rehash_period));
+        strata_build_buckets(h, grid, kk);
+        const size_t W = (size_t)grid * kWavesPerBlock;
+        if (sptr) h->sptr.download(sptr, W * 8 + 1, h->stream);
+        if (rec_u) h->rec_u.download(rec_u, (size_t)h->nnz, h->stream);
+        if (rec_i) h->rec_i.download(rec_i, (size_t)h->nnz, h->stream);
+        if (rank_item) std::copy(h->h_rank_item.begin(), h->h_rank_item.end(), rank_item);
+        if (key) *key = kk;
+        HIP_CHECK(hipStreamSynchronize(h->stream));
     });
 }
 

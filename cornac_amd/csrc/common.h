@@ -65,6 +65,19 @@ int guarded(F &&f) {
 
 void use_device(int device);  // validates it is a gfx950 part and makes it current
 
+// ---- profiling switches: environment variables are read in -DCORNAC_PROFILE builds only (make PROFILE=1 ->
+// libcornac_hip_profile.so); the shipped library always takes the default ------------------------------------
+#ifdef CORNAC_PROFILE
+inline int prof_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+inline bool prof_env_set(const char *name) { return getenv(name) != nullptr; }
+#else
+constexpr int prof_env_int(const char *, int dflt) { return dflt; }
+constexpr bool prof_env_set(const char *) { return false; }
+#endif
+
 // ---- device buffer -----------------------------------------------------------------------------
 template <class T>
 struct DevBuf {

@@ -99,7 +99,11 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
 
 /* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
  * reference's per-epoch counters over the epochs run (either may be NULL).
- * hogwild_flags (experiment switches, 0 = default): bit0 = plain (racy,
+ * hogwild_flags (0 = default).  With flags 0, uniform negatives, k in 33..256, whole epochs and a matrix large enough
+ * for user-row ownership the epoch runs in the XCD-strata form (csrc/bpr_strata.inc: 8 launches per epoch, item rows
+ * touched by one XCD per launch and updated by plain read-modify-write like the reference's threads, hot rows and
+ * shared users by fp32 atomics); bit7 = opt out of the strata form (every item-row update a device-scope atomic: the
+ * fused kernel).  Experiment switches of the fused kernel: bit0 = plain (racy,
  * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
  * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic);
  * bit4 = (k in 33..64) the four sampling lanes 4g..4g+3 share one negative item and its row gets ONE combined atomic
@@ -124,6 +128,18 @@ int cornac_hip_bpr_debug_draw(cornac_hip_bpr_t h, int stream, uint64_t hi, int64
  * ~u), own_i[nnz] receive the tables when non-NULL. */
 int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t *wave_ptr, int32_t *own_u,
                                    int32_t *own_i);
+/* Tuning and inspection of the XCD-strata form.  strata_config: the hot item rows (atomic updates) are the most
+ * popular ranks that are touched at least hot_min_mult_x100 / 100 times as often as the average row and together
+ * receive at most hot_permille / 1000 of the item-row touches (defaults 200, 120); the item partitions are re-dealt
+ * every rehash_period epochs (default 1).  strata_stats: out4 = {hot rows (-1: tables not built yet), workgroup
+ * launches the dispatcher placed off their logical XCD since create (those fell back to atomics), bucket builds, grid
+ * width in waves (0: the strata form has not run)}.  debug_strata (test hook): deals the partitions of `epoch` and
+ * returns the bucket offsets sptr[8 W + 1], the bucketed records rec_u / rec_i [nnz] (rec_i: bit 31 = hot row),
+ * rank_item [n_items] (popularity rank -> item) and the epoch key; any pointer may be NULL. */
+int cornac_hip_bpr_strata_config(cornac_hip_bpr_t h, int hot_permille, int hot_min_mult_x100, int rehash_period);
+int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
+int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
+                                int32_t *rank_item, uint32_t *key);
 /* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
  * stream: returns the summed duration and count of the launches recorded since
  * the previous call, then enables/disables recording for the following ones. */

@@ -470,6 +470,48 @@ void oracle_hogwild_sample_owned(uint64_t seed, uint32_t epoch, uint32_t wave_id
     }
 }
 
+/* XCD-strata variant of the device sampler (csrc/bpr_strata.inc; like the two above it restates the HIP
+ * path's own integer arithmetic — the reference's multi-thread streams are not reproducible).
+ * strata_rot: rotation of rank group g's 8 items over the 8 item partitions under an epoch key;
+ * strata_key: the key of epoch e; strata_sample: the draws of wave `wave_id` in partition p, whose bucket
+ * holds `len` interactions: r_out = index into the bucket, code_out = popularity rank of the negative item
+ * (item = rank_item[code]); counter = (local, wave_id, epoch, 0x10 | p). */
+uint32_t oracle_strata_rot(uint32_t g, uint32_t key) {
+    uint32_t h = g * 0x9E3779B1u + key;
+    h ^= h >> 15; h *= 0x85EBCA77u;
+    h ^= h >> 13; h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h & 7u;
+}
+
+uint32_t oracle_strata_key(uint64_t seed, uint32_t epoch) {
+    uint32_t w[4];
+    oracle_philox4x32(epoch, 0x57A7Au, 0u, 3u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    return w[0];
+}
+
+/* partition of every popularity rank under `key` */
+void oracle_strata_partitions(uint32_t key, int64_t n_items, uint8_t *part_of_rank) {
+    for (int64_t c = 0; c < n_items; ++c)
+        part_of_rank[c] = (uint8_t)((((uint32_t)c & 7u) + oracle_strata_rot((uint32_t)(c >> 3), key)) & 7u);
+}
+
+int64_t oracle_strata_sample(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t wave_id, uint32_t p, uint32_t len,
+                             uint32_t n_items, int64_t *r_out, int64_t *code_out) {
+    const uint32_t n_full = n_items >> 3, rem = n_items & 7u;
+    uint32_t n_p = n_full;
+    if (rem && ((p - oracle_strata_rot(n_full, key)) & 7u) < rem) n_p += 1;
+    if (n_p == 0) return 0;
+    for (uint32_t t = 0; t < len; ++t) {
+        uint32_t w[4];
+        oracle_philox4x32(t, wave_id, epoch, 0x10u | p, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        r_out[t] = lemire_bounded2(w[0], w[1], len);
+        const uint32_t g = lemire_bounded2(w[2], w[3], n_p);
+        code_out[t] = (int64_t)g * 8 + ((p - oracle_strata_rot(g, key)) & 7u);
+    }
+    return (int64_t)len;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

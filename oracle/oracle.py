@@ -87,6 +87,14 @@ def _bind(L):
                                             i64p, i64p]
         L.oracle_hogwild_sample_owned.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                   C.c_int64, C.c_int64, i64p, i64p]
+        L.oracle_strata_rot.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_strata_rot.restype = C.c_uint32
+        L.oracle_strata_key.argtypes = [C.c_uint64, C.c_uint32]
+        L.oracle_strata_key.restype = C.c_uint32
+        L.oracle_strata_partitions.argtypes = [C.c_uint32, C.c_int64, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+        L.oracle_strata_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, i64p, i64p]
+        L.oracle_strata_sample.restype = C.c_int64
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
     return L
@@ -372,6 +380,46 @@ def hogwild_sample(seed, epoch, s0, n, n_pos, n_neg):
     jj = np.empty(n, np.int64)
     lib().oracle_hogwild_sample(int(seed), int(epoch), int(s0), int(n), int(n_pos), int(n_neg), ii, jj)
     return ii, jj
+
+
+def strata_key(seed, epoch):
+    return int(lib().oracle_strata_key(int(seed), int(epoch)))
+
+
+def strata_partitions(key, n_items):
+    """partition (0..7) of every popularity rank under the epoch key (csrc/bpr_strata.inc)"""
+    out = np.empty(n_items, np.uint8)
+    lib().oracle_strata_partitions(int(key), int(n_items), out)
+    return out
+
+
+def strata_sample(seed, epoch, key, wave_id, p, length, n_items):
+    """(index into the wave's bucket p, popularity rank of the negative) for the bucket's `length` draws"""
+    r = np.empty(length, np.int64)
+    code = np.empty(length, np.int64)
+    n = lib().oracle_strata_sample(int(seed), int(epoch), int(key), int(wave_id), int(p), int(length), int(n_items), r, code)
+    return r[:n], code[:n]
+
+
+def strata_buckets(wave_ptr, own_u, own_i, deg, key, n_hot):
+    """CPU restatement of strata_bucket_kernel: every wave slice stably re-ordered by the partition of its items.
+    Returns (sptr [8 W + 1], rec_u, rec_i with bit 31 = hot, rank_item)."""
+    n_items = len(deg)
+    rank_item = np.argsort(-deg.astype(np.int64), kind="stable").astype(np.int32)
+    item_rank = np.empty(n_items, np.int64)
+    item_rank[rank_item] = np.arange(n_items)
+    part_rank = strata_partitions(key, n_items)
+    W = len(wave_ptr) - 1
+    code = item_rank[own_i]
+    part = part_rank[code].astype(np.int64)
+    wave_of = np.repeat(np.arange(W, dtype=np.int64), np.diff(wave_ptr))
+    order = np.argsort(wave_of * 8 + part, kind="stable")
+    counts = np.bincount(wave_of * 8 + part, minlength=8 * W)
+    sptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rec_u = own_u[order]
+    rec_i = own_i[order].astype(np.int64)
+    rec_i = np.where(code[order] < n_hot, rec_i | 0x80000000, rec_i).astype(np.uint32).view(np.int32)
+    return sptr, rec_u, rec_i, rank_item
 
 
 def hogwild_sample_owned(seed, epoch, wave_id, length, n_neg, lo, hi):

@@ -183,7 +183,11 @@ def test_owned_sampler_and_ownership_tables(oracle):
     users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
     indptr, indices = synth.csr_from_sorted(users, items, n_users)
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
-    own = tr.debug_ownership()
+    seed = 0x1234ABCD5678
+    tr.seed_hogwild(seed)
+    # bit 7 = the fused kernel (flags 0 would run the XCD-strata form, whose sampler has its own test below)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=128)
+    own = tr.debug_ownership()  # the tables the two epochs used
     assert own is not None, "expected the ownership kernel for k=64, nnz=700k"
     wave_ptr, own_u, own_i = own
     W = len(wave_ptr) - 1
@@ -202,9 +206,6 @@ def test_owned_sampler_and_ownership_tables(oracle):
     deg = np.diff(indptr)
     assert set(np.unique(real_u[~excl]).tolist()) == set(np.flatnonzero(deg > max(1, nnz // W // 2)).tolist())
     # skip-counter parity (lr = 0: tables untouched), 2 epochs
-    seed = 0x1234ABCD5678
-    tr.seed_hogwild(seed)
-    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
     tr.close()
     import scipy.sparse as sp
 
@@ -219,6 +220,56 @@ def test_owned_sampler_and_ownership_tables(oracle):
             u = real_u[wave_ptr[w] + r]
             skipped += int(np.sum(np.asarray(X[u, jj]).ravel() != 0))
     assert s == skipped
+
+
+def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
+    """The XCD-strata form (csrc/bpr_strata.inc, the default for k = 64 at this size): the partition buckets the device
+    deals for an epoch equal the CPU restatement (popularity ranks, rotation hash, stable counting sort of every wave
+    slice, hot marks) bit for bit, every partition holds one item of every rank group, and with lr = 0 the device's
+    skip counter over two epochs equals the restated sampler's count — integer work, exact."""
+    import scipy.sparse as sp
+
+    from cornac_amd import synth
+
+    n_users, n_items = 6000, 3003  # 3003 % 8 = 3: the last rank group is partial
+    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    nnz = len(indices)
+    seed = 0xABCDEF0123
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
+    tr.seed_hogwild(seed)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    st = tr.strata_stats()
+    assert st["waves"] > 0 and st["bucket_builds"] == 2, "flags 0 must run the strata form here: %r" % (st,)
+    assert st["misplaced_workgroups"] == 0, "dispatcher placed workgroups off blockIdx % 8: " + repr(st)
+    wave_ptr, own_u, own_i = tr.debug_ownership()
+    W = len(wave_ptr) - 1
+    deg = np.bincount(indices, minlength=n_items)
+    X = sp.csr_matrix((np.ones(nnz, np.int8), indices, indptr), shape=(n_users, n_items))
+    skipped = 0
+    for epoch in range(2):
+        sptr, rec_u, rec_i, rank_item, key = tr.debug_strata(epoch)
+        assert key == oracle.strata_key(seed, epoch)
+        w_sptr, w_u, w_i, w_rank = oracle.strata_buckets(wave_ptr, own_u, own_i, deg, key, st["n_hot"])
+        assert np.array_equal(rank_item, w_rank)
+        assert np.array_equal(sptr, w_sptr) and np.array_equal(rec_u, w_u) and np.array_equal(rec_i, w_i)
+        part_rank = oracle.strata_partitions(key, n_items)
+        sizes = np.bincount(part_rank, minlength=8)
+        assert sizes.min() >= n_items // 8 and sizes.max() <= n_items // 8 + 1
+        assert all(len(set(part_rank[g * 8:g * 8 + 8].tolist())) == len(part_rank[g * 8:g * 8 + 8]) for g in range(0, n_items // 8 + 1, 37))
+        real_u = np.where(rec_u < 0, ~rec_u, rec_u).astype(np.int64)
+        for w in range(W):
+            for p in range(8):
+                lo, hi = int(sptr[8 * w + p]), int(sptr[8 * w + p + 1])
+                if hi == lo:
+                    continue
+                r, code = oracle.strata_sample(seed, epoch, key, w, p, hi - lo, n_items)
+                assert (part_rank[code] == p).all()
+                u = real_u[lo + r]
+                skipped += int(np.sum(np.asarray(X[u, rank_item[code]]).ravel() != 0))
+    tr.close()
+    assert s == skipped
+    assert 0 < st["n_hot"] < n_items // 4
 
 
 def test_owned_kernel_user_rows_are_exact():
@@ -237,7 +288,7 @@ def test_owned_kernel_user_rows_are_exact():
     U0 = rs.normal(0, 0.1, (n_users, 64)).astype(np.float32)
     V0 = rs.normal(0, 0.1, (n_items, 64)).astype(np.float32)
     res = []
-    for flags in (0, 4):  # ownership vs all-atomic
+    for flags in (128, 4, 0):  # ownership (fused kernel) vs all-atomic vs the XCD-strata form (same ownership of U rows)
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
         tr.set_factors(U0, V0, np.zeros(n_items, np.float32))
         tr.seed_hogwild(77)
@@ -249,7 +300,9 @@ def test_owned_kernel_user_rows_are_exact():
     # different sample streams, same optimisation problem: both must have moved U by a similar amount
     d_owned = np.linalg.norm(res[0][0] - U0)
     d_atomic = np.linalg.norm(res[1][0] - U0)
+    d_strata = np.linalg.norm(res[2][0] - U0)
     assert 0.8 < d_owned / d_atomic < 1.25, (d_owned, d_atomic)
+    assert 0.8 < d_strata / d_atomic < 1.25, (d_strata, d_atomic)
 
 
 def test_atomic_updates_do_not_lose_writes():
@@ -397,13 +450,13 @@ def test_binned_item_updates_learn_like_the_fused_atomic_kernel():
     U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
     V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
     out = {}
-    for flags in (64, 0):
+    for flags in (64, 128):
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
         tr.set_factors(U, V, np.zeros(n_items, np.float32))
         tr.seed_hogwild(9)
         tr.fit_epochs(6, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
         c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
-        out[flags] = (c / (len(indices) - s), s, tr.get_factors())
+        out[flags & 64] = (c / (len(indices) - s), s, tr.get_factors())
         tr.close()
     assert abs(out[64][1] - out[0][1]) < 0.05 * out[0][1] + 50
     assert abs(out[64][0] - out[0][0]) < 0.01, (out[64][0], out[0][0])

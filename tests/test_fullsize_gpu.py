@@ -69,7 +69,7 @@ def test_hogwild_full_size_invariants(ml20m):
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
     tr.set_factors(U, V, B)
     tr.seed_hogwild(2024)
-    c, s = tr.fit_epochs(2, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c, s = tr.fit_epochs(2, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=128)  # bit 7: every update atomic
     U2, V2, B2 = tr.get_factors()
     tr.close()
     nnz = len(indices)

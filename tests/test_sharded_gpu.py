@@ -289,7 +289,7 @@ def test_row_sharded_trainer_single_rank_through_rccl():
     ref = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
     ref.set_factors(U, V, np.zeros(n_items, np.float32))
     ref.seed_hogwild(5)
-    c_ref, s_ref = ref.fit_epochs(epochs, lr, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c_ref, s_ref = ref.fit_epochs(epochs, lr, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=128)
     ref.close()
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
