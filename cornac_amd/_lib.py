@@ -18,6 +18,8 @@ CSRC = os.path.join(_HERE, "csrc")
 
 MODE_DETERMINISTIC = 0
 MODE_HOGWILD = 1
+# hogwild_flags bits 16..19: the form of a whole-epoch hogwild call (include/cornac_hip.h)
+FORM_AUTO, FORM_FUSED, FORM_STRATA, FORM_LDSBIN = 0, 1 << 16, 2 << 16, 3 << 16
 NEG_UNIFORM = 0
 NEG_POPULARITY = 1
 
@@ -32,6 +34,7 @@ SYMBOLS = [
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs",
     "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
+    "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
     "cornac_hip_bpr_staged_slots", "cornac_hip_bpr_emit_triplets", "cornac_hip_bpr_apply_staged",
     "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
@@ -159,6 +162,8 @@ def lib():
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_strata_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_strata.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
+        L.cornac_hip_bpr_ldsbin_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+        L.cornac_hip_bpr_ldsbin_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_vbpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _f32]
@@ -395,6 +400,15 @@ class BprTrainer:
         check(lib().cornac_hip_bpr_debug_ownership(self.h, C.byref(w), wp.ctypes.data, ou.ctypes.data,
                                                    oi.ctypes.data))
         return wp, ou, oi
+
+    def ldsbin_config(self, hot_x1000=50, min_candidates=48, max_rounds=4):
+        check(lib().cornac_hip_bpr_ldsbin_config(self.h, int(hot_x1000), int(min_candidates), int(max_rounds)))
+
+    def ldsbin_stats(self):
+        o = (C.c_int64 * 6)()
+        check(lib().cornac_hip_bpr_ldsbin_stats(self.h, o))
+        return {"bins": o[0], "rows_per_bin": o[1], "n_hot": o[2], "hot_interactions": o[3], "bitmap_words": o[4],
+                "lds_bytes": o[5]}
 
     def strata_config(self, hot_permille=120, hot_min_mult_x100=200, rehash_period=1):
         check(lib().cornac_hip_bpr_strata_config(self.h, int(hot_permille), int(hot_min_mult_x100), int(rehash_period)))

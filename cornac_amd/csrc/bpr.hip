@@ -643,6 +643,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_generic_kernel(const HogAr
 }  // namespace chip
 #include "bpr_binned.inc"
 #include "bpr_strata.inc"
+#include "bpr_ldsbin.inc"
 
 namespace chip {
 
@@ -709,6 +710,14 @@ struct cornac_hip_bpr {
     int64_t strata_misplaced = 0, strata_builds = 0;
     void (*strata_kernel)(const chip::HogArgs) = nullptr;
     int strata_blocks_per_cu = 0;
+    // LDS-resident item bins (bpr_ldsbin.inc): CSC, hot interaction list, membership bitmap
+    bool lb_built = false;
+    DevBuf<int32_t> lb_cptr, lb_cusers, lb_hot_u, lb_hot_i;
+    DevBuf<uint32_t> lb_bitmap;
+    int lb_bins = 0, lb_cap = 0, lb_n_hot = 0, lb_n_hot_inter = 0, lb_bm_words = 0;
+    int lb_hot_x1000 = 50, lb_min_candidates = 48, lb_max_rounds = 4;
+    size_t lb_lds_bytes = 0;
+    bool lb_attr_set = false;
     // binned item updates (bpr_binned.inc): item -> (bucket, local row), bucket -> items, message segments
     int bin_buckets = 0, bin_neg_population = -1, bin_max_rows = 0, bin_wg_per_cu = 0, bin_n_hot = 0;
     int bin_hot_threshold = 0;
@@ -1446,10 +1455,12 @@ static void build_item_ranks(cornac_hip_bpr_t h) {
 }
 
 static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_population, int flags) {
+    const int form = (flags >> 16) & 15;  // 2 = asked for; 0 = automatic: item tables of >= 2^20 rows
 #ifdef CORNAC_PROFILE
-    flags &= 0xff;  // (profile builds: the ablation bits 8.. are honoured by the strata kernel too)
+    flags &= ~0xff00;  // (profile builds: the ablation bits 8..15 are honoured by the strata kernel too)
 #endif
-    return flags == 0 && neg_population == CORNAC_HIP_NEG_UNIFORM && hogwild_uses_ownership(h, 0) &&
+    if ((flags & 0xffff) != 0 || !(form == 2 || (form == 0 && h->n_items >= (int64_t(1) << 20)))) return false;
+    return neg_population == CORNAC_HIP_NEG_UNIFORM && hogwild_uses_ownership(h, 0) &&
            h->n_items >= 64 && h->hog_offset == 0 && n_samples > 0 && n_samples % h->nnz == 0 &&
            device_info(h->device).xcds == 8;
 }
@@ -1515,14 +1526,160 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_epochs, float lr, float
     }
 }
 
+// ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
+typedef void (*LdsBinKernel)(const LdsBinArgs);
+static LdsBinKernel pick_ldsbin_kernel(int k) {
+#ifdef CORNAC_PROFILE
+    if (k <= 64) switch (prof_env_int("CORNAC_HIP_LDSBIN_UNR", 0)) {
+        case 1: return bpr_ldsbin_kernel<1, 1>;
+        case 2: return bpr_ldsbin_kernel<1, 2>;
+        case 8: return bpr_ldsbin_kernel<1, 8>;
+        default: break;
+    }
+#endif
+    if (k <= 64) return bpr_ldsbin_kernel<1, 4>;
+    if (k <= 128) return bpr_ldsbin_kernel<2, 2>;
+    if (k <= 192) return bpr_ldsbin_kernel<3, 2>;
+    return bpr_ldsbin_kernel<4, 1>;
+}
+
+constexpr size_t kLbLdsBudget = 96 * 1024;   // of the 160 KiB per CU
+constexpr size_t kLbLdsExclusive = 82 * 1024;  // requested at least: two workgroups never share a CU's LDS
+static size_t ldsbin_lds_bytes(int cap, int k) {
+    const int kp = ((k + kWave - 1) / kWave) * kWave;
+    return ((size_t)cap * (kp + 5) + 1) * sizeof(float) + (size_t)kLbWaves * 3 * kWave * sizeof(int32_t);
+}
+
+// bins = the smallest multiple of the CU count whose rows fit the LDS budget; 0 = this shape does not use the form
+static int ldsbin_plan_bins(cornac_hip_bpr_t h) {
+    const int cus = device_info(h->device).cus;
+    if (h->k > 256 || h->nnz < (int64_t)cus * kLbWaves * kWave) return 0;
+    for (int rounds = 1; rounds <= h->lb_max_rounds; ++rounds) {
+        const int64_t bins = (int64_t)cus * rounds;
+        const int64_t cap = (h->n_items + bins - 1) / bins;
+        if (cap < h->lb_min_candidates) return 0;  // negatives would be drawn from too few items
+        if (ldsbin_lds_bytes((int)cap, h->k) <= kLbLdsBudget) return (int)bins;
+    }
+    return 0;
+}
+
+static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_population, int flags) {
+    const int form = (flags >> 16) & 15;
+#ifdef CORNAC_PROFILE
+    flags &= ~0xff00;
+#endif
+    if (!(form == 0 || form == 3) || (flags & 0xffff) != 0) return false;
+    return neg_population == CORNAC_HIP_NEG_UNIFORM && h->hog_offset == 0 && n_samples > 0 && n_samples % h->nnz == 0 &&
+           ldsbin_plan_bins(h) > 0;
+}
+
+static void ldsbin_build(cornac_hip_bpr_t h) {
+    const int bins = ldsbin_plan_bins(h);
+    if (h->lb_built && h->lb_bins == bins) return;
+    build_item_ranks(h);
+    const int64_t ni = h->n_items, nnz = h->nnz, nu = h->n_users;
+    // CSC: users of every item, in user order
+    std::vector<int32_t> cptr((size_t)ni + 1, 0), cusers((size_t)nnz);
+    for (int64_t t = 0; t < nnz; ++t) ++cptr[(size_t)h->h_indices[(size_t)t] + 1];
+    for (int64_t i = 0; i < ni; ++i) cptr[(size_t)i + 1] += cptr[(size_t)i];
+    {
+        std::vector<int32_t> cur(cptr.begin(), cptr.end() - 1);
+        for (int64_t u = 0; u < nu; ++u)
+            for (int32_t p = h->h_indptr[(size_t)u]; p < h->h_indptr[(size_t)u + 1]; ++p)
+                cusers[(size_t)cur[(size_t)h->h_indices[(size_t)p]]++] = (int32_t)u;
+    }
+    // hot items: degree above hot_x1000 / 1000 of a bin's share of the interactions (they would serialise their bin)
+    const double share = (double)nnz / bins;
+    int n_hot = 0;
+    while (n_hot < ni && (double)(cptr[(size_t)h->h_rank_item[(size_t)n_hot] + 1] - cptr[(size_t)h->h_rank_item[(size_t)n_hot]]) * 1000.0 >
+                             share * h->lb_hot_x1000)
+        ++n_hot;
+    std::vector<int32_t> hot_u, hot_i;
+    for (int r = 0; r < n_hot; ++r) {
+        const int32_t it = h->h_rank_item[(size_t)r];
+        for (int32_t p = cptr[(size_t)it]; p < cptr[(size_t)it + 1]; ++p) {
+            hot_u.push_back(cusers[(size_t)p]);
+            hot_i.push_back(it);
+        }
+    }
+    h->lb_cptr.ensure((size_t)ni + 1);
+    h->lb_cusers.ensure((size_t)nnz);
+    h->lb_cptr.upload(cptr.data(), (size_t)ni + 1, h->stream);
+    h->lb_cusers.upload(cusers.data(), (size_t)nnz, h->stream);
+    h->lb_hot_u.ensure(std::max<size_t>(1, hot_u.size()));
+    h->lb_hot_i.ensure(std::max<size_t>(1, hot_i.size()));
+    if (!hot_u.empty()) {
+        h->lb_hot_u.upload(hot_u.data(), hot_u.size(), h->stream);
+        h->lb_hot_i.upload(hot_i.data(), hot_i.size(), h->stream);
+    }
+    // membership bitmap when it fits 2 GiB, else the kernel searches the CSR row
+    const int64_t words = (ni + 31) / 32;
+    h->lb_bm_words = 0;
+    if (nu * words * 4 <= (int64_t(2) << 30)) {
+        h->lb_bm_words = (int)words;
+        h->lb_bitmap.ensure((size_t)(nu * words));
+        HIP_CHECK(hipMemsetAsync(h->lb_bitmap.p, 0, (size_t)(nu * words) * sizeof(uint32_t), h->stream));
+        hipLaunchKernelGGL(ldsbin_bitmap_kernel, dim3((unsigned)((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                           h->user_ids.p, h->indices.p, nnz, h->lb_bm_words, h->lb_bitmap.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->lb_bins = bins;
+    h->lb_cap = (int)((ni + bins - 1) / bins);
+    h->lb_n_hot = n_hot;
+    h->lb_n_hot_inter = (int)hot_u.size();
+    h->lb_lds_bytes = std::max(ldsbin_lds_bytes(h->lb_cap, h->k), kLbLdsExclusive);
+    h->lb_built = true;
+}
+
+static uint32_t ldsbin_key(uint64_t seed, uint32_t epoch) {
+    uint32_t w[4];
+    philox4x32_10(epoch, 0x1D5B1Au, 0u, 4u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    return w[0];
+}
+
+static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float reg, int use_bias, int flags) {
+    a.cptr = h->lb_cptr.p; a.cusers = h->lb_cusers.p; a.rank_item = h->rank_item.p;
+    a.hot_u = h->lb_hot_u.p; a.hot_i = h->lb_hot_i.p;
+    a.indptr = h->indptr.p; a.indices = h->indices.p;
+    a.bitmap = h->lb_bm_words ? h->lb_bitmap.p : nullptr;
+    a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
+    a.counters = h->counters.p;
+    a.seed = h->hog_seed; a.epoch = h->hog_epoch; a.key = ldsbin_key(h->hog_seed, h->hog_epoch);
+    a.n_items = (int32_t)h->n_items; a.n_bins = h->lb_bins; a.n_hot = h->lb_n_hot; a.n_hot_inter = h->lb_n_hot_inter;
+    a.bm_words = h->lb_bm_words; a.cap = h->lb_cap;
+    a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg;
+    a.ablate = (flags >> 8) & 0xff;
+}
+
+// whole epochs only: one launch per epoch, one workgroup per bin
+static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_epochs, float lr, float reg, int use_bias, int flags) {
+    ldsbin_build(h);
+    LdsBinKernel kern = pick_ldsbin_kernel(h->k);
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
+    for (int64_t e = 0; e < n_epochs; ++e) {
+        LdsBinArgs a;
+        ldsbin_fill_args(h, a, lr, reg, use_bias, flags);
+        h->ktimer.before(h->stream);
+        hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
+        h->ktimer.after(h->stream);
+        HIP_CHECK(hipGetLastError());
+        advance_hog_offset(h, h->nnz);
+    }
+}
+
 static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+    if (hogwild_uses_ldsbin(h, n_samples, neg_population, flags)) {
+        ldsbin_enqueue(h, n_samples / h->nnz, lr, reg, use_bias, flags);
+        return;
+    }
     if (hogwild_uses_strata(h, n_samples, neg_population, flags)) {
         strata_enqueue(h, n_samples / h->nnz, lr, reg, use_bias, flags);
         return;
     }
-    flags &= ~128;  // bit7 only opts out of the strata form
+    flags &= 0xffff & ~128;  // bits 16..19 select the form, bit7 only opts out of the LDS-bin / strata forms
     const BinPlan pl = plan_binned(h, flags, lr);
     if (pl.ok) {
         binned_enqueue(h, pl, n_samples, lr, reg, use_bias, neg_population, flags);
@@ -1640,7 +1797,8 @@ int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t
         // the tables of the default throughput path (flags == 0): the strata kernel's grid where that form applies,
         // else the fused kernel's; tables already built for a launch are returned as they are
         if (h->own_waves == 0) {
-            if (hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0)) {
+            if (!hogwild_uses_ldsbin(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0) &&
+                hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0)) {
                 strata_prepare(h);
             } else {
                 HogKernel kern = pick_hogwild_kernel<true>(h->k, 0);
@@ -1697,7 +1855,7 @@ int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *spt
     return guarded([&] {
         bpr_check(h);
         REQUIRE(h->hog_seeded, "seed the hogwild sampler first");
-        REQUIRE(hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 0), "this handle does not use the strata form");
+        REQUIRE(hogwild_uses_strata(h, h->nnz, CORNAC_HIP_NEG_UNIFORM, 2 << 16), "this shape cannot run the strata form");
         const int grid = strata_prepare(h);
         const uint32_t kk = strata_key(h->hog_seed, epoch / (uint32_t)std::max(1, h->strata_rehash_period));
         strata_build_buckets(h, grid, kk);
@@ -1708,6 +1866,34 @@ int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *spt
         if (rank_item) std::copy(h->h_rank_item.begin(), h->h_rank_item.end(), rank_item);
         if (key) *key = kk;
         HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_candidates, int max_rounds) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(hot_x1000 >= 1, "hot_x1000 must be >= 1");
+        REQUIRE(min_candidates >= 1, "min_candidates must be >= 1");
+        REQUIRE(max_rounds >= 1 && max_rounds <= 1024, "max_rounds must be in [1, 1024]");
+        h->lb_hot_x1000 = hot_x1000;
+        h->lb_min_candidates = min_candidates;
+        h->lb_max_rounds = max_rounds;
+        h->lb_built = false;
+    });
+}
+
+int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(out6 != nullptr, "out6 is NULL");
+        const int bins = ldsbin_plan_bins(h);
+        if (bins > 0) ldsbin_build(h);
+        out6[0] = bins;
+        out6[1] = bins ? h->lb_cap : 0;
+        out6[2] = bins ? h->lb_n_hot : 0;
+        out6[3] = bins ? h->lb_n_hot_inter : 0;
+        out6[4] = bins ? h->lb_bm_words : 0;
+        out6[5] = bins ? (int64_t)h->lb_lds_bytes : 0;
     });
 }
 

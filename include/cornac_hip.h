@@ -99,11 +99,15 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
 
 /* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
  * reference's per-epoch counters over the epochs run (either may be NULL).
- * hogwild_flags (0 = default).  With flags 0, uniform negatives, k in 33..256, whole epochs and a matrix large enough
- * for user-row ownership the epoch runs in the XCD-strata form (csrc/bpr_strata.inc: 8 launches per epoch, item rows
- * touched by one XCD per launch and updated by plain read-modify-write like the reference's threads, hot rows and
- * shared users by fp32 atomics); bit7 = opt out of the strata form (every item-row update a device-scope atomic: the
- * fused kernel).  Experiment switches of the fused kernel: bit0 = plain (racy,
+ * hogwild_flags (0 = default).  Bits 16..19 select the form of a whole-epoch hogwild call with uniform negatives:
+ * 0 = automatic, 1 = the fused kernel (every item-row update a device-scope fp32 atomic; also bit7), 2 = XCD strata
+ * (csrc/bpr_strata.inc: 8 launches per epoch, an item row is touched by one XCD per launch and updated by plain
+ * read-modify-write like the reference's threads), 3 = LDS-resident item bins (csrc/bpr_ldsbin.inc: the item rows
+ * of a bin live in one CU's LDS for the epoch, exact updates, user rows by atomics).  Automatic = LDS bins when the
+ * item table fits the LDS in at most max_rounds rounds with at least min_candidates items per bin, else XCD strata
+ * for item tables of >= 2^20 rows, else the fused kernel.  Partial epochs (hogwild_enqueue of a chunk), popularity
+ * negatives and every experiment switch below run the fused kernel.
+ * Experiment switches of the fused kernel: bit0 = plain (racy,
  * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
  * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic);
  * bit4 = (k in 33..64) the four sampling lanes 4g..4g+3 share one negative item and its row gets ONE combined atomic
@@ -140,6 +144,14 @@ int cornac_hip_bpr_strata_config(cornac_hip_bpr_t h, int hot_permille, int hot_m
 int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
 int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
                                 int32_t *rank_item, uint32_t *key);
+/* Tuning and inspection of the LDS-bin form.  ldsbin_config: an item is hot (rows in global memory under atomics, its
+ * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 50);
+ * the form is used when every bin holds at least min_candidates items (default 48: the negative of a draw comes from
+ * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4).  ldsbin_stats: out6 =
+ * {bins (0: the shape does not use the form), LDS rows per bin, hot items, their interactions, bitmap words per user
+ * (0: CSR binary search), dynamic LDS bytes per workgroup}. */
+int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_candidates, int max_rounds);
+int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6);
 /* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
  * stream: returns the summed duration and count of the launches recorded since
  * the previous call, then enables/disables recording for the following ones. */

@@ -512,6 +512,96 @@ int64_t oracle_strata_sample(uint64_t seed, uint32_t epoch, uint32_t key, uint32
     return (int64_t)len;
 }
 
+/* LDS-bin variant of the device sampler (csrc/bpr_ldsbin.inc; restates the HIP path's own integer arithmetic).
+ * Bin b of n_bins holds, for every popularity-rank group g, the item of rank g * n_bins + (b - rot(g)) mod n_bins;
+ * ranks < n_hot are hot (no local positives; their interactions hot_u/hot_i[h], h = b mod n_bins, belong to bin b).
+ * Draw `local` of bin b: counter (local, b, epoch, 0x20); words (0,1) pick the positive among cold_mass + hot_share
+ * interactions, words (2,3) the negative among the bin's slots.  Returns the number of draws whose negative is a
+ * positive of the user (the device's skip counter for the epoch) and the total number of draws. */
+static uint32_t ldsbin_rot(uint32_t g, uint32_t key, uint32_t n_bins) {
+    uint32_t h = g * 0x9E3779B1u + key;
+    h ^= h >> 15; h *= 0x85EBCA77u;
+    h ^= h >> 13; h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h % n_bins;
+}
+
+uint32_t oracle_ldsbin_key(uint64_t seed, uint32_t epoch) {
+    uint32_t w[4];
+    oracle_philox4x32(epoch, 0x1D5B1Au, 0u, 4u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    return w[0];
+}
+
+static int csr_has(const int32_t *indices, int32_t lo, int32_t hi, int32_t col) {
+    const int32_t end = hi;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if (indices[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo < end && indices[lo] == col;
+}
+
+int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
+                                  uint32_t n_hot, const int32_t *rank_item, const int32_t *cptr, const int32_t *cusers,
+                                  const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
+                                  const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count) {
+    const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
+    int32_t *item = (int32_t *)malloc(sizeof(int32_t) * n_groups);
+    int32_t *cp = (int32_t *)malloc(sizeof(int32_t) * n_groups);
+    uint32_t *cum = (uint32_t *)malloc(sizeof(uint32_t) * (n_groups + 1));
+    uint8_t *hot = (uint8_t *)malloc(n_groups);
+    int64_t skipped = 0, total = 0;
+    for (uint32_t b = 0; b < n_bins; ++b) {
+        uint32_t n_slots = n_groups;
+        cum[0] = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const uint32_t code = g * n_bins + (b + n_bins - ldsbin_rot(g, key, n_bins)) % n_bins;
+            uint32_t d = 0;
+            item[g] = -1; cp[g] = 0; hot[g] = 0;
+            if (code < n_items) {
+                item[g] = rank_item[code];
+                cp[g] = cptr[item[g]];
+                hot[g] = code < n_hot;
+                if (!hot[g]) d = (uint32_t)(cptr[item[g] + 1] - cp[g]);
+            }
+            cum[g + 1] = cum[g] + d;
+        }
+        if (n_groups && item[n_groups - 1] == -1) n_slots = n_groups - 1;
+        const uint32_t cold_mass = cum[n_groups];
+        const uint32_t hot_share = n_hot_inter > b ? (n_hot_inter - b + n_bins - 1) / n_bins : 0u;
+        const uint32_t n_draws = n_slots ? cold_mass + hot_share : 0u;
+        if (!n_slots) skipped += cold_mass + hot_share;
+        total += cold_mass + hot_share;
+        for (uint32_t local = 0; local < n_draws; ++local) {
+            uint32_t w[4];
+            oracle_philox4x32(local, b, epoch, 0x20u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            const uint32_t r_pos = lemire_bounded2(w[0], w[1], n_draws);
+            const uint32_t s_j = lemire_bounded2(w[2], w[3], n_slots);
+            int32_t u, i;
+            if (r_pos < cold_mass) {
+                uint32_t lo = 0, hi = n_slots;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (cum[mid] <= r_pos) lo = mid; else hi = mid;
+                }
+                i = item[lo];
+                u = cusers[cp[lo] + (int32_t)(r_pos - cum[lo])];
+            } else {
+                const uint32_t h = b + n_bins * (r_pos - cold_mass);
+                u = hot_u[h];
+                i = hot_i[h];
+            }
+            const int32_t j = item[s_j];
+            if (csr_has(indices, indptr[u], indptr[u + 1], j)) { ++skipped; continue; }
+            if (pos_count) ++pos_count[i];
+            if (neg_count) ++neg_count[j];
+        }
+    }
+    free(item); free(cp); free(cum); free(hot);
+    if (n_draws_out) *n_draws_out = total;
+    return skipped;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

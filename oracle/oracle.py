@@ -95,6 +95,12 @@ def _bind(L):
         L.oracle_strata_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_uint32, i64p, i64p]
         L.oracle_strata_sample.restype = C.c_int64
+        L.oracle_ldsbin_key.argtypes = [C.c_uint64, C.c_uint32]
+        L.oracle_ldsbin_key.restype = C.c_uint32
+        L.oracle_ldsbin_epoch_skips.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i32p,
+                                                i32p, i32p, i32p, i32p, C.c_uint32, i32p, i32p, C.POINTER(C.c_int64),
+                                                C.c_void_p, C.c_void_p]
+        L.oracle_ldsbin_epoch_skips.restype = C.c_int64
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
     return L
@@ -420,6 +426,41 @@ def strata_buckets(wave_ptr, own_u, own_i, deg, key, n_hot):
     rec_i = own_i[order].astype(np.int64)
     rec_i = np.where(code[order] < n_hot, rec_i | 0x80000000, rec_i).astype(np.uint32).view(np.int32)
     return sptr, rec_u, rec_i, rank_item
+
+
+def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False):
+    """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
+    positive touches per item, negative touches per item])."""
+    import scipy.sparse as sp
+
+    indptr = np.ascontiguousarray(indptr, np.int32)
+    indices = np.ascontiguousarray(indices, np.int32)
+    nnz, n_users = len(indices), len(indptr) - 1
+    X = sp.csr_matrix((np.ones(nnz, np.int8), indices, indptr), shape=(n_users, n_items)).tocsc()
+    X.sort_indices()
+    cptr, cusers = X.indptr.astype(np.int32), X.indices.astype(np.int32)
+    deg = np.diff(cptr)
+    rank_item = np.argsort(-deg.astype(np.int64), kind="stable").astype(np.int32)
+    share = nnz / n_bins
+    n_hot = 0
+    while n_hot < n_items and deg[rank_item[n_hot]] * 1000.0 > share * hot_x1000:
+        n_hot += 1
+    hot_u = np.concatenate([cusers[cptr[i]:cptr[i + 1]] for i in rank_item[:n_hot]] + [np.zeros(0, np.int32)]).astype(np.int32)
+    hot_i = np.repeat(rank_item[:n_hot], deg[rank_item[:n_hot]]).astype(np.int32)
+    if len(hot_u) == 0:
+        hot_u = hot_i = np.zeros(1, np.int32)
+        n_hot_inter = 0
+    else:
+        n_hot_inter = len(hot_u)
+    key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)))
+    draws = C.c_int64()
+    pos = np.zeros(n_items, np.int64) if count_touches else None
+    neg = np.zeros(n_items, np.int64) if count_touches else None
+    s = lib().oracle_ldsbin_epoch_skips(int(seed), int(epoch), key, int(n_bins), int(n_items), int(n_hot), rank_item,
+                                        cptr, cusers, np.ascontiguousarray(hot_u), np.ascontiguousarray(hot_i),
+                                        int(n_hot_inter), indptr, indices, C.byref(draws),
+                                        pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None)
+    return (int(s), int(draws.value), n_hot) + ((pos, neg) if count_touches else ())
 
 
 def hogwild_sample_owned(seed, epoch, wave_id, length, n_neg, lo, hi):

@@ -185,7 +185,7 @@ def test_owned_sampler_and_ownership_tables(oracle):
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
     seed = 0x1234ABCD5678
     tr.seed_hogwild(seed)
-    # bit 7 = the fused kernel (flags 0 would run the XCD-strata form, whose sampler has its own test below)
+    # bit 7 = the fused kernel whatever the shape (the LDS-bin and XCD-strata samplers have their own tests below)
     c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=128)
     own = tr.debug_ownership()  # the tables the two epochs used
     assert own is not None, "expected the ownership kernel for k=64, nnz=700k"
@@ -223,7 +223,7 @@ def test_owned_sampler_and_ownership_tables(oracle):
 
 
 def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
-    """The XCD-strata form (csrc/bpr_strata.inc, the default for k = 64 at this size): the partition buckets the device
+    """The XCD-strata form (csrc/bpr_strata.inc; hogwild_flags form 2): the partition buckets the device
     deals for an epoch equal the CPU restatement (popularity ranks, rotation hash, stable counting sort of every wave
     slice, hot marks) bit for bit, every partition holds one item of every rank group, and with lr = 0 the device's
     skip counter over two epochs equals the restated sampler's count — integer work, exact."""
@@ -238,9 +238,9 @@ def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
     seed = 0xABCDEF0123
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
     tr.seed_hogwild(seed)
-    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
     st = tr.strata_stats()
-    assert st["waves"] > 0 and st["bucket_builds"] == 2, "flags 0 must run the strata form here: %r" % (st,)
+    assert st["waves"] > 0 and st["bucket_builds"] == 2, "form 2 must run the strata kernel here: %r" % (st,)
     assert st["misplaced_workgroups"] == 0, "dispatcher placed workgroups off blockIdx % 8: " + repr(st)
     wave_ptr, own_u, own_i = tr.debug_ownership()
     W = len(wave_ptr) - 1
@@ -272,6 +272,73 @@ def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
     assert 0 < st["n_hot"] < n_items // 4
 
 
+def _ldsbin_case(n_users=6000, n_items=3003, nnz=700_000, zipf=0.8, seed=3):
+    from cornac_amd import synth
+
+    users, items = synth.zipf_interactions(n_users, n_items, nnz, zipf, seed)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    return n_users, n_items, indptr, indices
+
+
+def test_ldsbin_sampler_matches_its_cpu_restatement(oracle):
+    """The LDS-bin form (csrc/bpr_ldsbin.inc): with lr = 0 the device's skip counter over two epochs equals the CPU
+    restatement of the bin deal + sampler (integer work, exact), the draws are nnz per epoch, and the factors are
+    returned untouched (rows went through the LDS and back)."""
+    n_users, n_items, indptr, indices = _ldsbin_case()
+    nnz = len(indices)
+    seed = 0xABCDEF0123
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
+    tr.ldsbin_config(hot_x1000=50, min_candidates=8)  # 3003 items / 256 bins: ~12 items per bin
+    st = tr.ldsbin_stats()
+    assert st["bins"] == 256 and st["rows_per_bin"] == 12 and st["bitmap_words"] == (n_items + 31) // 32, st
+    rs = np.random.RandomState(0)
+    U = rs.normal(0, 0.1, (n_users, 64)).astype(np.float32)
+    V = rs.normal(0, 0.1, (n_items, 64)).astype(np.float32)
+    B = rs.normal(0, 0.1, n_items).astype(np.float32)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(seed)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_LDSBIN)
+    U2, V2, B2 = tr.get_factors()
+    tr.close()
+    want = 0
+    for epoch in range(2):
+        sk, draws, n_hot = oracle.ldsbin_epoch(seed, epoch, 256, 50, indptr, indices, n_items)
+        assert draws == nnz and n_hot == st["n_hot"]
+        want += sk
+    assert s == want
+    assert np.array_equal(V2, V) and np.array_equal(B2, B) and np.array_equal(U2, U)
+
+
+def test_ldsbin_updates_are_exact_and_learn_like_the_fused_kernel(oracle):
+    """Every item-row update of the LDS-bin form is applied exactly once (LDS read-modify-write under the row lock, hot
+    rows and user rows by atomics): with reg = 0 a triplet adds +d to row i and -d to row j, so the column sums of V and
+    the sum of B are conserved, and the per-item touch counts equal the CPU restatement's.  Same optimisation problem
+    as the fused atomic kernel: same 'correct' fraction within noise."""
+    n_users, n_items, indptr, indices = _ldsbin_case(20000, 3003, 2_500_000, 0.8, 3)
+    k = 64
+    rs = np.random.RandomState(0)
+    U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
+    out = {}
+    for flags in (_lib.FORM_LDSBIN, _lib.FORM_FUSED):
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.ldsbin_config(min_candidates=8)
+        tr.set_factors(U, V, np.zeros(n_items, np.float32))
+        tr.seed_hogwild(9)
+        tr.fit_epochs(6, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        out[flags] = (c / (len(indices) - s), s, tr.get_factors())
+        tr.close()
+    a, f = out[_lib.FORM_LDSBIN], out[_lib.FORM_FUSED]
+    assert abs(a[0] - f[0]) < 0.015, (a[0], f[0])
+    for res in (a, f):
+        V2, B2 = res[2][1], res[2][2]
+        assert np.isfinite(V2).all() and np.abs(V2 - V).max() > 1e-3
+        moved = np.abs(V2.astype(np.float64) - V).sum(0)
+        assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+        assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
+
+
 def test_owned_kernel_user_rows_are_exact():
     """With reg = 0 and lr > 0 the only writers of an exclusive user's row are its owner wave's
     plain stores (incl. the same-user merge inside a batch).  Conservation check: for every
@@ -288,7 +355,7 @@ def test_owned_kernel_user_rows_are_exact():
     U0 = rs.normal(0, 0.1, (n_users, 64)).astype(np.float32)
     V0 = rs.normal(0, 0.1, (n_items, 64)).astype(np.float32)
     res = []
-    for flags in (128, 4, 0):  # ownership (fused kernel) vs all-atomic vs the XCD-strata form (same ownership of U rows)
+    for flags in (128, 4, _lib.FORM_STRATA):  # ownership (fused kernel) vs all-atomic vs the XCD-strata form (same ownership of U rows)
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
         tr.set_factors(U0, V0, np.zeros(n_items, np.float32))
         tr.seed_hogwild(77)

@@ -59,17 +59,21 @@ def test_deterministic_full_epoch_matches_sequential_oracle(oracle, ml20m):
     assert np.mean(Ud == U) > 0.99, "expected (almost) bit-identical user factors"
 
 
-def test_hogwild_full_size_invariants(ml20m):
-    """Size-independent properties of the throughput kernel at full size: with reg = 0 every
-    triplet's item-row deltas cancel (dV_i = -dV_j, dB_i = -dB_j), so the column sums of V and the sum
-    of B are conserved by exact (atomic) updates; the counters cover exactly nnz draws per epoch."""
+@pytest.mark.parametrize("form", ["ldsbin", "fused"])
+def test_hogwild_full_size_invariants(ml20m, form):
+    """Size-independent properties of the throughput kernels at full size: with reg = 0 every triplet's item-row deltas
+    cancel (dV_i = -dV_j, dB_i = -dB_j), so the column sums of V and the sum of B are conserved by exact updates —
+    the LDS-bin form (the default at this shape: LDS read-modify-writes under row locks) and the fused kernel (fp32
+    atomics) both apply every update exactly once; the counters cover exactly nnz draws per epoch."""
     n_users, n_items, indptr, indices, init_factors = ml20m
     k = 64
     U, V, B = init_factors(n_users, n_items, k, 3)
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    if form == "ldsbin":
+        assert tr.ldsbin_stats()["bins"] == 256, "the default form at the ML-20M shape must be the LDS-bin kernel"
     tr.set_factors(U, V, B)
     tr.seed_hogwild(2024)
-    c, s = tr.fit_epochs(2, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=128)  # bit 7: every update atomic
+    c, s = tr.fit_epochs(2, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=0 if form == "ldsbin" else _lib.FORM_FUSED)
     U2, V2, B2 = tr.get_factors()
     tr.close()
     nnz = len(indices)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the XCD-strata BPR epoch (csrc/bpr_strata.inc) against the fused atomic kernel at the ML-20M shape.
 
-An arm is a dash-separated spec: `atomic` (hogwild_flags bit 7: the fused kernel), `strata` (the default), then
+An arm is a dash-separated spec: `atomic` (the fused kernel), `strata`, `ldsbin` (the form, hogwild_flags bits 16..19), then `uN` (LDS-bin triplets in flight, profile build), `xN` (LDS-bin hot_x1000),
 `hN` (hot_permille), `mN` (hot_min_mult_x100), `rN` (rehash period), `vN` (kernel variant, profile build),
 `ablN` (ablation bits, profile build).  Run with CORNAC_HIP_PROFILE=1 for the v / abl tokens.
 Per arm: ms per epoch by HIP events (sum of the epoch's launches) and by wall clock, the 'correct' fraction of the last
@@ -47,9 +47,15 @@ def parse(spec):
     flags, cfg, env = 0, {}, {}
     for tok in spec.split("-"):
         if tok == "atomic":
-            flags |= 128
+            flags |= _lib.FORM_FUSED
         elif tok == "strata":
-            pass
+            flags |= _lib.FORM_STRATA
+        elif tok == "ldsbin":
+            flags |= _lib.FORM_LDSBIN
+        elif tok.startswith("u"):
+            env["CORNAC_HIP_LDSBIN_UNR"] = tok[1:]
+        elif tok.startswith("x"):
+            cfg["hot_x1000"] = int(tok[1:])
         elif tok.startswith("abl"):
             flags |= int(tok[3:]) << 8
         elif tok.startswith("h"):
@@ -67,8 +73,11 @@ def parse(spec):
 
 def make(flags, cfg, env):
     os.environ.pop("CORNAC_HIP_STRATA_VARIANT", None)
+    os.environ.pop("CORNAC_HIP_LDSBIN_UNR", None)
     os.environ.update(env)
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    if "hot_x1000" in cfg:
+        tr.ldsbin_config(hot_x1000=cfg.pop("hot_x1000"))
     if cfg:
         tr.strata_config(**cfg)
     U, V, B = bench.init_factors(n_users, n_items, k, 100)
@@ -109,6 +118,7 @@ for name in args.arms.split(","):
     dt = time.perf_counter() - t0
     kms, launches = tr.kernel_timing(False)
     st = tr.strata_stats()
+    lb = tr.ldsbin_stats() if (flags >> 16) in (0, 3) else None
     tr.close()
     n_ep = args.epochs - 1
     # lossless-ness: column sums of V under reg = 0
@@ -119,7 +129,7 @@ for name in args.arms.split(","):
     moved = np.abs(V2.astype(np.float64) - V).sum(0)
     drift = np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0))
     print("%-20s kernel %.3f ms/epoch (%d launches, %.3f ms each)  wall %.3f ms/epoch = %.3f G triplets/s | correct %.4f "
-          "skipped %.4f | probe %s | colsum drift/moved %.2e | hot %d misplaced %d builds %d"
+          "skipped %.4f | probe %s | colsum drift/moved %.2e | hot %d misplaced %d builds %d | %s"
           % (name, kms / n_ep, launches // n_ep, kms / max(launches, 1), 1e3 * dt / n_ep, nnz * n_ep / dt / 1e9,
              c / max(nnz - s, 1), s / nnz, "  ".join(lines), float((drift / moved.max()).max()), st["n_hot"],
-             st["misplaced_workgroups"], st["bucket_builds"]), flush=True)
+             st["misplaced_workgroups"], st["bucket_builds"], lb), flush=True)
