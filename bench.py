@@ -433,7 +433,10 @@ def leg_bpr_k128_scale(args, _lib):
     tr.close()
     b_full, b_skip = algorithmic_bytes_per_triplet(k, d)
     skip = sk / float(nnz * epochs)
-    bytes_launch = nnz * ((1 - skip) * b_full + skip * b_skip)
+    # an epoch is one launch of the fused kernel or 8 partition launches of the XCD-strata form (the automatic choice for
+    # item tables of >= 2^20 rows): bytes per launch = the epoch's bytes x epochs / launches recorded
+    bytes_launch = nnz * ((1 - skip) * b_full + skip * b_skip) * epochs / max(launches, 1)
+    strata = launches == 8 * epochs
     out = {"metric": "bpr_triplets_per_sec", "value": nnz * epochs / dt, "unit": "triplets/s", "steps": epochs,
            "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BPR k=%d on one GPU's user slice of the 100 M x 10 M synthetic (%d users x %d items, "
@@ -442,7 +445,8 @@ def leg_bpr_k128_scale(args, _lib):
            "roofline": {"bound": "hbm", "achieved": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>", "launches": launches,
+                        "kernel": "bpr_strata_kernel<2,2>" if strata else "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>",
+                        "launches": launches,
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
            "train_stats": {"correct_frac": c / max(nnz * epochs - sk, 1), "skipped_frac": skip},
            "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
@@ -564,6 +568,20 @@ def dry_run(args):
                           "config": {"workload": "dry run of the launcher (no GPU work)", "parallelism": "dp%d" % world}}))
 
 
+SAMPLING = {
+    "ldsbin": "every draw picks an interaction with the reference's probability 1 / nnz (nnz draws per epoch); the negative is "
+              "uniform over the ~n_items / bins items dealt to the positive's LDS bin in that epoch (bins re-dealt every epoch by "
+              "popularity-rank groups, so every bin carries the same popularity mass) instead of uniform over all items; item "
+              "updates exact (LDS read-modify-write under a row lock), user rows and hot item rows by fp32 atomics",
+    "strata": "stratified by user ownership (every wave draws its positives i.i.d. from its own users' interactions) and by XCD "
+              "item partition (8 partitions re-dealt every epoch; the negative is uniform inside the positive's partition); "
+              "item rows by plain read-modify-write inside one XCD (racy like the reference's threads)",
+    "fused": "stratified by user ownership: every wave of the persistent grid draws its positives i.i.d. from its own users' "
+             "interactions (len(slice) draws per epoch), negatives uniform over all items - not the reference's single global "
+             "draw stream; every item-row update a device-scope fp32 atomic",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,6 +652,12 @@ def main():
         V, B = init_factors(n_users, n_items, k, 100)[1:]  # identical item table on every rank
     trainer.set_factors(U, V, B)
     trainer.seed_hogwild(0xC0FFEE + 7919 * rank)
+    # the form a whole-epoch call with these flags takes (include/cornac_hip.h: hogwild_flags bits 16..19)
+    trainer_stats = {"ldsbin": trainer.ldsbin_stats()}
+    sel = (args.flags >> 16) & 15
+    form = ("fused" if (args.flags & 0xffff) or sel == 1 or distributed else
+            "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
+            "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 
     sharded = None
     if distributed and args.sharded_items:
@@ -692,9 +716,8 @@ def main():
         "config": {"workload": "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
                                "GPU), hogwild mode, fp32 tables resident in HBM" % (k, n_users, n_items, nnz),
                    "k": k, "lr": args.lr, "reg": args.reg, "hogwild_flags": args.flags,
-                   "sampling": "stratified by user ownership: every wave of the persistent grid draws its positives i.i.d. "
-                               "from its own users' interactions (len(slice) draws per epoch), negatives uniform over all "
-                               "items - not the reference's single global draw stream",
+                   "form": form,
+                   "sampling": SAMPLING[form],
                    "parallelism": "1 gpu" if world == 1 and not distributed else
                                   ("user-partitioned dp%d, item table sharded by row, all-to-all every %d draws"
                                    % (world, args.micro_batch)) if args.sharded_items else
@@ -712,8 +735,10 @@ def main():
         bytes_per_launch = draws_per_launch * ((1.0 - skip_frac) * b_full + skip_frac * b_skip)
         avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else None
-        kernel_name = ("bpr_hogwild_rowwise_kernel<64,1,4,atomic,owned>" if not args.sharded_items
-                       else "sample/apply kernels of the row-sharded path (no fused SGD kernel)")
+        kernel_name = ("sample/apply kernels of the row-sharded path (no fused SGD kernel)" if args.sharded_items else
+                       "bpr_ldsbin_kernel<%d,%d>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]) if form == "ldsbin" else
+                       "bpr_strata_kernel<%d>" % ((k + 63) // 64) if form == "strata" else
+                       "bpr_hogwild_rowwise_kernel<64,%d,%d,atomic,owned>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]))
         # counter-measured traffic is only quoted for the kernel + workload it was taken on (profiles/traffic.json
         # names both); any other launch configuration reports null rather than a stale number
         traffic = None
@@ -734,10 +759,19 @@ def main():
                            "kernel": kernel_name, "launches": launches,
                            "avg_launch_ms": 1e3 * avg_launch_s, "algorithmic_bytes_per_triplet": b_full,
                            "skip_fraction": skip_frac}
-        if achieved and not args.sharded_items and k == 64 and args.flags == 0:
-            # what actually bounds the kernel: every processed triplet issues 10.04 64-byte fp32 atomic
-            # requests (TCC_ATOMIC counters, profiles/r02_sgd_pmc.csv: all forwarded to the memory side); the chip
-            # retires ~10 G 128-byte atomic line-touches/s = ~20 G such requests/s in tools/atomic_probe.hip
+        if achieved and form == "ldsbin":
+            # what bounds the LDS-bin kernel: item rows never leave the LDS, every processed triplet still
+            # issues the 64-byte fp32 atomic requests of its user row (k / 16) plus those of the hot item rows
+            lb = trainer_stats["ldsbin"]
+            req_per = k / 16.0 + (lb["hot_interactions"] / float(nnz)) * (k / 16.0 + 1.0)
+            req = (n_draws - skipped) / max(launches, 1) * req_per / avg_launch_s / 1e9
+            out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules) of the user rows and the hot item rows",
+                                          "requests_per_triplet": req_per, "achieved_G_per_s": req, "probe_ceiling_G_per_s": 20.0,
+                                          "frac_of_probe_ceiling": req / 20.0, "bins": lb["bins"], "rows_per_bin": lb["rows_per_bin"],
+                                          "hot_items": lb["n_hot"], "evidence": "profiles/r03_sgd_pmc.csv, profiles/r01_pmc_calibration.txt"}
+        elif achieved and form == "fused" and k == 64:
+            # every processed triplet issues 10.04 64-byte fp32 atomic requests (TCC_ATOMIC counters, profiles/r02_sgd_pmc.csv:
+            # all forwarded to the memory side); the chip retires ~20 G such requests/s in tools/atomic_probe.hip
             req = (n_draws - skipped) / max(launches, 1) * 10.04 / avg_launch_s / 1e9
             out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules)", "requests_per_triplet": 10.04,
                                           "achieved_G_per_s": req, "probe_ceiling_G_per_s": 20.0, "frac_of_probe_ceiling": req / 20.0,

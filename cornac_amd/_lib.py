@@ -401,14 +401,14 @@ class BprTrainer:
                                                    oi.ctypes.data))
         return wp, ou, oi
 
-    def ldsbin_config(self, hot_x1000=50, min_candidates=48, max_rounds=4):
+    def ldsbin_config(self, hot_x1000=100, min_candidates=48, max_rounds=4):
         check(lib().cornac_hip_bpr_ldsbin_config(self.h, int(hot_x1000), int(min_candidates), int(max_rounds)))
 
     def ldsbin_stats(self):
-        o = (C.c_int64 * 6)()
+        o = (C.c_int64 * 7)()
         check(lib().cornac_hip_bpr_ldsbin_stats(self.h, o))
         return {"bins": o[0], "rows_per_bin": o[1], "n_hot": o[2], "hot_interactions": o[3], "bitmap_words": o[4],
-                "lds_bytes": o[5]}
+                "lds_bytes": o[5], "lock_timeouts": o[6]}
 
     def strata_config(self, hot_permille=120, hot_min_mult_x100=200, rehash_period=1):
         check(lib().cornac_hip_bpr_strata_config(self.h, int(hot_permille), int(hot_min_mult_x100), int(rehash_period)))

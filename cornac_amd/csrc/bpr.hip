@@ -715,9 +715,10 @@ struct cornac_hip_bpr {
     DevBuf<int32_t> lb_cptr, lb_cusers, lb_hot_u, lb_hot_i;
     DevBuf<uint32_t> lb_bitmap;
     int lb_bins = 0, lb_cap = 0, lb_n_hot = 0, lb_n_hot_inter = 0, lb_bm_words = 0;
-    int lb_hot_x1000 = 50, lb_min_candidates = 48, lb_max_rounds = 4;
+    int lb_hot_x1000 = 100, lb_min_candidates = 48, lb_max_rounds = 4;
     size_t lb_lds_bytes = 0;
     bool lb_attr_set = false;
+    int64_t lb_lock_timeouts = 0;
     // binned item updates (bpr_binned.inc): item -> (bucket, local row), bucket -> items, message segments
     int bin_buckets = 0, bin_neg_population = -1, bin_max_rows = 0, bin_wg_per_cu = 0, bin_n_hot = 0;
     int bin_hot_threshold = 0;
@@ -1718,6 +1719,7 @@ static void fetch_counters(cornac_hip_bpr_t h, int64_t *correct, int64_t *skippe
     if (correct) *correct += (int64_t)c[0];
     if (skipped) *skipped += (int64_t)c[1];
     h->strata_misplaced += (int64_t)c[2];
+    h->lb_lock_timeouts += (int64_t)c[3];
 }
 
 extern "C" {
@@ -1885,7 +1887,8 @@ int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_cand
 int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6) {
     return guarded([&] {
         bpr_check(h);
-        REQUIRE(out6 != nullptr, "out6 is NULL");
+        REQUIRE(out6 != nullptr, "out7 is NULL");
+        out6[6] = h->lb_lock_timeouts;
         const int bins = ldsbin_plan_bins(h);
         if (bins > 0) ldsbin_build(h);
         out6[0] = bins;

@@ -145,13 +145,14 @@ int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
 int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
                                 int32_t *rank_item, uint32_t *key);
 /* Tuning and inspection of the LDS-bin form.  ldsbin_config: an item is hot (rows in global memory under atomics, its
- * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 50);
+ * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 100);
  * the form is used when every bin holds at least min_candidates items (default 48: the negative of a draw comes from
- * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4).  ldsbin_stats: out6 =
+ * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4).  ldsbin_stats: out7 =
  * {bins (0: the shape does not use the form), LDS rows per bin, hot items, their interactions, bitmap words per user
- * (0: CSR binary search), dynamic LDS bytes per workgroup}. */
+ * (0: CSR binary search), dynamic LDS bytes per workgroup, row-lock spins that hit their bound since create (0
+ * unless there is a bug: fetched with the epoch counters)}. */
 int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_candidates, int max_rounds);
-int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6);
+int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out7);
 /* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
  * stream: returns the summed duration and count of the launches recorded since
  * the previous call, then enables/disables recording for the following ones. */
