@@ -516,7 +516,7 @@ int64_t oracle_strata_sample(uint64_t seed, uint32_t epoch, uint32_t key, uint32
  * Bin b of n_bins holds, for every popularity-rank group g, the item of rank g * n_bins + (b - rot(g)) mod n_bins;
  * ranks < n_hot are hot (no local positives; their interactions hot_u/hot_i[h], h = b mod n_bins, belong to bin b).
  * Draw `local` of bin b: counter (local, b, epoch, 0x20); words (0,1) pick the positive among cold_mass + hot_share
- * interactions, words (2,3) the negative among the bin's slots.  Returns the number of draws whose negative is a
+ * interactions, words (2,3) the negative among the bin's OTHER slots (all slots for a hot positive).  Returns the number of draws whose negative is a
  * positive of the user (the device's skip counter for the epoch) and the total number of draws. */
 static uint32_t ldsbin_rot(uint32_t g, uint32_t key, uint32_t n_bins) {
     uint32_t h = g * 0x9E3779B1u + key;
@@ -576,7 +576,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
             uint32_t w[4];
             oracle_philox4x32(local, b, epoch, 0x20u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
             const uint32_t r_pos = lemire_bounded2(w[0], w[1], n_draws);
-            const uint32_t s_j = lemire_bounded2(w[2], w[3], n_slots);
+            uint32_t s_j;
             int32_t u, i;
             if (r_pos < cold_mass) {
                 uint32_t lo = 0, hi = n_slots;
@@ -586,10 +586,13 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
                 }
                 i = item[lo];
                 u = cusers[cp[lo] + (int32_t)(r_pos - cum[lo])];
+                s_j = n_slots > 1 ? lemire_bounded2(w[2], w[3], n_slots - 1) : 0u;  /* the other slots of the bin */
+                if (n_slots > 1 && s_j >= lo) ++s_j;
             } else {
                 const uint32_t h = b + n_bins * (r_pos - cold_mass);
                 u = hot_u[h];
                 i = hot_i[h];
+                s_j = lemire_bounded2(w[2], w[3], n_slots);
             }
             const int32_t j = item[s_j];
             if (csr_has(indices, indptr[u], indptr[u + 1], j)) { ++skipped; continue; }
