@@ -7,7 +7,7 @@ there is no CPU fallback.
 """
 from .data import Dataset, FeatureModality, ImageModality, PurchaseViewDataset
 from .reader import Reader
-from .recommender import Recommender, ScoreException
+from .recommender import Recommender, ScoreException, adopt_reference_classes
 from .bpr import BPR, WBPR, VEBPR
 from .mf import MF
 from .vbpr import VBPR
@@ -15,5 +15,5 @@ from .wmf import WMF
 from .experiment import BaseMethod, CrossValidation, CVResult, Experiment, RatioSplit, Result, StratifiedSplit
 from . import eval, metrics  # noqa: A004,F401
 
-__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "FeatureModality", "ImageModality", "RatioSplit", "StratifiedSplit", "CrossValidation", "CVResult", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
+__all__ = ["Dataset", "PurchaseViewDataset", "Reader", "FeatureModality", "ImageModality", "RatioSplit", "StratifiedSplit", "CrossValidation", "CVResult", "BaseMethod", "Experiment", "Result", "Recommender", "ScoreException", "adopt_reference_classes", "BPR", "WBPR", "VEBPR", "MF", "VBPR", "WMF"]
 __version__ = "0.1.0"

@@ -21,12 +21,53 @@ from glob import glob
 import numpy as np
 
 
-class CornacException(Exception):
+class _ExceptionRoot(Exception):
+    """(a Python-level root so that adopt_reference_classes() can re-base the two exceptions below)"""
+
+
+class CornacException(_ExceptionRoot):
     """cornac/exception.py:16-20"""
 
 
 class ScoreException(CornacException):
     """Raised by score() for unknown users/items (cornac/exception.py:22-26)."""
+
+
+class _RecommenderRoot:
+    """(a Python-level root so that adopt_reference_classes() can re-base Recommender)"""
+
+
+_adopted = False
+
+
+def adopt_reference_classes():
+    """Class identity with the reference, where the reference is importable (the boundary is the class).
+
+    The reference keeps only `isinstance(model, cornac.models.Recommender)` objects in an `Experiment`
+    (cornac/experiment/experiment.py:90-100), `BaseSearch` is itself a `Recommender` wrapping one
+    (cornac/hyperopt.py:96-183), and its evaluators catch `cornac.exception.ScoreException`
+    (cornac/eval_methods/base_method.py, cornac/models/recommender.py:447-474).  When `cornac.models.recommender` is
+    loaded in this process, this re-bases `cornac_amd.Recommender` on the reference's class and the two exceptions on
+    the reference's, so every cornac_amd model IS a `cornac.models.Recommender` and what it raises IS a
+    `cornac.exception.ScoreException`.  Every method of the mirror overrides the reference's, so behaviour does not
+    change.  Called at import and whenever a model is constructed; a no-op without the reference (the GPU box)."""
+    global _adopted
+    if _adopted:
+        return True
+    import sys
+
+    rec = sys.modules.get("cornac.models.recommender")
+    exc = sys.modules.get("cornac.exception")
+    if rec is None or exc is None or not hasattr(rec, "Recommender"):
+        return False
+    try:
+        CornacException.__bases__ = (exc.CornacException,)
+        ScoreException.__bases__ = (exc.ScoreException, CornacException)
+        Recommender.__bases__ = (rec.Recommender,)
+    except (TypeError, AttributeError):  # an incompatible class layout: stay the standalone mirror
+        return False
+    _adopted = True
+    return True
 
 
 def clip(values, lower_bound, upper_bound):
@@ -36,11 +77,12 @@ def clip(values, lower_bound, upper_bound):
     return values
 
 
-class Recommender:
+class Recommender(_RecommenderRoot):
     # what prediction needs to remember about the training set (recommender.py:330-337)
     _DATASET_FACTS = ("num_users", "num_items", "uid_map", "iid_map", "min_rating", "max_rating", "global_mean")
 
     def __init__(self, name, trainable=True, verbose=False):
+        adopt_reference_classes()
         self.name = name
         self.trainable = trainable
         self.verbose = verbose
@@ -341,3 +383,6 @@ class Recommender:
             ranked = ranked[:k]
         names = self.item_ids
         return [names[i] for i in ranked]
+
+
+adopt_reference_classes()

@@ -81,6 +81,48 @@ def test_reference_eval_method_runs_our_models(device_double):
     assert np.allclose(reports[0], reports[1], atol=3e-3), reports
 
 
+def test_reference_experiment_and_gridsearch_keep_our_models(device_double, capsys):
+    """Class identity: with the reference loaded, cornac_amd models ARE cornac.models.Recommender, so the
+    reference's OWN Experiment (experiment.py:90-100 keeps only isinstance(model, Recommender) objects) runs them and its
+    GridSearch (hyperopt.py:96-183, itself a Recommender around a model) tunes them; reports equal the reference
+    models' under the same seeds.  What our models raise is the reference's ScoreException."""
+    import importlib
+
+    import cornac_amd as ca
+
+    ns = ref_loader.load()
+    assert ca.adopt_reference_classes()
+    exc = importlib.import_module("cornac.exception")
+    assert issubclass(ca.Recommender, ns.Recommender) and issubclass(ca.ScoreException, exc.ScoreException)
+    assert isinstance(ca.BPR(), ns.Recommender) and isinstance(ca.MF(), ns.Recommender)
+    Experiment = importlib.import_module("cornac.experiment").Experiment
+    hyperopt = importlib.import_module("cornac.hyperopt")
+    rm = ns.metrics
+    RatioSplit = ns.eval_methods.RatioSplit
+    data = _data(7, nu=80, ni=50, n=2200)
+    kw = dict(k=6, max_iter=10, learning_rate=0.03, lambda_reg=0.01, seed=5)
+    reports = []
+    for models in ([ca.MF(**kw), ca.BPR(**kw)], [ns.MF(**kw), ns.BPR(**kw)]):
+        rs = RatioSplit(data=data, test_size=0.2, val_size=0.1, rating_threshold=3.0, exclude_unknowns=True, seed=9, verbose=False)
+        ex = Experiment(eval_method=rs, models=models, metrics=[rm.MAE(), rm.RMSE(), rm.Recall(k=10), rm.AUC()], user_based=True)
+        assert len(ex.models) == 2, "the reference's Experiment dropped a model"
+        ex.run()
+        reports.append([[r.metric_avg_results[m] for m in ("MAE", "RMSE", "Recall@10", "AUC")] for r in ex.result])
+    assert np.allclose(reports[0], reports[1], atol=3e-3), reports
+    best = []
+    for base in (ca.BPR(**kw), ns.BPR(**kw)):
+        rs = RatioSplit(data=data, test_size=0.2, val_size=0.1, rating_threshold=3.0, exclude_unknowns=True, seed=9, verbose=False)
+        gs = hyperopt.GridSearch(model=base, space=[hyperopt.Discrete("k", [4, 6]), hyperopt.Discrete("learning_rate", [0.01, 0.05])],
+                                 metric=rm.AUC(), eval_method=rs)
+        gs.fit(rs.train_set, rs.val_set)
+        best.append((gs.best_params, gs.best_score))
+    assert best[0][0] == best[1][0] and abs(best[0][1] - best[1][1]) < 3e-3, best
+    m = ca.MF(**kw).fit(ns.Dataset.build(data[:500]))
+    with pytest.raises(exc.ScoreException):
+        m.score(0, 10 ** 6)
+    capsys.readouterr()
+
+
 def test_refit_does_not_serve_the_previous_fit(device_double):
     """MF caches item_base = global_mean + i_biases; a second fit() refreshes the biases in place, so the
     cache (and the device scorer built from it) must be dropped — BaseMethod.evaluate refits without cloning."""
