@@ -655,8 +655,9 @@ def main():
     # the form a whole-epoch call with these flags takes (include/cornac_hip.h: hogwild_flags bits 16..19)
     trainer_stats = {"ldsbin": trainer.ldsbin_stats()}
     sel = (args.flags >> 16) & 15
-    form = ("fused" if (args.flags & 0xffff) or sel == 1 or distributed else
+    form = ("fused" if (args.flags & 0xffff) or sel == 1 or (distributed and args.sharded_items) else
             "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
+            "fused" if distributed else  # (XCD strata takes whole epochs only; the replicated-table regime enqueues chunks)
             "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 
     sharded = None

@@ -1570,8 +1570,8 @@ static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
     flags &= ~0xff00;
 #endif
     if (!(form == 0 || form == 3) || (flags & 0xffff) != 0) return false;
-    return neg_population == CORNAC_HIP_NEG_UNIFORM && h->hog_offset == 0 && n_samples > 0 && n_samples % h->nnz == 0 &&
-           ldsbin_plan_bins(h) > 0;
+    (void)n_samples;  // any chunk of an epoch: a launch takes its share of every bin's draws
+    return neg_population == CORNAC_HIP_NEG_UNIFORM && ldsbin_plan_bins(h) > 0;
 }
 
 static void ldsbin_build(cornac_hip_bpr_t h) {
@@ -1653,19 +1653,25 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
     a.ablate = (flags >> 8) & 0xff;
 }
 
-// whole epochs only: one launch per epoch, one workgroup per bin
-static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_epochs, float lr, float reg, int use_bias, int flags) {
+// one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
+static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int flags) {
     ldsbin_build(h);
     LdsBinKernel kern = pick_ldsbin_kernel(h->k);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
-    for (int64_t e = 0; e < n_epochs; ++e) {
+    int64_t left = n_samples;
+    while (left > 0) {
+        const int64_t n = std::min(left, h->nnz - h->hog_offset);
         LdsBinArgs a;
         ldsbin_fill_args(h, a, lr, reg, use_bias, flags);
+        a.s_begin = (uint64_t)h->hog_offset;
+        a.n = (uint64_t)n;
+        a.nnz = (uint64_t)h->nnz;
         h->ktimer.before(h->stream);
         hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
         h->ktimer.after(h->stream);
         HIP_CHECK(hipGetLastError());
-        advance_hog_offset(h, h->nnz);
+        advance_hog_offset(h, n);
+        left -= n;
     }
 }
 
@@ -1673,7 +1679,7 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
     if (hogwild_uses_ldsbin(h, n_samples, neg_population, flags)) {
-        ldsbin_enqueue(h, n_samples / h->nnz, lr, reg, use_bias, flags);
+        ldsbin_enqueue(h, n_samples, lr, reg, use_bias, flags);
         return;
     }
     if (hogwild_uses_strata(h, n_samples, neg_population, flags)) {

@@ -33,7 +33,7 @@ class ItemTableReplica:
     rank's worth of progress per epoch; 1/sqrt(c) with >= 16 exchanges per epoch keeps the consolidated model
     within 0.01-0.02 pairwise accuracy of a single rank's at R = 2, 4, 8 (tools/emulate_ranks.py)."""
 
-    def __init__(self, total_items, k, device, group=None, trainer=None):
+    def __init__(self, total_items, k, device, group=None, trainer=None, sparse_threshold=None):
         self.total_items, self.k = int(total_items), int(k)
         n = self.total_items * self.k + self.total_items
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
@@ -41,6 +41,12 @@ class ItemTableReplica:
         self.group = group
         self.trainer = trainer  # on a GPU the two elementwise passes are fused HIP kernels of libcornac_hip
         self._pending = None
+        # sparse exchange: when at most this fraction of the item rows was touched since the last
+        # exchange ON EVERY RANK, the ranks all_gather (row id, delta row) records instead of all-reducing the dense
+        # table; None = always dense.  The reconciliation rule is the same, so both forms give the same table.
+        self.sparse_threshold = sparse_threshold
+        self.exchanges = {"dense": 0, "sparse": 0, "sparse_rows": 0}
+        self._count_host = None
 
     @property
     def V(self):
@@ -71,6 +77,9 @@ class ItemTableReplica:
         if not (dist.is_available() and dist.is_initialized()):
             self._pending = (None, None, None)
             return
+        if self.sparse_threshold is not None and self._begin_sparse():
+            return
+        self.exchanges["dense"] += 1
         n, k = self.total_items, self.k
         bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
         delta = bucket[: n * k + n]
@@ -86,10 +95,82 @@ class ItemTableReplica:
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, bucket, local)
 
+    # ---- sparse form: records (row id, [delta V row | delta bias]) of the touched rows, all_gather'ed ----------------
+    def _begin_sparse(self):
+        """Returns False (nothing started) when some rank touched more than sparse_threshold of the rows: every rank
+        then takes the dense path.  One device->host copy of ONE count (the max over ranks) sizes the buffers."""
+        n, k = self.total_items, self.k
+        dV = (self.flat[: n * k] - self.base[: n * k]).view(n, k)
+        dB = self.flat[n * k:] - self.base[n * k:]
+        touched = (dV != 0).any(dim=1) | (dB != 0)
+        cnt = touched.sum().to(torch.int64).reshape(1)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
+        if cnt.is_cuda:
+            if self._count_host is None:
+                self._count_host = torch.empty(1, dtype=torch.int64).pin_memory()
+            self._count_host.copy_(cnt, non_blocking=True)
+            torch.cuda.current_stream(cnt.device).synchronize()
+            cap = int(self._count_host[0])
+        else:
+            cap = int(cnt[0])
+        if cap > self.sparse_threshold * n:
+            return False
+        world = dist.get_world_size(self.group)
+        ids = torch.nonzero(touched).reshape(-1)
+        m = int(ids.numel())
+        ids_pad = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=self.flat.device)
+        rec = torch.zeros((max(cap, 1), k + 1), dtype=torch.float32, device=self.flat.device)
+        ids_pad[:m] = ids
+        rec[:m, :k] = dV[ids]
+        rec[:m, k] = dB[ids]
+        all_ids = torch.empty(world * max(cap, 1), dtype=torch.int64, device=self.flat.device)
+        all_rec = torch.empty((world * max(cap, 1), k + 1), dtype=torch.float32, device=self.flat.device)
+        w1 = dist.all_gather_into_tensor(all_ids, ids_pad, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(all_rec, rec, group=self.group, async_op=True)
+        self.exchanges["sparse"] += 1
+        self.exchanges["sparse_rows"] += m
+        self._pending = ("sparse", (w1, w2, all_ids, all_rec), (ids, rec[:m]))
+        return True
+
+    def _finish_sparse(self, payload, local):
+        w1, w2, all_ids, all_rec = payload
+        ids_local, rec_local = local
+        w1.wait()
+        w2.wait()
+        n, k = self.total_items, self.k
+        valid = all_ids >= 0
+        uniq, inv = torch.unique(all_ids[valid], return_inverse=True)
+        if uniq.numel() == 0:
+            return
+        recs = all_rec[valid]
+        S = torch.zeros((uniq.numel(), k + 1), dtype=torch.float32, device=self.flat.device).index_add_(0, inv, recs)
+        cV = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(
+            0, inv, (recs[:, :k] != 0).any(dim=1).to(torch.float32))
+        cB = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(
+            0, inv, (recs[:, k] != 0).to(torch.float32))
+        RV = S[:, :k] / cV.clamp_(min=1.0).sqrt_().unsqueeze(1)
+        RB = S[:, k] / cB.clamp_(min=1.0).sqrt_()
+        V, B = self.V, self.B
+        baseV, baseB = self.base[: n * k].view(n, k), self.base[n * k:]
+        # base' = base + R, flat' = base' + ((flat - base) - d_local) on the union of the touched rows (the dense form's
+        # arithmetic, so an untrained row ends with flat' == base' bit for bit)
+        dl = torch.zeros((uniq.numel(), k + 1), dtype=torch.float32, device=self.flat.device)
+        if ids_local.numel():
+            dl[torch.searchsorted(uniq, ids_local)] = rec_local
+        bV, bB = baseV[uniq], baseB[uniq]
+        pV, pB = (V[uniq] - bV).sub_(dl[:, :k]), (B[uniq] - bB).sub_(dl[:, k])
+        bV.add_(RV)
+        bB.add_(RB)
+        baseV[uniq] = bV
+        baseB[uniq] = bB
+        V[uniq] = bV + pV
+        B[uniq] = bB + pB
+
     def step_sync(self):
         """finish_sync() of the pending exchange followed by begin_sync() of the next one; on a GPU the two table
         passes are one fused kernel"""
-        if self._pending is None or self._pending[0] is None or self.trainer is None or not self.flat.is_cuda:
+        if (self._pending is None or self._pending[0] is None or self._pending[0] == "sparse" or self.trainer is None
+                or not self.flat.is_cuda or self.sparse_threshold is not None):
             self.finish_sync()
             self.begin_sync()
             return
@@ -112,6 +193,9 @@ class ItemTableReplica:
         if work is None:
             self.base.copy_(self.flat)
             return
+        if work == "sparse":
+            self._finish_sparse(bucket, local)
+            return
         work.wait()  # stream-level wait on CUDA, blocking on gloo
         n, k = self.total_items, self.k
         if self.trainer is not None and self.flat.is_cuda:
@@ -121,16 +205,20 @@ class ItemTableReplica:
         delta = bucket[: n * k + n]
         delta[: n * k].view(n, k).div_(bucket[n * k + n: n * k + 2 * n].clamp_(min=1.0).sqrt_().unsqueeze(1))
         delta[n * k:].div_(bucket[n * k + 2 * n:].clamp_(min=1.0).sqrt_())
-        self.flat.add_(delta - local)
+        # base' = base + R, flat' = base' + ((flat - base) - local): a row nobody trained since begin_sync ends with
+        # flat' == base' bit for bit (see table_delta_finish_kernel), so the next exchange sees it as untouched
+        progress = (self.flat - self.base).sub_(local)
         self.base.add_(delta)
+        torch.add(self.base, progress, out=self.flat)
 
 
 class ShardedBprTrainer:
     """Drives one rank's cornac_hip BPR handle plus the replicated item table."""
 
-    def __init__(self, trainer, total_items, k, device, sync_every, group=None):
+    def __init__(self, trainer, total_items, k, device, sync_every, group=None, sparse_threshold=None):
         self.trainer = trainer
-        self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None)
+        self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None,
+                                      sparse_threshold=sparse_threshold)
         self.sync_every = int(sync_every)
         self.device = device
         self.stream = None

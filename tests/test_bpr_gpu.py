@@ -307,6 +307,21 @@ def test_ldsbin_sampler_matches_its_cpu_restatement(oracle):
         want += sk
     assert s == want
     assert np.array_equal(V2, V) and np.array_equal(B2, B) and np.array_equal(U2, U)
+    # the same two epochs cut into uneven chunks (the multi-GPU driver's exchange points): every launch takes its share
+    # of every bin's draws, so the chunks cover exactly the same draws
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 64)
+    tr.ldsbin_config(hot_x1000=50, min_candidates=8)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(seed)
+    left, chunk = 2 * nnz, 0
+    while left > 0:
+        n = min(left, 90_001 + 37_777 * (chunk % 5))
+        tr.hogwild_enqueue(n, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.FORM_LDSBIN)
+        left -= n
+        chunk += 1
+    c2, s2 = tr.sync()
+    tr.close()
+    assert s2 == want and chunk > 5
 
 
 def test_ldsbin_updates_are_exact_and_learn_like_the_fused_kernel(oracle):

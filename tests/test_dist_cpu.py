@@ -35,28 +35,34 @@ class _FakeTrainer:
         return (sum(self.calls), 0)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, sparse_threshold=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cpu")
-        sh = ShardedBprTrainer(None, total_items=6, k=4, device=dev, sync_every=100)
+        sh = ShardedBprTrainer(None, total_items=6, k=4, device=dev, sync_every=100, sparse_threshold=sparse_threshold)
         sh.trainer = _FakeTrainer(sh.table, rank)
         V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
         sh.load_items(V0, np.zeros(6, np.float32))
         sh.run(250, lr=0.01, reg=0.0)  # chunks of 100, 100, 50 -> 3 syncs
         correct, _ = sh.finish()
         out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), sh.trainer.calls, correct)
+        out["exchanges%d" % rank] = dict(sh.table.exchanges)
     finally:
         dist.destroy_process_group()
 
 
-def test_item_table_allreduce_of_deltas_world2():
+@pytest.mark.parametrize("sparse_threshold", [None, 1.0])
+def test_item_table_allreduce_of_deltas_world2(sparse_threshold):
+    """dense form (one all-reduced bucket) and sparse form (all_gather of the touched rows' records): the same
+    reconciliation rule, the same table"""
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, sparse_threshold), nprocs=2, join=True)
     (V_a, B_a, calls_a, c_a), (V_b, B_b, calls_b, c_b) = out[0], out[1]
+    ex = out["exchanges0"]
+    assert (ex["sparse"], ex["dense"]) == ((3, 0) if sparse_threshold else (0, 3)), ex
     assert calls_a == calls_b == [100, 100, 50] and c_a == 250
     assert np.array_equal(V_a, V_b) and np.array_equal(B_a, B_b), "replicas must agree after every sync"
     V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
@@ -248,7 +254,7 @@ class _OracleTrainer:
         return (self.correct, self.skipped)
 
 
-def _popularity_data(rank, n_users=250, n_items=90, per_user=24):
+def _popularity_data(rank, n_users=250, n_items=90, per_user=24):  # noqa: D401
     """every rank has its own users; all draw from one Zipf item popularity, so the item side is shared knowledge"""
     rs = np.random.RandomState(100 + rank)
     p = 1.0 / np.arange(1, n_items + 1) ** 1.1
@@ -269,13 +275,14 @@ def _pairwise_accuracy(U, V, B, indptr, indices, n_items, seed=0):
     return hit / n
 
 
-def _learn_worker(rank, world, port, out):
+def _learn_worker(rank, world, port, out, sparse_threshold=None, n_items_total=90, per_epoch=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        indptr, indices, n_items = _popularity_data(rank)
+        indptr, indices, n_items = _popularity_data(rank, n_items=n_items_total)
         k, nnz = 8, len(indices)
-        sh = ShardedBprTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"), sync_every=(nnz + 7) // 8)
+        sh = ShardedBprTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"),
+                               sync_every=(nnz + per_epoch - 1) // per_epoch, sparse_threshold=sparse_threshold)
         init = np.random.RandomState(7)                                  # identical item table on every rank
         sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
         sh.trainer = _OracleTrainer(sh.table, indptr, indices, n_items, k, seed=11 + rank)
@@ -286,8 +293,28 @@ def _learn_worker(rank, world, port, out):
         after = _pairwise_accuracy(sh.trainer.U, sh.table.V.numpy(), sh.table.B.numpy(), indptr, indices, n_items)
         out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), before, after, correct, skipped, nnz,
                      sh.table.base.numpy().copy())
+        out["exchanges%d" % rank] = dict(sh.table.exchanges)
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_sparse_exchange_equals_the_dense_one_with_real_bpr_arithmetic():
+    """regime 1 with the SPARSE delta exchange (records of the touched rows through all_gather; dense bucket only when a
+    rank touched more than the threshold) on two gloo ranks with real BPR arithmetic: a long-tailed catalogue of 2 000
+    items and 64 exchanges per epoch, so most exchanges touch a small part of the table.  Same sample streams ->
+    the sparse run ends with the same consolidated table as the dense run (to fp32 summation order), and it really went
+    through the sparse path."""
+    res = {}
+    for thr in (None, 0.5):
+        out = mp.Manager().dict()
+        mp.spawn(_learn_worker, args=(2, _free_port(), out, thr, 2000, 64), nprocs=2, join=True)
+        res[thr] = (out[0], out[1], out["exchanges0"])
+    (d0, d1, exd), (s0, s1, exs) = res[None], res[0.5]
+    assert exd["sparse"] == 0 and exs["sparse"] > 0.9 * (exs["sparse"] + exs["dense"]), (exd, exs)
+    assert np.array_equal(s0[7], s1[7]), "both ranks hold the same rebased table"
+    # same rule, same per-row arithmetic: only the order in which the ranks' records are summed differs
+    assert np.abs(s0[0] - d0[0]).max() < 2e-5 and np.abs(s0[1] - d0[1]).max() < 2e-5, (np.abs(s0[0] - d0[0]).max(), np.abs(s0[1] - d0[1]).max())
+    assert s0[3] > 0.7 and abs(s0[3] - d0[3]) < 0.01
 
 
 def test_two_ranks_learn_one_consolidated_item_table():

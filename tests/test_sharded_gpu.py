@@ -350,7 +350,7 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     cv = red[n * k + n: n * k + 2 * n].clamp(min=1).sqrt().unsqueeze(1)
     cb = red[n * k + 2 * n:].clamp(min=1).sqrt()
     R = torch.cat([(red[: n * k].view(n, k) / cv).reshape(-1), red[n * k: n * k + n] / cb])
-    want_flat, want_base = flat + (R - local), base + R
+    want_flat, want_base = (base + R) + ((flat - base) - local), base + R  # (an untrained row ends bit-identical to its base)
     flat2, base2 = flat.clone(), base.clone()  # for the fused finish + begin pass below
     torch.cuda.synchronize()
     tr.table_delta_finish(flat.data_ptr(), base.data_ptr(), red.data_ptr(), local.data_ptr(), n, k)
