@@ -61,6 +61,32 @@ def load_dataset(name, seed_shift, cache_dir):
     return n_users, n_items, indptr, indices
 
 
+SCALE = {"users_per_gpu": 12_500_000, "items": 10_000_000, "degree": 5, "k": 128}
+
+
+def scale_slice(rank):
+    """One GPU's user slice of BASELINE configs[4] (100 M users x 10 M items over 8 GPUs): 12.5 M users with 5 distinct
+    items each, generated from seed 45 + rank.  Returns (n_users, n_items, indptr, indices)."""
+    nu, ni, d = SCALE["users_per_gpu"], SCALE["items"], SCALE["degree"]
+    rs = np.random.RandomState(45 + rank)
+    base = rs.randint(0, ni, size=nu, dtype=np.int64)
+    step = rs.randint(1, ni // (2 * d), size=nu, dtype=np.int64)
+    items = (base[:, None] + step[:, None] * np.arange(d, dtype=np.int64)[None, :]) % ni
+    items.sort(axis=1)
+    indices = items.astype(np.int32).ravel()
+    indptr = (np.arange(nu + 1, dtype=np.int64) * d).astype(np.int32)
+    return nu, ni, indptr, indices
+
+
+def scale_factors(nu, ni, k, rank):
+    """item table from a fixed seed (identical on every rank), user rows from a per-rank seed"""
+    r2 = np.random.RandomState(2)
+    V = ((r2.uniform(0, 1, (ni, k)).astype(np.float32) - 0.5) / k)
+    ru = r2 if rank == 0 else np.random.RandomState(200 + rank)
+    U = ((ru.uniform(0, 1, (nu, k)).astype(np.float32) - 0.5) / k)
+    return U, V, np.zeros(ni, np.float32)
+
+
 def init_factors(n_users, n_items, k, seed):
     rng = np.random.RandomState(seed)
     U = ((rng.uniform(0, 1, (n_users, k)).astype(np.float32) - 0.5) / k)
@@ -403,24 +429,15 @@ def cpu_baseline_vbpr(F, u, i, j, params, nu, ni, k, k2, B, budget_s):
 def leg_bpr_k128_scale(args, _lib):
     """One GPU's share of configs[4] (100 M users x 10 M items, k = 128, 8 GPUs): users are partitioned, so a rank
     owns 12.5 M users; the item table (10 M x 128 fp32 = 5.1 GB) is held whole.  5 distinct items per user."""
-    nu, ni, d, k = 12_500_000, 10_000_000, 5, 128
-    rs = np.random.RandomState(45)
+    d, k = SCALE["degree"], SCALE["k"]
     t0 = time.time()
-    base = rs.randint(0, ni, size=nu, dtype=np.int64)
-    step = rs.randint(1, ni // (2 * d), size=nu, dtype=np.int64)
-    items = (base[:, None] + step[:, None] * np.arange(d, dtype=np.int64)[None, :]) % ni
-    items.sort(axis=1)
-    indices = items.astype(np.int32).ravel()
-    indptr = (np.arange(nu + 1, dtype=np.int64) * d).astype(np.int32)
-    del items, base, step
+    nu, ni, indptr, indices = scale_slice(0)
     t_gen = time.time() - t0
     nnz = len(indices)
     t0 = time.time()
     tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
-    r2 = np.random.RandomState(2)
-    V = ((r2.uniform(0, 1, (ni, k)).astype(np.float32) - 0.5) / k)
-    U = ((r2.uniform(0, 1, (nu, k)).astype(np.float32) - 0.5) / k)
-    tr.set_factors(U, V, np.zeros(ni, np.float32))
+    U, V, B = scale_factors(nu, ni, k, 0)
+    tr.set_factors(U, V, B)
     tr.seed_hogwild(7)
     tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)  # warm-up: builds ownership tables
     t_setup = time.time() - t0
@@ -587,8 +604,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="ml20m")
-    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--config", default="ml20m", help="ml20m (BASELINE configs[1], the headline) | scale (configs[4]: every "
+                    "rank holds one GPU's 12.5 M-user slice of the 100 M x 10 M synthetic, k = 128)")
+    ap.add_argument("--k", type=int, default=0, help="0 = the config's own (64; scale: 128)")
+    ap.add_argument("--sparse-threshold", type=float, default=-1.0,
+                    help="replicated-table regime: exchange (row id, delta row) records instead of the dense table when every "
+                         "rank touched at most this fraction of the item rows since the last exchange; < 0 = the config's own "
+                         "(ml20m: dense always; scale: 0.5)")
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--reg", type=float, default=0.01)
     ap.add_argument("--flags", type=int, default=0, help="hogwild_flags of cornac_hip_bpr_fit_epochs")
@@ -643,13 +665,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_users, n_items, indptr, indices = load_dataset(args.config, rank, args.cache_dir)
+    scale = args.config == "scale"
+    k = args.k or (SCALE["k"] if scale else 64)
+    if scale:
+        n_users, n_items, indptr, indices = scale_slice(rank)
+        args.no_rank = args.no_legs = True  # the scoring leg and the other legs belong to the headline configuration
+    else:
+        n_users, n_items, indptr, indices = load_dataset(args.config, rank, args.cache_dir)
     nnz = len(indices)
-    k = args.k
     trainer = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k, device=local_rank)
-    U, V, B = init_factors(n_users, n_items, k, 100 + rank)
-    if distributed:
-        V, B = init_factors(n_users, n_items, k, 100)[1:]  # identical item table on every rank
+    if scale:
+        U, V, B = scale_factors(n_users, n_items, k, rank)
+    else:
+        U, V, B = init_factors(n_users, n_items, k, 100 + rank)
+        if distributed:
+            V, B = init_factors(n_users, n_items, k, 100)[1:]  # identical item table on every rank
     trainer.set_factors(U, V, B)
     trainer.seed_hogwild(0xC0FFEE + 7919 * rank)
     # the form a whole-epoch call with these flags takes (include/cornac_hip.h: hogwild_flags bits 16..19)
@@ -657,7 +687,6 @@ def main():
     sel = (args.flags >> 16) & 15
     form = ("fused" if (args.flags & 0xffff) or sel == 1 or (distributed and args.sharded_items) else
             "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
-            "fused" if distributed else  # (XCD strata takes whole epochs only; the replicated-table regime enqueues chunks)
             "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 
     sharded = None
@@ -669,8 +698,9 @@ def main():
     elif distributed:
         from cornac_amd.dist import ShardedBprTrainer
 
+        sparse = args.sparse_threshold if args.sparse_threshold >= 0 else (0.5 if scale else None)
         sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
-                                    // args.sync_per_epoch)
+                                    // args.sync_per_epoch, sparse_threshold=sparse)
         sharded.load_items(V, B)
 
     def step():
@@ -714,7 +744,10 @@ def main():
         "metric": "bpr_triplets_per_sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
+        "config": {"workload": ("BPR k=%d on one GPU's user slice per rank of the 100 M x 10 M synthetic (%d users x %d items, "
+                                "%d interactions per GPU, U %.1f GB + V %.1f GB per GPU), hogwild mode, fp32 tables resident in HBM"
+                                % (k, n_users, n_items, nnz, n_users * k * 4 / 1e9, n_items * k * 4 / 1e9)) if scale else
+                               "BPR k=%d on ML-20M-shaped synthetic interactions (%d users x %d items, nnz %d per "
                                "GPU), hogwild mode, fp32 tables resident in HBM" % (k, n_users, n_items, nnz),
                    "k": k, "lr": args.lr, "reg": args.reg, "hogwild_flags": args.flags,
                    "form": form,
@@ -738,7 +771,7 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else None
         kernel_name = ("sample/apply kernels of the row-sharded path (no fused SGD kernel)" if args.sharded_items else
                        "bpr_ldsbin_kernel<%d,%d>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]) if form == "ldsbin" else
-                       "bpr_strata_kernel<%d>" % ((k + 63) // 64) if form == "strata" else
+                       "bpr_strata_kernel<%d,%d>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]) if form == "strata" else
                        "bpr_hogwild_rowwise_kernel<64,%d,%d,atomic,owned>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]))
         # counter-measured traffic is only quoted for the kernel + workload it was taken on (profiles/traffic.json
         # names both); any other launch configuration reports null rather than a stale number
@@ -852,7 +885,14 @@ def main():
     # ---- CPU baseline leg (rank 0, N = 1 only) ------------------------------------------------------------------
     if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(indptr, indices, n_items, k, args.lr, args.reg, args.cpu_baseline_seconds)
+            if scale:  # the reference kernel on the first 1 M users of the slice (its U slice is 0.5 GB instead of 6.4 GB)
+                sub = 1_000_000
+                out["cpu_baseline"] = cpu_baseline(indptr[:sub + 1], indices[:indptr[sub]], n_items, k, args.lr, args.reg,
+                                                   min(args.cpu_baseline_seconds, 8.0))
+                out["cpu_baseline"]["sample"] = ("first %d users of the slice; " % sub +
+                                                 out["cpu_baseline"]["sample"].replace("ML-20M-shaped", "scale-config"))
+            else:
+                out["cpu_baseline"] = cpu_baseline(indptr, indices, n_items, k, args.lr, args.reg, args.cpu_baseline_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         except Exception as e:  # the measured GPU line must not be lost to a host-side baseline problem
             print("[bench] cpu_baseline failed: %r" % (e,), file=sys.stderr)

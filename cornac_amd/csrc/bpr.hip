@@ -1461,8 +1461,8 @@ static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
     flags &= ~0xff00;  // (profile builds: the ablation bits 8..15 are honoured by the strata kernel too)
 #endif
     if ((flags & 0xffff) != 0 || !(form == 2 || (form == 0 && h->n_items >= (int64_t(1) << 20)))) return false;
-    return neg_population == CORNAC_HIP_NEG_UNIFORM && hogwild_uses_ownership(h, 0) &&
-           h->n_items >= 64 && h->hog_offset == 0 && n_samples > 0 && n_samples % h->nnz == 0 &&
+    (void)n_samples;  // any chunk of an epoch: a launch runs the partition phases that begin inside it
+    return neg_population == CORNAC_HIP_NEG_UNIFORM && hogwild_uses_ownership(h, 0) && h->n_items >= 64 &&
            device_info(h->device).xcds == 8;
 }
 
@@ -1500,30 +1500,39 @@ static void strata_build_buckets(cornac_hip_bpr_t h, int grid, uint32_t key) {
     ++h->strata_builds;
 }
 
-// whole epochs only: 8 phase launches per epoch, buckets re-dealt when the epoch key changes
-static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_epochs, float lr, float reg, int use_bias, int flags) {
+// 8 phase launches per epoch, buckets re-dealt when the epoch key changes.  A chunk of an epoch (the multi-GPU driver's
+// exchange points) runs the phases whose nominal start p * nnz / 8 lies inside it, so consecutive chunks run every
+// phase of the epoch exactly once.
+static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int flags) {
     const int grid = strata_prepare(h);
     h->Bpad.ensure((size_t)h->total_items * kBiasStride);
     const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
-    for (int64_t e = 0; e < n_epochs; ++e) {
-        const uint32_t key = strata_key(h->hog_seed, h->hog_epoch / (uint32_t)std::max(1, h->strata_rehash_period));
-        strata_build_buckets(h, grid, key);
-        HogArgs a;
-        fill_hog_args(h, a, h->nnz, lr, reg, use_bias, CORNAC_HIP_NEG_UNIFORM, flags);
-        a.B = h->Bpad.p;
-        a.bstride = kBiasStride;
-        a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
-        a.strata_key = key; a.n_hot = h->strata_n_hot;
-        hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
-        for (int ph = 0; ph < 8; ++ph) {
-            a.phase = ph;
-            h->ktimer.before(h->stream);
-            hipLaunchKernelGGL(h->strata_kernel, dim3(grid), dim3(kBlock), 0, h->stream, a);
-            h->ktimer.after(h->stream);
+    int64_t left = n_samples;
+    while (left > 0) {
+        const int64_t n = std::min(left, h->nnz - h->hog_offset);
+        const auto first_phase = [&](int64_t s) { return (int)((8 * (__int128)s + h->nnz - 1) / h->nnz); };
+        const int p_lo = first_phase(h->hog_offset), p_hi = h->hog_offset + n >= h->nnz ? 8 : first_phase(h->hog_offset + n);
+        if (p_hi > p_lo) {
+            const uint32_t key = strata_key(h->hog_seed, h->hog_epoch / (uint32_t)std::max(1, h->strata_rehash_period));
+            strata_build_buckets(h, grid, key);
+            HogArgs a;
+            fill_hog_args(h, a, h->nnz, lr, reg, use_bias, CORNAC_HIP_NEG_UNIFORM, flags);
+            a.B = h->Bpad.p;
+            a.bstride = kBiasStride;
+            a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
+            a.strata_key = key; a.n_hot = h->strata_n_hot;
+            hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
+            for (int ph = p_lo; ph < p_hi; ++ph) {
+                a.phase = ph;
+                h->ktimer.before(h->stream);
+                hipLaunchKernelGGL(h->strata_kernel, dim3(grid), dim3(kBlock), 0, h->stream, a);
+                h->ktimer.after(h->stream);
+            }
+            hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
+            HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
-        HIP_CHECK(hipGetLastError());
-        advance_hog_offset(h, h->nnz);
+        advance_hog_offset(h, n);
+        left -= n;
     }
 }
 
@@ -1683,7 +1692,7 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
         return;
     }
     if (hogwild_uses_strata(h, n_samples, neg_population, flags)) {
-        strata_enqueue(h, n_samples / h->nnz, lr, reg, use_bias, flags);
+        strata_enqueue(h, n_samples, lr, reg, use_bias, flags);
         return;
     }
     flags &= 0xffff & ~128;  // bits 16..19 select the form, bit7 only opts out of the LDS-bin / strata forms

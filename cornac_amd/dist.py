@@ -77,9 +77,6 @@ class ItemTableReplica:
         if not (dist.is_available() and dist.is_initialized()):
             self._pending = (None, None, None)
             return
-        if self.sparse_threshold is not None and self._begin_sparse():
-            return
-        self.exchanges["dense"] += 1
         n, k = self.total_items, self.k
         bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
         delta = bucket[: n * k + n]
@@ -92,17 +89,19 @@ class ItemTableReplica:
             bucket[n * k + n: n * k + 2 * n] = (delta[: n * k].view(n, k) != 0).any(dim=1)   # V rows touched
             bucket[n * k + 2 * n:] = delta[n * k:] != 0                                         # biases touched
             local = delta.clone()
+        if self.sparse_threshold is not None and self._begin_sparse(bucket):
+            return
+        self.exchanges["dense"] += 1
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, bucket, local)
 
     # ---- sparse form: records (row id, [delta V row | delta bias]) of the touched rows, all_gather'ed ----------------
-    def _begin_sparse(self):
-        """Returns False (nothing started) when some rank touched more than sparse_threshold of the rows: every rank
-        then takes the dense path.  One device->host copy of ONE count (the max over ranks) sizes the buffers."""
+    def _begin_sparse(self, bucket):
+        """`bucket` = the dense form's [dV | dB | V-row flags | bias flags].  Returns False (nothing started) when some
+        rank touched more than sparse_threshold of the rows: every rank then all-reduces the bucket it already has.
+        One device->host copy of ONE count (the max over ranks) sizes the buffers."""
         n, k = self.total_items, self.k
-        dV = (self.flat[: n * k] - self.base[: n * k]).view(n, k)
-        dB = self.flat[n * k:] - self.base[n * k:]
-        touched = (dV != 0).any(dim=1) | (dB != 0)
+        touched = (bucket[n * k + n: n * k + 2 * n] + bucket[n * k + 2 * n:]) > 0
         cnt = touched.sum().to(torch.int64).reshape(1)
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
         if cnt.is_cuda:
@@ -121,8 +120,8 @@ class ItemTableReplica:
         ids_pad = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=self.flat.device)
         rec = torch.zeros((max(cap, 1), k + 1), dtype=torch.float32, device=self.flat.device)
         ids_pad[:m] = ids
-        rec[:m, :k] = dV[ids]
-        rec[:m, k] = dB[ids]
+        rec[:m, :k] = bucket[: n * k].view(n, k)[ids]
+        rec[:m, k] = bucket[n * k: n * k + n][ids]
         all_ids = torch.empty(world * max(cap, 1), dtype=torch.int64, device=self.flat.device)
         all_rec = torch.empty((world * max(cap, 1), k + 1), dtype=torch.float32, device=self.flat.device)
         w1 = dist.all_gather_into_tensor(all_ids, ids_pad, group=self.group, async_op=True)

@@ -105,9 +105,9 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
  * read-modify-write like the reference's threads), 3 = LDS-resident item bins (csrc/bpr_ldsbin.inc: the item rows
  * of a bin live in one CU's LDS for the epoch, exact updates, user rows by atomics).  Automatic = LDS bins when the
  * item table fits the LDS in at most max_rounds rounds with at least min_candidates items per bin, else XCD strata
- * for item tables of >= 2^20 rows, else the fused kernel.  A chunk of an epoch (hogwild_enqueue) runs the LDS-bin form
- * too (every launch takes its share of every bin's draws) but not XCD strata (whole epochs only); popularity
- * negatives and every experiment switch below run the fused kernel.
+ * for item tables of >= 2^20 rows, else the fused kernel.  A chunk of an epoch (hogwild_enqueue) runs in the same form:
+ * an LDS-bin launch takes its share of every bin's draws, an XCD-strata chunk runs the partition phases that begin
+ * inside it.  Popularity negatives and every experiment switch below run the fused kernel.
  * Experiment switches of the fused kernel: bit0 = plain (racy,
  * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
  * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic);
