@@ -191,7 +191,7 @@ __device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int3
     u = a.user_ids[ii];
     i = a.indices[ii];
     j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
-    const bool skip = (a.ablate & 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
+    const bool skip = HOG_ABLATE(a, 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
 }
 
@@ -210,7 +210,7 @@ __device__ __forceinline__ bool hog_sample_owned(const HogArgs &a, uint32_t wave
     const int32_t u = u_enc < 0 ? ~u_enc : u_enc;
     j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
     if (share_neg) j = __shfl(j, lane_id() & ~3, kWave);  // every lane draws; groups of 4 keep their leader's
-    const bool skip = (a.ablate & 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
+    const bool skip = HOG_ABLATE(a, 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
 }
 
@@ -433,13 +433,13 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 pj[q] = Vt + (size_t)tj[q] * a.k + lg;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const bool ld = inb[r] && !(a.ablate & 4);
+                    const bool ld = inb[r] && !HOG_ABLATE(a, 4);
                     u[q][r] = ld ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
                     vi[q][r] = ld ? __builtin_nontemporal_load(pi[q] + G * r) : 0.f;
                     vj[q][r] = ld ? __builtin_nontemporal_load(pj[q] + G * r) : 0.f;
                 }
-                bi[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)ti[q] * a.bstride);
-                bj[q] = (a.ablate & 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)tj[q] * a.bstride);
+                bi[q] = HOG_ABLATE(a, 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)ti[q] * a.bstride);
+                bj[q] = HOG_ABLATE(a, 8) ? 0.f : __builtin_nontemporal_load(Bt + (size_t)tj[q] * a.bstride);
             }
             float du_all[UNR][R];
             float dvj_all[SHARE ? UNR : 1][R], dbj_all[SHARE ? UNR : 1];  // (SHARE: the negative rows' deltas, combined below)
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 if (act[q]) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        if (inb[r] && !(a.ablate & 2)) {
+                        if (inb[r] && !HOG_ABLATE(a, 2)) {
                             const float du = du_all[q][r];
                             const float dvi = a.lr * (z * u[q][r] - a.reg * vi[q][r]);
                             const float dvj = a.lr * (-z * u[q][r] - a.reg * vj[q][r]);
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                         }
                     }
                     if (lg == 0) {
-                        if (a.use_bias && !(a.ablate & 8)) {
+                        if (a.use_bias && !HOG_ABLATE(a, 8)) {
                             const float dbi = a.lr * (z - a.reg * bi[q]), dbj = a.lr * (-z - a.reg * bj[q]);
                             if (SHARE) dbj_all[SHARE ? q : 0] = dbj;
                             if (ATOMIC || OWNED) {
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 // the sum of the deltas of all of them (each computed against the same loaded row)
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) {
-                    if (!act[q] || (a.ablate & 2)) continue;
+                    if (!act[q] || HOG_ABLATE(a, 2)) continue;
                     bool lead = true;
 #pragma unroll
                     for (int q2 = 0; q2 < q; ++q2) lead = lead && !(act[q2] && tj[q2] == tj[q]);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         if (inb[r]) atomic_add_f32(pj[q] + G * r, tot[r]);
-                    if (lg == 0 && a.use_bias && !(a.ablate & 8)) atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, totb);
+                    if (lg == 0 && a.use_bias && !HOG_ABLATE(a, 8)) atomic_add_f32(a.B + (size_t)tj[q] * a.bstride, totb);
                 }
             }
             if (OWNED) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void bpr_hogwild_rowwise_kernel(const HogAr
                 // batch that has the same user) — all four loads saw the same u_old
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) {
-                    if (act[q] && tue[q] >= 0 && !(a.ablate & 2)) {
+                    if (act[q] && tue[q] >= 0 && !HOG_ABLATE(a, 2)) {
                         float tot[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) tot[r] = du_all[q][r];
@@ -1247,11 +1247,7 @@ static void build_item_buckets(cornac_hip_bpr_t h, int n_buckets, int neg_popula
     h->bin_hot_threshold = hot_threshold;
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
+static int env_int(const char *name, int dflt) { return prof_env_int(name, dflt); }  // profile builds only
 typedef void (*BinTripletKernel)(const HogArgs, const BinArgs);
 typedef void (*BinApplyKernel)(const BinApplyArgs);
 static void pick_binned_kernels(int k, int occ, BinTripletKernel *ka, BinApplyKernel *kb) {
@@ -1389,7 +1385,7 @@ static void binned_enqueue(cornac_hip_bpr_t h, const BinPlan &pl, int64_t n_samp
                                h->bin_hot_bias.p, h->bin_n_hot);
         h->ktimer.before(h->stream);
         hipLaunchKernelGGL(ka, dim3(pl.grid_a), dim3(kBinBlock), pl.lds_a, h->stream, a, g);
-        if (!(a.ablate & 16))
+        if (!HOG_ABLATE(a, 16))
             hipLaunchKernelGGL(kb, dim3(pl.n_buckets), dim3(kBinBlock), lds_b, h->stream, p);
         h->ktimer.after(h->stream);
         if (h->bin_n_hot)

@@ -1095,12 +1095,12 @@ static bool can_fuse(cornac_hip_scorer_t h, int topk) { return topk <= kFusedMax
 constexpr int64_t kMaxBitmapTiles = 8192;  // item tiles (x32 items) up to which the exclusion bitmap is used
 
 // excl_by_user: d_excl_indptr is indexed by user id (resident lists) instead of by row of this call
-static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int64_t u0, int64_t n, int topk,
-                              const int64_t *d_excl_indptr, const int32_t *d_excl_indices, int64_t excl_row0,
-                              int32_t *items_out, float *scores_out, bool excl_by_user = false) {
+static void launch_rank_fused_rows(cornac_hip_scorer_t h, const int32_t *d_users, int64_t u0, int64_t n, int topk,
+                                   const int64_t *d_excl_indptr, const int32_t *d_excl_indices, int64_t excl_row0,
+                                   int32_t *items_out, float *scores_out, bool excl_by_user) {
     const float *ub = h->has_user_base ? h->user_base.p : nullptr;
     const DeviceInfo &di = device_info(h->device);
-    static const int ablate = getenv("CORNAC_HIP_RANK_ABLATE") ? atoi(getenv("CORNAC_HIP_RANK_ABLATE")) : 0;  // profiling only
+    const int ablate = prof_env_int("CORNAC_HIP_RANK_ABLATE", 0);  // profile builds only (csrc/common.h)
     const int64_t n_item_tiles = (h->n_items + 31) / 32;
     const int64_t wg_rows = (n + 127) / 128;  // 4 waves x 32 rows per workgroup
     // balanced persistent decomposition (see rank_fused_kernel): one range of (row block, item tile) work per
@@ -1119,7 +1119,7 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     // scalar operations; without it they flood the candidate buffers — a trained model scores a user's training
     // positives highest — and are only dropped at compaction)
     const uint32_t *d_bits = nullptr;
-    static const bool no_bitmap = getenv("CORNAC_HIP_RANK_NO_BITMAP") != nullptr;  // A/B switch for profiling
+    const bool no_bitmap = prof_env_set("CORNAC_HIP_RANK_NO_BITMAP");  // A/B switch, profile builds only
     if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles && !no_bitmap) {
         const int64_t rows_padded = wg_rows * 128;  // whole workgroups of the top-k kernel: it reads every wave's words
         h->excl_bits.ensure((size_t)(rows_padded * n_item_tiles));
@@ -1132,7 +1132,7 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     }
     dim3 grid((unsigned)n_wgs), block(kBlk);
 #define FUSED(KT_, CAP_) do {                                                                                    \
-    if (getenv("CORNAC_HIP_RANK_ABLATE")) {                                                                       \
+    if (prof_env_set("CORNAC_HIP_RANK_ABLATE")) {                                                                 \
         int occ = 0;                                                                                              \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rank_fused_kernel<KT_, CAP_, true>, kBlk, 0);     \
         fprintf(stderr, "[rank_fused<%d,%d>] %u workgroups x %lld block-tiles, <= %lld segments/row, %d workgroups/CU\n", \
@@ -1165,6 +1165,25 @@ static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int
     hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)n), dim3(64), (size_t)pad * 8, h->stream, h->part.p,
                        (int)max_segs, n, topk, pad, items_out, scores_out);
     HIP_CHECK(hipGetLastError());
+}
+
+// The exclusion bitmap costs rows x ceil(n_items / 32) x 4 bytes.  Rows are ranked in chunks so that it never exceeds
+// kExclBitmapBudget (one chunk at the ML-20M shape: 138 493 users x 836 words = 463 MB; 65 536 users x 262 144 items
+// would otherwise ask for 2 GiB, 1 M users x 200 k items for 25 GB).
+constexpr int64_t kExclBitmapBudget = int64_t(512) << 20;
+static void launch_rank_fused(cornac_hip_scorer_t h, const int32_t *d_users, int64_t u0, int64_t n, int topk,
+                              const int64_t *d_excl_indptr, const int32_t *d_excl_indices, int64_t excl_row0,
+                              int32_t *items_out, float *scores_out, bool excl_by_user = false) {
+    const int64_t n_item_tiles = (h->n_items + 31) / 32;
+    int64_t rows = n;
+    if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles)
+        rows = std::max<int64_t>(128, (kExclBitmapBudget / (n_item_tiles * 4)) / 128 * 128);
+    for (int64_t r0 = 0; r0 < n; r0 += rows) {
+        const int64_t m = std::min(rows, n - r0);
+        launch_rank_fused_rows(h, d_users ? d_users + r0 : nullptr, u0 + r0, m, topk, d_excl_indptr, d_excl_indices,
+                               excl_row0 + r0, items_out + r0 * topk, scores_out ? scores_out + r0 * topk : nullptr,
+                               excl_by_user);
+    }
 }
 
 extern "C" {

@@ -8,6 +8,15 @@
 // contract a*b+c into an fma in these kernels (explicit fmaf is used where a fused op is wanted).
 #pragma clang fp contract(off)
 
+// Ablation bits of the SGD kernels (hogwild_flags bits 8..15: 1 no membership test, 2 no stores, 4 no row loads,
+// 8 no bias traffic, ...) exist in -DCORNAC_PROFILE builds only (make PROFILE=1); the shipped kernels compile the
+// branches away.
+#ifdef CORNAC_PROFILE
+#define HOG_ABLATE(args, bit) (((args).ablate & (bit)) != 0)
+#else
+#define HOG_ABLATE(args, bit) false
+#endif
+
 namespace chip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));

@@ -541,7 +541,7 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         // (two k-tiles per workgroup measured best: 16 / 32 / 64 / 128 features per chunk -> 63.1 / 61.0 / 64.5 / 72.1 us per
         // step of the small-kernel chain at n_feat = 4096)
         int feat_chunk = std::max(2 * kBK, (h->n_feat + 2 * di.cus - 1) / (2 * di.cus));
-        if (getenv("CORNAC_HIP_VBPR_PROJ_CHUNK")) feat_chunk = atoi(getenv("CORNAC_HIP_VBPR_PROJ_CHUNK"));
+        feat_chunk = prof_env_int("CORNAC_HIP_VBPR_PROJ_CHUNK", feat_chunk);  // (profile builds only, csrc/common.h)
         feat_chunk = (feat_chunk + kBK - 1) / kBK * kBK;
         const int n_chunks = (h->n_feat + feat_chunk - 1) / feat_chunk;
         // the dense sweep: one launch over the four row tables, 16-byte accesses where the row width allows
@@ -567,10 +567,10 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         // 7 of the 8 workgroup slots of a CU: the sweep is persistent (grid-stride) and would otherwise hold every wave
         // slot of the chip until it ends, and the kernels of the main stream could not even start beside it
         // (measured per step: 8 slots on ONE stream 99.8 us; two streams 7 slots 91.9, 6 slots 94.2, 5 slots 95.8)
-        static const int sweep_wg_per_cu = getenv("CORNAC_HIP_VBPR_SWEEP_WGS") ? atoi(getenv("CORNAC_HIP_VBPR_SWEEP_WGS")) : 7;
+        const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 7);
         const int sweep_grid = (int)std::min<int64_t>((sw.total + kVb - 1) / kVb, (int64_t)di.cus * sweep_wg_per_cu);
-        static const bool one_stream = getenv("CORNAC_HIP_VBPR_ONE_STREAM") != nullptr;  // A/B switch: everything in stream order
-        static const bool ext_events = getenv("CORNAC_HIP_VBPR_PLAIN_EVENTS") == nullptr;  // A/B switch: hipEventRecord hand-overs
+        const bool one_stream = prof_env_set("CORNAC_HIP_VBPR_ONE_STREAM");  // A/B switch (profile builds): everything in stream order
+        const bool ext_events = !prof_env_set("CORNAC_HIP_VBPR_PLAIN_EVENTS");  // A/B switch (profile builds): hipEventRecord hand-overs
         for (int64_t b0 = 0; b0 < n_total; b0 += batch_size) {
             const int n = (int)std::min<int64_t>(batch_size, n_total - b0);
             ++h->step;

@@ -755,10 +755,10 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
         chunk = (chunk + kBK - 1) / kBK * kBK;
         const int n_chunks = (int)((nu + chunk - 1) / chunk);
         // k <= 128: the whole user side of a step is one persistent kernel (wmf_user_step_kernel)
-        static const bool no_fuse = getenv("CORNAC_HIP_WMF_UNFUSED") != nullptr;  // A/B switch for profiling
-        static const int wmf_ablate = getenv("CORNAC_HIP_WMF_ABLATE") ? atoi(getenv("CORNAC_HIP_WMF_ABLATE")) : 0;
+        const bool no_fuse = prof_env_set("CORNAC_HIP_WMF_UNFUSED");  // A/B switch, profile builds only (csrc/common.h)
+        const int wmf_ablate = prof_env_int("CORNAC_HIP_WMF_ABLATE", 0);
         const bool fused = ld <= kBN && !no_fuse;
-        static const bool g_scratch = getenv("CORNAC_HIP_WMF_GSCRATCH") != nullptr;  // A/B switch: G in a global scratch tile
+        const bool g_scratch = prof_env_set("CORNAC_HIP_WMF_GSCRATCH");  // A/B switch: G in a global scratch tile
         if (fused && h->fused_wgs == 0) {
             int per_cu = 0;
             if (g_scratch) {
@@ -768,7 +768,7 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
                                               (int)kWmfLdsBytes));
                 HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_lds_kernel, kWb, kWmfLdsBytes));
             }
-            if (getenv("CORNAC_HIP_WMF_DEBUG")) fprintf(stderr, "[wmf] fused kernel: %d workgroups per CU\n", per_cu);
+            if (prof_env_set("CORNAC_HIP_WMF_DEBUG")) fprintf(stderr, "[wmf] fused kernel: %d workgroups per CU\n", per_cu);
             h->fused_wgs = (int)std::min<int64_t>(m_tiles, (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 2)));
             h->g_scratch.alloc((size_t)h->fused_wgs * kBM * kMaxBatch);
             h->dv_part.alloc((size_t)h->fused_wgs * kMaxBatch * kBN);

@@ -520,6 +520,9 @@ class RowShardedBprTrainer:
     @property
     def triplets(self):
         """valid (not skipped) draws applied so far"""
+        # the counter is accumulated on the driver's side stream: order the read after what is queued there
+        if self.stream is not None:
+            self.stream.synchronize()
         return int(self._valid_draws.item())
 
     def load_items(self, V, B):
@@ -684,9 +687,17 @@ def rank_users_sharded(rank_fn, users, k, device=None, group=None):
         items, scores = np.empty((0, k), np.int32), np.empty((0, k), np.float32)
     if world == 1:
         return items, scores
-    width = items.shape[1] if len(mine) else k
-    cap = int((cuts[1:] - cuts[:-1]).max())
     dev = device if device is not None else torch.device("cpu")
+    # the ranks agree on the list width before padding: rank_fn may clamp k (to the item count) and a rank with an empty
+    # block has nothing to read the width from — MAX over the ranks' widths, 0 from an empty one
+    w = torch.tensor([items.shape[1] if len(mine) else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+    width = int(w.item()) or k
+    if len(mine) and items.shape[1] != width:
+        grow = width - items.shape[1]
+        items = np.concatenate([items, np.full((len(mine), grow), -1, np.int32)], axis=1)
+        scores = np.concatenate([scores, np.full((len(mine), grow), -np.inf, np.float32)], axis=1)
+    cap = int((cuts[1:] - cuts[:-1]).max())
     pad_i = torch.full((cap, width), -1, dtype=torch.int32, device=dev)
     pad_s = torch.full((cap, width), float("-inf"), dtype=torch.float32, device=dev)
     pad_i[: len(mine)] = torch.as_tensor(items)

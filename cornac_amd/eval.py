@@ -58,9 +58,11 @@ def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
     import weakref
 
     mats = (train_mat, test_mat, val_mat)
+    # entries whose matrices have died are dropped (their int64 lists are hundreds of MB at the ML-20M / Netflix shapes)
+    _LISTS_CACHE[:] = [e for e in _LISTS_CACHE if all(r is None or r() is not None for r in e[0])]
     for entry in _LISTS_CACHE:
-        refs, thr, n_items, result = entry
-        if thr == rating_threshold and n_items == n_eval_items and all(
+        refs, thr, n_items, nnzs, result = entry
+        if thr == rating_threshold and n_items == n_eval_items and nnzs == tuple(None if m is None else m.nnz for m in mats) and all(
                 (m is None and r is None) or (r is not None and m is not None and r() is m) for m, r in zip(mats, refs)):
             return result
     result = _eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items)
@@ -68,8 +70,8 @@ def eval_lists(train_mat, test_mat, val_mat, rating_threshold, n_eval_items):
         refs = tuple(None if m is None else weakref.ref(m) for m in mats)
     except TypeError:
         return result
-    _LISTS_CACHE.insert(0, (refs, rating_threshold, n_eval_items, result))
-    del _LISTS_CACHE[4:]
+    _LISTS_CACHE.insert(0, (refs, rating_threshold, n_eval_items, tuple(None if m is None else m.nnz for m in mats), result))
+    del _LISTS_CACHE[2:]
     return result
 
 
@@ -260,12 +262,20 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         for r in range(len(users)):
             per_user(r)
     else:
+        # the split's exclusion lists go to the device ONCE per (model scorer, split) and stay there across the batches,
+        # the metrics passes and the epochs / models evaluated on the split (what bench.py's ranking leg times); only
+        # ranked item ids come back
+        resident = (hasattr(model, "register_exclusions") and bool(np.all(np.diff(users) > 0)) and
+                    model.register_exclusions((id(ex_idx), len(ex_idx), int(n_eval_items), len(users)), users, ex_ptr, ex_idx))
         for b0 in range(0, len(users), batch_users_topk):
             b1 = min(b0 + batch_users_topk, len(users))
             ub = [int(u) for u in users[b0:b1]]
-            indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
-            indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
-            items, _ = model.rank_batch(ub, k=max_k, exclude=(indptr, indices))
+            if resident:
+                items = model.rank_batch_resident(ub, k=max_k)
+            else:
+                indptr = (ex_ptr[b0:b1 + 1] - ex_ptr[b0]).astype(np.int64)  # exclusion CSR of the batch: a slice, no copies per user
+                indices = np.ascontiguousarray(ex_idx[ex_ptr[b0]:ex_ptr[b1]], dtype=np.int32)
+                items, _ = model.rank_batch(ub, k=max_k, exclude=(indptr, indices))
             hits = batch_hits(items, b0, b1)
             n_gt = np.diff(gt_ptr[b0:b1 + 1])
             slow = []

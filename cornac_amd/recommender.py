@@ -89,7 +89,7 @@ class Recommender(_RecommenderRoot):
         self.is_fitted = False
         # not pickled / deep-copied: datasets and device-side state
         self.ignored_attrs = ["train_set", "val_set", "test_set", "_scorer", "_scorer_key", "_trainer", "_item_base",
-                              "_item_base_src", "_item_base_mean", "_cat_u", "_cat_i", "_cat_b", "_cat_src"]
+                              "_item_base_src", "_item_base_mean", "_cat_u", "_cat_i", "_cat_b", "_cat_src", "_excl_reg"]
         for attr in self._DATASET_FACTS:
             setattr(self, attr, None)
         self._item_ids = None
@@ -340,6 +340,46 @@ class Recommender(_RecommenderRoot):
         sc = self._get_scorer()
         topk = sc.n_items if k == -1 else min(int(k), sc.n_items)
         return sc.rank_topk(rows.astype(np.int32), topk, exclude=exclude)
+
+    def register_exclusions(self, token, user_indices, ex_ptr, ex_idx):
+        """Keep the per-user exclusion lists of an evaluation split on the device, once per (device scorer, split):
+        `ex_ptr / ex_idx` is a CSR over `user_indices` (ascending users with a device row).  `token` identifies the
+        split; a repeated call with the same token on the same scorer is free.  Returns False when the scorer cannot
+        hold resident lists (the caller then passes the lists per call)."""
+        sc = self._get_scorer()
+        if not hasattr(sc, "set_exclusions"):
+            return False
+        self._excl_reg = (token, user_indices, ex_ptr, ex_idx)  # (a scorer rebuilt later re-registers from here)
+        self._register_exclusions_on(sc)
+        return True
+
+    def _register_exclusions_on(self, sc):
+        token, user_indices, ex_ptr, ex_idx = self._excl_reg
+        if getattr(sc, "_excl_token", None) == token:
+            return
+        rows = self._scorer_rows(user_indices)
+        if (rows < 0).any():
+            raise ScoreException("register_exclusions needs users known to the model")
+        counts = np.zeros(sc.n_users, dtype=np.int64)
+        counts[rows] = np.diff(np.asarray(ex_ptr, dtype=np.int64))
+        full_ptr = np.concatenate(([0], np.cumsum(counts)))
+        # the listed users ascend, so their lists concatenated in that order ARE the full CSR's index array
+        sc.set_exclusions(full_ptr, np.ascontiguousarray(ex_idx, dtype=np.int32))
+        sc._excl_token = token
+
+    def rank_batch_resident(self, user_indices, k=10):
+        """`rank_batch` against the lists of `register_exclusions`: nothing but the user ids goes to the device and
+        only the ranked item ids come back (page-locked buffer owned by the scorer: valid until the next call)."""
+        rows = self._scorer_rows(user_indices)
+        if (rows < 0).any():
+            raise ScoreException("rank_batch needs users known to the model")
+        if self.__dict__.get("_excl_reg") is None:
+            raise ScoreException("rank_batch_resident needs register_exclusions first")
+        sc = self._get_scorer()
+        self._register_exclusions_on(sc)  # (free unless the scorer was rebuilt since)
+        topk = min(int(k), sc.n_items)
+        items, _ = sc.rank_topk_resident(rows.astype(np.int32), topk, fetch="items", pinned=True)
+        return items
 
     def rank_positions_batch(self, user_indices, targets, exclude=None):
         """Where each listed item stands in its user's ranking, without producing the rankings: `targets` and

@@ -178,6 +178,18 @@ class FakeScorer:
             items[r, :len(order)], scores[r, :len(order)] = order, S[r][order]
         return items, scores
 
+    def set_exclusions(self, indptr=None, indices=None):
+        self._excl = None if indptr is None else (np.asarray(indptr, np.int64), np.asarray(indices, np.int32))
+
+    def rank_topk_resident(self, users, topk, fetch=True, timed=False, pinned=False):
+        users = np.asarray(users, np.int32)
+        ip, ix = self._excl
+        cnt = ip[users + 1] - ip[users]
+        ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        idx = np.concatenate([ix[ip[u]:ip[u + 1]] for u in users] + [np.zeros(0, np.int32)]).astype(np.int32)
+        items, scores = self.rank_topk(users, topk, exclude=(ptr, idx))
+        return (items, None if fetch == "items" else scores)
+
     def rank_positions(self, users, targets, exclude=None):
         S = self.score_block(users)
         out = [[], [], [], []]

@@ -355,3 +355,30 @@ def test_resident_exclusion_lists_rank_like_per_call_lists(oracle, k, n_items):
     assert np.array_equal(items4, items3) and np.array_equal(scores4, scores3)
     assert sc.rank_topk_resident((5, 1), topk, fetch=False) == (None, None)
     sc.close()
+
+
+def test_exclusion_bitmap_is_chunked_by_rows_beyond_its_budget():
+    """the exclusion bitmap of the fused top-k costs rows x ceil(n_items / 32) x 4 bytes; beyond 512 MB
+    the rows are ranked in chunks.  36 000 users x 200 000 items (900 MB unchunked): the chunked call must equal the same
+    ranking asked for in two halves and honour every exclusion."""
+    rs = np.random.RandomState(3)
+    n_users, n_items, k = 36_000, 200_000, 16
+    U = rs.normal(0, 0.3, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (n_items, k)).astype(np.float32)
+    Bi = rs.normal(0, 0.1, n_items).astype(np.float32)
+    sc = _lib.Scorer(U, V, Bi, None)
+    users = np.arange(n_users, dtype=np.int32)
+    per = 6
+    excl_idx = np.sort(rs.randint(0, n_items, (n_users, per)), axis=1)
+    excl_idx[:, 1:] += (np.diff(excl_idx, axis=1) == 0)  # (distinct within a row is not required, sorted is)
+    excl_idx = np.sort(np.minimum(excl_idx, n_items - 1), axis=1).astype(np.int32).ravel()
+    excl_ptr = (np.arange(n_users + 1, dtype=np.int64) * per)
+    items, scores = sc.rank_topk(users, 10, exclude=(excl_ptr, excl_idx))
+    h = n_users // 2
+    a, _ = sc.rank_topk(users[:h], 10, exclude=(excl_ptr[:h + 1], excl_idx[:h * per]))
+    b, _ = sc.rank_topk(users[h:], 10, exclude=(excl_ptr[h:] - excl_ptr[h], excl_idx[h * per:]))
+    sc.close()
+    assert np.array_equal(items[:h], a) and np.array_equal(items[h:], b)
+    ex = excl_idx.reshape(n_users, per)
+    assert not (items[:, :, None] == ex[:, None, :]).any()
+    assert (np.diff(scores, axis=1) <= 0).all()
