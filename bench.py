@@ -467,6 +467,17 @@ def leg_bpr_k128_scale(args, _lib):
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
            "train_stats": {"correct_frac": c / max(nnz * epochs - sk, 1), "skipped_frac": skip},
            "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
+    # this leg's rate differs by up to 25 % between GPU boxes (11.5 GB of randomly accessed tables); the line carries a
+    # calibration of the box it ran on — copy, streaming read and random 512-byte gather rates over 6 GiB buffers — and
+    # the partition modes rocm-smi reports, so that a slow run can be told from a slow box
+    try:
+        out["box"] = _lib.device_probe(0, 6 << 30)
+        import subprocess
+        smi = subprocess.run(["rocm-smi", "--showmemorypartition", "--showcomputepartition"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+        out["box"]["partitions"] = [ln.strip() for ln in smi.splitlines() if "artition" in ln and "GPU[0]" in ln]
+    except Exception as e:
+        out["box"] = {"error": repr(e)}
     if args.cpu_baseline_seconds > 0:
         try:
             # the reference kernel on the first 1 M users of the same matrix (its U slice is 0.5 GB instead of 6.4 GB)

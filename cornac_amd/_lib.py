@@ -26,6 +26,7 @@ NEG_POPULARITY = 1
 # every symbol include/cornac_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cornac_hip_last_error", "cornac_hip_version", "cornac_hip_device_count", "cornac_hip_device_info",
+    "cornac_hip_device_probe",
     "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
     "cornac_hip_bpr_bind_device", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
@@ -121,6 +122,7 @@ def lib():
         L.cornac_hip_version.restype = C.c_char_p
         L.cornac_hip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.cornac_hip_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.cornac_hip_device_probe.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_double)]
         L.cornac_hip_bpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                             C.c_int, _i32, _i32, C.c_int64]
         L.cornac_hip_bpr_destroy.argtypes = [_vp]
@@ -222,6 +224,14 @@ def device_count():
     n = C.c_int(0)
     check(lib().cornac_hip_device_count(C.byref(n)))
     return n.value
+
+
+def device_probe(device=0, nbytes=6 << 30):
+    """memory-system calibration of this box: GB/s of a device-to-device copy, a streaming read and random 512-byte
+    row gathers over buffers of nbytes"""
+    o = (C.c_double * 3)()
+    check(lib().cornac_hip_device_probe(device, int(nbytes), o))
+    return {"d2d_copy_GBps": o[0], "stream_read_GBps": o[1], "row_gather_512B_GBps": o[2], "buffer_bytes": int(nbytes)}
 
 
 def device_info(device=0):

@@ -175,6 +175,74 @@ int cornac_hip_device_count(int *count) {
     });
 }
 
+namespace chip {
+// random 512-byte row gathers over a table (the access pattern of the k = 128 SGD kernels): every wave reads whole rows
+// chosen by a hash of (row counter, seed) and folds them into a checksum so the loads are not optimised away
+__global__ __launch_bounds__(256) void probe_gather_kernel(const float *__restrict__ table, int64_t n_rows, int64_t n_gathers,
+                                                           float *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+    float acc = 0.f;
+    for (int64_t g = wave; g < n_gathers; g += n_waves) {
+        uint64_t h = (uint64_t)g * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        const int64_t r = (int64_t)(h % (uint64_t)n_rows);
+        acc += __builtin_nontemporal_load(table + r * 128 + lane) + __builtin_nontemporal_load(table + r * 128 + 64 + lane);
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+typedef float probe_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void probe_stream_kernel(const probe_v4f *__restrict__ src, int64_t n4, float *__restrict__ sink) {
+    float acc = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n4; t += (int64_t)gridDim.x * 256) {
+        const probe_v4f v = __builtin_nontemporal_load(src + t);
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+}  // namespace chip
+
+int cornac_hip_device_probe(int device, int64_t bytes, double *out3) {
+    return chip::guarded([&] {
+        REQUIRE(out3 != nullptr && bytes >= (int64_t(1) << 20), "bad arguments");
+        chip::use_device(device);
+        chip::DevBuf<float> a, b;
+        const int64_t n = bytes / 4 / 128 * 128;
+        a.alloc((size_t)n);
+        b.alloc((size_t)n);
+        HIP_CHECK(hipMemset(a.p, 0, (size_t)n * 4));
+        HIP_CHECK(hipMemset(b.p, 0, (size_t)n * 4));
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        auto timed = [&](auto &&f) {
+            f();  // warm-up
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            f();
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)ms * 1e-3;
+        };
+        const int grid = chip::device_info(device).cus * 8;
+        const double t_copy = timed([&] { HIP_CHECK(hipMemcpyAsync(b.p, a.p, (size_t)n * 4, hipMemcpyDeviceToDevice, nullptr)); });
+        const double t_stream = timed([&] {
+            hipLaunchKernelGGL(chip::probe_stream_kernel, dim3(grid), dim3(256), 0, nullptr, (const chip::probe_v4f *)a.p, n / 4, b.p);
+        });
+        const int64_t n_rows = n / 128, n_gathers = int64_t(1) << 25;
+        const double t_gather = timed([&] {
+            hipLaunchKernelGGL(chip::probe_gather_kernel, dim3(grid), dim3(256), 0, nullptr, a.p, n_rows, n_gathers, b.p);
+        });
+        HIP_CHECK(hipGetLastError());
+        out3[0] = 2.0 * (double)n * 4 / t_copy / 1e9;            // device-to-device copy, bytes read + written
+        out3[1] = (double)n * 4 / t_stream / 1e9;                // streaming read
+        out3[2] = (double)n_gathers * 512 / t_gather / 1e9;      // random 512-byte row gathers
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    });
+}
+
 int cornac_hip_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes) {
     return chip::guarded([&] {
         int n = 0;

@@ -51,6 +51,10 @@ const char *cornac_hip_version(void);
 int cornac_hip_device_count(int *count);
 /* name (<=255 chars), CU count and HBM bytes of a device */
 int cornac_hip_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+/* Memory-system calibration of the box a benchmark runs on (bench.py reports it beside the scale leg, whose
+ * throughput differs between boxes): over two scratch buffers of `bytes` each, out3 = {device-to-device copy GB/s
+ * (read + written), streaming read GB/s, random 512-byte row gather GB/s} */
+int cornac_hip_device_probe(int device, int64_t bytes, double *out3);
 
 /* ------------------------------------------------------------------------- *
  * BPR / WBPR trainer.
