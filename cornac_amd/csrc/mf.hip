@@ -60,6 +60,164 @@ __global__ __launch_bounds__(kBlock) void mf_det_level_kernel(const int32_t *__r
     if (lane_id() == 0 && e2 != 0.0) atomicAdd(loss_acc, e2);
 }
 
+// Deterministic mode WITHOUT one launch per level: a dataflow ("chain") kernel.
+//
+// The level schedule above costs a kernel launch per link of the longest row-dependency chain (255 k links for the
+// Netflix-shape epoch: 304 s).  Here the whole epoch is ONE persistent launch in which every rating waits for exactly
+// what the sequential loop (backend_cpu.pyx:58-83) would have finished before it:
+//   * every row of the OWNED side (users or items — the host picks the side whose ratings are adjacent in the stored
+//     order, else the one with the longer hottest chain) belongs to one wave, and that wave applies the row's ratings
+//     in their stored order: the row is read and written by one wave only — plain loads / stores;
+//   * a row of the other (SHARED) side can be needed by many waves: `ver[row]` counts its finished updates, `cseq[t]` is
+//     the position of rating t among that row's ratings; a rating runs when ver[row] == cseq[t], and afterwards the wave
+//     drains its stores and publishes ver[row] = cseq[t] + 1.  Shared rows, their biases and the counters travel with
+//     system-scope (sc0 sc1) loads and stores — they bypass the non-coherent per-XCD L2s, the valid cross-XCD form
+//     without fences (MI355X_MICROARCH.md, inter-workgroup visibility);
+//   * a wave never blocks on one rating: its lanes hold the cursors of 64 of its rows at a time, all 64 next ratings are
+//     polled with one vector load of the counters, the ready ones are executed one after the other (each wave-wide),
+//     the chunk is polled again while anything in it moves, then the next 64 rows — cyclically over all its rows.
+//     A stored order in which a row's early rating waits for another row's late one (items in random order inside
+//     a user's run) therefore stalls that row only, not the wave: measured 259 s -> see DESIGN.md 1.1 for the in-order
+//     form of this kernel.
+// Progress: the globally first unfinished rating is the next rating of its owned row, every earlier rating of its
+// shared row is finished, and its wave visits all its rows cyclically without ever blocking — it runs.  No wave waits
+// for a wave that is not resident: nothing blocks at all.  The float expression tree is the level kernel's (the
+// reference's), every row sees its updates in the stored order, so the result is bit-identical to the sequential loop.
+// A wave that makes no progress for `wait_bound_ticks` (a bug, never contention) raises `abort` and every wave leaves.
+struct MfChainArgs {
+    const int64_t *wrow_ptr;        // [W + 1] rows of wave w = [wrow_ptr[w], wrow_ptr[w + 1])
+    const int32_t *row_id;          // owned-side id of a row
+    const int64_t *row_end;         // end of the row's ratings in csid / cseq / cr
+    int64_t *row_cur;               // next rating of the row (reset to the row's begin every epoch)
+    const int32_t *csid, *cseq;     // shared-side id of a rating, its position among that row's ratings
+    const float *cr;
+    unsigned int *ver;              // [rows of the shared side] finished updates of the row in this epoch
+    unsigned int *abort;            // [8]: [0] a wave gave up, [1..5] who / what (diagnostics)
+    long long wait_bound_ticks;     // of the 100 MHz real-time counter
+    float *U, *V, *Bu, *Bi;
+    double *loss_acc;
+    int k, use_bias;
+    float lr, reg, mu;
+};
+
+__device__ __forceinline__ float load_f32_sys(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_f32_sys(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int R, bool OWN_USER>  // k <= 64 R
+__global__ __launch_bounds__(kBlock) void mf_det_chain_kernel(const MfChainArgs a) {
+    const int lane = lane_id();
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t q0 = a.wrow_ptr[w], q1 = a.wrow_ptr[w + 1];
+    double loss = 0.0;
+    unsigned long long t_idle = 0;  // real-time stamp of the first fruitless sweep in a row (0: progressing)
+    unsigned int idle_sweeps = 0;
+    bool give_up = false;
+    while (!give_up) {
+        bool unfinished = false, progressed = false;
+        for (int64_t base = q0; base < q1; base += kWave) {
+            const int64_t q = base + lane;
+            const bool mine = q < q1;
+            int64_t cur = mine ? a.row_cur[q] : 0;
+            const int64_t rend = mine ? a.row_end[q] : 0;
+            const int32_t oid = mine ? a.row_id[q] : 0;
+            for (;;) {
+                // ---- poll the next rating of up to 64 rows at once ----
+                const bool has = mine && cur < rend;
+                const int32_t sid = has ? a.csid[cur] : 0;
+                const unsigned int seq = has ? (unsigned int)a.cseq[cur] : 0u;
+                const unsigned int v = has ? __hip_atomic_load(a.ver + sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0u;
+                unsigned long long ready = __ballot(has && v == seq);
+                if (!ready) break;
+                asm volatile("" ::: "memory");  // (compiler: the row loads below stay behind the poll; the hardware issues in order)
+                progressed = true;
+                const float rr = has ? a.cr[cur] : 0.f;
+                while (ready) {
+                    const int l = __builtin_ctzll(ready);
+                    ready &= ready - 1;
+                    const int32_t o = __builtin_amdgcn_readlane(oid, l), s = __builtin_amdgcn_readlane(sid, l);
+                    const unsigned int sq = (unsigned int)__builtin_amdgcn_readlane((int)seq, l);
+                    const float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), l));
+                    const int32_t u = OWN_USER ? o : s, i = OWN_USER ? s : o;
+                    float *pu = a.U + (size_t)u * a.k, *pi = a.V + (size_t)i * a.k;
+                    float uf[R], vf[R];
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const int f = lane + kWave * c;
+                        uf[c] = f < a.k ? (OWN_USER ? pu[f] : load_f32_sys(pu + f)) : 0.f;
+                        vf[c] = f < a.k ? (OWN_USER ? load_f32_sys(pi + f) : pi[f]) : 0.f;
+                    }
+                    const float bu = OWN_USER ? a.Bu[u] : load_f32_sys(a.Bu + u), bi = OWN_USER ? load_f32_sys(a.Bi + i) : a.Bi[i];
+                    // ---- the reference's expression tree (mf_det_level_kernel) ----
+                    float pred = a.mu + bu + bi;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        if (kWave * c < a.k) pred = ordered_lane_sum<kWave>(pred, uf[c] * vf[c], min(kWave, a.k - kWave * c));
+                    }
+                    const float err = r - pred;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const int f = lane + kWave * c;
+                        if (f < a.k) {
+                            const float un = uf[c] + a.lr * (err * vf[c] - a.reg * uf[c]), vn = vf[c] + a.lr * (err * uf[c] - a.reg * vf[c]);
+                            if (OWN_USER) {
+                                pu[f] = un;
+                                store_f32_sys(pi + f, vn);
+                            } else {
+                                store_f32_sys(pu + f, un);
+                                pi[f] = vn;
+                            }
+                        }
+                    }
+                    if (lane == 0 && a.use_bias) {
+                        const float bun = bu + a.lr * (err - a.reg * bu), bin = bi + a.lr * (err - a.reg * bi);
+                        if (OWN_USER) {
+                            a.Bu[u] = bun;
+                            store_f32_sys(a.Bi + i, bin);
+                        } else {
+                            store_f32_sys(a.Bu + u, bun);
+                            a.Bi[i] = bin;
+                        }
+                    }
+                    if (lane == 0) loss += (double)err * (double)err;
+                    // ---- publish: every store of this wave has left before the counter moves ----
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(a.ver + s, sq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (lane == l) ++cur;
+                }
+            }
+            if (mine) a.row_cur[q] = cur;
+            unfinished = unfinished || __ballot(mine && cur < rend) != 0ull;
+        }
+        if (!unfinished) break;
+        if (progressed) {
+            t_idle = 0;
+            idle_sweeps = 0;
+            continue;
+        }
+        // nothing of this wave can run yet: back off (longer the longer it lasts) and watch the bound
+        ++idle_sweeps;
+        if (idle_sweeps < 8) __builtin_amdgcn_s_sleep(8);
+        else if (idle_sweeps < 64) __builtin_amdgcn_s_sleep(64);
+        else __builtin_amdgcn_s_sleep(127);
+        if ((idle_sweeps & 255u) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_idle == 0) t_idle = now;
+            int bad = 0;
+            if (lane == 0 && (now - t_idle > (unsigned long long)a.wait_bound_ticks ||
+                              __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+                if (atomicCAS(a.abort, 0u, 1u) == 0u) a.abort[1] = (unsigned int)w;
+                bad = 1;
+            }
+            give_up = __builtin_amdgcn_readfirstlane(bad) != 0;
+        }
+    }
+    if (lane == 0 && loss != 0.0) atomicAdd(a.loss_acc, loss);
+}
+
 struct MfHogArgs {
     const int64_t *rid, *cid;  // COO order (no ownership)
     const float *val;
@@ -277,6 +435,13 @@ struct cornac_hip_mf {
     LevelSchedule sched;
     std::vector<int64_t> host_rid, host_cid;
     std::vector<float> host_val;
+    // deterministic dataflow ("chain") kernel: ratings grouped by the wave that owns their item, per-user sequence numbers
+    bool chain_built = false, chain_own_user = false;
+    int chain_grid = 0;
+    DevBuf<int32_t> c_row_id, c_sid, c_seq;
+    DevBuf<float> c_r;
+    DevBuf<int64_t> c_wrow_ptr, c_row_beg, c_row_end, c_row_cur;
+    DevBuf<unsigned int> uver, chain_abort;
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
     DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
@@ -367,6 +532,139 @@ static void mf_epoch_deterministic(cornac_hip_mf_t h, float lr, float reg, float
         }
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// ---- deterministic dataflow kernel: schedule and launch ---------------------------------------------------------------
+typedef void (*MfChainKernel)(const MfChainArgs);
+static MfChainKernel pick_chain_kernel(int k, bool own_user) {
+    if (own_user) {
+        if (k <= 64) return mf_det_chain_kernel<1, true>;
+        if (k <= 128) return mf_det_chain_kernel<2, true>;
+        if (k <= 192) return mf_det_chain_kernel<3, true>;
+        return mf_det_chain_kernel<4, true>;
+    }
+    if (k <= 64) return mf_det_chain_kernel<1, false>;
+    if (k <= 128) return mf_det_chain_kernel<2, false>;
+    if (k <= 192) return mf_det_chain_kernel<3, false>;
+    return mf_det_chain_kernel<4, false>;
+}
+
+static bool mf_uses_chain(cornac_hip_mf_t h) { return h->k <= 256 && h->nnz >= 4096; }
+
+static void mf_build_chain(cornac_hip_mf_t h) {
+    if (h->chain_built) return;
+    Timer t;
+    const int64_t n = h->nnz, ni = h->n_items, nu = h->n_users;
+    // Which side do the waves own?  The side whose ratings are ADJACENT in the stored order (a uir_tuple sorted by user
+    // or by item): a run then stays inside one wave.  Without adjacency: the side with the longer hottest chain (its
+    // links are then wave-local instead of cross-wave hand-offs).
+    int64_t adj_u = 0, adj_i = 0;
+    std::vector<int64_t> cnt_u((size_t)nu, 0), cnt_i((size_t)ni, 0);
+    for (int64_t s = 0; s < n; ++s) {
+        ++cnt_u[(size_t)h->host_rid[(size_t)s]];
+        ++cnt_i[(size_t)h->host_cid[(size_t)s]];
+        if (s) {
+            adj_u += h->host_rid[(size_t)s] == h->host_rid[(size_t)s - 1];
+            adj_i += h->host_cid[(size_t)s] == h->host_cid[(size_t)s - 1];
+        }
+    }
+    const int64_t max_u = *std::max_element(cnt_u.begin(), cnt_u.end()), max_i = *std::max_element(cnt_i.begin(), cnt_i.end());
+    h->chain_own_user = std::max(adj_u, adj_i) * 10 > n * 3 ? adj_u > adj_i : max_u > max_i;
+    const bool own_user = h->chain_own_user;
+    int per_cu = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_chain_kernel(h->k, own_user), kBlock, 0));
+    // progress needs the wave that owns the globally first unfinished rating to be running: HALF of what the occupancy
+    // query admits keeps every block of the grid resident even where the hardware admits one block per CU fewer than
+    // the API says (kernels with more than 80 SGPRs, MI355X_MICROARCH.md, residency)
+    h->chain_grid = device_info(h->device).cus * std::max(1, std::min(per_cu, 8) / 2);
+    const int64_t W = (int64_t)h->chain_grid * kWavesPerBlock;
+    // owned rows -> waves, heaviest first onto the least loaded wave
+    const std::vector<int64_t> &cnt = own_user ? cnt_u : cnt_i;
+    const std::vector<int64_t> &own_id = own_user ? h->host_rid : h->host_cid, &sh_id = own_user ? h->host_cid : h->host_rid;
+    const int64_t n_own = own_user ? nu : ni, n_sh = own_user ? ni : nu;
+    std::vector<int32_t> order((size_t)n_own);
+    for (int64_t i = 0; i < n_own; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] > cnt[(size_t)y]; });
+    typedef std::pair<int64_t, int64_t> LW;
+    std::priority_queue<LW, std::vector<LW>, std::greater<LW>> heap;
+    for (int64_t w = 0; w < W; ++w) heap.push(LW(0, w));
+    std::vector<int32_t> owner((size_t)n_own, 0);
+    std::vector<int64_t> load((size_t)W, 0);
+    for (int32_t i : order) {
+        if (cnt[(size_t)i] == 0) continue;
+        LW top = heap.top();
+        heap.pop();
+        owner[(size_t)i] = (int32_t)top.second;
+        top.first += cnt[(size_t)i];
+        load[(size_t)top.second] = top.first;
+        heap.push(top);
+    }
+    // rows of a wave in the order of their first rating; a row's ratings in stored order
+    std::vector<int64_t> first((size_t)n_own, -1);
+    for (int64_t s = n - 1; s >= 0; --s) first[(size_t)own_id[(size_t)s]] = s;
+    std::vector<std::vector<int32_t>> wrows((size_t)W);
+    for (int64_t i = 0; i < n_own; ++i)
+        if (cnt[(size_t)i] > 0) wrows[(size_t)owner[(size_t)i]].push_back((int32_t)i);
+    std::vector<int64_t> wrow_ptr((size_t)W + 1, 0), row_beg, row_end, row_of((size_t)n_own, -1);
+    std::vector<int32_t> row_id;
+    int64_t pos = 0;
+    for (int64_t w = 0; w < W; ++w) {
+        std::sort(wrows[(size_t)w].begin(), wrows[(size_t)w].end(), [&](int32_t x, int32_t y) { return first[(size_t)x] < first[(size_t)y]; });
+        for (int32_t i : wrows[(size_t)w]) {
+            row_of[(size_t)i] = (int64_t)row_id.size();
+            row_id.push_back(i);
+            row_beg.push_back(pos);
+            pos += cnt[(size_t)i];
+            row_end.push_back(pos);
+        }
+        wrow_ptr[(size_t)w + 1] = (int64_t)row_id.size();
+    }
+    std::vector<int64_t> cur(row_beg);
+    std::vector<int32_t> csid((size_t)n), cseq((size_t)n), seen((size_t)n_sh, 0);
+    std::vector<float> cr((size_t)n);
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t p = cur[(size_t)row_of[(size_t)own_id[(size_t)s]]]++;
+        csid[(size_t)p] = (int32_t)sh_id[(size_t)s];
+        cr[(size_t)p] = h->host_val[(size_t)s];
+        cseq[(size_t)p] = seen[(size_t)sh_id[(size_t)s]]++;
+    }
+    const size_t n_rows = row_id.size();
+    h->c_sid.alloc((size_t)n); h->c_seq.alloc((size_t)n); h->c_r.alloc((size_t)n);
+    h->c_row_id.alloc(n_rows); h->c_row_beg.alloc(n_rows); h->c_row_end.alloc(n_rows); h->c_row_cur.alloc(n_rows);
+    h->c_wrow_ptr.alloc((size_t)W + 1);
+    h->uver.alloc((size_t)n_sh);
+    h->chain_abort.alloc(8);
+    h->c_sid.upload(csid.data(), (size_t)n, h->stream);
+    h->c_seq.upload(cseq.data(), (size_t)n, h->stream);
+    h->c_r.upload(cr.data(), (size_t)n, h->stream);
+    h->c_row_id.upload(row_id.data(), n_rows, h->stream);
+    h->c_row_beg.upload(row_beg.data(), n_rows, h->stream);
+    h->c_row_end.upload(row_end.data(), n_rows, h->stream);
+    h->c_wrow_ptr.upload(wrow_ptr.data(), (size_t)W + 1, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->chain_built = true;
+    h->timing[1] += t.ms();
+}
+
+static void mf_epoch_chain(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    mf_build_chain(h);
+    HIP_CHECK(hipMemsetAsync(h->uver.p, 0, h->uver.n * sizeof(unsigned int), h->stream));
+    HIP_CHECK(hipMemsetAsync(h->chain_abort.p, 0, 8 * sizeof(unsigned int), h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->c_row_cur.p, h->c_row_beg.p, h->c_row_beg.n * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+    MfChainArgs a;
+    a.wrow_ptr = h->c_wrow_ptr.p; a.row_id = h->c_row_id.p; a.row_end = h->c_row_end.p; a.row_cur = h->c_row_cur.p;
+    a.csid = h->c_sid.p; a.cseq = h->c_seq.p; a.cr = h->c_r.p;
+    a.ver = h->uver.p; a.abort = h->chain_abort.p;
+    a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p; a.Bi = h->Bi.p; a.loss_acc = loss_slot;
+    a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    a.wait_bound_ticks = (long long)prof_env_int("CORNAC_HIP_MF_CHAIN_WAIT_S", 120) * 100000000ll;
+    hipLaunchKernelGGL(pick_chain_kernel(h->k, h->chain_own_user), dim3(h->chain_grid), dim3(kBlock), 0, h->stream, a);
+    HIP_CHECK(hipGetLastError());
+    unsigned int ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(ab, h->chain_abort.p, sizeof ab, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (ab[0])
+        fail(CORNAC_HIP_ERR_HIP, "deterministic MF dataflow kernel: wave %u made no progress for its time bound (internal error)", ab[1]);
 }
 
 typedef void (*MfHogKernel)(const MfHogArgs);
@@ -624,12 +922,16 @@ int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, floa
         Timer total;
         h->loss.ensure((size_t)std::max(max_iter, 1));
         HIP_CHECK(hipMemsetAsync(h->loss.p, 0, h->loss.n * sizeof(double), h->stream));
-        if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_build_schedule(h);
+        const bool chain = mode == CORNAC_HIP_MODE_DETERMINISTIC && mf_uses_chain(h) && !prof_env_set("CORNAC_HIP_MF_LEVELS");
+        if (mode == CORNAC_HIP_MODE_DETERMINISTIC) {
+            if (chain) mf_build_chain(h); else mf_build_schedule(h);
+        }
         Timer t_k;
         float loss = 0.f, last_loss = 0.f;
         int e = 0;
         for (; e < max_iter; ++e) {
-            if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
+            if (chain) mf_epoch_chain(h, lr, reg, mu, use_bias, h->loss.p + e);
+            else if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
             else mf_epoch_hogwild(h, lr, reg, mu, use_bias, h->loss.p + e);
             if (early_stop) {  // needs this epoch's loss on the host (backend_cpu.pyx:89-93)
                 double l;

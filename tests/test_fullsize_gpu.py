@@ -196,45 +196,66 @@ def test_mf_full_size_deterministic_and_hogwild(oracle, ml20m):
 @pytest.mark.timeout(900)
 def test_mf_netflix_shape_deterministic_and_hogwild(oracle):
     """BASELINE configs[2] at its TRUE shape: 480 189 users x 17 770 items, 100 480 507 ratings (int64 COO, the
-    reference's uir_tuple dtypes), k = 128.  One deterministic epoch against the sequential oracle (the reference's
-    seeded loop, backend_cpu.pyx:35-97), then the hogwild kernel's epoch loss against the same oracle state."""
+    reference's uir_tuple dtypes), k = 128.  One deterministic epoch over ALL ratings against the sequential oracle
+    (the reference's seeded loop, backend_cpu.pyx:35-97) with both clocks in the log, a chain-like stored order on a
+    subsample, then the hogwild kernel's epoch loss against a float64 evaluation."""
     from bench import synth_ratings
     from cornac_amd import synth
 
     n_users, n_items, nnz, zipf_a, seed = synth.CONFIGS["netflix"]
     rid, cid, val = synth_ratings(n_users, n_items, nnz, zipf_a, seed)
     assert len(val) == 100_480_507 and rid.dtype == np.int64 and cid.dtype == np.int64
-    # insertion order != sorted order in a real uir_tuple: shuffle blocks of the list (a full permutation of 100 M
-    # entries costs more host time than the test needs)
+    k, lr, reg = 128, 0.01, 0.02
+    mu = np.float32(val.mean(dtype=np.float64))
     rs = np.random.RandomState(11)
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    import time
+
+    def det_epoch(r_, c_, v_):
+        """(device result, device seconds, oracle result, oracle seconds) of one sequential epoch"""
+        Uo, Vo, Buo, Bio = U0.copy(), V0.copy(), zu.copy(), zi.copy()
+        loss_o = np.zeros(1, np.float32)
+        t0 = time.perf_counter()
+        assert oracle.lib().oracle_mf_fit(r_, c_, v_, len(v_), Uo, Vo, Buo, Bio, k, lr, reg, float(mu), 1, 1, 1, 0,
+                                          loss_o.ctypes.data) == 1
+        t_cpu = time.perf_counter() - t0
+        tr = _lib.MfTrainer(r_, c_, v_, n_users, n_items, k)
+        tr.set_factors(U0, V0, zu, zi)
+        tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_DETERMINISTIC)
+        timing = tr.last_timing()
+        got = tr.get_factors()
+        tr.close()
+        return got, timing, (Uo, Vo, Buo, Bio), t_cpu
+
+    # (1) ALL 100 480 507 ratings in the order of the Netflix Prize files: one block of ratings per movie (item-major;
+    # the users inside a block in generation order).  The deterministic mode runs as ONE persistent dataflow launch
+    # (mf_det_chain_kernel: the waves own the items, user rows are handed over through per-row update counters); the
+    # reference's own sequential loop (the oracle, one host thread) is timed beside it.
+    order = np.argsort(cid, kind="stable")
+    rid_i, cid_i, val_i = (np.ascontiguousarray(x[order]) for x in (rid, cid, val))
+    got, timing, want, t_cpu = det_epoch(rid_i, cid_i, val_i)
+    err = max(np.abs(g - w).max() for g, w in zip(got, want))
+    print("Netflix-shape MF deterministic epoch, item-major order, %d ratings: max |err| = %.3g; device %s; the sequential "
+          "oracle on one host thread: %.1f s" % (len(val_i), err, timing, t_cpu))
+    assert err <= 1e-4 and np.mean(got[0] == want[0]) > 0.99
+    assert timing["sgd_ms"] / 1e3 < t_cpu, "the deterministic epoch must not be slower than the reference's sequential loop"
+    Vd = got[1]
+    del rid_i, cid_i, val_i, order
+    # (2) a stored order whose dependency DAG is almost a single chain — user-major with the items of a user in random
+    # order, blocks of the list shuffled (61 M links over 100 M ratings: an early rating of one user waits for a late
+    # rating of the previous one; no schedule can run it in parallel) — on every 10th rating: correctness of the waiting
+    # protocol where nearly every rating waits
     blocks = rs.permutation(1024)
     cuts = np.linspace(0, nnz, 1025).astype(np.int64)
     order = np.concatenate([np.arange(cuts[b], cuts[b + 1]) for b in blocks])
     rid, cid, val = rid[order], cid[order], val[order]
-    k, lr, reg = 128, 0.01, 0.02
-    mu = np.float32(val.mean(dtype=np.float64))
-    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
-    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
-    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
-    # Deterministic mode is a parity vehicle: its level schedule has one kernel launch per link of the longest
-    # dependency chain (hundreds of thousands at this shape; the full 100 M-rating epoch takes 304 s on the device and
-    # was checked once: max |err| = 0 against the oracle, DESIGN.md 3).  The routine check uses every 10th rating:
-    # all 480 189 x 17 770 rows of both tables, 10 M sequential updates.  CORNAC_TEST_FULL_DET=1 runs all of them.
-    step = 1 if os.environ.get("CORNAC_TEST_FULL_DET") else 10
-    rid_d, cid_d, val_d = (np.ascontiguousarray(x[::step]) for x in (rid, cid, val))
-    Uo, Vo, Buo, Bio = U0.copy(), V0.copy(), zu.copy(), zi.copy()
-    loss_o = np.zeros(1, np.float32)
-    assert oracle.lib().oracle_mf_fit(rid_d, cid_d, val_d, len(val_d), Uo, Vo, Buo, Bio, k, lr, reg, float(mu), 1, 1, 1, 0,
-                                      loss_o.ctypes.data) == 1
-    tr = _lib.MfTrainer(rid_d, cid_d, val_d, n_users, n_items, k)
-    tr.set_factors(U0, V0, zu, zi)
-    loss_d, _ = tr.fit(1, lr, reg, float(mu), True, False, _lib.MODE_DETERMINISTIC)
-    Ud, Vd, Bud, Bid = tr.get_factors()
-    timing = tr.last_timing()
-    tr.close()
-    err = max(np.abs(Ud - Uo).max(), np.abs(Vd - Vo).max(), np.abs(Bud - Buo).max(), np.abs(Bid - Bio).max())
-    print("Netflix-shape MF deterministic epoch over %d ratings: max |err| = %.3g, timing %s" % (len(val_d), err, timing))
-    assert err <= 1e-4 and np.mean(Ud == Uo) > 0.99
+    got, timing, want, t_cpu = det_epoch(*(np.ascontiguousarray(x[::10]) for x in (rid, cid, val)))
+    err = max(np.abs(g - w).max() for g, w in zip(got, want))
+    print("Netflix-shape MF deterministic epoch, chain-like order, %d ratings: max |err| = %.3g; device %s; oracle %.1f s"
+          % (len(val) // 10 + 1, err, timing, t_cpu))
+    assert err <= 1e-4
     # the hogwild kernel over ALL 100 480 507 ratings; its epoch loss against a float64 evaluation of the same
     # predictions from the start tables (the reference's own float32 running sum loses 30 % of its value at 1e8 terms)
     tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
@@ -252,7 +273,7 @@ def test_mf_netflix_shape_deterministic_and_hogwild(oracle):
     # (the reported loss is 0.5 x the sum of squared errors seen during the epoch, backend_cpu.pyx:88)
     assert 0.05 * sse0 < loss_h[0] < 0.5 * sse0 and loss_h2[0] < loss_h[0], (sse0, loss_h, loss_h2)
     # same optimisation problem as the sequential pass on the subsample: item rows moved in the same direction
-    dv_h, dv_d = (Vh - V0).ravel(), (Vd - V0).ravel()
+    dv_h, dv_d = (Vh - V0).ravel(), (Vd - V0).ravel()  # (Vd: the sequential pass over all ratings in item-major order)
     assert float(dv_h @ dv_d) / (np.linalg.norm(dv_h) * np.linalg.norm(dv_d)) > 0.5
 
 
