@@ -354,6 +354,46 @@ def test_ldsbin_updates_are_exact_and_learn_like_the_fused_kernel(oracle):
         assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
 
 
+@pytest.mark.parametrize("k,use_bias,form", [(40, True, "ldsbin"), (100, True, "ldsbin"), (128, False, "ldsbin"), (200, True, "ldsbin"),
+                                             (128, True, "strata"), (200, False, "strata")])
+def test_ldsbin_and_strata_forms_at_other_k(k, use_bias, form):
+    """every template instantiation of the two new forms (k <= 64 R, R = 1..4; k not a multiple of 64; no bias; item
+    rows beyond the trained range untouched).  LDS bins: exact — with reg = 0 the column sums of V (and the bias sum)
+    are conserved and the result is finite and has moved.  XCD strata: plain read-modify-write may lose updates on this
+    small table, so only the user-side exactness (wave-owned rows), finiteness, the counters and learning are checked."""
+    n_users, n_items, indptr, indices = _ldsbin_case(8000, 3003, 900_000, 0.7, 5)
+    total_items = n_items + 7  # test-only items: rows the sampler never names
+    nnz = len(indices)
+    rs = np.random.RandomState(k)
+    U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (total_items, k)) - 0.5) / k).astype(np.float32)
+    B = np.zeros(total_items, np.float32)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, total_items, k)
+    tr.ldsbin_config(min_candidates=8)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(77 + k)
+    flags = _lib.FORM_LDSBIN if form == "ldsbin" else _lib.FORM_STRATA
+    c1, s1 = tr.fit_epochs(1, 0.05, 0.0, use_bias, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+    c, s = tr.fit_epochs(4, 0.05, 0.0, use_bias, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+    U2, V2, B2 = tr.get_factors()
+    if form == "ldsbin":
+        assert tr.ldsbin_stats()["lock_timeouts"] == 0
+    else:
+        assert tr.strata_stats()["misplaced_workgroups"] == 0
+    tr.close()
+    assert 0 < s1 < 0.2 * nnz and c1 + s1 <= nnz and c + s <= 4 * nnz
+    assert c / (4 * nnz - s) > 0.6 and c / (4 * nnz - s) > c1 / (nnz - s1) - 0.01, "the model must learn to rank its positives"
+    assert np.isfinite(U2).all() and np.isfinite(V2).all() and np.isfinite(B2).all()
+    assert np.array_equal(V2[n_items:], V[n_items:]) and not B2[n_items:].any()
+    assert np.abs(V2[:n_items] - V[:n_items]).max() > 1e-3 and np.abs(U2 - U).max() > 1e-3
+    if not use_bias:
+        assert not B2.any()
+    if form == "ldsbin":
+        moved = np.abs(V2.astype(np.float64) - V).sum(0)
+        assert np.abs(V2.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+        assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
+
+
 def test_owned_kernel_user_rows_are_exact():
     """With reg = 0 and lr > 0 the only writers of an exclusive user's row are its owner wave's
     plain stores (incl. the same-user merge inside a batch).  Conservation check: for every
