@@ -293,16 +293,20 @@ def leg_mf_netflix(args, _lib):
     kms, launches = tr.kernel_timing(False)
     tr.close()
     b = 16 * k + 16 + 20
+    # an epoch is one launch of the fused kernel or 8 phase launches of the block rotation (csrc/mf_blocks.inc)
+    rotation = launches == 8 * epochs
+    kernel = ("mf_blocks_kernel<2,4> (8 launches = one epoch)" if rotation else "mf_hogwild_rowwise_kernel (one launch = one epoch)")
+    per_launch = nnz * epochs / max(launches, 1)
+    achieved = per_launch * b / (kms / max(launches, 1) / 1e3) / 1e9
     out = {"metric": "mf_ratings_per_sec", "value": nnz * epochs / dt, "unit": "ratings/s", "steps": epochs,
            "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "biased MF k=%d, Netflix-Prize-shaped synthetic ratings (%d users x %d items, %d "
                                   "ratings, int64 COO as the reference's uir_tuple), hogwild mode" % (k, n_users, n_items, nnz),
-                      "lr": lr, "reg": reg},
-           "roofline": {"bound": "hbm", "achieved": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": nnz * b / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": leg_traffic("mf_netflix", kernel="mf_hogwild_rowwise_kernel (one launch = one epoch)",
-                                               ratings_per_launch=int(nnz), k=int(k)),
-                        "kernel": "mf_hogwild_rowwise_kernel (one launch = one epoch)",
+                      "lr": lr, "reg": reg, "form": "block rotation" if rotation else "fused atomic kernel"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": leg_traffic("mf_netflix", kernel=kernel, ratings_per_launch=int(per_launch), k=int(k)),
+                        "kernel": kernel,
                         "launches": launches, "avg_launch_ms": kms / max(launches, 1),
                         "algorithmic_bytes_per_rating": b},
            "train_stats": {"mse_per_epoch": [float(x) / nnz for x in loss]},

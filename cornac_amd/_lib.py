@@ -48,6 +48,7 @@ SYMBOLS = [
     "cornac_hip_wmf_fit_batches", "cornac_hip_wmf_kernel_timing", "cornac_hip_wmf_last_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
     "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
+    "cornac_hip_mf_hogwild_form", "cornac_hip_mf_hogwild_stats",
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
@@ -199,6 +200,8 @@ def lib():
                                             C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                             C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]
         L.cornac_hip_mf_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
+        L.cornac_hip_mf_hogwild_form.argtypes = [_vp, C.c_int]
+        L.cornac_hip_mf_hogwild_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_scorer_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int]
         L.cornac_hip_scorer_destroy.argtypes = [_vp]
         L.cornac_hip_scorer_set.argtypes = [_vp, _f32, _f32, _vp, _vp]
@@ -505,6 +508,15 @@ class MfTrainer:
         ms, n = C.c_double(), C.c_int64()
         check(lib().cornac_hip_mf_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def hogwild_form(self, form):
+        """0 automatic, 1 fused atomic kernel, 2 block rotation (include/cornac_hip.h)"""
+        check(lib().cornac_hip_mf_hogwild_form(self.h, int(form)))
+
+    def hogwild_stats(self):
+        o = (C.c_int64 * 4)()
+        check(lib().cornac_hip_mf_hogwild_stats(self.h, o))
+        return {"form_used": o[0], "tiles": o[1], "rows_per_bin": o[2], "gave_up": bool(o[3])}
 
     def last_timing(self):
         t = (C.c_double * 4)()

@@ -442,6 +442,15 @@ struct cornac_hip_mf {
     DevBuf<float> c_r;
     DevBuf<int64_t> c_wrow_ptr, c_row_beg, c_row_end, c_row_cur;
     DevBuf<unsigned int> uver, chain_abort;
+    // hogwild block rotation (mf_blocks.inc): ratings grouped by (phase, xcd, slot, sub-round), tiles of whole user runs
+    bool blocks_built = false, blocks_failed = false;
+    int hog_form = 0, hog_form_used = 0;  // 0 automatic, 1 fused atomic kernel, 2 block rotation
+    int mb_cap = 0;
+    size_t mb_lds = 0;
+    DevBuf<int64_t> mb_blk_tile_ptr, mb_tile_ptr;
+    DevBuf<int32_t> mb_u, mb_slot, mb_bin_ptr, mb_bin_items;
+    DevBuf<float> mb_r;
+    DevBuf<unsigned int> mb_sync;  // [8 slot counters | 8 barrier counters | abort]
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
     DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
@@ -457,6 +466,8 @@ struct cornac_hip_mf {
     int64_t opt_step = 0;
     int opt_kind = -1;
 };
+
+#include "mf_blocks.inc"
 
 static void mf_check(cornac_hip_mf_t h) {
     REQUIRE(h != nullptr, "MF handle is NULL");
@@ -804,7 +815,225 @@ static void mf_build_ownership(cornac_hip_mf_t h, int64_t W) {
     h->own_waves = W;
 }
 
+// ---- hogwild block rotation (mf_blocks.inc): schedule and launch ----------------------------------------------------
+typedef void (*MfBlocksKernel)(const MfBlockArgs);
+static MfBlocksKernel pick_blocks_kernel(int k) {
+    if (k <= 64) return mf_blocks_kernel<1, 4>;
+    if (k <= 128) return mf_blocks_kernel<2, 4>;
+    if (k <= 192) return mf_blocks_kernel<3, 2>;
+    return mf_blocks_kernel<4, 2>;
+}
+
+constexpr int kMbTile = 16;
+static size_t mf_blocks_lds(int cap, int k) {
+    const int kp = ((k + kWave - 1) / kWave) * kWave;
+    return (size_t)cap * (kp + 2) * sizeof(float);
+}
+
+// 8 partitions x 32 parts: heaviest first onto the least loaded of the 256 parts
+static std::vector<int32_t> mf_lpt_256(const std::vector<int64_t> &cnt, int *max_rows) {
+    const int64_t n = (int64_t)cnt.size();
+    std::vector<int32_t> order((size_t)n), part((size_t)n, -1);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] > cnt[(size_t)y]; });
+    typedef std::pair<int64_t, int32_t> LW;
+    std::priority_queue<LW, std::vector<LW>, std::greater<LW>> heap;
+    for (int32_t b = 0; b < 256; ++b) heap.push(LW(0, b));
+    std::vector<int> rows(256, 0);
+    for (int32_t i : order) {
+        if (cnt[(size_t)i] == 0) continue;
+        LW top = heap.top();
+        heap.pop();
+        part[(size_t)i] = top.second;
+        ++rows[(size_t)top.second];
+        top.first += cnt[(size_t)i];
+        heap.push(top);
+    }
+    if (max_rows) *max_rows = *std::max_element(rows.begin(), rows.end());
+    return part;
+}
+
+static bool mf_uses_blocks(cornac_hip_mf_t h) {
+    const DeviceInfo &di = device_info(h->device);
+    if (h->blocks_failed || h->hog_form == 1 || di.cus != 256 || di.xcds != 8 || h->k <= 32 || h->k > 256 || h->n_items < 256)
+        return false;
+    return h->hog_form == 2 || h->nnz >= (int64_t(1) << 22);
+}
+
+static bool mf_build_blocks(cornac_hip_mf_t h) {
+    if (h->blocks_built) return true;
+    Timer t;
+    const int64_t n = h->nnz, ni = h->n_items, nu = h->n_users;
+    std::vector<int64_t> cnt_u((size_t)nu, 0), cnt_i((size_t)ni, 0);
+    for (int64_t s = 0; s < n; ++s) {
+        ++cnt_u[(size_t)h->host_rid[(size_t)s]];
+        ++cnt_i[(size_t)h->host_cid[(size_t)s]];
+    }
+    // hot items: more than a tenth of a bin's share of the ratings — their LDS row lock would serialise the bin's 16 waves.
+    // They stay in global memory under atomics and take no bin.
+    std::vector<int64_t> cnt_cold(cnt_i);
+    std::vector<char> hot((size_t)ni, 0);
+    for (int64_t i = 0; i < ni; ++i)
+        if (cnt_i[(size_t)i] * 10 * 256 > n) {
+            hot[(size_t)i] = 1;
+            cnt_cold[(size_t)i] = 0;
+        }
+    int cap = 0;
+    const std::vector<int32_t> ibin = mf_lpt_256(cnt_cold, &cap), ublk = mf_lpt_256(cnt_u, nullptr);
+    cap = std::max(cap, 1);
+    if (mf_blocks_lds(cap, h->k) > 140 * 1024) {
+        h->blocks_failed = true;
+        return false;
+    }
+    // bins: items of bin g in id order; an item's slot = its position there
+    std::vector<int32_t> bin_ptr(257, 0), slot((size_t)ni, 0);
+    for (int64_t i = 0; i < ni; ++i)
+        if (ibin[(size_t)i] >= 0) ++bin_ptr[(size_t)ibin[(size_t)i] + 1];
+    for (int g = 0; g < 256; ++g) bin_ptr[(size_t)g + 1] += bin_ptr[(size_t)g];
+    std::vector<int32_t> bin_items((size_t)std::max(1, bin_ptr[256])), bcur(bin_ptr.begin(), bin_ptr.end() - 1);
+    for (int64_t i = 0; i < ni; ++i) {
+        const int g = ibin[(size_t)i];
+        if (g < 0) continue;
+        slot[(size_t)i] = bcur[(size_t)g] - bin_ptr[(size_t)g];
+        bin_items[(size_t)bcur[(size_t)g]++] = (int32_t)i;
+    }
+    // rating -> block key (phase, xcd, slot, sub-round): item bin (ip, c), user block (up, q):
+    //   phase = (ip - up) mod 8, xcd = up, slot = c, sub-round = (q - c) mod 32
+    // (a hot item has no bin: its rating takes one of the 256 (ip, c) by a hash of its position)
+    const int64_t n_keys = 8 * 8 * 32 * 32;
+    auto key_of = [&](int64_t s) -> int64_t {
+        const int64_t it = h->host_cid[(size_t)s];
+        int g = ibin[(size_t)it];
+        if (hot[(size_t)it]) {
+            uint32_t x = (uint32_t)s * 0x9E3779B1u;
+            x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+            g = (int)(x & 255u);
+        }
+        const int b = ublk[(size_t)h->host_rid[(size_t)s]];
+        const int ip = g >> 5, c = g & 31, up = b >> 5, q = b & 31;
+        return ((((int64_t)((ip - up) & 7) * 8 + up) * 32 + c) * 32) + ((q - c) & 31);
+    };
+    std::vector<int64_t> kptr((size_t)n_keys + 1, 0);
+    for (int64_t s = 0; s < n; ++s) ++kptr[(size_t)key_of(s) + 1];
+    for (int64_t q = 0; q < n_keys; ++q) kptr[(size_t)q + 1] += kptr[(size_t)q];
+    std::vector<int64_t> kcur(kptr.begin(), kptr.end() - 1), perm((size_t)n);
+    for (int64_t s = 0; s < n; ++s) perm[(size_t)kcur[(size_t)key_of(s)]++] = s;
+    // inside a block: by user (a user's ratings contiguous = one run), then tiles of whole runs, at most kMbTile ratings
+    // (a block holds ~1 500 ratings for 16 waves: small tiles keep the waves level at the sub-round's barrier)
+    std::vector<int32_t> b_u((size_t)n), b_slot((size_t)n);
+    std::vector<float> b_r((size_t)n);
+    std::vector<int64_t> tile_ptr, blk_tile_ptr((size_t)n_keys + 1, 0);
+    tile_ptr.reserve((size_t)(n / 12 + n_keys));
+    for (int64_t q = 0; q < n_keys; ++q) {
+        const int64_t lo = kptr[(size_t)q], hi = kptr[(size_t)q + 1];
+        std::sort(perm.begin() + lo, perm.begin() + hi, [&](int64_t x, int64_t y) {
+            const int64_t ux = h->host_rid[(size_t)x], uy = h->host_rid[(size_t)y];
+            return ux != uy ? ux < uy : x < y;
+        });
+        blk_tile_ptr[(size_t)q] = (int64_t)tile_ptr.size();
+        int64_t tile_start = lo;
+        for (int64_t p = lo; p < hi;) {
+            int64_t e = p + 1;
+            while (e < hi && h->host_rid[(size_t)perm[(size_t)e]] == h->host_rid[(size_t)perm[(size_t)p]]) ++e;
+            // the run [p, e): start a new tile when it does not fit; a run is never cut (a run of more than 64 ratings —
+            // a user with > 64 ratings inside one block — becomes a tile of its own, walked by one wave in 64-rating chunks)
+            if (e - tile_start > kMbTile && p > tile_start) {
+                tile_ptr.push_back(tile_start);
+                tile_start = p;
+            }
+            p = e;
+        }
+        if (hi > tile_start) tile_ptr.push_back(tile_start);
+        // inside a tile: the k-th ratings of all its users before the (k+1)-th ones, so that the ratings a wave has in
+        // flight together name distinct users (the order inside a tile is free; a user stays inside ONE tile)
+        {
+            std::vector<std::pair<int64_t, int64_t>> keyed;  // (occurrence, position)
+            const size_t t_first = (size_t)blk_tile_ptr[(size_t)q];
+            for (size_t ti = t_first; ti < tile_ptr.size(); ++ti) {
+                const int64_t a0 = tile_ptr[ti], a1 = ti + 1 < tile_ptr.size() ? tile_ptr[ti + 1] : hi;
+                if (a1 - a0 < 3) continue;
+                keyed.clear();
+                int64_t occ = 0;
+                for (int64_t p = a0; p < a1; ++p) {
+                    occ = (p > a0 && h->host_rid[(size_t)perm[(size_t)p]] == h->host_rid[(size_t)perm[(size_t)p - 1]]) ? occ + 1 : 0;
+                    keyed.push_back(std::make_pair(occ, perm[(size_t)p]));
+                }
+                std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x.first < y.first; });
+                for (int64_t p = a0; p < a1; ++p) perm[(size_t)p] = keyed[(size_t)(p - a0)].second;
+            }
+        }
+        for (int64_t p = lo; p < hi; ++p) {
+            const int64_t s = perm[(size_t)p];
+            b_u[(size_t)p] = (int32_t)h->host_rid[(size_t)s];
+            b_slot[(size_t)p] = hot[(size_t)h->host_cid[(size_t)s]] ? (int32_t)(h->host_cid[(size_t)s] | 0x80000000ll)
+                                                                     : slot[(size_t)h->host_cid[(size_t)s]];
+            b_r[(size_t)p] = h->host_val[(size_t)s];
+        }
+    }
+    blk_tile_ptr[(size_t)n_keys] = (int64_t)tile_ptr.size();
+    tile_ptr.push_back(n);
+    // a tile's end is the next tile's start (tiles are contiguous over the whole array)
+    h->mb_blk_tile_ptr.alloc(blk_tile_ptr.size());
+    h->mb_tile_ptr.alloc(tile_ptr.size());
+    h->mb_u.alloc((size_t)n); h->mb_slot.alloc((size_t)n); h->mb_r.alloc((size_t)n);
+    h->mb_bin_ptr.alloc(257);
+    h->mb_bin_items.alloc(bin_items.size());
+    h->mb_sync.alloc(24);
+    h->mb_blk_tile_ptr.upload(blk_tile_ptr.data(), blk_tile_ptr.size(), h->stream);
+    h->mb_tile_ptr.upload(tile_ptr.data(), tile_ptr.size(), h->stream);
+    h->mb_u.upload(b_u.data(), (size_t)n, h->stream);
+    h->mb_slot.upload(b_slot.data(), (size_t)n, h->stream);
+    h->mb_r.upload(b_r.data(), (size_t)n, h->stream);
+    h->mb_bin_ptr.upload(bin_ptr.data(), 257, h->stream);
+    h->mb_bin_items.upload(bin_items.data(), bin_items.size(), h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->mb_cap = cap;
+    h->mb_lds = std::max(mf_blocks_lds(cap, h->k), (size_t)82 * 1024);  // >= 82 KB: one workgroup per CU
+    h->blocks_built = true;
+    h->timing[1] += t.ms();
+    return true;
+}
+
+// returns false when the launch had to give up (placement / barrier bound): the caller re-runs the epoch's REMAINING
+// work with the fused kernel?  No — an aborted epoch is reported as an error; the handle then stays on the fused kernel.
+static bool mf_epoch_blocks(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    if (!mf_build_blocks(h)) return false;
+    MfBlocksKernel kern = pick_blocks_kernel(h->k);
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mb_lds));
+    MfBlockArgs a;
+    a.blk_tile_ptr = h->mb_blk_tile_ptr.p; a.tile_ptr = h->mb_tile_ptr.p;
+    a.b_u = h->mb_u.p; a.b_slot = h->mb_slot.p; a.b_r = h->mb_r.p;
+    a.bin_ptr = h->mb_bin_ptr.p; a.bin_items = h->mb_bin_items.p;
+    a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p; a.Bi = h->Bi.p; a.loss_acc = loss_slot;
+    a.slot_cnt = h->mb_sync.p; a.bar = h->mb_sync.p + 8; a.abort = h->mb_sync.p + 16;
+    a.wait_bound_ticks = (long long)prof_env_int("CORNAC_HIP_MF_BLOCKS_WAIT_S", 20) * 100000000ll;
+    a.cap = h->mb_cap; a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 24 * sizeof(unsigned int), h->stream));
+    for (int ph = 0; ph < 8; ++ph) {
+        a.phase = ph;
+        if (ph) HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 16 * sizeof(unsigned int), h->stream));  // (the abort word stays)
+        h->ktimer.before(h->stream);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(kMbBlock), h->mb_lds, h->stream, a);
+        h->ktimer.after(h->stream);
+    }
+    HIP_CHECK(hipGetLastError());
+    unsigned int aborted = 0;
+    HIP_CHECK(hipMemcpyAsync(&aborted, h->mb_sync.p + 16, sizeof aborted, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (aborted) {
+        h->blocks_failed = true;
+        fail(CORNAC_HIP_ERR_HIP, "MF block-rotation kernel gave up (workgroup placement or a barrier bound); the handle "
+             "uses the fused kernel from now on — re-run the call");
+    }
+    return true;
+}
+
 static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    if (mf_uses_blocks(h) && mf_epoch_blocks(h, lr, reg, mu, use_bias, loss_slot)) {
+        h->hog_form_used = 2;
+        return;
+    }
+    h->hog_form_used = 1;
     const DeviceInfo &di = device_info(h->device);
     const int k = h->k;
     const bool owned = k > 32 && k <= 256 && h->nnz >= (int64_t)di.cus * 8 * kWavesPerBlock * kWave;
@@ -980,6 +1209,26 @@ int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms,
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->ktimer.collect(total_ms, launches);
         h->ktimer.enabled = enable != 0;
+    });
+}
+
+int cornac_hip_mf_hogwild_form(cornac_hip_mf_t h, int form) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(form >= 0 && form <= 2, "form must be 0 (automatic), 1 (fused atomic kernel) or 2 (block rotation)");
+        h->hog_form = form;
+        if (form == 2) h->blocks_failed = false;
+    });
+}
+
+int cornac_hip_mf_hogwild_stats(cornac_hip_mf_t h, int64_t *out4) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(out4 != nullptr, "out4 is NULL");
+        out4[0] = h->hog_form_used;
+        out4[1] = h->blocks_built ? (int64_t)h->mb_tile_ptr.n - 1 : 0;
+        out4[2] = h->blocks_built ? h->mb_cap : 0;
+        out4[3] = h->blocks_failed ? 1 : 0;
     });
 }
 

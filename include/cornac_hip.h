@@ -262,6 +262,14 @@ int cornac_hip_mf_get_factors(cornac_hip_mf_t h, float *U, float *V, float *Bu, 
  * epochs_run receives the number of epochs executed. */
 int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, float mu, int use_bias, int early_stop,
                       int mode, float *loss_per_epoch, int *epochs_run);
+/* Form of the hogwild MF epoch: 0 = automatic, 1 = the fused kernel (user rows owned by waves, item rows by fp32
+ * atomics), 2 = the block rotation (csrc/mf_blocks.inc: item bins in the CUs' LDS, user blocks rotating among the 32
+ * workgroups of an XCD, 8 launches x 32 barrier-separated sub-rounds per epoch; no atomics, every update applied exactly
+ * once).  Automatic = the block rotation for k in 33..256, >= 256 items and >= 2^22 ratings on a 256-CU / 8-XCD device.
+ * hogwild_stats: out4 = {form of the last epoch (1 / 2, 0: none yet), tiles of the block schedule, LDS rows per bin,
+ * 1 if the rotation gave up once (workgroup placement / barrier bound) and the handle went back to the fused kernel}. */
+int cornac_hip_mf_hogwild_form(cornac_hip_mf_t h, int form);
+int cornac_hip_mf_hogwild_stats(cornac_hip_mf_t h, int64_t *out4);
 /* One-shot form with the reference's exact argument list (host buffers, in place). */
 int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, const float *val, int64_t nnz, float *U,
                           float *V, float *Bu, float *Bi, int64_t n_users, int64_t n_items, int k, float lr, float reg,

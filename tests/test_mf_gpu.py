@@ -109,3 +109,72 @@ def test_errors():
     rid, cid, val = ds.uir_tuple
     with pytest.raises(_lib.HipError, match="out-of-range"):
         _lib.MfTrainer(rid + 1000, cid, val, ds.num_users, ds.num_items, 4)
+
+
+def _coo(n_users, n_items, nnz, seed):
+    rs = np.random.RandomState(seed)
+    act = rs.lognormal(0, 1.0, n_users)
+    rid = rs.choice(n_users, nnz, p=act / act.sum()).astype(np.int64)
+    pop = 1.0 / np.arange(1, n_items + 1) ** 0.6
+    cid = rs.permutation(n_items)[rs.choice(n_items, nnz, p=pop / pop.sum())].astype(np.int64)
+    bu, bi = rs.normal(0, 0.5, n_users), rs.normal(0, 0.5, n_items)
+    val = np.clip(np.rint(3.5 + bu[rid] + bi[cid] + rs.normal(0, 0.7, nnz)), 1, 5).astype(np.float32)
+    return rid, cid, val
+
+
+@pytest.mark.parametrize("k", [64, 100, 128, 200])
+def test_block_rotation_applies_every_rating_exactly_once(k):
+    """The hogwild block rotation (csrc/mf_blocks.inc; 8 launches x 32 sub-rounds, item bins in LDS, user blocks rotating
+    inside an XCD): with lr = 0 the epoch loss is 0.5 x the squared error of the START tables over ALL ratings — every
+    rating visited exactly once, none twice — and the tables come back bit-identical (rows went through the LDS)."""
+    n_users, n_items, nnz = 30_000, 2_000, 1_200_000
+    rid, cid, val = _coo(n_users, n_items, nnz, 4)
+    rs = np.random.RandomState(k)
+    U = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    Bu, Bi = rs.normal(0, 0.1, n_users).astype(np.float32), rs.normal(0, 0.1, n_items).astype(np.float32)
+    mu = float(val.mean())
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.hogwild_form(2)
+    tr.set_factors(U, V, Bu, Bi)
+    loss, _ = tr.fit(2, 0.0, 0.0, mu, True, False, _lib.MODE_HOGWILD)
+    st = tr.hogwild_stats()
+    got = tr.get_factors()
+    tr.close()
+    assert st["form_used"] == 2 and not st["gave_up"], st
+    pred = mu + Bu[rid] + Bi[cid] + np.einsum("nk,nk->n", U[rid].astype(np.float64), V[cid].astype(np.float64))
+    want = 0.5 * float(np.sum((val.astype(np.float64) - pred) ** 2))
+    assert abs(loss[0] - want) <= 2e-5 * want and abs(loss[1] - want) <= 2e-5 * want, (loss, want)
+    for g, w in zip(got, (U, V, Bu, Bi)):
+        assert np.array_equal(g, w)
+
+
+def test_block_rotation_learns_like_the_fused_kernel():
+    """same optimisation problem, same data: the exact block rotation and the fused atomic kernel reach the same
+    training error within noise; biases off leaves them untouched"""
+    n_users, n_items, nnz, k = 30_000, 2_000, 1_500_000, 64
+    rid, cid, val = _coo(n_users, n_items, nnz, 5)
+    rs = np.random.RandomState(0)
+    U = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    mu = float(val.mean())
+    out = {}
+    for form in (2, 1):
+        tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+        tr.hogwild_form(form)
+        tr.set_factors(U, V, zu, zi)
+        loss, _ = tr.fit(8, 0.01, 0.02, mu, True, False, _lib.MODE_HOGWILD)
+        assert tr.hogwild_stats()["form_used"] == form
+        out[form] = (loss, tr.get_factors())
+        tr.close()
+    l2, l1 = out[2][0], out[1][0]
+    assert l2[-1] < 0.85 * l2[0] and abs(l2[-1] - l1[-1]) < 0.03 * l1[-1], (l2, l1)
+    assert all(np.isfinite(x).all() for x in out[2][1])
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.hogwild_form(2)
+    tr.set_factors(U, V, zu, zi)
+    tr.fit(2, 0.01, 0.02, mu, False, False, _lib.MODE_HOGWILD)
+    _, _, Bu2, Bi2 = tr.get_factors()
+    tr.close()
+    assert not Bu2.any() and not Bi2.any()
