@@ -824,7 +824,6 @@ static MfBlocksKernel pick_blocks_kernel(int k) {
     return mf_blocks_kernel<4, 2>;
 }
 
-constexpr int kMbTile = 16;
 static size_t mf_blocks_lds(int cap, int k) {
     const int kp = ((k + kWave - 1) / kWave) * kWave;
     return (size_t)cap * (kp + 2) * sizeof(float);
@@ -918,60 +917,58 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     for (int64_t q = 0; q < n_keys; ++q) kptr[(size_t)q + 1] += kptr[(size_t)q];
     std::vector<int64_t> kcur(kptr.begin(), kptr.end() - 1), perm((size_t)n);
     for (int64_t s = 0; s < n; ++s) perm[(size_t)kcur[(size_t)key_of(s)]++] = s;
-    // inside a block: by user (a user's ratings contiguous = one run), then tiles of whole runs, at most kMbTile ratings
-    // (a block holds ~1 500 ratings for 16 waves: small tiles keep the waves level at the sub-round's barrier)
+    // inside a block: the ratings of a user form a run; the runs are dealt to the workgroup's 16 waves (longest first
+    // onto the shortest list), so every wave has its own list of ~100 ratings per sub-round, level with the others at the
+    // barrier, and a user row belongs to one wave.  Inside a list the k-th ratings of all its users come before the
+    // (k+1)-th ones: the ratings a wave has in flight together name distinct users.  Tile (block q, wave w) = q * 16 + w.
     std::vector<int32_t> b_u((size_t)n), b_slot((size_t)n);
     std::vector<float> b_r((size_t)n);
-    std::vector<int64_t> tile_ptr, blk_tile_ptr((size_t)n_keys + 1, 0);
-    tile_ptr.reserve((size_t)(n / 12 + n_keys));
-    for (int64_t q = 0; q < n_keys; ++q) {
-        const int64_t lo = kptr[(size_t)q], hi = kptr[(size_t)q + 1];
-        std::sort(perm.begin() + lo, perm.begin() + hi, [&](int64_t x, int64_t y) {
-            const int64_t ux = h->host_rid[(size_t)x], uy = h->host_rid[(size_t)y];
-            return ux != uy ? ux < uy : x < y;
-        });
-        blk_tile_ptr[(size_t)q] = (int64_t)tile_ptr.size();
-        int64_t tile_start = lo;
-        for (int64_t p = lo; p < hi;) {
-            int64_t e = p + 1;
-            while (e < hi && h->host_rid[(size_t)perm[(size_t)e]] == h->host_rid[(size_t)perm[(size_t)p]]) ++e;
-            // the run [p, e): start a new tile when it does not fit; a run is never cut (a run of more than 64 ratings —
-            // a user with > 64 ratings inside one block — becomes a tile of its own, walked by one wave in 64-rating chunks)
-            if (e - tile_start > kMbTile && p > tile_start) {
-                tile_ptr.push_back(tile_start);
-                tile_start = p;
+    std::vector<int64_t> tile_ptr((size_t)n_keys * kMbWaves + 1, 0), blk_tile_ptr(1, 0);
+    {
+        std::vector<std::pair<int64_t, int64_t>> runs;                    // (length, start in perm)
+        std::vector<std::vector<std::pair<int64_t, int64_t>>> lists(kMbWaves);  // (occurrence, rating)
+        std::vector<int64_t> fill(kMbWaves);
+        for (int64_t q = 0; q < n_keys; ++q) {
+            const int64_t lo = kptr[(size_t)q], hi = kptr[(size_t)q + 1];
+            std::sort(perm.begin() + lo, perm.begin() + hi, [&](int64_t x, int64_t y) {
+                const int64_t ux = h->host_rid[(size_t)x], uy = h->host_rid[(size_t)y];
+                return ux != uy ? ux < uy : x < y;
+            });
+            runs.clear();
+            for (int64_t p = lo; p < hi;) {
+                int64_t e = p + 1;
+                while (e < hi && h->host_rid[(size_t)perm[(size_t)e]] == h->host_rid[(size_t)perm[(size_t)p]]) ++e;
+                runs.push_back(std::make_pair(e - p, p));
+                p = e;
             }
-            p = e;
-        }
-        if (hi > tile_start) tile_ptr.push_back(tile_start);
-        // inside a tile: the k-th ratings of all its users before the (k+1)-th ones, so that the ratings a wave has in
-        // flight together name distinct users (the order inside a tile is free; a user stays inside ONE tile)
-        {
-            std::vector<std::pair<int64_t, int64_t>> keyed;  // (occurrence, position)
-            const size_t t_first = (size_t)blk_tile_ptr[(size_t)q];
-            for (size_t ti = t_first; ti < tile_ptr.size(); ++ti) {
-                const int64_t a0 = tile_ptr[ti], a1 = ti + 1 < tile_ptr.size() ? tile_ptr[ti + 1] : hi;
-                if (a1 - a0 < 3) continue;
-                keyed.clear();
-                int64_t occ = 0;
-                for (int64_t p = a0; p < a1; ++p) {
-                    occ = (p > a0 && h->host_rid[(size_t)perm[(size_t)p]] == h->host_rid[(size_t)perm[(size_t)p - 1]]) ? occ + 1 : 0;
-                    keyed.push_back(std::make_pair(occ, perm[(size_t)p]));
+            std::stable_sort(runs.begin(), runs.end(), [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x.first > y.first; });
+            for (int w = 0; w < kMbWaves; ++w) {
+                lists[(size_t)w].clear();
+                fill[(size_t)w] = 0;
+            }
+            for (const auto &run : runs) {
+                const int w = (int)(std::min_element(fill.begin(), fill.end()) - fill.begin());
+                for (int64_t t = 0; t < run.first; ++t) lists[(size_t)w].push_back(std::make_pair(t, perm[(size_t)(run.second + t)]));
+                fill[(size_t)w] += run.first;
+            }
+            int64_t pos = lo;
+            for (int w = 0; w < kMbWaves; ++w) {
+                tile_ptr[(size_t)(q * kMbWaves + w)] = pos;
+                auto &L = lists[(size_t)w];
+                std::stable_sort(L.begin(), L.end(), [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x.first < y.first; });
+                for (const auto &e : L) {
+                    const int64_t sidx = e.second;
+                    b_u[(size_t)pos] = (int32_t)h->host_rid[(size_t)sidx];
+                    b_slot[(size_t)pos] = hot[(size_t)h->host_cid[(size_t)sidx]] ? (int32_t)(h->host_cid[(size_t)sidx] | 0x80000000ll)
+                                                                                 : slot[(size_t)h->host_cid[(size_t)sidx]];
+                    b_r[(size_t)pos] = h->host_val[(size_t)sidx];
+                    ++pos;
                 }
-                std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x.first < y.first; });
-                for (int64_t p = a0; p < a1; ++p) perm[(size_t)p] = keyed[(size_t)(p - a0)].second;
             }
         }
-        for (int64_t p = lo; p < hi; ++p) {
-            const int64_t s = perm[(size_t)p];
-            b_u[(size_t)p] = (int32_t)h->host_rid[(size_t)s];
-            b_slot[(size_t)p] = hot[(size_t)h->host_cid[(size_t)s]] ? (int32_t)(h->host_cid[(size_t)s] | 0x80000000ll)
-                                                                     : slot[(size_t)h->host_cid[(size_t)s]];
-            b_r[(size_t)p] = h->host_val[(size_t)s];
-        }
+        tile_ptr[(size_t)n_keys * kMbWaves] = n;
     }
-    blk_tile_ptr[(size_t)n_keys] = (int64_t)tile_ptr.size();
-    tile_ptr.push_back(n);
+
     // a tile's end is the next tile's start (tiles are contiguous over the whole array)
     h->mb_blk_tile_ptr.alloc(blk_tile_ptr.size());
     h->mb_tile_ptr.alloc(tile_ptr.size());

@@ -30,6 +30,6 @@ if [ "${SKIP_LEGS:-0}" != 1 ]; then
 CMD="env CORNAC_BENCH_VBPR_FEEDBACK=30000 python $R/bench.py --steps 2 --warmup 1 --cpu-baseline-seconds 0 --legs ${LEGS:-mf_netflix,wmf_netflix,vbpr_tradesy} --rank-full-users 0"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-( cd $R && for p in fetch write; do python tools/rocpd_summary.py pmc $O/$p/p_results.db | grep -E "^kernel|mf_hogwild|mf_ldsbin|wmf_user_step|adam_sweep|rank_fused|feat_adam|touched|$KPAT"; done > gpurun_out/${ROUND}_legs_pmc.csv
+( cd $R && for p in fetch write; do python tools/rocpd_summary.py pmc $O/$p/p_results.db | grep -E "^kernel|mf_hogwild|mf_blocks|mf_det_chain|wmf_user_step|adam_sweep|rank_fused|feat_adam|touched|$KPAT"; done > gpurun_out/${ROUND}_legs_pmc.csv
   cut -c1-220 gpurun_out/${ROUND}_legs_pmc.csv )
 fi
