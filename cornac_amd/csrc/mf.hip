@@ -872,8 +872,13 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     // They stay in global memory under atomics and take no bin.
     std::vector<int64_t> cnt_cold(cnt_i);
     std::vector<char> hot((size_t)ni, 0);
+    // ... unless the row is so popular (> 0.5 % of ALL ratings) that thousands of atomic updates computed from one stale
+    // copy would be in flight at once: summed, they overshoot and the factorisation diverges (measured at SURVEY 8d's
+    // Zipf(0.8): one row with 3.2 % of the ratings, loss = nan in this form AND in the fused kernel).  Such a row keeps a
+    // bin (alone, LPT) and its lock: at most the workgroup's 64 ratings in flight see a stale copy, like the reference's
+    // threads do, at the price of serialising that row.
     for (int64_t i = 0; i < ni; ++i)
-        if (cnt_i[(size_t)i] * 10 * 256 > n) {
+        if (cnt_i[(size_t)i] * 10 * 256 > n && cnt_i[(size_t)i] * 200 <= n) {
             hot[(size_t)i] = 1;
             cnt_cold[(size_t)i] = 0;
         }
