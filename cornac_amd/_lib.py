@@ -30,6 +30,7 @@ SYMBOLS = [
     "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
     "cornac_hip_bpr_bind_device", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
+    "cornac_hip_bpr_set_factors_f64", "cornac_hip_bpr_get_factors_f64", "cornac_hip_bpr_fit_epochs_f64",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
@@ -51,6 +52,7 @@ SYMBOLS = [
     "cornac_hip_mf_hogwild_form", "cornac_hip_mf_hogwild_stats",
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
+    "cornac_hip_scorer_set_f64", "cornac_hip_score_user_f64",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
     "cornac_hip_scorer_set_exclusions", "cornac_hip_rank_topk_resident", "cornac_hip_scorer_host_buffer",
     "cornac_hip_rank_positions",
@@ -137,6 +139,10 @@ def lib():
         L.cornac_hip_bpr_seed_hogwild.argtypes = [_vp, C.c_uint64]
         L.cornac_hip_bpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_set_factors_f64.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_get_factors_f64.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_fit_epochs_f64.argtypes = [_vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_hogwild_enqueue.argtypes = [_vp, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_sync.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_draw.argtypes = [_vp, C.c_int, C.c_uint64, C.c_int64, _i64]
@@ -206,6 +212,8 @@ def lib():
         L.cornac_hip_scorer_destroy.argtypes = [_vp]
         L.cornac_hip_scorer_set.argtypes = [_vp, _f32, _f32, _vp, _vp]
         L.cornac_hip_score_user.argtypes = [_vp, C.c_int64, _f32]
+        L.cornac_hip_scorer_set_f64.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        L.cornac_hip_score_user_f64.argtypes = [_vp, C.c_int64, _vp]
         L.cornac_hip_score_block.argtypes = [_vp, _i32, C.c_int64, _f32]
         L.cornac_hip_score_pairs.argtypes = [_vp, _i32, _i32, C.c_int64, C.c_int, C.c_float, C.c_float, _f32]
         L.cornac_hip_rank_topk.argtypes = [_vp, _i32, C.c_int64, C.c_int, _vp, _vp, _i32, _f32]
@@ -286,6 +294,25 @@ class BprTrainer:
         U, V, B = np.empty((tu, k), np.float32), np.empty((ti, k), np.float32), np.empty(ti, np.float32)
         check(lib().cornac_hip_bpr_get_factors(self.h, U.ctypes.data, V.ctypes.data, B.ctypes.data))
         return U, V, B
+
+    def set_factors_f64(self, U, V, B):
+        """float64 tables (recom_bpr.pyx:211-214 is a fused-type function): the handle then trains in double"""
+        tu, ti, k = self.shape
+        U, V, B = (np.ascontiguousarray(a, np.float64) for a in (U, V, B))
+        assert U.shape == (tu, k) and V.shape == (ti, k) and B.shape == (ti,)
+        check(lib().cornac_hip_bpr_set_factors_f64(self.h, U.ctypes.data, V.ctypes.data, B.ctypes.data))
+
+    def get_factors_f64(self):
+        tu, ti, k = self.shape
+        U, V, B = np.empty((tu, k), np.float64), np.empty((ti, k), np.float64), np.empty(ti, np.float64)
+        check(lib().cornac_hip_bpr_get_factors_f64(self.h, U.ctypes.data, V.ctypes.data, B.ctypes.data))
+        return U, V, B
+
+    def fit_epochs_f64(self, n_epochs, lr, reg, use_bias=True, neg_population=NEG_UNIFORM):
+        c, s = C.c_int64(), C.c_int64()
+        check(lib().cornac_hip_bpr_fit_epochs_f64(self.h, n_epochs, float(lr), float(reg), int(use_bias), neg_population,
+                                                  C.byref(c), C.byref(s)))
+        return c.value, s.value
 
     def get_user_factors(self):
         """U only (the item tables may live elsewhere: row-sharded multi-GPU mode binds a local shard)"""
@@ -558,6 +585,19 @@ class Scorer:
     def score_user(self, user):
         out = np.empty(self.n_items, np.float32)
         check(lib().cornac_hip_score_user(self.h, int(user), out))
+        return out
+
+    def set_f64(self, U, V, item_base=None, user_base=None):
+        """the float64 tables of a model trained in double (fast_dot's ddot variant, fast_dot.pyx:25-43)"""
+        U, V = np.ascontiguousarray(U, np.float64), np.ascontiguousarray(V, np.float64)
+        assert U.shape == (self.n_users, self.k) and V.shape == (self.n_items, self.k)
+        ib = None if item_base is None else np.ascontiguousarray(item_base, np.float64)
+        ub = None if user_base is None else np.ascontiguousarray(user_base, np.float64)
+        check(lib().cornac_hip_scorer_set_f64(self.h, U.ctypes.data, V.ctypes.data, _ptr(ib), _ptr(ub)))
+
+    def score_user_f64(self, user):
+        out = np.empty(self.n_items, np.float64)
+        check(lib().cornac_hip_score_user_f64(self.h, int(user), out.ctypes.data))
         return out
 
     def score_block(self, users):

@@ -75,11 +75,19 @@ class BPR(Recommender):
             self.i_factors = (_uniform((n_items, self.k), self.rng) - 0.5) / self.k
         if self.i_biases is None or self.use_bias is False:
             self.i_biases = np.zeros(n_items, dtype=DTYPE)
-        if self.u_factors.dtype != DTYPE or self.i_factors.dtype != DTYPE or self.i_biases.dtype != DTYPE:
-            raise ValueError("the HIP backend trains float32 factors (the reference's DTYPE, recom_bpr.pyx:40)")
+        # `_fit_sgd` is a fused-type (`floating`) function (recom_bpr.pyx:211-214): three float32 tables train in float,
+        # three float64 tables (all given through init_params) in double; a mix fails its buffer check (ValueError)
+        kinds = {np.asarray(a).dtype for a in (self.u_factors, self.i_factors, self.i_biases)}
+        if len(kinds) != 1 or next(iter(kinds)) not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("Buffer dtype mismatch: U, V and Bi must all be float32 or all be float64 "
+                             "(recom_bpr.pyx:211-214)")
+
+    @property
+    def trains_float64(self):
+        return self.u_factors is not None and np.asarray(self.u_factors).dtype == np.float64
 
     def _seed_trainer(self, trainer):
-        if self.effective_mode == "deterministic":
+        if self.effective_mode == "deterministic" or self.trains_float64:
             # recom_bpr.pyx:190-191: two draws from self.rng, in this order, AFTER _init
             seed_pos = rngvector_mt_seed(self.rng.randint(2 ** 31))
             seed_neg = rngvector_mt_seed(self.rng.randint(2 ** 31))
@@ -99,18 +107,30 @@ class BPR(Recommender):
         trainer = _lib.BprTrainer(X.indptr, X.indices, train_set.num_users, train_set.num_items, self.total_users,
                                   self.total_items, self.k, device=self.device)
         try:
-            trainer.set_factors(self.u_factors, self.i_factors, self.i_biases)
+            f64 = self.trains_float64
+            if f64:
+                # float64 tables: the sequential engine in double, whatever the mode (there is no float64 throughput
+                # kernel; the reference's unseeded float64 run is its racy OpenMP loop, to which the sequential order
+                # is one admissible interleaving)
+                trainer.set_factors_f64(self.u_factors, self.i_factors, self.i_biases)
+            else:
+                trainer.set_factors(self.u_factors, self.i_factors, self.i_biases)
             self._seed_trainer(trainer)
             mode = _lib.MODE_DETERMINISTIC if self.effective_mode == "deterministic" else _lib.MODE_HOGWILD
             nnz = X.nnz
             self.fit_stats = []
+
+            def run(n):
+                if f64:
+                    return trainer.fit_epochs_f64(n, self.learning_rate, self.lambda_reg, self.use_bias, self._neg_population)
+                return trainer.fit_epochs(n, self.learning_rate, self.lambda_reg, self.use_bias, self._neg_population, mode)
+
             if self.verbose:
                 from tqdm.auto import trange
 
                 with trange(self.max_iter) as progress:
                     for _ in progress:
-                        correct, skipped = trainer.fit_epochs(1, self.learning_rate, self.lambda_reg, self.use_bias,
-                                                              self._neg_population, mode)
+                        correct, skipped = run(1)
                         self.fit_stats.append((correct, skipped))
                         progress.set_postfix({
                             "correct": "%.2f%%" % (100.0 * correct / (nnz - skipped + 1e-8)),
@@ -118,11 +138,10 @@ class BPR(Recommender):
                         })
                 print("Optimization finished!")
             else:
-                correct, skipped = trainer.fit_epochs(self.max_iter, self.learning_rate, self.lambda_reg,
-                                                      self.use_bias, self._neg_population, mode)
+                correct, skipped = run(self.max_iter)
                 self.fit_stats.append((correct, skipped))
             self.last_timing = trainer.last_timing()
-            U, V, B = trainer.get_factors()
+            U, V, B = trainer.get_factors_f64() if f64 else trainer.get_factors()
             # the reference mutates the arrays in place (also user-provided init_params)
             self.u_factors[...] = U
             self.i_factors[...] = V
@@ -136,14 +155,18 @@ class BPR(Recommender):
     def _scoring_tables(self):
         return self.u_factors, self.i_factors, self.i_biases, None
 
-    def _scorer_row_count(self):
-        return len(self.u_factors)
-
     def score(self, user_idx, item_idx=None):
         """recom_bpr.pyx:272-297: scores over len(i_biases) items, or one scalar."""
         if item_idx is None:
+            if self.trains_float64:
+                return self._get_scorer().score_user_f64(user_idx)
             return self._get_scorer().score_user(user_idx)
         return self.i_biases[item_idx] + np.dot(self.u_factors[user_idx], self.i_factors[item_idx])
+
+    def _scorer_row_count(self):
+        # a float64 model is not served by the float32 batched kernels (rank_batch, rank_topk, score_pairs): with no
+        # device rows the evaluators and rank() take the per-user flow over score() — float64, like the reference's
+        return 0 if self.trains_float64 else len(self.u_factors)
 
     # ANN mixin surface (recom_bpr.pyx:299-333)
     def get_vector_measure(self):
@@ -171,7 +194,7 @@ class WBPR(BPR):
                          init_params=init_params, seed=seed, mode=mode, device=device)
 
     def _seed_trainer(self, trainer):
-        if self.effective_mode == "deterministic":
+        if self.effective_mode == "deterministic" or self.trains_float64:
             s = rngvector_mt_seed(self.rng.randint(2 ** 31))  # recom_wbpr.pyx:131
             trainer.seed_mt19937(s, s, shared_stream=True)
         else:

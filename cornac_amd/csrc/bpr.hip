@@ -53,57 +53,59 @@ __global__ __launch_bounds__(kBlock) void bpr_det_sample_kernel(
 // One level of the conflict-free schedule: samples [off, off+cnt) touch pairwise-disjoint rows.
 // G lanes per triplet.  The dot product is accumulated in index order (score = B_i - B_j, then
 // += u_f * (vi_f - vj_f) for f = 0..k-1) so the result is bit-identical to the sequential oracle.
-template <int G>
+// T = float (the reference's default tables) or double: `_fit_sgd` is a fused-type function (recom_bpr.pyx:211-214) and
+// runs in double when the model was given float64 factors through init_params — every local is then a double (:219-224)
+template <int G, class T>
 __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__restrict__ su,
                                                                const int32_t *__restrict__ si,
                                                                const int32_t *__restrict__ sj, int64_t off, int cnt,
-                                                               float *U, float *V, float *B, int k, float lr,
-                                                               float reg, int use_bias,
+                                                               T *U, T *V, T *B, int k, T lr,
+                                                               T reg, int use_bias,
                                                                unsigned long long *__restrict__ counters) {
     const int gid = (blockIdx.x * kBlock + threadIdx.x) / G;
     const int lg = threadIdx.x & (G - 1);
     const bool active = gid < cnt;
     const int64_t t = off + (active ? gid : cnt - 1);
     const int32_t u = su[t], i = si[t], j = sj[t];
-    float *pu = U + (size_t)u * k, *pi = V + (size_t)i * k, *pj = V + (size_t)j * k;
-    const float bi = B[i], bj = B[j];
-    float score = bi - bj;
+    T *pu = U + (size_t)u * k, *pi = V + (size_t)i * k, *pj = V + (size_t)j * k;
+    const T bi = B[i], bj = B[j];
+    T score = bi - bj;
     // rows are read ONCE (kept in registers for the update when k <= 4 G): a level's latency is its chain of
     // dependent memory round trips, ids -> rows -> stores
     constexpr int RMAX = 4;
-    float ru[RMAX], ri[RMAX], rj[RMAX];
+    T ru[RMAX], ri[RMAX], rj[RMAX];
     const bool in_regs = k <= RMAX * G;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         const int f = r * G + lg;
-        ru[r] = ri[r] = rj[r] = 0.f;
+        ru[r] = ri[r] = rj[r] = T(0);
         if (in_regs && f < k) {
             ru[r] = pu[f];
             ri[r] = pi[f];
             rj[r] = pj[f];
         }
     }
-    auto ordered_add = [&](float p, int lim) { score = ordered_lane_sum<G>(score, p, lim); };
+    auto ordered_add = [&](T p, int lim) { score = ordered_lane_sum_t<G>(score, p, lim); };
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int base = r * G;
-            if (base < k) ordered_add(base + lg < k ? ru[r] * (ri[r] - rj[r]) : 0.f, min(G, k - base));
+            if (base < k) ordered_add(base + lg < k ? ru[r] * (ri[r] - rj[r]) : T(0), min(G, k - base));
         }
     } else {
         for (int base = 0; base < k; base += G) {
             const int f = base + lg;
-            ordered_add(f < k ? pu[f] * (pi[f] - pj[f]) : 0.f, min(G, k - base));
+            ordered_add(f < k ? pu[f] * (pi[f] - pj[f]) : T(0), min(G, k - base));
         }
     }
-    const float z = sigmoid_neg_exact(score);
+    const T z = sigmoid_neg_exact_t(score);
     if (active) {
         if (in_regs) {
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
                 const int f = r * G + lg;
                 if (f < k) {
-                    const float uf = ru[r], vi = ri[r], vj = rj[r];
+                    const T uf = ru[r], vi = ri[r], vj = rj[r];
                     pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
                     pi[f] = vi + lr * (z * uf - reg * vi);
                     pj[f] = vj + lr * (-z * uf - reg * vj);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__
             }
         } else {
             for (int f = lg; f < k; f += G) {
-                const float uf = pu[f], vi = pi[f], vj = pj[f];
+                const T uf = pu[f], vi = pi[f], vj = pj[f];
                 pu[f] = uf + lr * (z * (vi - vj) - reg * uf);
                 pi[f] = vi + lr * (z * uf - reg * vi);
                 pj[f] = vj + lr * (-z * uf - reg * vj);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void bpr_det_level_kernel(const int32_t *__
             B[j] = bj + lr * (-z - reg * bj);
         }
     }
-    const unsigned long long m = __ballot(active && lg == 0 && z < .5f);
+    const unsigned long long m = __ballot(active && lg == 0 && z < T(.5));
     if (lane_id() == 0 && m) atomicAdd(&counters[0], (unsigned long long)__popcll(m));
 }
 
@@ -667,6 +669,8 @@ struct cornac_hip_bpr {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
+    bool f64 = false;  // float64 tables (set_factors_f64): deterministic mode only, like the reference's fused-type loop
+    DevBuf<double> U64, V64, B64;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped, [2] strata workgroups placed off their logical XCD
     // deterministic sampler state
@@ -808,6 +812,7 @@ int cornac_hip_bpr_destroy(cornac_hip_bpr_t h) {
 int cornac_hip_bpr_set_factors(cornac_hip_bpr_t h, const float *U, const float *V, const float *B) {
     return guarded([&] {
         bpr_check(h);
+        h->f64 = false;
         if (U) h->U.upload(U, (size_t)h->total_users * h->k, h->stream);
         if (V) h->V.upload(V, (size_t)h->total_items * h->k, h->stream);
         if (B) h->B.upload(B, (size_t)h->total_items, h->stream);
@@ -818,6 +823,7 @@ int cornac_hip_bpr_set_factors(cornac_hip_bpr_t h, const float *U, const float *
 int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B) {
     return guarded([&] {
         bpr_check(h);
+        REQUIRE(!h->f64, "the handle holds float64 tables (use cornac_hip_bpr_get_factors_f64)");
         if (U) h->U.download(U, (size_t)h->total_users * h->k, h->stream);
         if (V) h->V.download(V, (size_t)h->total_items * h->k, h->stream);
         if (B) h->B.download(B, (size_t)h->total_items, h->stream);
@@ -825,6 +831,30 @@ int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B)
     });
 }
 
+int cornac_hip_bpr_set_factors_f64(cornac_hip_bpr_t h, const double *U, const double *V, const double *B) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(U && V && B, "float64 tables are set together (the reference's fused type is one type for U, V and B)");
+        h->U64.ensure((size_t)h->total_users * h->k);
+        h->V64.ensure((size_t)h->total_items * h->k);
+        h->B64.ensure((size_t)h->total_items);
+        h->U64.upload(U, (size_t)h->total_users * h->k, h->stream);
+        h->V64.upload(V, (size_t)h->total_items * h->k, h->stream);
+        h->B64.upload(B, (size_t)h->total_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->f64 = true;
+    });
+}
+int cornac_hip_bpr_get_factors_f64(cornac_hip_bpr_t h, double *U, double *V, double *B) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->f64, "the handle holds float32 tables (use cornac_hip_bpr_get_factors)");
+        if (U) h->U64.download(U, (size_t)h->total_users * h->k, h->stream);
+        if (V) h->V64.download(V, (size_t)h->total_items * h->k, h->stream);
+        if (B) h->B64.download(B, (size_t)h->total_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
 int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB) {
     return guarded([&] {
         bpr_check(h);
@@ -938,14 +968,18 @@ static void mt_draw(cornac_hip_bpr_t h, int n_streams, const int *streams, const
 
 template <int G>
 static void launch_det_level(cornac_hip_bpr_t h, const int32_t *ou, const int32_t *oi, const int32_t *oj, int64_t off,
-                             int cnt, float lr, float reg, int use_bias) {
+                             int cnt, double lr, double reg, int use_bias) {
     const int groups_per_block = kBlock / G;
     const int grid = (cnt + groups_per_block - 1) / groups_per_block;
-    hipLaunchKernelGGL(bpr_det_level_kernel<G>, dim3(grid), dim3(kBlock), 0, h->stream, ou, oi, oj, off, cnt, h->U.p,
-                       h->V.p, h->B.p, h->k, lr, reg, use_bias, h->counters.p);
+    if (h->f64)
+        hipLaunchKernelGGL((bpr_det_level_kernel<G, double>), dim3(grid), dim3(kBlock), 0, h->stream, ou, oi, oj, off, cnt,
+                           h->U64.p, h->V64.p, h->B64.p, h->k, lr, reg, use_bias, h->counters.p);
+    else
+        hipLaunchKernelGGL((bpr_det_level_kernel<G, float>), dim3(grid), dim3(kBlock), 0, h->stream, ou, oi, oj, off, cnt,
+                           h->U.p, h->V.p, h->B.p, h->k, (float)lr, (float)reg, use_bias, h->counters.p);
 }
 
-static void bpr_epoch_deterministic(cornac_hip_bpr_t h, float lr, float reg, int use_bias, int neg_population) {
+static void bpr_epoch_deterministic(cornac_hip_bpr_t h, double lr, double reg, int use_bias, int neg_population) {
     REQUIRE(h->mt_seeded, "deterministic mode needs cornac_hip_bpr_seed_mt19937 first");
     const int64_t nnz = h->nnz;
     const uint64_t pos_hi = (uint64_t)nnz - 1;
@@ -1743,6 +1777,7 @@ int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float 
         REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
                 "unknown neg_population %d", neg_population);
         REQUIRE(mode == CORNAC_HIP_MODE_DETERMINISTIC || mode == CORNAC_HIP_MODE_HOGWILD, "unknown mode %d", mode);
+        REQUIRE(!h->f64, "the handle holds float64 tables: use cornac_hip_bpr_fit_epochs_f64 (sequential semantics only)");
         if (correct) *correct = 0;
         if (skipped) *skipped = 0;
         for (double &t : h->timing) t = 0;
@@ -1764,11 +1799,31 @@ int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float 
     });
 }
 
+int cornac_hip_bpr_fit_epochs_f64(cornac_hip_bpr_t h, int n_epochs, double lr, double reg, int use_bias, int neg_population,
+                                  int64_t *correct, int64_t *skipped) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->f64, "set float64 tables first (cornac_hip_bpr_set_factors_f64)");
+        REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
+        REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
+                "unknown neg_population %d", neg_population);
+        if (correct) *correct = 0;
+        if (skipped) *skipped = 0;
+        for (double &t : h->timing) t = 0;
+        Timer total;
+        HIP_CHECK(hipMemsetAsync(h->counters.p, 0, 4 * sizeof(unsigned long long), h->stream));
+        for (int e = 0; e < n_epochs; ++e) bpr_epoch_deterministic(h, lr, reg, use_bias, neg_population);
+        fetch_counters(h, correct, skipped);
+        h->timing[3] = total.ms();
+    });
+}
+
 int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                                    int neg_population, int hogwild_flags) {
     return guarded([&] {
         bpr_check(h);
         REQUIRE(n_samples >= 0, "n_samples must be >= 0");
+        REQUIRE(!h->f64, "the handle holds float64 tables: use cornac_hip_bpr_fit_epochs_f64 (sequential semantics only)");
         hogwild_enqueue(h, n_samples, lr, reg, use_bias, neg_population, hogwild_flags);
     });
 }

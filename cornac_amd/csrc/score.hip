@@ -924,6 +924,9 @@ struct cornac_hip_scorer {
     DevBuf<int32_t> d_tgt_indices, d_tgt_counts;
     DevBuf<float> d_tgt_scores;
     DevBuf<unsigned long long> sort_scratch, part;
+    // float64 tables of a model trained in double (cornac_hip_scorer_set_f64): score_user only
+    DevBuf<double> U64, V64, ib64, ub64, scores64;
+    bool f64_set = false, f64_user_base = false;
 };
 
 // The fused top-k kernel appends every score that beats its row's running topk-th score, so its cost depends on
@@ -1251,6 +1254,61 @@ int cornac_hip_score_user(cornac_hip_scorer_t h, int64_t user, float *out) {
         h->scores.ensure((size_t)h->n_items);
         launch_scores(h, nullptr, user, 1, false);
         h->scores.download(out, (size_t)h->n_items, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+namespace chip {
+// fast_dot's float64 variant (cornac/utils/fast_dot.pyx:25-43: ddot per item row): one thread per item, the products
+// summed in index order in double
+__global__ __launch_bounds__(256) void score_user_f64_kernel(const double *__restrict__ u, const double *__restrict__ V,
+                                                             const double *__restrict__ item_base, double user_base,
+                                                             int64_t n_items, int k, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    double acc = 0.0;
+    const double *v = V + i * k;
+    for (int f = 0; f < k; ++f) acc = acc + u[f] * v[f];
+    out[i] = (item_base ? item_base[i] : 0.0) + user_base + acc;
+}
+}  // namespace chip
+
+int cornac_hip_scorer_set_f64(cornac_hip_scorer_t h, const double *U, const double *V, const double *item_base,
+                              const double *user_base) {
+    return guarded([&] {
+        sc_check(h, false);
+        REQUIRE(U && V, "U and V are required");
+        h->U64.ensure((size_t)h->n_users * h->k);
+        h->V64.ensure((size_t)h->n_items * h->k);
+        h->U64.upload(U, (size_t)h->n_users * h->k, h->stream);
+        h->V64.upload(V, (size_t)h->n_items * h->k, h->stream);
+        h->ib64.ensure((size_t)h->n_items);
+        if (item_base) h->ib64.upload(item_base, (size_t)h->n_items, h->stream);
+        else HIP_CHECK(hipMemsetAsync(h->ib64.p, 0, (size_t)h->n_items * sizeof(double), h->stream));
+        h->f64_user_base = user_base != nullptr;
+        if (user_base) {
+            h->ub64.ensure((size_t)h->n_users);
+            h->ub64.upload(user_base, (size_t)h->n_users, h->stream);
+        }
+        h->scores64.ensure((size_t)h->n_items);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->f64_set = true;
+    });
+}
+
+int cornac_hip_score_user_f64(cornac_hip_scorer_t h, int64_t user, double *out) {
+    return guarded([&] {
+        sc_check(h, false);
+        REQUIRE(h->f64_set, "no float64 tables (cornac_hip_scorer_set_f64)");
+        REQUIRE(user >= 0 && user < h->n_users, "user %lld out of range", (long long)user);
+        REQUIRE(out != nullptr, "out is NULL");
+        double ub = 0.0;
+        if (h->f64_user_base) HIP_CHECK(hipMemcpyAsync(&ub, h->ub64.p + user, sizeof ub, hipMemcpyDeviceToHost, h->stream));
+        if (h->f64_user_base) HIP_CHECK(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(score_user_f64_kernel, dim3((unsigned)((h->n_items + 255) / 256)), dim3(256), 0, h->stream,
+                           h->U64.p + (size_t)user * h->k, h->V64.p, h->ib64.p, ub, h->n_items, h->k, h->scores64.p);
+        HIP_CHECK(hipGetLastError());
+        h->scores64.download(out, (size_t)h->n_items, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
     });
 }

@@ -50,12 +50,23 @@ __device__ __forceinline__ float ordered_lane_sum(float acc, float p, int lim) {
     return acc;
 }
 
+// the same for either table type (double: lane broadcasts of the two halves)
+template <int G>
+__device__ __forceinline__ float ordered_lane_sum_t(float acc, float p, int lim) { return ordered_lane_sum<G>(acc, p, lim); }
+template <int G>
+__device__ __forceinline__ double ordered_lane_sum_t(double acc, double p, int lim) {
+    for (int l = 0; l < lim; ++l) acc = acc + __shfl(p, l, G);
+    return acc;
+}
+
 // sigmoid(-score) exactly as the reference evaluates it (cornac/models/bpr/recom_bpr.pyx:250):
 // exp on a float, then 1.0/(1.0+e) in double, rounded to float on assignment.
 __device__ __forceinline__ float sigmoid_neg_exact(float score) {
     const float e = (float)exp((double)score);
     return (float)(1.0 / (1.0 + (double)e));
 }
+__device__ __forceinline__ float sigmoid_neg_exact_t(float score) { return sigmoid_neg_exact(score); }
+__device__ __forceinline__ double sigmoid_neg_exact_t(double score) { return 1.0 / (1.0 + exp(score)); }  // all-double locals
 __device__ __forceinline__ float sigmoid_neg_fast(float score) {
     return __frcp_rn(1.0f + __expf(score));
 }

@@ -273,6 +273,8 @@ class Recommender(_RecommenderRoot):
         if self.__dict__.get("_scorer") is None or self.__dict__.get("_scorer_key") != key:
             self._drop_scorer()
             self._scorer = _lib.Scorer(U, V, ib, ub, device=getattr(self, "device", 0))
+            if np.asarray(U).dtype == np.float64:   # a model trained in double also serves score() in double
+                self._scorer.set_f64(U, V, ib, ub)
             self._scorer_key = key
         return self._scorer
 

@@ -81,6 +81,16 @@ int cornac_hip_bpr_destroy(cornac_hip_bpr_t h);
 int cornac_hip_bpr_set_factors(cornac_hip_bpr_t h, const float *U, const float *V, const float *B);
 int cornac_hip_bpr_get_factors(cornac_hip_bpr_t h, float *U, float *V, float *B);
 
+/* float64 tables.  `_fit_sgd` is a fused-type (`floating`) function (recom_bpr.pyx:211-214): a model given float64
+ * U / V / Bi through init_params trains in double, every local of the step included (:219-224).  set_factors_f64 puts
+ * the handle into that state (all three tables together; set_factors puts it back), fit_epochs_f64 runs the SEQUENTIAL
+ * semantics (the deterministic engine with the mt19937 streams of seed_mt19937; lr / reg as doubles) — there is no
+ * float64 throughput kernel: an unseeded float64 model is trained by this engine too (cornac_amd/bpr.py). */
+int cornac_hip_bpr_set_factors_f64(cornac_hip_bpr_t h, const double *U, const double *V, const double *B);
+int cornac_hip_bpr_get_factors_f64(cornac_hip_bpr_t h, double *U, double *V, double *B);
+int cornac_hip_bpr_fit_epochs_f64(cornac_hip_bpr_t h, int n_epochs, double lr, double reg, int use_bias, int neg_population,
+                                  int64_t *correct, int64_t *skipped);
+
 /* Use caller-owned device buffers (same shapes) instead of the library's. */
 int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB);
 int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB);
@@ -380,6 +390,13 @@ int cornac_hip_scorer_set(cornac_hip_scorer_t h, const float *U, const float *V,
                           const float *user_base);
 /* out[n_items] for one user  (= model.score(user_idx)) */
 int cornac_hip_score_user(cornac_hip_scorer_t h, int64_t user, float *out);
+/* fast_dot's float64 variant (cornac/utils/fast_dot.pyx:25-43, ddot): the scorer can additionally hold the float64 tables
+ * of a model trained in double; score_user_f64 = item_base + user_base + <U[user], V[i]> summed in index order in double.
+ * The batched top-k kernels stay float32 (MFMA): a float64 model ranks through score_user_f64 + the reference's own
+ * host-side ordering (cornac/models/recommender.py:503-530 is NumPy). */
+int cornac_hip_scorer_set_f64(cornac_hip_scorer_t h, const double *U, const double *V, const double *item_base,
+                              const double *user_base);
+int cornac_hip_score_user_f64(cornac_hip_scorer_t h, int64_t user, double *out);
 /* out[n * n_items] for a block of users */
 int cornac_hip_score_block(cornac_hip_scorer_t h, const int32_t *users, int64_t n, float *out);
 /* out[p] = score(users[p], items[p]) for n pairs, optionally clipped to [lo, hi]:

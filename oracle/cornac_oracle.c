@@ -184,6 +184,53 @@ int oracle_bpr_epoch_seq(oracle_mt19937 *rng_pos, oracle_mt19937 *rng_neg, uint6
 }
 
 /* ------------------------------------------------------------------------- *
+ * The same epoch for float64 factors: `_fit_sgd` is a fused-type (`floating`) function (recom_bpr.pyx:211-214), so
+ * with double U / V / B every local (`z`, `score`, `temp`, `lr`, `reg`, :219-224) is a double and the whole step is
+ * double arithmetic in the order written at :245-266.
+ * ------------------------------------------------------------------------- */
+static inline int bpr_step_f64(double *user, double *item_i, double *item_j, double *B, int32_t i_id, int32_t j_id,
+                               int k, double lr, double reg, int use_bias) {
+    double score = B[i_id] - B[j_id];
+    for (int f = 0; f < k; ++f) score = score + user[f] * (item_i[f] - item_j[f]);
+    double z = 1.0 / (1.0 + exp(score));
+    for (int f = 0; f < k; ++f) {
+        double temp = user[f];
+        user[f] += lr * (z * (item_i[f] - item_j[f]) - reg * user[f]);
+        item_i[f] += lr * (z * temp - reg * item_i[f]);
+        item_j[f] += lr * (-z * temp - reg * item_j[f]);
+    }
+    if (use_bias) {
+        B[i_id] += lr * (z - reg * B[i_id]);
+        B[j_id] += lr * (-z - reg * B[j_id]);
+    }
+    return z < .5;
+}
+
+int oracle_bpr_epoch_seq_f64(oracle_mt19937 *rng_pos, oracle_mt19937 *rng_neg, uint64_t pos_hi, uint64_t neg_hi,
+                             int64_t num_samples, const int32_t *user_ids, const int32_t *item_ids,
+                             const int32_t *neg_item_ids, const int32_t *indptr, double *U, double *V, double *B, int k,
+                             double lr, double reg, int use_bias, int64_t *correct_out, int64_t *skipped_out) {
+    int64_t correct = 0, skipped = 0;
+    for (int64_t s = 0; s < num_samples; ++s) {
+        int64_t i_index = oracle_boost_uniform(rng_pos, pos_hi);
+        int64_t j_index = oracle_boost_uniform(rng_neg, neg_hi);
+        if (i_index < 0 || j_index < 0) return -1;
+        int32_t i_id = item_ids[i_index];
+        int32_t j_id = neg_item_ids[j_index];
+        int32_t u_id = user_ids[i_index];
+        if (has_non_zero(indptr, item_ids, u_id, j_id)) {
+            ++skipped;
+            continue;
+        }
+        correct += bpr_step_f64(U + (int64_t)u_id * k, V + (int64_t)i_id * k, V + (int64_t)j_id * k, B, i_id, j_id, k,
+                                lr, reg, use_bias);
+    }
+    *correct_out = correct;
+    *skipped_out = skipped;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- *
  * BPR._fit_sgd, unseeded (num_threads = T > 1): racy Hogwild, one generator
  * pair per thread (recom_bpr.pyx:228-267, `prange(..., schedule='guided')`).
  * This is the CPU throughput baseline ("port" of the OpenMP path); results

@@ -71,6 +71,10 @@ def _bind(L):
                                            i32p, i32p, f32p, f32p, f32p, C.c_int, C.c_float, C.c_float, C.c_int,
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                            C.c_void_p]
+        f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.oracle_bpr_epoch_seq_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, i32p, i32p,
+                                               i32p, i32p, f64p, f64p, f64p, C.c_int, C.c_double, C.c_double, C.c_int,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.oracle_bpr_epoch_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, i32p,
                                            i32p, i32p, i32p, f32p, f32p, f32p, C.c_int, C.c_float, C.c_float,
                                            C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -181,8 +185,17 @@ class BPROracle:
             self.i_factors = (_uniform((ni, self.k), self.rng) - 0.5) / self.k
         if self.i_biases is None or not self.use_bias:
             self.i_biases = np.zeros(ni, np.float32)
+        # `_fit_sgd` is a fused-type function (recom_bpr.pyx:211-214): three float64 tables train in double, three
+        # float32 tables in float; a mix fails the buffer check (the reference raises ValueError)
+        kinds = {np.asarray(getattr(self, n)).dtype for n in ("u_factors", "i_factors", "i_biases")}
+        if kinds == {np.dtype(np.float64)}:
+            self.dtype = np.float64
+        elif kinds == {np.dtype(np.float32)}:
+            self.dtype = np.float32
+        else:
+            raise ValueError("Buffer dtype mismatch: U, V and Bi must share one dtype")
         for n in ("u_factors", "i_factors", "i_biases"):
-            setattr(self, n, np.ascontiguousarray(getattr(self, n), dtype=np.float32))
+            setattr(self, n, np.ascontiguousarray(getattr(self, n), dtype=self.dtype))
 
     def fit(self, train_set, record=False):
         L = lib()
@@ -206,10 +219,16 @@ class BPROracle:
             rec = [None, None, None]
             if record:
                 rec = [np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.uint8)]
-            rc = L.oracle_bpr_epoch_seq(gp.ptr, gn.ptr, nnz - 1, neg_hi, nnz, user_ids, indices, neg_ids, indptr,
-                                        self.u_factors, self.i_factors, self.i_biases, self.k, self.lr, self.reg,
-                                        int(self.use_bias), C.byref(c), C.byref(s),
-                                        *[r.ctypes.data if r is not None else None for r in rec])
+            if self.dtype == np.float64:
+                assert not record, "the float64 restatement keeps no draw record"
+                rc = L.oracle_bpr_epoch_seq_f64(gp.ptr, gn.ptr, nnz - 1, neg_hi, nnz, user_ids, indices, neg_ids, indptr,
+                                                self.u_factors, self.i_factors, self.i_biases, self.k, self.lr, self.reg,
+                                                int(self.use_bias), C.byref(c), C.byref(s))
+            else:
+                rc = L.oracle_bpr_epoch_seq(gp.ptr, gn.ptr, nnz - 1, neg_hi, nnz, user_ids, indices, neg_ids, indptr,
+                                            self.u_factors, self.i_factors, self.i_biases, self.k, self.lr, self.reg,
+                                            int(self.use_bias), C.byref(c), C.byref(s),
+                                            *[r.ctypes.data if r is not None else None for r in rec])
             if rc != 0:
                 raise ValueError("oracle_bpr_epoch_seq failed")
             self.correct.append(c.value)
@@ -220,6 +239,8 @@ class BPROracle:
 
     def score(self, user_idx, mode=1):
         out = np.copy(self.i_biases)
+        if out.dtype == np.float64:  # fast_dot's ddot variant (fast_dot.pyx:25-43); the BLAS summation order is not pinned
+            return out + self.i_factors @ self.u_factors[user_idx]
         lib().oracle_fast_dot(self.u_factors[user_idx], self.i_factors, out, len(out), self.k, mode)
         return out
 

@@ -25,6 +25,29 @@ class FakeBprTrainer:
         self.U, self.V = (np.array(x, dtype=np.float32, order="C") for x in (U, V))
         self.B = None if B is None else np.array(B, dtype=np.float32, order="C")
 
+    def set_factors_f64(self, U, V, B):
+        self.U, self.V, self.B = (np.array(x, dtype=np.float64, order="C") for x in (U, V, B))
+
+    def get_factors_f64(self):
+        assert self.U.dtype == np.float64
+        return self.U.copy(), self.V.copy(), self.B.copy()
+
+    def fit_epochs_f64(self, n_epochs, lr, reg, use_bias=True, neg_population=_lib.NEG_UNIFORM):
+        assert self.U.dtype == np.float64
+        nnz = len(self.user_ids)
+        popularity = neg_population == _lib.NEG_POPULARITY
+        neg_ids = self.indices if popularity else np.arange(self.n_items, dtype=np.int32)
+        neg_hi = nnz - 1 if popularity else self.n_items - 1
+        correct = skipped = 0
+        for _ in range(n_epochs):
+            c, s = C.c_int64(), C.c_int64()
+            rc = orc.lib().oracle_bpr_epoch_seq_f64(self.gp.ptr, self.gn.ptr, nnz - 1, neg_hi, nnz, self.user_ids,
+                                                    self.indices, neg_ids, self.indptr, self.U, self.V, self.B, self.k,
+                                                    lr, reg, int(use_bias), C.byref(c), C.byref(s))
+            assert rc == 0
+            correct, skipped = correct + c.value, skipped + s.value
+        return correct, skipped
+
     def seed_mt19937(self, seed_pos, seed_neg, shared_stream=False):
         self.calls.append(("mt19937", int(seed_pos), int(seed_neg), bool(shared_stream)))
         self.gp = orc.MT19937(seed_pos)
@@ -154,6 +177,14 @@ class FakeScorer:
 
     def score_user(self, user):
         return self.score_block([int(user)])[0]
+
+    def set_f64(self, U, V, item_base=None, user_base=None):
+        self.f64 = tuple(None if a is None else np.array(a, np.float64) for a in (U, V, item_base, user_base))
+
+    def score_user_f64(self, user):
+        U, V, ib, ub = self.f64
+        out = V @ U[int(user)]
+        return out + (0.0 if ib is None else ib) + (0.0 if ub is None else ub[int(user)])
 
     def score_pairs(self, users, items, clip=None):
         users, items = np.asarray(users), np.asarray(items)

@@ -61,6 +61,58 @@ def test_deterministic_matches_oracle_and_reference_golden(oracle, name, cls_nam
     assert m.fit_stats[0] == (sum(o.correct), sum(o.skipped))
 
 
+@pytest.mark.parametrize("cls_name", ["BPR", "WBPR"])
+def test_float64_tables_train_and_score_in_double(oracle, cls_name):
+    """float64 init_params (the reference's fused-type `_fit_sgd`, recom_bpr.pyx:211-214): the level kernel in double
+    against the float64 oracle and the reference's own float64 run (tests/golden/f64_small.npz), score() through the
+    float64 scoring kernel; rank()/evaluation take the per-user flow; float32 entry points refuse a float64 handle"""
+    import cornac_amd.eval as ev
+    import cornac_amd.metrics as mm
+    from cornac_amd import ScoreException
+
+    fx = load_golden("f64_small")
+    ds = golden_dataset(fx)
+    cls, ocls, tag = (BPR, oracle.BPROracle, "bpr") if cls_name == "BPR" else (WBPR, oracle.WBPROracle, "wbpr")
+    init = lambda: {"U": fx["init_U"].copy(), "V": fx["init_V"].copy(), "Bi": fx["init_Bi"].copy()}  # noqa: E731
+    ip = init()
+    m = cls(init_params=ip, **_kw(fx)).fit(ds)
+    o = ocls(init_params=init(), **_kw(fx)).fit(ds)
+    assert m.u_factors is ip["U"] and m.u_factors.dtype == np.float64
+    for a, b, g in ((m.u_factors, o.u_factors, "_U"), (m.i_factors, o.i_factors, "_V"), (m.i_biases, o.i_biases, "_B")):
+        assert np.abs(a - b).max() <= 1e-12, "HIP float64 vs float64 oracle"
+        assert np.abs(a - fx[tag + g]).max() <= 1e-12, "HIP float64 vs the reference's float64 run"
+    assert m.fit_stats[0] == (sum(o.correct), sum(o.skipped))
+    f32 = cls(init_params={n: a.astype(np.float32) for n, a in init().items()}, **_kw(fx)).fit(ds)
+    assert 1e-9 < np.abs(f32.u_factors - m.u_factors).max() < 1e-4, "the double run must differ from the float run"
+    for t, u in enumerate(fx["score_users"]):
+        s = m.score(int(u))
+        assert s.dtype == np.float64 and np.abs(s - fx[tag + "_scores"][t]).max() <= 1e-12
+        ranked, _ = m.rank(int(u))
+        assert np.array_equal(np.sort(ranked), np.arange(ds.num_items)) and np.all(np.diff(s[ranked]) <= 0)
+    with pytest.raises(ScoreException):
+        m.rank_batch(np.arange(4), k=5)
+    res = ev.ranking_eval(m, [mm.Recall(k=5), mm.AUC()], ds, ds)
+    assert 0.0 < res[0][1] <= 1.0
+    # the raw handle: float32 entry points refuse float64 tables, set_factors puts it back; epochs continue the streams
+    tr = _trainer(ds, int(fx["k"]))
+    tr.set_factors_f64(fx["init_U"], fx["init_V"], fx["init_Bi"])
+    tr.seed_mt19937(11, 12, shared_stream=False)
+    with pytest.raises(_lib.HipError):
+        tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_DETERMINISTIC)
+    a = tr.fit_epochs_f64(1, 0.05, 0.01) + tr.fit_epochs_f64(2, 0.05, 0.01)
+    U3, V3, B3 = tr.get_factors_f64()
+    tr.set_factors_f64(fx["init_U"], fx["init_V"], fx["init_Bi"])
+    tr.seed_mt19937(11, 12, shared_stream=False)
+    b = tr.fit_epochs_f64(3, 0.05, 0.01)
+    U3b, V3b, B3b = tr.get_factors_f64()
+    assert (a[0] + a[2], a[1] + a[3]) == b and np.array_equal(U3, U3b) and np.array_equal(V3, V3b) and np.array_equal(B3, B3b)
+    tr.set_factors(fx["init_U"], fx["init_V"], fx["init_Bi"])
+    tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_DETERMINISTIC)
+    with pytest.raises(_lib.HipError):
+        tr.get_factors_f64()
+    tr.close()
+
+
 def test_deterministic_no_bias_and_bit_exact_fraction(oracle):
     fx = load_golden("small")
     ds = golden_dataset(fx)

@@ -219,3 +219,32 @@ def test_mf_minibatch_oracle_matches_live_reference(opt):
                                   val.astype(np.float32), batches, opt, 0.03, 0.01, True)
     for a, b in zip(got[:4], (m.u_factors, m.i_factors, m.u_biases, m.i_biases)):
         assert_close(a, np.asarray(b))
+
+
+def _f64_init(nu, ni, k, seed):
+    rs = np.random.RandomState(seed)
+    return {"U": (rs.rand(nu, k) - 0.5) / k, "V": (rs.rand(ni, k) - 0.5) / k, "Bi": 0.01 * rs.randn(ni)}
+
+
+@pytest.mark.parametrize("k,seed", [(5, 1), (16, 2), (33, 3)])
+def test_float64_models_match_live_reference(oracle, k, seed):
+    """`_fit_sgd` is a fused-type function (recom_bpr.pyx:211-214): float64 init_params train in double.  The oracle's
+    float64 restatement against the live reference, BPR and WBPR, score() included; a dtype mix raises on both sides."""
+    ns = ref_loader.load()
+    ds = ns.Dataset.from_uir(_pairs(80, 60, 1500, seed), seed=1)
+    kw = dict(k=k, max_iter=6, learning_rate=0.03, lambda_reg=0.01, seed=seed)
+    for ref_cls, or_cls in ((ns.BPR, oracle.BPROracle), (ns.WBPR, oracle.WBPROracle)):
+        ip = _f64_init(ds.num_users, ds.num_items, k, seed)
+        m = ref_cls(init_params={n: a.copy() for n, a in ip.items()}, **kw).fit(ds)
+        o = or_cls(init_params={n: a.copy() for n, a in ip.items()}, **kw).fit(ds)
+        assert m.u_factors.dtype == np.float64 and o.u_factors.dtype == np.float64
+        for name in ("u_factors", "i_factors", "i_biases"):
+            assert np.abs(getattr(m, name) - getattr(o, name)).max() < 1e-13, name
+        assert np.abs(m.score(3) - o.score(3)).max() < 1e-13
+        assert np.abs(m.u_factors - ip["U"]).max() > 1e-4, "the run must have trained"
+    ip = _f64_init(ds.num_users, ds.num_items, k, seed)
+    ip["V"] = ip["V"].astype(np.float32)
+    with pytest.raises(ValueError):
+        ns.BPR(init_params=dict(ip), **kw).fit(ds)
+    with pytest.raises(ValueError):
+        oracle.BPROracle(init_params=dict(ip), **kw).fit(ds)
