@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 MODE_DETERMINISTIC = 0
 MODE_HOGWILD = 1
+VEBPR_NO_OWNERSHIP = 0x100
 # hogwild_flags bits 16..19: the form of a whole-epoch hogwild call (include/cornac_hip.h)
 FORM_AUTO, FORM_FUSED, FORM_STRATA, FORM_LDSBIN = 0, 1 << 16, 2 << 16, 3 << 16
 NEG_UNIFORM = 0
@@ -34,7 +35,7 @@ SYMBOLS = [
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
-    "cornac_hip_vebpr_fit_epochs",
+    "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_hogwild_form",
     "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
     "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
@@ -149,6 +150,7 @@ def lib():
         L.cornac_hip_bpr_last_timing.argtypes = [_vp, C.POINTER(C.c_double)]
         L.cornac_hip_bpr_set_views.argtypes = [_vp, _i32, _i32, C.c_int64]
         L.cornac_hip_bpr_seed_view_stream.argtypes = [_vp, C.c_uint32]
+        L.cornac_hip_vebpr_hogwild_form.argtypes = [_vp, C.POINTER(C.c_int)]
         L.cornac_hip_vebpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_sample_triplets.argtypes = [_vp, C.c_int64, C.c_int, _vp, _vp, _vp]
@@ -424,10 +426,17 @@ class BprTrainer:
     def seed_view_stream(self, seed_view):
         check(lib().cornac_hip_bpr_seed_view_stream(self.h, seed_view))
 
-    def fit_epochs_vebpr(self, n_epochs, lr, reg, alpha, mode=MODE_HOGWILD):
+    def fit_epochs_vebpr(self, n_epochs, lr, reg, alpha, mode=MODE_HOGWILD, ownership=True):
         c, s = C.c_int64(), C.c_int64()
-        check(lib().cornac_hip_vebpr_fit_epochs(self.h, n_epochs, lr, reg, alpha, mode, C.byref(c), C.byref(s)))
+        check(lib().cornac_hip_vebpr_fit_epochs(self.h, n_epochs, lr, reg, alpha, mode | (0 if ownership else VEBPR_NO_OWNERSHIP),
+                                                C.byref(c), C.byref(s)))
         return c.value, s.value
+
+    def vebpr_hogwild_owned(self):
+        """True if the last VEBPR hogwild epoch ran with user-row ownership (k > 32, enough interactions per wave)"""
+        o = C.c_int()
+        check(lib().cornac_hip_vebpr_hogwild_form(self.h, C.byref(o)))
+        return bool(o.value)
 
     def debug_ownership(self):
         """(wave_ptr, own_u, own_i) of the hogwild sampler's user-row ownership, or None if unused"""

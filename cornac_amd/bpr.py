@@ -244,6 +244,9 @@ class VEBPR(Recommender):
             self.u_factor = (_uniform((n_users, self.k), self.rng) - 0.5) / self.k
         if self.i_factor is None:
             self.i_factor = (_uniform((n_items, self.k), self.rng) - 0.5) / self.k
+        if np.asarray(self.u_factor).dtype != DTYPE or np.asarray(self.i_factor).dtype != DTYPE:
+            raise ValueError("VEBPR on the HIP backend trains float32 tables (recom_vebpr.pyx:219's float64 "
+                             "instantiation is not provided)")
         if not self.trainable:
             return self
         X, Vw = train_set.matrix, train_set.view_matrix

@@ -669,6 +669,7 @@ struct cornac_hip_bpr {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<int32_t> indptr, indices, user_ids;
     DevBuf<float> U, V, B;
+    bool vebpr_owned = false;  // the last VEBPR hogwild epoch ran with user-row ownership
     bool f64 = false;  // float64 tables (set_factors_f64): deterministic mode only, like the reference's fused-type loop
     DevBuf<double> U64, V64, B64;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line

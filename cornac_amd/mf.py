@@ -11,7 +11,7 @@ attributes (`u_factors, i_factors, u_biases, i_biases, global_mean`) of the refe
 import numpy as np
 
 from . import _lib
-from .recommender import Recommender, ScoreException
+from .recommender import Recommender, ScoreException, _table_fingerprint
 
 DTYPE = np.float32
 
@@ -130,16 +130,15 @@ class MF(Recommender):
 
     # ---- prediction -------------------------------------------------------------------------------
     def _scoring_tables(self):
-        if (self.__dict__.get("_item_base") is None or self._item_base_src is not self.i_biases
-                or self._item_base_mean != float(self.global_mean)):
+        src = (_table_fingerprint(self.i_biases), float(self.global_mean))
+        if self.__dict__.get("_item_base") is None or self._item_base_src != src:
             self._item_base = (self.global_mean + self.i_biases).astype(DTYPE)
-            self._item_base_src = self.i_biases
-            self._item_base_mean = float(self.global_mean)
+            self._item_base_src = src
         return self.u_factors, self.i_factors, self._item_base, self.u_biases
 
     def _drop_scorer(self):
         # the biases are refreshed IN PLACE by a refit: the derived item_base table must go with the device scorer
-        for name in ("_item_base", "_item_base_src", "_item_base_mean"):
+        for name in ("_item_base", "_item_base_src"):
             self.__dict__.pop(name, None)
         super()._drop_scorer()
 

@@ -70,6 +70,25 @@ def adopt_reference_classes():
     return True
 
 
+_PROBE = 2048
+
+
+def _table_fingerprint(a):
+    """Identity AND a content probe of a host table: (id, buffer address, shape, dtype, hash of <= 2048 evenly spaced
+    elements).  The device copy of the scoring tables is keyed on it, so re-assigned attributes and whole-table in-place
+    edits (`m.i_biases += 1`, a warm-start loader writing into the existing arrays) are noticed without
+    `invalidate_scorer()`; only a sparse edit that misses every probed element still needs that call."""
+    if a is None:
+        return None
+    a = np.asarray(a)
+    n = a.size
+    if n <= _PROBE:
+        probe = a.tobytes()
+    else:
+        probe = a.flat[np.arange(_PROBE, dtype=np.int64) * ((n - 1) // (_PROBE - 1))].tobytes()
+    return (id(a), a.__array_interface__["data"][0], a.shape, a.dtype.str, hash(probe))
+
+
 def clip(values, lower_bound, upper_bound):
     """cornac/utils/common.py `clip`: clamp into [lower_bound, upper_bound]."""
     values = np.where(values > upper_bound, upper_bound, values)
@@ -260,16 +279,16 @@ class Recommender(_RecommenderRoot):
             sc.close()
 
     def invalidate_scorer(self):
-        """Call after editing learned parameters IN PLACE (warm-start tweaks, loading values into the existing
-        arrays): the device copy of the scoring tables is keyed on the identity of the host arrays and would
-        otherwise go stale.  `fit()` calls it itself."""
+        """Drop the device copy of the scoring tables.  The copy is keyed on identity plus a content probe of the host
+        arrays (`_table_fingerprint`), so whole-table in-place edits are noticed on their own; call this after a SPARSE
+        in-place edit (a handful of rows).  `fit()` calls it itself."""
         self._drop_scorer()
 
     def _get_scorer(self):
         from . import _lib
 
         U, V, ib, ub = self._scoring_tables()
-        key = tuple(id(x) for x in (U, V, ib, ub))
+        key = tuple(_table_fingerprint(x) for x in (U, V, ib, ub))
         if self.__dict__.get("_scorer") is None or self.__dict__.get("_scorer_key") != key:
             self._drop_scorer()
             self._scorer = _lib.Scorer(U, V, ib, ub, device=getattr(self, "device", 0))
@@ -305,10 +324,14 @@ class Recommender(_RecommenderRoot):
         n_cand = len(item_indices)
         topk = n_cand if k == -1 else min(int(k), n_cand)
         row = self._scorer_row(user_idx)
+        mask = None
         if row is not None and n_cand > 0 and int(item_indices.max()) < self._get_scorer().n_items:
-            sc = self._get_scorer()
-            mask = np.ones(sc.n_items, dtype=bool)
+            mask = np.ones(self._get_scorer().n_items, dtype=bool)
             mask[item_indices] = False
+            if n_cand != mask.size - int(mask.sum()):
+                mask = None   # repeated candidates: the reference returns them as given (recommender.py:515-530)
+        if mask is not None:
+            sc = self._get_scorer()
             excl = np.flatnonzero(mask).astype(np.int32)
             items, _ = sc.rank_topk(np.array([row], np.int32), topk,
                                     exclude=(np.array([0, len(excl)], np.int64), excl) if len(excl) else None)
@@ -318,10 +341,11 @@ class Recommender(_RecommenderRoot):
                 in_top[ranked_items] = True
                 ranked_items = np.concatenate([ranked_items, item_indices[~in_top[item_indices]]])
         else:
-            # user unknown to the device tables (constant scores) or candidates beyond the scored
-            # items (all tied at the row minimum): only the pinned tie rule is left to apply.
-            order = np.argsort(item_scores, kind="stable")[::-1]
-            ranked_items = item_indices[order]
+            # user unknown to the device tables (constant scores), candidates beyond the scored items (all tied at the
+            # row minimum) or repeated candidates: the scores are on the host already — order them there under the
+            # pinned rule (descending score, ties by descending item index); every candidate is returned, repeats too
+            order = np.lexsort((item_indices, item_scores))[::-1]
+            ranked_items = item_indices[order]   # all of them ranked: more than k != -1 asks for
         return ranked_items, item_scores
 
     @property

@@ -251,6 +251,13 @@ int cornac_hip_bpr_set_views(cornac_hip_bpr_t h, const int32_t *view_indptr, con
 int cornac_hip_bpr_seed_view_stream(cornac_hip_bpr_t h, uint32_t mt_seed_view);
 int cornac_hip_vebpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, float alpha, int mode,
                                 int64_t *correct, int64_t *skipped);
+/* Hogwild mode (the reference's prange over samples, recom_vebpr.pyx:211-337) gives every wave of the grid a fixed set of
+ * users (k > 32 and enough interactions for one 64-sample tile per wave): positives come from the wave's own users, so
+ * an exclusive user's row has one writer and is updated by plain load / store; the three item rows keep fp32 atomics.
+ * OR this bit into `mode` for the all-atomic form (diagnostics, A/B); vebpr_hogwild_form reports what the last hogwild
+ * epoch ran (1 = user-row ownership). */
+#define CORNAC_HIP_VEBPR_NO_OWNERSHIP 0x100
+int cornac_hip_vebpr_hogwild_form(cornac_hip_bpr_t h, int *owned);
 
 /* ------------------------------------------------------------------------- *
  * Matrix factorisation trainer.

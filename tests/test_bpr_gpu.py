@@ -566,6 +566,50 @@ def test_vebpr_hogwild_learns_like_the_sequential_oracle(oracle):
         VEBPR().fit(synth_dataset(20, 15, 100, seed=1))
 
 
+def test_vebpr_hogwild_user_row_ownership():
+    """VEBPR hogwild at k > 32 gives every wave its own users (plain stores on their rows, recom_vebpr.pyx:211-337 is the
+    loop); A/B against the all-atomic form on the same data: both finite, both lossless on the item side (reg = 0: the
+    three item deltas of a quadruple cancel, so V's column sums stay put up to fp32 summation), the same skip rate and
+    'correct' fraction, and U moved by a similar amount; small k keeps the atomic form."""
+    from cornac_amd import synth
+
+    n_users, n_items, k = 4000, 3000, 64
+    pu, pi = synth.zipf_interactions(n_users, n_items, 600_000, 0.5, 3)
+    vu, vi = synth.zipf_interactions(n_users - 500, n_items, 400_000, 0.4, 4)    # the last 500 users have no views
+    indptr, indices = synth.csr_from_sorted(pu, pi, n_users)
+    v_indptr, v_indices = synth.csr_from_sorted(vu, vi, n_users)
+    rs = np.random.RandomState(2)
+    U0 = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    out = {}
+    for owned in (True, False):
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.set_views(v_indptr, v_indices)
+        tr.set_factors(U0, V0, None)
+        tr.seed_hogwild(91)
+        c, s = tr.fit_epochs_vebpr(3, 0.02, 0.0, 0.5, _lib.MODE_HOGWILD, ownership=owned)
+        assert tr.vebpr_hogwild_owned() == owned
+        U, V, _ = tr.get_factors()
+        tr.close()
+        assert np.isfinite(U).all() and np.isfinite(V).all()
+        drift = np.abs(V.astype(np.float64).sum(0) - V0.astype(np.float64).sum(0)).max()
+        moved = np.abs(V.astype(np.float64) - V0).sum(0).max()
+        assert drift < 2e-4 * moved, (owned, drift, moved)
+        out[owned] = (c, s, np.linalg.norm(U - U0))
+    n = 3 * len(indices)
+    (c1, s1, d1), (c0, s0, d0) = out[True], out[False]
+    assert abs(s1 - s0) < 0.02 * s0 + 200, (s1, s0)
+    assert abs(c1 / (n - s1) - c0 / (n - s0)) < 0.02, (c1 / (n - s1), c0 / (n - s0))
+    assert 0.85 < d1 / d0 < 1.18, (d1, d0)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 16)
+    tr.set_views(v_indptr, v_indices)
+    tr.set_factors(U0[:, :16].copy(), V0[:, :16].copy(), None)
+    tr.seed_hogwild(5)
+    tr.fit_epochs_vebpr(1, 0.02, 0.01, 0.5, _lib.MODE_HOGWILD)
+    assert not tr.vebpr_hogwild_owned()
+    tr.close()
+
+
 def test_sharded_trainer_single_rank_stream_ordering():
     """the multi-GPU driver on one rank (NCCL group of size 1): kernels write the torch-owned item table on the
     driver's side stream, interleaved with delta / all-reduce / rebase ops.  With reg = 0 the column sums of V

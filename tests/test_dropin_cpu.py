@@ -138,10 +138,16 @@ def test_refit_does_not_serve_the_previous_fit(device_double):
         ranked, scores = m.rank(2)
         assert np.array_equal(np.sort(ranked), np.arange(ds.num_items)) and np.all(np.diff(want[ranked]) <= 1e-6)
         assert abs(m.rate_batch([2], [3])[0] - np.clip(want[3], ds.min_rating, ds.max_rating)) < 1e-5
-    # in-place edits need an explicit invalidation (documented): after it the device tables follow
+    # whole-table in-place edits are noticed through the content probe of the cache key ...
     m.i_biases[...] += 1.0
-    m.invalidate_scorer()
     assert np.abs(m.score(2) - (want + 1.0)).max() < 1e-5
+    m.u_factors[...] *= 0.5
+    want2 = m.global_mean + m.i_biases + m.u_biases[2] + m.i_factors @ m.u_factors[2]
+    assert np.abs(m.score(2) - want2).max() < 1e-5
+    # ... a sparse edit may miss every probed element: that still takes the documented explicit call
+    m.i_biases[7] += 3.0
+    m.invalidate_scorer()
+    assert abs(m.score(2)[7] - (want2[7] + 3.0)) < 1e-5
 
 
 def test_batched_ranking_eval_with_users_the_model_has_no_row_for(device_double):
@@ -166,3 +172,26 @@ def test_batched_ranking_eval_with_users_the_model_has_no_row_for(device_double)
         ref = ref_eval(m, picks(rm), train, test, exclude_unknowns=False)
         assert np.allclose(mine[0], ref[0], atol=1e-9), (mine[0], ref[0])
         assert all(x.keys() == y.keys() for x, y in zip(mine[1], ref[1]))
+
+
+def test_rank_with_repeated_and_unsorted_candidates_matches_the_reference(device_double):
+    """the reference's rank() hands back the candidates as given — repeats included, any order
+    (recommender.py:503-530).  Same multiset, same scores per position, descending order; k != -1 keeps every candidate."""
+    import cornac_amd as ca
+
+    ns = ref_loader.load()
+    data = _data(11)
+    train = ns.Dataset.build(data)
+    kw = dict(k=6, max_iter=8, learning_rate=0.05, lambda_reg=0.01, seed=3)
+    ours, theirs = ca.BPR(**kw).fit(train), ns.BPR(**kw).fit(train)
+    rs = np.random.RandomState(0)
+    for cand in (np.array([5, 3, 3, 9, 5, 5, 0]), rs.randint(0, train.num_items, 80), rs.permutation(train.num_items)[:17]):
+        for k in (-1, 4):
+            a_items, a_scores = ours.rank(2, item_indices=cand, k=k)
+            b_items, b_scores = theirs.rank(2, item_indices=cand, k=k)
+            assert np.allclose(a_scores, b_scores, atol=1e-5)
+            assert len(a_items) == len(cand) and np.array_equal(np.sort(a_items), np.sort(cand))
+            s = ours.score(2)
+            top = len(cand) if k == -1 else k
+            assert np.all(np.diff(s[a_items[:top]]) <= 0)
+            assert np.allclose(np.sort(s[a_items[:top]]), np.sort(theirs.score(2)[b_items[:top]]), atol=1e-5)
