@@ -43,13 +43,14 @@ SYMBOLS = [
     "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
     "cornac_hip_bpr_scatter_diff_rows", "cornac_hip_bpr_switch_stream",
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
-    "cornac_hip_bpr_table_delta_step",
+    "cornac_hip_bpr_table_delta_step", "cornac_hip_table_delta",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
     "cornac_hip_wmf_fit_batches", "cornac_hip_wmf_kernel_timing", "cornac_hip_wmf_last_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
-    "cornac_hip_mf_fit", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
+    "cornac_hip_mf_fit", "cornac_hip_mf_bind_items", "cornac_hip_mf_set_stream", "cornac_hip_mf_epoch_enqueue",
+    "cornac_hip_mf_sync", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_mf_hogwild_form", "cornac_hip_mf_hogwild_stats",
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
@@ -169,6 +170,7 @@ def lib():
         L.cornac_hip_bpr_table_delta_begin.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
         L.cornac_hip_bpr_table_delta_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
+        L.cornac_hip_table_delta.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_strata_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
@@ -202,6 +204,10 @@ def lib():
         L.cornac_hip_mf_destroy.argtypes = [_vp]
         L.cornac_hip_mf_set_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
         L.cornac_hip_mf_get_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        L.cornac_hip_mf_bind_items.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_mf_set_stream.argtypes = [_vp, _vp]
+        L.cornac_hip_mf_epoch_enqueue.argtypes = [_vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.cornac_hip_mf_sync.argtypes = [_vp, C.POINTER(C.c_double)]
         L.cornac_hip_mf_fit.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp,
                                         C.POINTER(C.c_int)]
         L.cornac_hip_mf_fit_sgd.argtypes = [C.c_int, _i64, _i64, _f32, C.c_int64, _f32, _f32, _f32, _f32, C.c_int64,
@@ -500,6 +506,7 @@ class MfTrainer:
         self.h = _vp()
         check(lib().cornac_hip_mf_create(C.byref(self.h), device, n_users, n_items, k, self.rid, self.cid, self.val,
                                          len(self.val)))
+        self.device, self._stream = int(device), None
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h and lib is not None:
@@ -525,6 +532,38 @@ class MfTrainer:
         check(lib().cornac_hip_mf_fit(self.h, max_iter, lr, reg, mu, int(use_bias), int(early_stop), mode,
                                       loss.ctypes.data, C.byref(n)))
         return loss[:n.value], n.value
+
+    # ---- multi-GPU driver surface (cornac_amd/dist.py ShardedMfTrainer) ----------------------------------------
+    def bind_items(self, d_V, d_Bi):
+        """train into caller-owned device buffers for the item side (the replicated [V | Bi] table)"""
+        check(lib().cornac_hip_mf_bind_items(self.h, d_V, d_Bi))
+
+    def set_stream(self, hip_stream):
+        check(lib().cornac_hip_mf_set_stream(self.h, hip_stream))
+        self._stream = hip_stream
+
+    def epoch_enqueue(self, part, n_parts, lr, reg, mu, use_bias=True):
+        """ratings [nnz*part/n_parts, nnz*(part+1)/n_parts) of the stored order, no host synchronisation"""
+        check(lib().cornac_hip_mf_epoch_enqueue(self.h, int(part), int(n_parts), lr, reg, mu, int(use_bias)))
+
+    def sync(self):
+        """wait for the enqueued slices; the sum of squared errors they saw"""
+        l = C.c_double()
+        check(lib().cornac_hip_mf_sync(self.h, C.byref(l)))
+        return l.value
+
+    # the replicated table's elementwise passes (ItemTableReplica), on the stream of set_stream
+    def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local):
+        check(lib().cornac_hip_table_delta(0, self.device, self._stream, d_flat, d_base, None, None, int(n_items), int(k),
+                                           d_bucket, d_local))
+
+    def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k):
+        check(lib().cornac_hip_table_delta(1, self.device, self._stream, d_flat, d_base, d_bucket, d_local, int(n_items),
+                                           int(k), None, None))
+
+    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local):
+        check(lib().cornac_hip_table_delta(2, self.device, self._stream, d_flat, d_base, d_bucket_prev, d_local_prev,
+                                           int(n_items), int(k), d_bucket, d_local))
 
     OPTIMIZERS = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3}
 

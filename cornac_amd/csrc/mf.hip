@@ -423,7 +423,7 @@ struct cornac_hip_mf {
     int device = 0;
     int64_t n_users = 0, n_items = 0, nnz = 0;
     int k = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr;   // stream == own_stream unless cornac_hip_mf_set_stream
     DevBuf<int64_t> rid, cid;
     DevBuf<float> val;
     DevBuf<float> U, V, Bu, Bi;
@@ -465,6 +465,7 @@ struct cornac_hip_mf {
     DevBuf<int64_t> opt_order;
     int64_t opt_step = 0;
     int opt_kind = -1;
+    bool enqueue_open = false;  // epoch_enqueue has accumulated into loss[0] since the last cornac_hip_mf_sync
 };
 
 #include "mf_blocks.inc"
@@ -1030,15 +1031,14 @@ static bool mf_epoch_blocks(cornac_hip_mf_t h, float lr, float reg, float mu, in
     return true;
 }
 
-static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
-    if (mf_uses_blocks(h) && mf_epoch_blocks(h, lr, reg, mu, use_bias, loss_slot)) {
-        h->hog_form_used = 2;
-        return;
-    }
-    h->hog_form_used = 1;
+// The fused atomic kernel over ratings [s0, s0 + n) of the stored order (the whole epoch: s0 = 0, n = nnz, where user-row
+// ownership applies too; a slice — the chunks of the multi-GPU driver — runs the all-atomic instantiation).
+static void mf_launch_fused(cornac_hip_mf_t h, int64_t s0, int64_t n, float lr, float reg, float mu, int use_bias,
+                            double *loss_slot) {
     const DeviceInfo &di = device_info(h->device);
     const int k = h->k;
-    const bool owned = k > 32 && k <= 256 && h->nnz >= (int64_t)di.cus * 8 * kWavesPerBlock * kWave;
+    const bool whole = s0 == 0 && n == h->nnz;
+    const bool owned = whole && k > 32 && k <= 256 && h->nnz >= (int64_t)di.cus * 8 * kWavesPerBlock * kWave;
     MfHogKernel kern = pick_mf_kernel(k, owned);
     if (h->hog_kernel != kern) {
         int per_cu = 0;
@@ -1047,14 +1047,14 @@ static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, i
         h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
     }
     MfHogArgs a;
-    a.rid = h->rid.p; a.cid = h->cid.p; a.val = h->val.p;
+    a.rid = h->rid.p + s0; a.cid = h->cid.p + s0; a.val = h->val.p + s0;
     a.own_u = nullptr; a.own_i = nullptr; a.own_r = nullptr; a.wave_ptr = nullptr;
     a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p;
     h->Bipad.ensure((size_t)h->n_items * kBiasStride);
     a.Bi = h->Bipad.p;
     a.bstride = kBiasStride;
     a.loss_acc = loss_slot;
-    a.n = h->nnz; a.k = k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    a.n = n; a.k = k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
     int grid;
     if (owned) {
         grid = di.cus * h->hog_blocks_per_cu;
@@ -1074,6 +1074,15 @@ static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, i
     HIP_CHECK(hipGetLastError());
 }
 
+static void mf_epoch_hogwild(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+    if (mf_uses_blocks(h) && mf_epoch_blocks(h, lr, reg, mu, use_bias, loss_slot)) {
+        h->hog_form_used = 2;
+        return;
+    }
+    h->hog_form_used = 1;
+    mf_launch_fused(h, 0, h->nnz, lr, reg, mu, use_bias, loss_slot);
+}
+
 extern "C" {
 
 int cornac_hip_mf_create(cornac_hip_mf_t *out, int device, int64_t n_users, int64_t n_items, int k,
@@ -1090,7 +1099,8 @@ int cornac_hip_mf_create(cornac_hip_mf_t *out, int device, int64_t n_users, int6
         use_device(device);
         std::unique_ptr<cornac_hip_mf> h(new cornac_hip_mf());
         h->device = device; h->n_users = n_users; h->n_items = n_items; h->k = k; h->nnz = nnz;
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->stream = h->own_stream;
         h->rid.alloc((size_t)nnz); h->cid.alloc((size_t)nnz); h->val.alloc((size_t)nnz);
         h->rid.upload(rid, (size_t)nnz, h->stream);
         h->cid.upload(cid, (size_t)nnz, h->stream);
@@ -1113,10 +1123,8 @@ int cornac_hip_mf_destroy(cornac_hip_mf_t h) {
     return guarded([&] {
         if (!h) return;
         (void)hipSetDevice(h->device);
-        if (h->stream) {
-            (void)hipStreamSynchronize(h->stream);
-            (void)hipStreamDestroy(h->stream);
-        }
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
         delete h;
     });
 }
@@ -1140,6 +1148,57 @@ int cornac_hip_mf_get_factors(cornac_hip_mf_t h, float *U, float *V, float *Bu, 
         if (Bu) h->Bu.download(Bu, (size_t)h->n_users, h->stream);
         if (Bi) h->Bi.download(Bi, (size_t)h->n_items, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+// ---- multi-GPU driver surface (cornac_amd/dist.py ShardedMfTrainer): item side in caller-owned device memory, a caller
+// stream, and epochs enqueued in slices without host synchronisation -----------------------------------------------------
+int cornac_hip_mf_bind_items(cornac_hip_mf_t h, float *dV, float *dBi) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(dV && dBi, "dV and dBi are required");
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->V.bind(dV, (size_t)h->n_items * h->k);
+        h->Bi.bind(dBi, (size_t)h->n_items);
+    });
+}
+
+int cornac_hip_mf_set_stream(cornac_hip_mf_t h, void *hip_stream) {
+    return guarded([&] {
+        mf_check(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    });
+}
+
+int cornac_hip_mf_epoch_enqueue(cornac_hip_mf_t h, int part, int n_parts, float lr, float reg, float mu, int use_bias) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "part %d of %d", part, n_parts);
+        h->loss.ensure(1);
+        if (!h->enqueue_open) {
+            HIP_CHECK(hipMemsetAsync(h->loss.p, 0, sizeof(double), h->stream));
+            h->enqueue_open = true;
+        }
+        if (n_parts == 1) {
+            mf_epoch_hogwild(h, lr, reg, mu, use_bias, h->loss.p);
+            return;
+        }
+        const int64_t s0 = (int64_t)(((unsigned __int128)h->nnz * (unsigned)part) / (unsigned)n_parts);
+        const int64_t s1 = (int64_t)(((unsigned __int128)h->nnz * (unsigned)(part + 1)) / (unsigned)n_parts);
+        h->hog_form_used = 1;
+        if (s1 > s0) mf_launch_fused(h, s0, s1 - s0, lr, reg, mu, use_bias, h->loss.p);
+    });
+}
+
+int cornac_hip_mf_sync(cornac_hip_mf_t h, double *sq_err_sum) {
+    return guarded([&] {
+        mf_check(h);
+        double l = 0.0;
+        if (h->enqueue_open) HIP_CHECK(hipMemcpyAsync(&l, h->loss.p, sizeof l, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->enqueue_open = false;
+        if (sq_err_sum) *sq_err_sum = l;
     });
 }
 

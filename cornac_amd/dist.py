@@ -1,4 +1,4 @@
-"""Multi-GPU BPR: one process per GPU, users partitioned across ranks.  Two regimes for the item table
+"""Multi-GPU BPR (and MF, `ShardedMfTrainer`): one process per GPU, users partitioned across ranks.  Two regimes for the item table
 (SURVEY.md §8e): (1) replicated and reconciled with RCCL all-reduce of its deltas — `ShardedBprTrainer`,
 described first; (2) sharded by row with all-to-all exchanges of the touched rows — `RowShardedBprTrainer`.
 
@@ -255,6 +255,66 @@ class ShardedBprTrainer:
         if self.stream is not None:
             self.stream.synchronize()
         return out
+
+
+class ShardedMfTrainer:
+    """Multi-GPU MF (fit_sgd, backend_cpu.pyx:35-97), regime 1: the ratings are partitioned BY USER, so every rank keeps
+    its users' rows of U and Bu to itself (no collective for them); the item side [V | Bi] is replicated and reconciled
+    like BPR's item table (ItemTableReplica: deltas summed over the ranks, divided by sqrt(touching ranks), sparse
+    records when few rows moved).  An epoch of a rank = its own ratings once, enqueued in `parts_per_epoch` slices of the
+    stored order; the exchange of slice p is in flight while slice p + 1 trains.  `mu` is the GLOBAL mean rating
+    (global_mean_across_ranks).  The slices run the fused atomic kernel (the block rotation needs whole epochs:
+    parts_per_epoch = 1 picks it where cornac_hip_mf_fit would)."""
+
+    def __init__(self, trainer, total_items, k, device, parts_per_epoch=16, group=None, sparse_threshold=None):
+        self.trainer = trainer
+        self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None,
+                                      sparse_threshold=sparse_threshold)
+        self.parts = max(1, int(parts_per_epoch))
+        self.device = device
+        self.stream = None
+        if device.type == "cuda":
+            self.stream = torch.cuda.Stream(device)
+            if trainer is not None:
+                torch.cuda.synchronize(device)
+                trainer.bind_items(self.table.V.data_ptr(), self.table.B.data_ptr())
+                trainer.set_stream(self.stream.cuda_stream)
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def load_items(self, V, Bi):
+        with self._on_stream():
+            self.table.load(V, Bi)
+        if self.stream is not None:
+            self.stream.synchronize()
+
+    def run_epoch(self, lr, reg, mu, use_bias=True):
+        with self._on_stream():
+            for part in range(self.parts):
+                self.trainer.epoch_enqueue(part, self.parts, lr, reg, mu, use_bias)
+                self.table.step_sync()
+
+    def finish(self):
+        """completes the pending exchange; returns the sum of squared errors of this rank's ratings since the last
+        finish() (0.5 x the all-reduced sum is the reference's epoch loss, backend_cpu.pyx:86-88)"""
+        with self._on_stream():
+            self.table.finish_sync()
+        out = self.trainer.sync()
+        if self.stream is not None:
+            self.stream.synchronize()
+        return out
+
+
+def global_mean_across_ranks(values, group=None):
+    """train_set.global_mean of the union of the ranks' ratings: one all-reduce of (sum, count) in float64"""
+    t = torch.tensor([float(np.sum(values, dtype=np.float64)), float(len(values))], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t = t.cpu()
+    return float(t[0] / max(float(t[1]), 1.0))
 
 
 class RowShardedItemTable:

@@ -236,6 +236,10 @@ int cornac_hip_bpr_table_delta_finish(cornac_hip_bpr_t h, float *d_flat, float *
 /* finish of the previous exchange followed by begin of the next one, in one pass (adjacent in the overlapped schedule) */
 int cornac_hip_bpr_table_delta_step(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket_prev,
                                     const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
+/* The same passes for a caller without a BPR handle (the MF driver): op 0 = begin, 1 = finish, 2 = step, on `hip_stream`
+ * of `device`; begin ignores the *_prev pointers, finish the next-exchange pointers. */
+int cornac_hip_table_delta(int op, int device, void *hip_stream, float *d_flat, float *d_base, const float *d_bucket_prev,
+                           const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
 
 /* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.
@@ -292,6 +296,16 @@ int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, co
                           float *V, float *Bu, float *Bi, int64_t n_users, int64_t n_items, int k, float lr, float reg,
                           float mu, int max_iter, int use_bias, int early_stop, int mode, float *loss_per_epoch,
                           int *epochs_run);
+/* Multi-GPU driver surface (no counterpart in the reference; cornac_amd/dist.py ShardedMfTrainer): every rank holds the
+ * ratings of its own users (U, Bu local), the item side [V | Bi] is replicated in caller-owned device memory and
+ * reconciled by the caller between slices.  bind_items: train into caller-owned V (n_items x k) and Bi (n_items);
+ * set_stream: run on a caller stream (NULL = the handle's own); epoch_enqueue: ratings [nnz*part/n_parts,
+ * nnz*(part+1)/n_parts) of the stored order, hogwild semantics, NO host synchronisation (n_parts = 1: the whole epoch in
+ * the form cornac_hip_mf_fit would pick); sync: wait, and return the sum of squared errors enqueued since the last sync. */
+int cornac_hip_mf_bind_items(cornac_hip_mf_t h, float *dV, float *dBi);
+int cornac_hip_mf_set_stream(cornac_hip_mf_t h, void *hip_stream);
+int cornac_hip_mf_epoch_enqueue(cornac_hip_mf_t h, int part, int n_parts, float lr, float reg, float mu, int use_bias);
+int cornac_hip_mf_sync(cornac_hip_mf_t h, double *sq_err_sum);
 int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms, int64_t *launches);
 int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 

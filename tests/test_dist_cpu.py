@@ -492,3 +492,114 @@ def test_user_block_sharded_ranking_gathers_the_topk_lists():
     want = np.argsort(-S, axis=1, kind="stable")[:, :5]
     assert np.array_equal(i0, want) and np.array_equal(i1, want) and np.allclose(s0, np.take_along_axis(S, want, 1))
     assert len(seen0) + len(seen1) == 37 and set(seen0.tolist()).isdisjoint(seen1.tolist())
+
+
+# ---- MF over the replicated item side (ShardedMfTrainer) ------------------------------------------------------------
+class _OracleMfTrainer:
+    """stands in for _lib.MfTrainer with real MF arithmetic: the oracle's sequential fit_sgd loop (backend_cpu.pyx:56-90)
+    runs the ratings of a slice IN PLACE on the replica's item side"""
+
+    def __init__(self, table, rid, cid, val, n_users, k, seed):
+        from oracle import oracle as orc
+
+        self.orc = orc
+        self.rid, self.cid = np.ascontiguousarray(rid, np.int64), np.ascontiguousarray(cid, np.int64)
+        self.val = np.ascontiguousarray(val, np.float32)
+        self.V, self.Bi = table.V.numpy(), table.B.numpy()
+        rs = np.random.RandomState(seed)
+        self.U = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+        self.Bu = np.zeros(n_users, np.float32)
+        self.k, self.sq = k, 0.0
+
+    def epoch_enqueue(self, part, n_parts, lr, reg, mu, use_bias=True):
+        nnz = len(self.val)
+        s0, s1 = nnz * part // n_parts, nnz * (part + 1) // n_parts
+        if s1 == s0:
+            return
+        loss = np.zeros(1, np.float32)
+        self.orc.lib().oracle_mf_fit(self.rid[s0:s1].copy(), self.cid[s0:s1].copy(), self.val[s0:s1].copy(), s1 - s0, self.U,
+                                     self.V, self.Bu, self.Bi, self.k, lr, reg, mu, 1, 1, int(use_bias), 0, loss.ctypes.data)
+        self.sq += 2.0 * float(loss[0])
+
+    def sync(self):
+        sq, self.sq = self.sq, 0.0
+        return sq
+
+
+def _mf_data(rank, n_users=200, n_items=70, per_user=20):
+    """every rank has its own users; ratings = a shared low-rank item structure + user taste + noise"""
+    rs_items = np.random.RandomState(5)
+    q = rs_items.normal(0, 1, (n_items, 3))
+    item_bias = rs_items.normal(0, 0.5, n_items)
+    rs = np.random.RandomState(200 + rank)
+    p = 1.0 / np.arange(1, n_items + 1) ** 0.9
+    rid, cid, val = [], [], []
+    for u in range(n_users):
+        items = np.sort(rs.choice(n_items, per_user, replace=False, p=p / p.sum()))
+        taste = rs.normal(0, 1, 3)
+        r = 3.0 + item_bias[items] + 0.6 * q[items] @ taste + rs.normal(0, 0.3, per_user)
+        rid += [u] * per_user
+        cid += list(items)
+        val += list(np.clip(r, 1, 5))
+    return np.array(rid, np.int64), np.array(cid, np.int64), np.array(val, np.float32), n_users, n_items
+
+
+def _mf_rmse(U, V, Bu, Bi, mu, rid, cid, val):
+    pred = mu + Bu[rid] + Bi[cid] + np.einsum("nk,nk->n", U[rid], V[cid])
+    return float(np.sqrt(np.mean((pred - val) ** 2)))
+
+
+def _mf_worker(rank, world, port, out, sparse_threshold=None):
+    from cornac_amd.dist import ShardedMfTrainer, global_mean_across_ranks
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rid, cid, val, n_users, n_items = _mf_data(rank)
+        k = 6
+        mu = global_mean_across_ranks(val)
+        sh = ShardedMfTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"), parts_per_epoch=8,
+                              sparse_threshold=sparse_threshold)
+        init = np.random.RandomState(7)
+        sh.load_items(init.normal(0, 0.01, (n_items, k)).astype(np.float32), np.zeros(n_items, np.float32))
+        sh.trainer = _OracleMfTrainer(sh.table, rid, cid, val, n_users, k, seed=31 + rank)
+        tr = sh.trainer
+        before = _mf_rmse(tr.U, tr.V, tr.Bu, tr.Bi, mu, rid, cid, val)
+        losses = []
+        for _ in range(25):
+            sh.run_epoch(lr=0.02, reg=0.02, mu=mu)
+            losses.append(sh.finish())
+        after = _mf_rmse(tr.U, tr.V, tr.Bu, tr.Bi, mu, rid, cid, val)
+        out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), sh.table.base.numpy().copy(), before, after, mu,
+                     losses, dict(sh.table.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sparse_threshold", [None, 1.0])
+def test_two_ranks_train_mf_over_one_replicated_item_side(sparse_threshold):
+    """ShardedMfTrainer on two gloo ranks with REAL MF arithmetic (the oracle's fit_sgd loop on every slice): users split
+    across the ranks, [V | Bi] reconciled 8 times per epoch (dense all-reduce, and the sparse record exchange).  Both
+    ranks end with the same item side, the global mean is the mean of the union, the per-epoch loss falls, and each
+    rank's own ratings are fitted about as well as by a single process training on that rank's data alone."""
+    out = mp.Manager().dict()
+    mp.spawn(_mf_worker, args=(2, _free_port(), out, sparse_threshold), nprocs=2, join=True)
+    (V0, B0, base0, before0, after0, mu0, loss0, ex0), (V1, B1, base1, before1, after1, mu1, loss1, _) = out[0], out[1]
+    assert np.array_equal(base0, base1)
+    assert np.allclose(V0, V1, rtol=0, atol=1e-6) and np.allclose(B0, B1, rtol=0, atol=1e-6)
+    all_val = np.concatenate([_mf_data(r)[2] for r in (0, 1)])
+    assert mu0 == mu1 and abs(mu0 - float(all_val.astype(np.float64).mean())) < 1e-9
+    assert (ex0["sparse"] > 0) == (sparse_threshold is not None) and ex0["dense"] + ex0["sparse"] >= 25 * 8
+    assert loss0[-1] < 0.5 * loss0[0] and loss1[-1] < 0.5 * loss1[0]
+    assert before0 > 0.8 and after0 < 0.6 * before0 and after1 < 0.6 * before1, (before0, after0, after1)
+    # single process on rank 0's data, same slices, no exchange
+    rid, cid, val, n_users, n_items = _mf_data(0)
+    table = ItemTableReplica(n_items, 6, torch.device("cpu"))
+    init = np.random.RandomState(7)
+    table.load(init.normal(0, 0.01, (n_items, 6)).astype(np.float32), np.zeros(n_items, np.float32))
+    solo = _OracleMfTrainer(table, rid, cid, val, n_users, 6, seed=31)
+    for _ in range(25):
+        for part in range(8):
+            solo.epoch_enqueue(part, 8, 0.02, 0.02, mu0)
+    alone = _mf_rmse(solo.U, solo.V, solo.Bu, solo.Bi, mu0, rid, cid, val)
+    assert after0 < alone + 0.05, (after0, alone)

@@ -366,3 +366,66 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     assert torch.equal(flat2, flat) and torch.equal(base2, base)
     assert torch.equal(b_fus, b_sep) and torch.equal(l_fus, l_sep)
     tr.close()
+
+
+def test_sharded_mf_trainer_single_rank_through_rccl():
+    """the multi-GPU MF driver (ShardedMfTrainer: item side [V | Bi] in a torch-owned replica, epochs enqueued in slices on
+    the driver's stream, the replica's delta passes through cornac_hip_table_delta, a real RCCL group of size 1) against
+    the plain cornac_hip_mf_fit on the same data: with one rank every exchange is a rebase, so both learn the same model
+    up to hogwild scheduling — same loss curve, same RMSE; parts_per_epoch = 1 takes the whole-epoch form."""
+    import torch
+    import torch.distributed as dist
+
+    from cornac_amd import synth
+    from cornac_amd.dist import ShardedMfTrainer, global_mean_across_ranks
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_users, n_items, k = 5000, 2000, 64
+    users, items = synth.zipf_interactions(n_users, n_items, 600_000, 0.6, 3)
+    rs = np.random.RandomState(0)
+    P, Q = rs.normal(0, 1, (n_users, 4)), rs.normal(0, 1, (n_items, 4))
+    val = np.clip(3.0 + 0.5 * np.einsum("nk,nk->n", P[users], Q[items]) + rs.normal(0, 0.3, len(users)), 1, 5).astype(np.float32)
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    epochs, lr, reg = 6, 0.01, 0.02
+
+    def rmse(U, V, Bu, Bi, mu):
+        pred = mu + Bu[users] + Bi[items] + np.einsum("nk,nk->n", U[users], V[items])
+        return float(np.sqrt(np.mean((pred - val) ** 2)))
+
+    mu_ref = float(val.astype(np.float64).mean())
+    ref = _lib.MfTrainer(users, items, val, n_users, n_items, k)
+    ref.set_factors(U0, V0, zu, zi)
+    ref.hogwild_form(1)
+    loss_ref, _ = ref.fit(epochs, lr, reg, mu_ref, True, False, _lib.MODE_HOGWILD)
+    rmse_ref = rmse(*ref.get_factors(), mu_ref)
+    ref.close()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        mu = global_mean_across_ranks(val)
+        assert abs(mu - mu_ref) < 1e-9
+        for parts in (8, 1):
+            tr = _lib.MfTrainer(users, items, val, n_users, n_items, k)
+            tr.set_factors(U0, None, zu, None)
+            sh = ShardedMfTrainer(tr, n_items, k, dev, parts_per_epoch=parts)
+            sh.load_items(V0, zi)
+            losses = []
+            for _ in range(epochs):
+                sh.run_epoch(lr, reg, mu)
+                losses.append(0.5 * sh.finish())
+            U, _, Bu, _ = tr.get_factors()
+            V, Bi = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
+            assert np.array_equal(sh.table.base.cpu().numpy(), sh.table.flat.cpu().numpy()), "finish() leaves a rebased table"
+            assert sh.table.exchanges["dense"] == epochs * parts
+            tr.close()
+            got = rmse(U, V, Bu, Bi, mu)
+            assert np.isfinite(U).all() and np.isfinite(V).all()
+            assert abs(got - rmse_ref) < 0.03 * rmse_ref, (parts, got, rmse_ref)
+            assert abs(losses[-1] - float(loss_ref[-1])) < 0.05 * float(loss_ref[-1]), (parts, losses, loss_ref)
+            assert losses[-1] < losses[0]
+    finally:
+        dist.destroy_process_group()
