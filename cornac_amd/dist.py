@@ -181,6 +181,7 @@ class ItemTableReplica:
         local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
         self.trainer.table_delta_step(self.flat.data_ptr(), self.base.data_ptr(), bucket_prev.data_ptr(),
                                       local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr())
+        self.exchanges["dense"] += 1
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, bucket, local)
 
