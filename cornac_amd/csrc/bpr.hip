@@ -1611,7 +1611,8 @@ static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
 #endif
     if (!(form == 0 || form == 3) || (flags & 0xffff) != 0) return false;
     (void)n_samples;  // any chunk of an epoch: a launch takes its share of every bin's draws
-    return neg_population == CORNAC_HIP_NEG_UNIFORM && ldsbin_plan_bins(h) > 0;
+    (void)neg_population;  // uniform (BPR) and popularity-weighted (WBPR) negatives both have a binned form
+    return ldsbin_plan_bins(h) > 0;
 }
 
 static void ldsbin_build(cornac_hip_bpr_t h) {
@@ -1679,7 +1680,9 @@ static uint32_t ldsbin_key(uint64_t seed, uint32_t epoch) {
     return w[0];
 }
 
-static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float reg, int use_bias, int flags) {
+static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float reg, int use_bias, int neg_population,
+                             int flags) {
+    a.neg_pop = neg_population == CORNAC_HIP_NEG_POPULARITY ? 1 : 0;
     a.cptr = h->lb_cptr.p; a.cusers = h->lb_cusers.p; a.rank_item = h->rank_item.p;
     a.hot_u = h->lb_hot_u.p; a.hot_i = h->lb_hot_i.p;
     a.indptr = h->indptr.p; a.indices = h->indices.p;
@@ -1694,7 +1697,8 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
 }
 
 // one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
-static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int flags) {
+static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int neg_population,
+                           int flags) {
     ldsbin_build(h);
     LdsBinKernel kern = pick_ldsbin_kernel(h->k);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
@@ -1702,7 +1706,7 @@ static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
     while (left > 0) {
         const int64_t n = std::min(left, h->nnz - h->hog_offset);
         LdsBinArgs a;
-        ldsbin_fill_args(h, a, lr, reg, use_bias, flags);
+        ldsbin_fill_args(h, a, lr, reg, use_bias, neg_population, flags);
         a.s_begin = (uint64_t)h->hog_offset;
         a.n = (uint64_t)n;
         a.nnz = (uint64_t)h->nnz;
@@ -1719,7 +1723,7 @@ static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, flo
                             int neg_population, int flags) {
     REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
     if (hogwild_uses_ldsbin(h, n_samples, neg_population, flags)) {
-        ldsbin_enqueue(h, n_samples, lr, reg, use_bias, flags);
+        ldsbin_enqueue(h, n_samples, lr, reg, use_bias, neg_population, flags);
         return;
     }
     if (hogwild_uses_strata(h, n_samples, neg_population, flags)) {

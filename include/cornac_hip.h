@@ -113,7 +113,7 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
 
 /* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
  * reference's per-epoch counters over the epochs run (either may be NULL).
- * hogwild_flags (0 = default).  Bits 16..19 select the form of a whole-epoch hogwild call with uniform negatives:
+ * hogwild_flags (0 = default).  Bits 16..19 select the form of a hogwild call:
  * 0 = automatic, 1 = the fused kernel (every item-row update a device-scope fp32 atomic; also bit7), 2 = XCD strata
  * (csrc/bpr_strata.inc: 8 launches per epoch, an item row is touched by one XCD per launch and updated by plain
  * read-modify-write like the reference's threads), 3 = LDS-resident item bins (csrc/bpr_ldsbin.inc: the item rows
@@ -121,7 +121,9 @@ int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
  * item table fits the LDS in at most max_rounds rounds with at least min_candidates items per bin, else XCD strata
  * for item tables of >= 2^20 rows, else the fused kernel.  A chunk of an epoch (hogwild_enqueue) runs in the same form:
  * an LDS-bin launch takes its share of every bin's draws, an XCD-strata chunk runs the partition phases that begin
- * inside it.  Popularity negatives and every experiment switch below run the fused kernel.
+ * inside it.  Popularity negatives (WBPR) have the LDS-bin form too — the negative is the item of a second interaction
+ * drawn from the bin's own draw space, hot items dealt to every bin — but not the XCD-strata one; every experiment
+ * switch below runs the fused kernel.
  * Experiment switches of the fused kernel: bit0 = plain (racy,
  * non-atomic, XCD-incoherent) row stores instead of fp32 atomics; bit1 = the
  * float4-per-lane row layout; bit2 = no user-row ownership (all rows atomic);

@@ -591,7 +591,8 @@ static int csr_has(const int32_t *indices, int32_t lo, int32_t hi, int32_t col) 
 int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
                                   uint32_t n_hot, const int32_t *rank_item, const int32_t *cptr, const int32_t *cusers,
                                   const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
-                                  const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count) {
+                                  const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count,
+                                  int neg_pop) {
     const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
     int32_t *item = (int32_t *)malloc(sizeof(int32_t) * n_groups);
     int32_t *cp = (int32_t *)malloc(sizeof(int32_t) * n_groups);
@@ -623,7 +624,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
             uint32_t w[4];
             oracle_philox4x32(local, b, epoch, 0x20u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
             const uint32_t r_pos = lemire_bounded2(w[0], w[1], n_draws);
-            uint32_t s_j;
+            uint32_t s_j, excl = 0, excl_lo = 0xffffffffu;
             int32_t u, i;
             if (r_pos < cold_mass) {
                 uint32_t lo = 0, hi = n_slots;
@@ -635,13 +636,32 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
                 u = cusers[cp[lo] + (int32_t)(r_pos - cum[lo])];
                 s_j = n_slots > 1 ? lemire_bounded2(w[2], w[3], n_slots - 1) : 0u;  /* the other slots of the bin */
                 if (n_slots > 1 && s_j >= lo) ++s_j;
+                excl_lo = cum[lo];
+                excl = cum[lo + 1] - excl_lo;
             } else {
                 const uint32_t h = b + n_bins * (r_pos - cold_mass);
                 u = hot_u[h];
                 i = hot_i[h];
                 s_j = lemire_bounded2(w[2], w[3], n_slots);
             }
-            const int32_t j = item[s_j];
+            int32_t j = item[s_j];
+            if (neg_pop) { /* WBPR: the item of a second interaction of the bin's draw space, the positive slot's left out */
+                const uint32_t m = n_draws - excl;
+                uint32_t r_neg = (uint32_t)(((uint64_t)w[2] * m) >> 32);
+                if (r_neg >= excl_lo) r_neg += excl;
+                if (m == 0) {
+                    j = i;
+                } else if (r_neg < cold_mass) {
+                    uint32_t lo = 0, hi = n_slots;
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (cum[mid] <= r_neg) lo = mid; else hi = mid;
+                    }
+                    j = item[lo];
+                } else {
+                    j = hot_i[b + n_bins * (r_neg - cold_mass)];
+                }
+            }
             if (csr_has(indices, indptr[u], indptr[u + 1], j)) { ++skipped; continue; }
             if (pos_count) ++pos_count[i];
             if (neg_count) ++neg_count[j];

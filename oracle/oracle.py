@@ -103,7 +103,7 @@ def _bind(L):
         L.oracle_ldsbin_key.restype = C.c_uint32
         L.oracle_ldsbin_epoch_skips.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i32p,
                                                 i32p, i32p, i32p, i32p, C.c_uint32, i32p, i32p, C.POINTER(C.c_int64),
-                                                C.c_void_p, C.c_void_p]
+                                                C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_ldsbin_epoch_skips.restype = C.c_int64
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
@@ -449,7 +449,7 @@ def strata_buckets(wave_ptr, own_u, own_i, deg, key, n_hot):
     return sptr, rec_u, rec_i, rank_item
 
 
-def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False):
+def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False, neg_pop=False):
     """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
     positive touches per item, negative touches per item])."""
     import scipy.sparse as sp
@@ -480,7 +480,8 @@ def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count
     s = lib().oracle_ldsbin_epoch_skips(int(seed), int(epoch), key, int(n_bins), int(n_items), int(n_hot), rank_item,
                                         cptr, cusers, np.ascontiguousarray(hot_u), np.ascontiguousarray(hot_i),
                                         int(n_hot_inter), indptr, indices, C.byref(draws),
-                                        pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None)
+                                        pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None,
+                                        int(bool(neg_pop)))
     return (int(s), int(draws.value), n_hot) + ((pos, neg) if count_touches else ())
 
 

@@ -406,6 +406,68 @@ def test_ldsbin_updates_are_exact_and_learn_like_the_fused_kernel(oracle):
         assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
 
 
+def test_ldsbin_popularity_negatives_wbpr(oracle):
+    """WBPR in the LDS-bin form (recom_wbpr.pyx:131-139: the negative is the item of a uniformly drawn interaction): the
+    negative of a draw is the item of a second interaction of the bin's draw space.  (1) lr = 0: the skip counter over two
+    epochs equals the CPU restatement exactly and nothing moves; (2) the restatement's accepted negatives per item and
+    its skip rate follow the reference's global sampler (a hot item is dealt to every bin, a cold one meets its bin);
+    (3) the same optimisation problem as the fused kernel with popularity negatives: 'correct' fraction and skip rate
+    agree, updates are lossless (reg = 0 column sums)."""
+    n_users, n_items, indptr, indices = _ldsbin_case(20000, 3003, 2_500_000, 0.8, 3)
+    nnz, k, seed = len(indices), 64, 0x5EED5
+    rs = np.random.RandomState(0)
+    U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
+    B = np.zeros(n_items, np.float32)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    tr.ldsbin_config(min_candidates=8)
+    st = tr.ldsbin_stats()
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(seed)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD, flags=_lib.FORM_LDSBIN)
+    U2, V2, B2 = tr.get_factors()
+    tr.close()
+    want, neg_tot = 0, np.zeros(n_items, np.int64)
+    for epoch in range(2):
+        sk, draws, n_hot, pos, neg = oracle.ldsbin_epoch(seed, epoch, st["bins"], 100, indptr, indices, n_items,
+                                                         count_touches=True, neg_pop=True)
+        assert draws == nnz and n_hot == st["n_hot"]
+        want += sk
+        neg_tot += neg
+    assert s == want and np.array_equal(V2, V) and np.array_equal(U2, U)
+    # the reference's global sampler (recom_wbpr.pyx:131-139), simulated: accepted negatives per item and the skip rate
+    import scipy.sparse as sp
+
+    g = np.random.RandomState(1)
+    X = sp.csr_matrix((np.ones(nnz, np.int8), indices, indptr), shape=(n_users, n_items))
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr))
+    gu, gj = user_ids[g.randint(nnz, size=2 * nnz)], indices[g.randint(nnz, size=2 * nnz)]
+    has = np.asarray(X[gu, gj]).ravel() != 0
+    ref = np.bincount(gj[~has], minlength=n_items)
+    assert abs(want / (2 * nnz) - has.mean()) < 0.01, (want / (2 * nnz), has.mean())
+    top = np.argsort(-np.bincount(indices, minlength=n_items))[:300]
+    ratio = (neg_tot[top] / neg_tot.sum()) / (ref[top] / ref.sum())
+    assert np.abs(ratio - 1).mean() < 0.06 and np.abs(ratio - 1).max() < 0.25, (np.abs(ratio - 1).mean(), np.abs(ratio - 1).max())
+    out = {}
+    for flags in (_lib.FORM_LDSBIN, _lib.FORM_FUSED):
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.ldsbin_config(min_candidates=8)
+        tr.set_factors(U, V, B)
+        tr.seed_hogwild(9)
+        tr.fit_epochs(6, 0.05, 0.0, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD, flags=flags)
+        c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD, flags=flags)
+        out[flags] = (c / (nnz - s), s / nnz, tr.get_factors())
+        tr.close()
+    a, f = out[_lib.FORM_LDSBIN], out[_lib.FORM_FUSED]
+    assert abs(a[0] - f[0]) < 0.02 and abs(a[1] - f[1]) < 0.02, (a[:2], f[:2])
+    for res in (a, f):
+        V3, B3 = res[2][1], res[2][2]
+        assert np.isfinite(V3).all() and np.abs(V3 - V).max() > 1e-3
+        moved = np.abs(V3.astype(np.float64) - V).sum(0)
+        assert np.abs(V3.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+        assert abs(float(B3.astype(np.float64).sum())) <= 1e-4 * np.abs(B3).sum() + 1e-3
+
+
 @pytest.mark.parametrize("k,use_bias,form", [(40, True, "ldsbin"), (100, True, "ldsbin"), (128, False, "ldsbin"), (200, True, "ldsbin"),
                                              (128, True, "strata"), (200, False, "strata")])
 def test_ldsbin_and_strata_forms_at_other_k(k, use_bias, form):

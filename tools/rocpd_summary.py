@@ -34,5 +34,16 @@ def dispatches(path, pattern="%"):
         print('"%s",%d,%d,%d,%d,%.1f' % (name[:90], gx, wx, lds + slds, vg, dur / 1e3))
 
 
+def timeline(path, last="120"):
+    """the last N dispatches in start order: offset from the first of them, duration, gap since the previous kernel's end"""
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, start, duration from kernels order by start"))[-int(last):]
+    print("kernel,start_us,duration_us,gap_before_us")
+    t0, prev_end = rows[0][1], rows[0][1]
+    for name, start, dur in rows:
+        print('"%s",%.1f,%.1f,%.1f' % (name[:60], (start - t0) / 1e3, dur / 1e3, (start - prev_end) / 1e3))
+        prev_end = max(prev_end, start + dur)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "dispatches": dispatches}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "dispatches": dispatches, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])
