@@ -1569,7 +1569,13 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
 
 // ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
 typedef void (*LdsBinKernel)(const LdsBinArgs);
-static LdsBinKernel pick_ldsbin_kernel(int k) {
+static LdsBinKernel pick_ldsbin_kernel(int k, bool pop) {
+    if (pop) {
+        if (k <= 64) return bpr_ldsbin_kernel<1, 4, true>;
+        if (k <= 128) return bpr_ldsbin_kernel<2, 2, true>;
+        if (k <= 192) return bpr_ldsbin_kernel<3, 2, true>;
+        return bpr_ldsbin_kernel<4, 1, true>;
+    }
 #ifdef CORNAC_PROFILE
     if (k <= 64) switch (prof_env_int("CORNAC_HIP_LDSBIN_UNR", 0)) {
         case 1: return bpr_ldsbin_kernel<1, 1>;
@@ -1700,7 +1706,7 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
 static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int neg_population,
                            int flags) {
     ldsbin_build(h);
-    LdsBinKernel kern = pick_ldsbin_kernel(h->k);
+    LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
     int64_t left = n_samples;
     while (left > 0) {
