@@ -1,9 +1,13 @@
 """CPU restatement of the reference's WMF training step — TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference computes this path inside TensorFlow (`tensorflow==2.12.0`,
-cornac/models/wmf/requirements.txt), TensorFlow is absent from this image and no reference test
-touches WMF, so this file restates the published arithmetic of the reference's graph and of TF1's
-`tf.train.AdamOptimizer`; it could not be checked against the reference itself.
+PARITY: pinned against the reference's OWN WMF code, not against TensorFlow.  The reference computes this path inside
+TensorFlow (`tensorflow==2.12.0`, cornac/models/wmf/requirements.txt), which is absent from this image, and no
+reference test touches WMF.  What IS checked (tests/test_oracle_vs_reference.py::test_wmf_oracle_and_host_class_match_the_reference_wmf_code,
+tests/golden/wmf_ref.npz): cornac/models/wmf/recom_wmf.py + wmf.py run unmodified over oracle/tf1_shim — torch forward
+and autograd of the loss THEIR code builds, their xavier initialisation, their item_iter shuffling and batch_C — and
+this restatement (hand-derived gradients, loop, Adam) reproduces the result to 5e-6.  What stays restated on both
+sides, from TensorFlow's published source rather than by running it: the IndexedSlices gradient of tf.gather,
+clip_by_value on it, and tf.train.AdamOptimizer's dense / sparse update rules (listed in the shim's header).
 
 Follows:
   * cornac/models/wmf/wmf.py:34-55        graph: P = U V_b^T, loss = sum(C (R - P)^2) + lambda_u l2(U) + lambda_v l2(V_b)

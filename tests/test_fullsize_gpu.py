@@ -322,7 +322,7 @@ def test_wmf_netflix_user_count_matches_the_oracle():
     """configs[2]'s user count (480 189 users, k = 128, 128-item batches): every workgroup of the fused user-step kernel
     walks 7-8 consecutive user tiles (column cursors carried from tile to tile, the LDS-resident G tile and the dV
     accumulators re-used across them, a ragged last tile) — none of which the small parity cases reach — against the
-    numpy restatement of the reference's graph (oracle/wmf_oracle.py; parity unpinned: no TensorFlow here)."""
+    numpy restatement of the reference's graph (oracle/wmf_oracle.py; pinned to the reference's own WMF code over oracle/tf1_shim, TensorFlow itself absent)."""
     import scipy.sparse as sp
 
     from oracle.wmf_oracle import WmfOracle

@@ -248,3 +248,39 @@ def test_float64_models_match_live_reference(oracle, k, seed):
         ns.BPR(init_params=dict(ip), **kw).fit(ds)
     with pytest.raises(ValueError):
         oracle.BPROracle(init_params=dict(ip), **kw).fit(ds)
+
+
+@pytest.mark.parametrize("given_init", [False, True])
+def test_wmf_oracle_and_host_class_match_the_reference_wmf_code(monkeypatch, given_init):
+    """The reference's OWN WMF (cornac/models/wmf/recom_wmf.py + wmf.py, unmodified: xavier init from the seed, item_iter
+    shuffling, batch_C construction, the TF1 graph, sess.run per batch) executed over oracle/tf1_shim — torch forward and
+    autograd of the loss the reference's code builds; only the gather gradient / clip / TF1 Adam rules are restated
+    there — against cornac_amd.WMF whose device layer is the WMF oracle (tests/fake_device.py).  Same U, V to float32
+    rounding over 3 epochs of 4 batches, same scores; so the oracle's hand-derived gradients, its Adam and the host class's
+    loop are the reference's.  (With a real TensorFlow importable the same test runs against it.)"""
+    import fake_device
+    from oracle import ref_wmf
+
+    import cornac_amd as ca
+
+    RefWMF = ref_wmf.load_wmf()
+    ns = ref_loader.load()
+    fake_device.install(monkeypatch)
+    rs = np.random.RandomState(4)
+    keys = rs.permutation(70 * 50)[:900]
+    data = [("u%d" % (k // 50), "i%d" % (k % 50), float(rs.randint(1, 6))) for k in keys]
+    build = lambda: ns.Dataset.from_uir(data, seed=11)   # noqa: E731 — item_iter shuffles with the data set's own generator
+    ds = build()
+    kw = dict(k=6, max_iter=3, batch_size=16, learning_rate=0.01, lambda_u=0.02, lambda_v=0.03, a=1.0, b=0.05, seed=7,
+              verbose=False)
+    init = None
+    if given_init:
+        init = {"U": rs.normal(0, 0.1, (ds.num_users, 6)).astype(np.float32),
+                "V": rs.normal(0, 0.1, (ds.num_items, 6)).astype(np.float32)}
+    theirs = RefWMF(init_params=None if init is None else {n: a.copy() for n, a in init.items()}, **kw).fit(build())
+    ours = ca.WMF(init_params=None if init is None else {n: a.copy() for n, a in init.items()}, **kw).fit(build())
+    assert np.abs(theirs.U).max() > 0.05 and (init is None or np.abs(theirs.U - init["U"]).max() > 0.01)
+    assert np.abs(ours.U - theirs.U).max() < 5e-6, np.abs(ours.U - theirs.U).max()
+    assert np.abs(ours.V - theirs.V).max() < 5e-6, np.abs(ours.V - theirs.V).max()
+    assert np.abs(ours.score(3) - theirs.score(3)).max() < 1e-5
+    assert abs(ours.score(3, 5) - theirs.score(3, 5)) < 1e-5

@@ -1,7 +1,7 @@
-"""CPU checks of the WMF oracle (oracle/wmf_oracle.py).  Parity is UNPINNED against the reference
-(TensorFlow is absent): what can be checked here is that the restated gradients are the gradients of
-the reference's loss expression (torch autograd of cornac/models/wmf/wmf.py:44-48) and that the
-optimiser follows TF1 Adam's published update, plus the committed fixture for regression."""
+"""CPU checks of the WMF oracle (oracle/wmf_oracle.py).  TensorFlow is absent, so the pin is the reference's own WMF
+code run over oracle/tf1_shim (tests/golden/wmf_ref.npz here, the live run in tests/test_oracle_vs_reference.py); besides
+that: the restated gradients are the gradients of the reference's loss expression (torch autograd of
+cornac/models/wmf/wmf.py:44-48), the optimiser follows TF1 Adam's published update, and a regression fixture."""
 import numpy as np
 import scipy.sparse as sp
 
@@ -66,3 +66,29 @@ def test_fixture_regression():
     losses = o.fit_batches([fx["batch_ids"][ptr[t]:ptr[t + 1]] for t in range(len(ptr) - 1)])
     assert np.abs(o.U - fx["U"]).max() <= 2e-6 and np.abs(o.V - fx["V"]).max() <= 2e-6
     assert np.allclose(losses, fx["losses"], rtol=1e-6)
+
+
+def _wmf_ref_case():
+    from cornac_amd import Dataset
+
+    fx = load_golden("wmf_ref")
+    ds = Dataset.from_uir([(int(u), int(i), float(r)) for u, i, r in zip(fx["users"], fx["items"], fx["ratings"])], seed=123)
+    kw = {n: (int(fx[n]) if n in ("k", "max_iter", "batch_size", "seed") else float(fx[n]))
+          for n in ("k", "max_iter", "batch_size", "learning_rate", "lambda_u", "lambda_v", "a", "b", "seed")}
+    return fx, ds, kw
+
+
+def test_host_class_and_oracle_reproduce_the_reference_codes_fixture(monkeypatch):
+    """tests/golden/wmf_ref.npz: what the reference's OWN WMF code learned (run over oracle/tf1_shim, see
+    make_wmf_ref_golden.py) from its own xavier initialisation and item_iter shuffling.  cornac_amd.WMF with the oracle
+    as device layer reproduces it to float32 rounding: initialisation, batch order, gradients, Adam, score()."""
+    import fake_device
+
+    from cornac_amd import WMF
+
+    fake_device.install(monkeypatch)
+    fx, ds, kw = _wmf_ref_case()
+    m = WMF(verbose=False, **kw).fit(ds)
+    assert np.abs(m.U - fx["U"]).max() < 5e-6 and np.abs(m.V - fx["V"]).max() < 5e-6
+    for t, u in enumerate(fx["score_users"]):
+        assert np.abs(m.score(int(u)) - fx["scores"][t]).max() < 1e-5

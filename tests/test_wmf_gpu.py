@@ -71,3 +71,19 @@ def test_training_learns_and_errors():
     with pytest.raises(_lib.HipError):
         tr.fit_batches([np.array([10 ** 6])], 0.1, 0.1, 1, 0.01, 0.01)
     tr.close()
+
+
+def test_hip_wmf_matches_the_reference_codes_fixture():
+    """cornac_amd.WMF on the device against tests/golden/wmf_ref.npz — U, V and score() as learned by the reference's own
+    WMF code (cornac/models/wmf/recom_wmf.py + wmf.py over oracle/tf1_shim; tests/golden/make_wmf_ref_golden.py) from its
+    own initialisation and batch order: north_star's 1e-4"""
+    from cornac_amd import Dataset
+
+    fx = load_golden("wmf_ref")
+    ds = Dataset.from_uir([(int(u), int(i), float(r)) for u, i, r in zip(fx["users"], fx["items"], fx["ratings"])], seed=123)
+    kw = {n: (int(fx[n]) if n in ("k", "max_iter", "batch_size", "seed") else float(fx[n]))
+          for n in ("k", "max_iter", "batch_size", "learning_rate", "lambda_u", "lambda_v", "a", "b", "seed")}
+    m = WMF(verbose=False, **kw).fit(ds)
+    assert np.abs(m.U - fx["U"]).max() <= 1e-4 and np.abs(m.V - fx["V"]).max() <= 1e-4
+    for t, u in enumerate(fx["score_users"]):
+        assert np.abs(m.score(int(u)) - fx["scores"][t]).max() <= 1e-4
