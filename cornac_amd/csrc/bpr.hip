@@ -177,6 +177,7 @@ struct HogArgs {
     const int32_t *rec_u, *rec_i, *rank_item;
     const int64_t *sptr;
     uint32_t strata_key, n_hot;
+    uint32_t xcd_map;  // physical XCD of the workgroups with blockIdx % 8 == c, 4 bits per c (strata_probe_placement)
     int phase;
 };
 constexpr int32_t kTripShared = 0x40000000;  // bit 30 of an emitted user id: a shared (heavy) user, atomics on its row
@@ -713,6 +714,8 @@ struct cornac_hip_bpr {
     bool strata_built = false;
     int strata_hot_permille = 120, strata_hot_min_mult_x100 = 200, strata_rehash_period = 1;
     int64_t strata_misplaced = 0, strata_builds = 0;
+    uint32_t strata_xcd_map = 0x76543210u;  // residue -> physical XCD, probed for strata_probe_grid workgroups
+    int strata_probe_grid = 0;
     void (*strata_kernel)(const chip::HogArgs) = nullptr;
     int strata_blocks_per_cu = 0;
     // LDS-resident item bins (bpr_ldsbin.inc): CSC, hot interaction list, membership bitmap
@@ -1360,6 +1363,7 @@ static void fill_hog_args(cornac_hip_bpr_t h, HogArgs &a, int64_t n, float lr, f
     a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
     a.lr = lr; a.reg = reg;
     a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr; a.own_tmax = 0;
+    a.xcd_map = 0x76543210u;
     a.nnz = h->nnz;
     a.ablate = (flags >> 8) & 0xff;
 }
@@ -1498,6 +1502,34 @@ static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
 }
 
 // grid / ownership / rank tables of the strata kernel; returns the grid width
+// Where does the dispatcher put workgroup b of a `grid`-wide launch?  One tiny launch of the same shape records every
+// workgroup's HW_REG_XCC_ID; if all workgroups of a residue class b % 8 share one XCD and the 8 classes sit on 8
+// different XCDs, that permutation is what the strata kernel verifies against (the identity on most boxes, a rotation on
+// some); anything else keeps the identity, i.e. the kernel falls back to atomics wherever it is not met.
+static void strata_probe_placement(cornac_hip_bpr_t h, int grid) {
+    if (h->strata_probe_grid == grid) return;
+    h->strata_probe_grid = grid;
+    h->strata_xcd_map = 0x76543210u;
+    DevBuf<uint32_t> d;
+    d.ensure((size_t)grid);
+    hipLaunchKernelGGL(strata_xcd_probe_kernel, dim3(grid), dim3(kBlock), 0, h->stream, d.p);
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> x((size_t)grid);
+    d.download(x.data(), (size_t)grid, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (grid < 8) return;
+    uint32_t map = 0, seen = 0;
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t phys = x[(size_t)c] & 7u;
+        for (int b = c; b < grid; b += 8)
+            if ((x[(size_t)b] & 7u) != phys) return;   // a residue class spread over XCDs: no usable map
+        if (seen & (1u << phys)) return;               // two classes on one XCD
+        seen |= 1u << phys;
+        map |= phys << (4 * c);
+    }
+    h->strata_xcd_map = map;
+}
+
 static int strata_prepare(cornac_hip_bpr_t h) {
     const DeviceInfo &di = device_info(h->device);
     StrataKernel kern = pick_strata_kernel(h->k);
@@ -1515,6 +1547,7 @@ static int strata_prepare(cornac_hip_bpr_t h) {
     h->rec_u.ensure((size_t)h->nnz);
     h->rec_i.ensure((size_t)h->nnz);
     h->sptr.ensure((size_t)W * 8 + 1);
+    strata_probe_placement(h, grid);
     return grid;
 }
 
@@ -1551,7 +1584,7 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
             a.B = h->Bpad.p;
             a.bstride = kBiasStride;
             a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
-            a.strata_key = key; a.n_hot = h->strata_n_hot;
+            a.strata_key = key; a.n_hot = h->strata_n_hot; a.xcd_map = h->strata_xcd_map;
             hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
             for (int ph = p_lo; ph < p_hi; ++ph) {
                 a.phase = ph;
