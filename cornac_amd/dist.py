@@ -265,10 +265,19 @@ class ShardedMfTrainer:
     records when few rows moved).  An epoch of a rank = its own ratings once, enqueued in `parts_per_epoch` slices of the
     stored order; the exchange of slice p is in flight while slice p + 1 trains.  `mu` is the GLOBAL mean rating
     (global_mean_across_ranks).  The slices run the fused atomic kernel (the block rotation needs whole epochs:
-    parts_per_epoch = 1 picks it where cornac_hip_mf_fit would)."""
+    parts_per_epoch = 1 picks it where cornac_hip_mf_fit would — for a single rank only: see the note on the default
+    below).  parts_per_epoch = None: 4 exchanges per rank and epoch, at least 16."""
 
-    def __init__(self, trainer, total_items, k, device, parts_per_epoch=16, group=None, sparse_threshold=None):
+    def __init__(self, trainer, total_items, k, device, parts_per_epoch=None, group=None, sparse_threshold=None):
         self.trainer = trainer
+        if parts_per_epoch is None:
+            # MF's squared-error steps are not bounded like BPR's sigmoid: R stale copies of an item's update, summed and
+            # divided by sqrt(R), overshoot unless the exchanges are frequent.  Emulation of this algebra with the oracle's
+            # fit_sgd loop (tools/emulate_ranks_mf.py, profiles/r03_emulate_ranks_mf.log): at R = 8, <= 8 exchanges per
+            # epoch diverge, 16 is marginal, 32 reaches the held-out RMSE of ONE process training on all ratings
+            # (0.443 vs 0.428; 64: 0.436), at two rating densities.  Hence 4 R, at least 16.
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+            parts_per_epoch = max(16, 4 * world)
         self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None,
                                       sparse_threshold=sparse_threshold)
         self.parts = max(1, int(parts_per_epoch))
