@@ -117,3 +117,42 @@ def test_split_protocols_on_random_data():
             assert np.array_equal(em.CrossValidation(uir, n_folds=folds, seed=seed)._partition,
                                   CrossValidation(uir, n_folds=folds, seed=seed)._partition)
     assert compared >= 30
+
+
+def test_init_params_dtypes_and_shapes_through_the_host_classes(monkeypatch):
+    """init_params fuzz for BPR / WBPR: float32 or float64 tables (the reference's fused-type `_fit_sgd`), any subset of
+    {U, V, Bi} given, use_bias on or off, a dtype mix now and then — same learned tables (dtype included), or the same
+    exception type on both sides"""
+    from cornac_amd import BPR, WBPR, Dataset
+
+    fake_device.install(monkeypatch)
+    ns = ref_loader.load()
+    outcomes = {"f32": 0, "f64": 0, "error": 0}
+    for seed in range(48):
+        rs = np.random.RandomState(1000 + seed)
+        nu, ni, k = rs.randint(8, 30), rs.randint(6, 25), int(rs.randint(1, 7))
+        keys = rs.permutation(nu * ni)[: rs.randint(ni, nu * ni // 2 + ni)]
+        data = [("u%d" % (q // ni), "i%d" % (q % ni), float(rs.randint(1, 6))) for q in keys]
+        rd, md = ns.Dataset.from_uir(data, seed=1), Dataset.from_uir(data, seed=1)
+        dt = [np.float32, np.float64][seed % 2]
+        tables = {"U": ((rs.rand(rd.num_users, k) - 0.5) / k).astype(dt), "V": ((rs.rand(rd.num_items, k) - 0.5) / k).astype(dt),
+                  "Bi": (0.01 * rs.randn(rd.num_items)).astype(dt)}
+        given = [n for n in ("U", "V", "Bi") if rs.rand() < 0.8]
+        if seed % 7 == 3 and "V" in given:
+            tables["V"] = tables["V"].astype(np.float64 if dt == np.float32 else np.float32)   # a mix
+        kw = dict(k=k, max_iter=3, seed=seed, learning_rate=0.05, use_bias=bool(seed % 5))
+        for R, M in ((ns.BPR, BPR), (ns.WBPR, WBPR)):
+            r = _outcome(lambda: R(init_params={n: tables[n].copy() for n in given}, **kw).fit(rd))
+            m = _outcome(lambda: M(init_params={n: tables[n].copy() for n in given}, **kw).fit(md))
+            if isinstance(r, str) or isinstance(m, str):
+                assert r == m, (seed, R.__name__, given, r, m)
+                outcomes["error"] += 1
+                continue
+            for name in ("u_factors", "i_factors", "i_biases"):
+                a, b = getattr(r, name), getattr(m, name)
+                assert a.dtype == b.dtype, (seed, R.__name__, name, a.dtype, b.dtype)
+                assert np.abs(a - b).max() < (1e-12 if a.dtype == np.float64 else 1e-5), (seed, R.__name__, name)
+            outcomes["f64" if r.u_factors.dtype == np.float64 else "f32"] += 1
+            s_r, s_m = r.score(0), m.score(0)
+            assert np.abs(s_r - s_m).max() < (1e-12 if s_r.dtype == np.float64 and s_m.dtype == np.float64 else 1e-5)
+    assert min(outcomes.values()) > 0, outcomes
