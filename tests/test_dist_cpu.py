@@ -603,3 +603,39 @@ def test_two_ranks_train_mf_over_one_replicated_item_side(sparse_threshold):
             solo.epoch_enqueue(part, 8, 0.02, 0.02, mu0)
     alone = _mf_rmse(solo.U, solo.V, solo.Bu, solo.Bi, mu0, rid, cid, val)
     assert after0 < alone + 0.05, (after0, alone)
+
+
+def _mf_uneven_worker(rank, world, port, out):
+    from cornac_amd.dist import ShardedMfTrainer, global_mean_across_ranks
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 1 holds a tenth of rank 0's users, and with the default slicing (4 per rank, at least 16) most of its
+        # slices are a handful of ratings — some exchanges touch few rows (sparse records), some many (dense bucket)
+        rid, cid, val, n_users, n_items = _mf_data(rank, n_users=200 if rank == 0 else 20)
+        mu = global_mean_across_ranks(val)
+        sh = ShardedMfTrainer(None, total_items=n_items, k=5, device=torch.device("cpu"), sparse_threshold=0.5)
+        assert sh.parts == 16
+        init = np.random.RandomState(7)
+        sh.load_items(init.normal(0, 0.01, (n_items, 5)).astype(np.float32), np.zeros(n_items, np.float32))
+        sh.trainer = _OracleMfTrainer(sh.table, rid, cid, val, n_users, 5, seed=31 + rank)
+        for _ in range(6):
+            sh.run_epoch(lr=0.02, reg=0.02, mu=mu)
+            sh.finish()
+        tr = sh.trainer
+        out[rank] = (sh.table.base.numpy().copy(), _mf_rmse(tr.U, tr.V, tr.Bu, tr.Bi, mu, rid, cid, val), dict(sh.table.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mf_ranks_of_very_different_sizes_exchange_in_lockstep():
+    """the number of exchanges per epoch is a property of the driver (parts_per_epoch), not of a rank's data: a rank with a
+    tenth of the ratings runs the same 16 collectives per epoch (no deadlock, no mismatch), the dense / sparse decision is
+    taken collectively, and both ranks end on one item side"""
+    out = mp.Manager().dict()
+    mp.spawn(_mf_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (base0, rmse0, ex0), (base1, rmse1, ex1) = out[0], out[1]
+    assert np.array_equal(base0, base1) and np.isfinite(base0).all()
+    assert ex0["dense"] == ex1["dense"] and ex0["sparse"] == ex1["sparse"] and ex0["dense"] + ex0["sparse"] >= 6 * 16
+    assert rmse0 < 1.0 and rmse1 < 1.2
