@@ -249,6 +249,18 @@ class ShardedBprTrainer:
                 self.table.step_sync()   # finish chunk c-1's exchange (its all-reduce overlapped this launch), begin c's
                 left -= n
 
+    def run_epoch_in_parts(self, nnz, parts, lr, reg, use_bias=True, neg_population=0, flags=0):
+        """one epoch of `nnz` samples as EXACTLY `parts` chunks (sizes differ by at most one) — the form for ranks whose
+        sample counts differ: every rank issues the same number of exchanges whatever its nnz (run() derives the chunk
+        count from the sample count)"""
+        nnz, parts = int(nnz), int(parts)
+        with self._on_stream():
+            for c in range(parts):
+                n = nnz * (c + 1) // parts - nnz * c // parts
+                if n:
+                    self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
+                self.table.step_sync()
+
     def finish(self):
         with self._on_stream():
             self.table.finish_sync()
@@ -721,6 +733,172 @@ class RowShardedBprTrainer:
         if self.stream is not None:
             self.stream.synchronize()
         return out
+
+
+# ---- model-level entry points: model.fit(train_set) over all ranks of a process group ----------------------------------
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _comm_device(device, group):
+    return device if (device is not None and device.type == "cuda") else torch.device("cpu")
+
+
+def _broadcast_from_rank0(arrays, device, group):
+    """in place: every rank's arrays become rank 0's (identical initial tables whatever the ranks' generators did)"""
+    if _world(group)[0] == 1:
+        return
+    for a in arrays:
+        t = torch.as_tensor(np.ascontiguousarray(a)).to(_comm_device(device, group))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        a[...] = t.cpu().numpy()
+
+
+def _gather_user_rows(local, bounds, device, group):
+    """rows [bounds[r], bounds[r+1]) live on rank r: every rank receives the full array (one padded all_gather)"""
+    world, _ = _world(group)
+    local = np.ascontiguousarray(local)
+    if world == 1:
+        return local
+    width = local.shape[1:] if local.ndim > 1 else ()
+    cap = int(np.max(np.diff(bounds)))
+    pad = torch.zeros((cap,) + tuple(width), dtype=torch.as_tensor(local).dtype, device=_comm_device(device, group))
+    pad[: len(local)] = torch.as_tensor(local)
+    out = torch.empty((world * cap,) + tuple(width), dtype=pad.dtype, device=pad.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.cpu().numpy().reshape((world, cap) + tuple(width))
+    return np.concatenate([out[r, : int(bounds[r + 1] - bounds[r])] for r in range(world)])
+
+
+def _sum_over_ranks(values, device, group):
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=_comm_device(device, group))
+    if _world(group)[0] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(x) for x in t.cpu()]
+
+
+def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=16, sparse_threshold=None,
+                    trainer_factory=None):
+    """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
+    calls it with a model built from the same arguments and the SAME train_set; the users are cut into contiguous ranges
+    of equal interaction counts, rank r trains its range in hogwild mode against its replica of the item table
+    (ShardedBprTrainer), and on return every rank's model holds the complete u_factors / i_factors / i_biases.
+    The reference has no counterpart (single process); seeded SEQUENTIAL semantics do not shard, so the model must be in
+    hogwild mode (`mode="hogwild"`, or no seed) — a seed then fixes the initial tables and the sample streams.
+    trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo)."""
+    from . import _lib
+    from .recommender import Recommender
+
+    if model.effective_mode != "hogwild":
+        raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
+    world, rank = _world(group)
+    device = device if device is not None else torch.device("cpu")
+    Recommender.fit(model, train_set)
+    model._init()
+    if model.trains_float64:
+        raise ValueError("float64 tables train on the sequential engine only")
+    _broadcast_from_rank0([model.u_factors, model.i_factors, model.i_biases], device, group)
+    X = train_set.matrix
+    if not X.has_sorted_indices:
+        X.sort_indices()
+    bounds = partition_users_by_nnz(X.indptr, world)
+    counts = [int(X.indptr[bounds[r + 1]] - X.indptr[bounds[r]]) for r in range(world)]
+    if min(counts) == 0:
+        raise ValueError("a rank would receive no interactions (%r): use fewer ranks" % (counts,))
+    u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
+    indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
+    n_local, nnz = u1 - u0, counts[rank]
+    parts = max(1, min(int(sync_per_epoch), min(counts)))
+    if trainer_factory is None:
+        trainer = _lib.BprTrainer(indptr, indices, n_local, train_set.num_items, n_local, model.total_items, model.k,
+                                  device=device.index or 0)
+        sh = ShardedBprTrainer(trainer, model.total_items, model.k, device, sync_every=nnz, group=group,
+                               sparse_threshold=sparse_threshold)
+    else:
+        sh = ShardedBprTrainer(None, model.total_items, model.k, device, sync_every=nnz, group=group,
+                               sparse_threshold=sparse_threshold)
+        trainer = sh.trainer = trainer_factory(sh.table, indptr, indices, n_local, train_set.num_items, model.total_items,
+                                               model.k)
+    try:
+        trainer.set_factors(model.u_factors[u0:u1], None, None)
+        lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
+        trainer.seed_hogwild((((hi << 32) | lo) + 7919 * rank) & 0xFFFFFFFFFFFFFFFF)
+        sh.load_items(model.i_factors, model.i_biases)
+        for _ in range(model.max_iter):
+            sh.run_epoch_in_parts(nnz, parts, model.learning_rate, model.lambda_reg, model.use_bias, model._neg_population)
+        correct, skipped = sh.finish()
+        U_local = trainer.get_user_factors()
+        V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
+    finally:
+        trainer.close()
+    model.u_factors[: bounds[-1]] = _gather_user_rows(U_local, bounds, device, group)
+    model.i_factors[...] = V
+    model.i_biases[...] = B
+    c, s = _sum_over_ranks([correct, skipped], device, group)
+    model.fit_stats = [(int(c), int(s))]
+    model._drop_scorer()
+    return model
+
+
+def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=None, sparse_threshold=None,
+                   trainer_factory=None):
+    """`model.fit(train_set)` for a cornac_amd MF (backend "hip", hogwild mode) over all ranks of the process group:
+    users — with their ratings, in stored order — cut into contiguous ranges of equal rating counts, the item side
+    replicated and reconciled (ShardedMfTrainer); every rank returns with the complete model.  Same calling convention
+    and restrictions as fit_bpr_sharded; `early_stop` is not supported (it would need the global loss every epoch on
+    the host).  model.loss_history holds 0.5 x the summed squared error of all ranks per epoch.
+    trainer_factory(table, rid_local, cid, val, n_local, n_items, k): test hook."""
+    from . import _lib
+    from .recommender import Recommender
+
+    if model.effective_mode != "hogwild":
+        raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
+    if getattr(model, "early_stop", False):
+        raise ValueError("early_stop is not supported by the sharded fit")
+    world, rank = _world(group)
+    device = device if device is not None else torch.device("cpu")
+    Recommender.fit(model, train_set)
+    model._init()
+    _broadcast_from_rank0([model.u_factors, model.i_factors, model.u_biases, model.i_biases], device, group)
+    X = train_set.matrix
+    bounds = partition_users_by_nnz(X.indptr, world)
+    counts = [int(X.indptr[bounds[r + 1]] - X.indptr[bounds[r]]) for r in range(world)]
+    if min(counts) == 0:
+        raise ValueError("a rank would receive no ratings (%r): use fewer ranks" % (counts,))
+    u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
+    rid, cid, val = train_set.uir_tuple
+    mine = (rid >= u0) & (rid < u1)
+    rid_l, cid_l, val_l = (rid[mine] - u0).astype(np.int64), cid[mine].astype(np.int64), val[mine].astype(np.float32)
+    n_local = u1 - u0
+    mu = float(model.global_mean)
+    if trainer_factory is None:
+        trainer = _lib.MfTrainer(rid_l, cid_l, val_l, n_local, model.num_items, model.k, device=device.index or 0)
+        sh = ShardedMfTrainer(trainer, model.num_items, model.k, device, parts_per_epoch=parts_per_epoch, group=group,
+                              sparse_threshold=sparse_threshold)
+    else:
+        sh = ShardedMfTrainer(None, model.num_items, model.k, device, parts_per_epoch=parts_per_epoch, group=group,
+                              sparse_threshold=sparse_threshold)
+        trainer = sh.trainer = trainer_factory(sh.table, rid_l, cid_l, val_l, n_local, model.num_items, model.k)
+    try:
+        trainer.set_factors(model.u_factors[u0:u1], None, model.u_biases[u0:u1], None)
+        sh.load_items(model.i_factors[: model.num_items], model.i_biases[: model.num_items])
+        losses = []
+        for _ in range(model.max_iter):
+            sh.run_epoch(model.learning_rate, model.lambda_reg, mu, model.use_bias)
+            losses.append(0.5 * _sum_over_ranks([sh.finish()], device, group)[0])
+        U_local, _, Bu_local, _ = trainer.get_factors()
+        V, Bi = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
+    finally:
+        trainer.close()
+    model.u_factors[: bounds[-1]] = _gather_user_rows(U_local, bounds, device, group)
+    model.u_biases[: bounds[-1]] = _gather_user_rows(Bu_local, bounds, device, group)
+    model.i_factors[: model.num_items] = V
+    model.i_biases[: model.num_items] = Bi
+    model.loss_history, model.epochs_run = np.asarray(losses, np.float32), len(losses)
+    model._drop_scorer()
+    return model
 
 
 def partition_users_by_nnz(indptr, world_size):

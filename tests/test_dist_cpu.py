@@ -639,3 +639,104 @@ def test_mf_ranks_of_very_different_sizes_exchange_in_lockstep():
     assert np.array_equal(base0, base1) and np.isfinite(base0).all()
     assert ex0["dense"] == ex1["dense"] and ex0["sparse"] == ex1["sparse"] and ex0["dense"] + ex0["sparse"] >= 6 * 16
     assert rmse0 < 1.0 and rmse1 < 1.2
+
+
+# ---- model-level entry points: fit_bpr_sharded / fit_mf_sharded --------------------------------------------------------
+class _BprRankTrainer(_OracleTrainer):
+    """the trainer surface fit_bpr_sharded drives, over the oracle's sequential BPR loop on the replica's item table"""
+
+    def __init__(self, table, indptr, indices, n_local, n_items, total_items, k):
+        super().__init__(table, indptr, indices, n_items, k, seed=1)
+
+    def set_factors(self, U, V, B):
+        self.U = np.array(U, np.float32)
+
+    def seed_hogwild(self, seed):
+        self.gp, self.gn = self.orc.MT19937(seed % (2 ** 31)), self.orc.MT19937((seed >> 32) % (2 ** 31) + 1)
+
+    def get_user_factors(self):
+        return self.U.copy()
+
+    def close(self):
+        pass
+
+
+class _MfRankTrainer(_OracleMfTrainer):
+    def __init__(self, table, rid, cid, val, n_local, n_items, k):
+        super().__init__(table, rid, cid, val, n_local, k, seed=1)
+
+    def set_factors(self, U, V, Bu, Bi):
+        self.U, self.Bu = np.array(U, np.float32), np.array(Bu, np.float32)
+
+    def get_factors(self):
+        return self.U.copy(), None, self.Bu.copy(), None
+
+    def close(self):
+        pass
+
+
+def _model_data(seed=0, nu=160, ni=60, per_user=18):
+    rs = np.random.RandomState(seed)
+    p = 1.0 / np.arange(1, ni + 1) ** 0.9
+    q, ib = rs.normal(0, 1, (ni, 3)), rs.normal(0, 0.5, ni)
+    rows = []
+    for u in range(nu):
+        t = rs.normal(0, 1, 3)
+        for i in rs.choice(ni, per_user + (u % 7), replace=False, p=p / p.sum()):
+            rows.append(("u%d" % u, "i%d" % i, float(np.clip(np.rint(3 + ib[i] + 0.6 * q[i] @ t + rs.normal(0, 0.3)), 1, 5))))
+    return rows
+
+
+def _fit_sharded_worker(rank, world, port, out):
+    import cornac_amd as ca
+    from cornac_amd.dist import fit_bpr_sharded, fit_mf_sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = ca.Dataset.from_uir(_model_data(), seed=3)
+        # the ranks' own generators differ on purpose (seed = rank): rank 0's initial tables must win
+        bpr = ca.BPR(k=6, max_iter=8, learning_rate=0.05, lambda_reg=0.01, seed=rank, mode="hogwild")
+        fit_bpr_sharded(bpr, ds, sync_per_epoch=8, trainer_factory=_BprRankTrainer)
+        mf = ca.MF(k=6, max_iter=15, learning_rate=0.02, lambda_reg=0.02, seed=rank, mode="hogwild")
+        fit_mf_sharded(mf, ds, parts_per_epoch=8, trainer_factory=_MfRankTrainer)
+        out[rank] = dict(bU=bpr.u_factors.copy(), bV=bpr.i_factors.copy(), bB=bpr.i_biases.copy(), bstats=bpr.fit_stats,
+                         mU=mf.u_factors.copy(), mV=mf.i_factors.copy(), mBu=mf.u_biases.copy(), mBi=mf.i_biases.copy(),
+                         mloss=mf.loss_history.copy(), mu=float(mf.global_mean))
+        with pytest.raises(ValueError):
+            fit_bpr_sharded(ca.BPR(k=4, seed=1), ds, trainer_factory=_BprRankTrainer)   # seeded => sequential semantics
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_level_sharded_fits_return_one_complete_model_on_every_rank():
+    """fit_bpr_sharded / fit_mf_sharded on two gloo ranks with real arithmetic behind the trainer surface: the users are
+    cut by interaction count, every rank trains its range, and BOTH ranks return with the same complete model — user rows
+    of both ranges gathered, one item side — that has learnt (pairwise accuracy / RMSE on all the data), starting from
+    rank 0's initial tables although the ranks' generators differ."""
+    import cornac_amd as ca
+
+    out = mp.Manager().dict()
+    mp.spawn(_fit_sharded_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    for name in ("bU", "bV", "bB", "mU", "mV", "mBu", "mBi"):
+        assert np.allclose(a[name], b[name], rtol=0, atol=1e-6), name
+    assert a["bstats"] == b["bstats"] and a["bstats"][0][0] > 0
+    assert np.allclose(a["mloss"], b["mloss"]) and a["mloss"][-1] < 0.85 * a["mloss"][0] and np.all(np.diff(a["mloss"]) < 0)
+    ds = ca.Dataset.from_uir(_model_data(), seed=3)
+    X = ds.matrix
+    # BPR: positives outrank random non-positives for users of BOTH ranges
+    rs, hit, n = np.random.RandomState(0), 0, 0
+    for u in range(ds.num_users):
+        pos = X.indices[X.indptr[u]:X.indptr[u + 1]]
+        neg = np.setdiff1d(np.arange(ds.num_items), pos)
+        s = a["bB"] + a["bV"] @ a["bU"][u]
+        i, j = rs.choice(pos, 6), rs.choice(neg, 6)
+        hit, n = hit + int((s[i] > s[j]).sum()), n + 6
+    assert hit / n > 0.68, hit / n   # (8 epochs from a cold start; 0.5 = chance)
+    rid, cid, val = ds.uir_tuple
+    pred = a["mu"] + a["mBu"][rid] + a["mBi"][cid] + np.einsum("nk,nk->n", a["mU"][rid], a["mV"][cid])
+    rmse, rmse_mean_only = float(np.sqrt(np.mean((pred - val) ** 2))), float(np.sqrt(np.mean((a["mu"] - val) ** 2)))
+    assert rmse < 0.9 * rmse_mean_only, (rmse, rmse_mean_only)
+    for lo, hi in ((0, 20), (ds.num_users - 20, ds.num_users)):     # users of both ranks' ranges were trained and gathered
+        assert np.abs(a["mBu"][lo:hi]).max() > 1e-3 and np.abs(a["bU"][lo:hi]).max() > 0.02
