@@ -431,3 +431,46 @@ def test_sharded_mf_trainer_single_rank_through_rccl():
             assert losses[-1] < losses[0]
     finally:
         dist.destroy_process_group()
+
+
+def test_model_level_sharded_fits_single_rank_through_rccl():
+    """dist.fit_bpr_sharded / fit_mf_sharded (model.fit over a process group) on one rank through a real RCCL group — the
+    device path of the drivers they compose: bound item table, driver stream, epochs in exactly N chunks, the size-one
+    broadcast / all-gathers — next to the plain model.fit on the same data: both learn the same model up to hogwild
+    scheduling (measured: BPR 'correct' 0.7215 vs 0.7206; MF final loss within 7 %)."""
+    import torch
+    import torch.distributed as dist
+
+    import cornac_amd as ca
+    from cornac_amd import synth
+    from cornac_amd.dist import fit_bpr_sharded, fit_mf_sharded
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    users, items = synth.zipf_interactions(4000, 1500, 300_000, 0.7, 3)
+    rs = np.random.RandomState(0)
+    P, Q = rs.normal(0, 1, (4000, 4)), rs.normal(0, 1, (1500, 4))
+    val = np.clip(np.rint(3.0 + 0.6 * np.einsum("nk,nk->n", P[users], Q[items]) + rs.normal(0, 0.3, len(users))), 1, 5)
+    ds = ca.Dataset.from_uir(list(zip(users.tolist(), items.tolist(), val.tolist())), seed=1)
+    nnz = ds.matrix.nnz
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        kw = dict(k=64, max_iter=6, learning_rate=0.05, lambda_reg=0.01, seed=5, mode="hogwild")
+        a = fit_bpr_sharded(ca.BPR(**kw), ds, device=dev, sync_per_epoch=8)
+        b = ca.BPR(**kw).fit(ds)
+        fa = a.fit_stats[0][0] / max(6 * nnz - a.fit_stats[0][1], 1)
+        fb = b.fit_stats[0][0] / max(6 * nnz - b.fit_stats[0][1], 1)
+        assert np.isfinite(a.u_factors).all() and np.isfinite(a.i_factors).all()
+        assert abs(fa - fb) < 0.03 and fa > 0.6, (fa, fb)
+        assert np.abs(a.score(3) - (a.i_biases + a.i_factors @ a.u_factors[3])).max() < 1e-5
+        with pytest.raises(ValueError):
+            fit_bpr_sharded(ca.BPR(k=8, seed=1), ds, device=dev)   # seeded => sequential semantics: refused
+        kw = dict(k=64, max_iter=8, learning_rate=0.01, lambda_reg=0.02, seed=5, mode="hogwild")
+        m = fit_mf_sharded(ca.MF(**kw), ds, device=dev, parts_per_epoch=8)
+        p = ca.MF(**kw).fit(ds)
+        assert m.epochs_run == 8 and m.loss_history[-1] < m.loss_history[0]
+        assert abs(m.loss_history[-1] - p.loss_history[-1]) < 0.15 * p.loss_history[-1], (m.loss_history, p.loss_history)
+    finally:
+        dist.destroy_process_group()
