@@ -400,7 +400,8 @@ def leg_vbpr_tradesy(args, _lib):
            "config": {"workload": "VBPR k=k2=%d, %d-d features, Tradesy-shaped synthetic (%d users x %d items, %d "
                                   "feedback), batch %d, one epoch on pre-sampled batches" % (k, nf, nu, ni, nnz, B)},
            "roofline": {"bound": "hbm", "achieved": bytes_step * steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_step * steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": bytes_step * steps / dt / 1e9 / HBM_PEAK_GBS,
+                        "traffic": leg_traffic("vbpr_tradesy", shape="%dx%d f%d k%d k2 %d batch%d" % (nu, ni, nf, k, k2, B)),
                         "kernel": "whole minibatch step (featdiff gather, projection GEMM, pair gradient, scatter, dense "
                                   "Adam sweep): bytes / wall time of the epoch, no per-kernel events",
                         "algorithmic_bytes_per_step": bytes_step},
@@ -531,10 +532,12 @@ def leg_wmf_netflix(args, _lib):
                                   % (k, n_users, n_items, B, (n_items + B - 1) // B)},
            "roofline": {"bound": "mfma", "achieved": flops * steps / (dev_ms / 1e3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": flops * steps / (dev_ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF,
-                        "kernel": "wmf_user_step_kernel (+ gather / reduce / scatter / item-side Adam): HIP events around "
-                                  "the whole batch loop", "flops_per_step": flops, "device_ms_per_step": dev_ms / steps},
+                        "kernel": "wmf_user_step_lds_kernel (+ gather / reduce / scatter / item-side Adam): HIP events around "
+                                  "the whole batch loop", "flops_per_step": flops, "device_ms_per_step": dev_ms / steps,
+                        "traffic": leg_traffic("wmf_netflix", n_users=n_users, k=k, batch=B)},
            "train_stats": {"loss_first_last": [float(loss[0]), float(loss[-1])]}, "host_s": {"generate": t_gen},
-           "parity": "oracle unpinned (no TensorFlow in the image): oracle/wmf_oracle.py restates the published graph"}
+           "parity": "oracle pinned to the reference's own WMF code run over oracle/tf1_shim (no TensorFlow in the image: its "
+                     "Adam / gather-gradient rules are restated)"}
     if args.cpu_baseline_seconds > 0:
         try:
             from oracle import wmf_oracle
