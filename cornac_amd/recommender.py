@@ -74,18 +74,19 @@ _PROBE = 64
 
 
 def _table_fingerprint(a):
-    """Identity AND a content probe of a host table: (id, buffer address, shape, dtype, hash of <= 64 evenly spaced
+    """Identity AND a content probe of a host table: (id, shape, dtype, hash of <= 64 evenly spaced
     elements).  The device copy of the scoring tables is keyed on it, so re-assigned attributes and whole-table in-place
     edits (`m.i_biases += 1`, a warm-start loader writing into the existing arrays) are noticed without
     `invalidate_scorer()`; only a sparse edit that misses every probed element still needs that call.  A few
     microseconds per table (a strided view, no index arrays): it runs on every score() call."""
     if a is None:
         return None
-    a = np.asarray(a)
+    if type(a) is not np.ndarray:
+        a = np.asarray(a)
     flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
     n = flat.size
     probe = flat[:: max(1, n // _PROBE)][:_PROBE].tobytes() if n else b""
-    return (id(a), a.__array_interface__["data"][0], a.shape, a.dtype.str, hash(probe))
+    return (id(a), a.shape, a.dtype.num, hash(probe))
 
 
 def clip(values, lower_bound, upper_bound):
