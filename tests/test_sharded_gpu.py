@@ -368,6 +368,15 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     tr.close()
 
 
+def _fresh_port():
+    """a free TCP port for this test's rendezvous (several tests of this process create and destroy process groups)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def test_sharded_mf_trainer_single_rank_through_rccl():
     """the multi-GPU MF driver (ShardedMfTrainer: item side [V | Bi] in a torch-owned replica, epochs enqueued in slices on
     the driver's stream, the replica's delta passes through cornac_hip_table_delta, a real RCCL group of size 1) against
@@ -380,7 +389,7 @@ def test_sharded_mf_trainer_single_rank_through_rccl():
     from cornac_amd.dist import ShardedMfTrainer, global_mean_across_ranks
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = _fresh_port()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     n_users, n_items, k = 5000, 2000, 64
@@ -446,7 +455,7 @@ def test_model_level_sharded_fits_single_rank_through_rccl():
     from cornac_amd.dist import fit_bpr_sharded, fit_mf_sharded
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = _fresh_port()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     users, items = synth.zipf_interactions(4000, 1500, 300_000, 0.7, 3)
