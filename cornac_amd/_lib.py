@@ -38,6 +38,7 @@ SYMBOLS = [
     "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_hogwild_form",
     "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
     "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
+    "cornac_hip_bpr_ldsbin_deal_config", "cornac_hip_bpr_debug_ldsbin_deal",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
     "cornac_hip_bpr_staged_slots", "cornac_hip_bpr_emit_triplets", "cornac_hip_bpr_apply_staged",
     "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
@@ -177,6 +178,8 @@ def lib():
         L.cornac_hip_bpr_debug_strata.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
         L.cornac_hip_bpr_ldsbin_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_ldsbin_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
+        L.cornac_hip_bpr_ldsbin_deal_config.argtypes = [_vp, C.c_int, C.c_int]
+        L.cornac_hip_bpr_debug_ldsbin_deal.argtypes = [_vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_mf_kernel_timing.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cornac_hip_vbpr_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _f32]
@@ -456,8 +459,22 @@ class BprTrainer:
                                                    oi.ctypes.data))
         return wp, ou, oi
 
-    def ldsbin_config(self, hot_x1000=100, min_candidates=48, max_rounds=4):
+    def ldsbin_config(self, hot_x1000=75, min_candidates=48, max_rounds=4):
         check(lib().cornac_hip_bpr_ldsbin_config(self.h, int(hot_x1000), int(min_candidates), int(max_rounds)))
+
+    def ldsbin_deal_config(self, strata_groups=16, hot_cost_x16=32):
+        check(lib().cornac_hip_bpr_ldsbin_deal_config(self.h, int(strata_groups), int(hot_cost_x16)))
+
+    def debug_ldsbin_deal(self, seed, epoch):
+        """(bin_of_item, cold_mass, hot_off, hot_u, hot_i) of the deal of `epoch` (test hook)."""
+        st = self.ldsbin_stats()
+        bins, nh = st["bins"], st["hot_interactions"]
+        bin_of = np.empty(self.n_items, np.int32)
+        cold, off = np.empty(bins, np.uint32), np.empty(bins + 1, np.uint32)
+        hu, hi = np.empty(max(nh, 1), np.int32), np.empty(max(nh, 1), np.int32)
+        check(lib().cornac_hip_bpr_debug_ldsbin_deal(self.h, int(seed), int(epoch), bin_of.ctypes.data, cold.ctypes.data,
+                                                     off.ctypes.data, hu.ctypes.data, hi.ctypes.data))
+        return bin_of, cold, off, hu[:nh], hi[:nh]
 
     def ldsbin_stats(self):
         o = (C.c_int64 * 7)()

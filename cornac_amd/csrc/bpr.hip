@@ -177,7 +177,7 @@ struct HogArgs {
     const int32_t *rec_u, *rec_i, *rank_item;
     const int64_t *sptr;
     uint32_t strata_key, n_hot;
-    uint32_t xcd_map;  // physical XCD of the workgroups with blockIdx % 8 == c, 4 bits per c (strata_probe_placement)
+    uint32_t *xcd_claim;  // [9] per-XCD slot counters + the surplus ticket, zero at launch (bpr_strata.inc)
     int phase;
 };
 constexpr int32_t kTripShared = 0x40000000;  // bit 30 of an emitted user id: a shared (heavy) user, atomics on its row
@@ -714,8 +714,9 @@ struct cornac_hip_bpr {
     bool strata_built = false;
     int strata_hot_permille = 120, strata_hot_min_mult_x100 = 200, strata_rehash_period = 1;
     int64_t strata_misplaced = 0, strata_builds = 0;
-    uint32_t strata_xcd_map = 0x76543210u;  // residue -> physical XCD, probed for strata_probe_grid workgroups
-    int strata_probe_grid = 0;
+    DevBuf<int32_t> strata_own_code;  // item_rank[own_i[t]] (static; rebuilt with the ownership tables)
+    int64_t strata_code_waves = -1;
+    DevBuf<uint32_t> strata_claim;  // [8 phases][16]: per-XCD slot counters of a phase launch (bpr_strata.inc), zeroed per epoch
     void (*strata_kernel)(const chip::HogArgs) = nullptr;
     int strata_blocks_per_cu = 0;
     // LDS-resident item bins (bpr_ldsbin.inc): CSC, hot interaction list, membership bitmap
@@ -723,7 +724,14 @@ struct cornac_hip_bpr {
     DevBuf<int32_t> lb_cptr, lb_cusers, lb_hot_u, lb_hot_i;
     DevBuf<uint32_t> lb_bitmap;
     int lb_bins = 0, lb_cap = 0, lb_n_hot = 0, lb_n_hot_inter = 0, lb_bm_words = 0;
-    int lb_hot_x1000 = 100, lb_min_candidates = 48, lb_max_rounds = 4;
+    int lb_hot_x1000 = 75, lb_min_candidates = 48, lb_max_rounds = 4;
+    int lb_strata_groups = 16, lb_hot_cost_x16 = 32;  // the deal: stratum width in groups, price of a hot draw
+    int lb_n_strata = 1;
+    DevBuf<uint32_t> lb_mass, lb_cold, lb_hot_off;
+    DevBuf<unsigned long long> lb_wg_clock;  // profile build, CORNAC_HIP_LDSBIN_CLOCKS=<file>
+    bool lb_deal_valid = false;   // lb_hot_off / lb_cold hold the deal of (lb_deal_seed, lb_deal_epoch)
+    uint64_t lb_deal_seed = 0;
+    uint32_t lb_deal_epoch = 0;
     size_t lb_lds_bytes = 0;
     bool lb_attr_set = false;
     int64_t lb_lock_timeouts = 0;
@@ -1363,7 +1371,7 @@ static void fill_hog_args(cornac_hip_bpr_t h, HogArgs &a, int64_t n, float lr, f
     a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
     a.lr = lr; a.reg = reg;
     a.own_u = nullptr; a.own_i = nullptr; a.wave_ptr = nullptr; a.own_tmax = 0;
-    a.xcd_map = 0x76543210u;
+    a.xcd_claim = nullptr;
     a.nnz = h->nnz;
     a.ablate = (flags >> 8) & 0xff;
 }
@@ -1483,11 +1491,34 @@ static void build_item_ranks(cornac_hip_bpr_t h) {
     h->strata_n_hot = (uint32_t)n_hot;
     h->item_rank.ensure((size_t)ni);
     h->rank_item.ensure((size_t)ni);
+    std::vector<int32_t> up_rank_item(h->h_rank_item);
+#ifdef CORNAC_PROFILE
+    if (prof_env_int("CORNAC_HIP_STRATA_CONTIG", 0)) {
+        // experiment (how much do the translation misses cost?): a static deal whose partitions are contiguous id ranges
+        // — "ranks" re-assigned so that the items [p n_full, (p + 1) n_full) form partition p under the fixed key below,
+        // in popularity order inside a partition.  Used with the strata kernel only (the LDS-bin deal reads the same table).
+        const uint32_t key = 0x12345u;
+        const int64_t n_full = ni >> 3;
+        std::vector<std::vector<int32_t>> part(8);
+        for (int64_t r = 0; r < ni; ++r) {
+            const int32_t it = h->h_rank_item[(size_t)r];
+            if (it < 8 * n_full) part[(size_t)(it / n_full)].push_back(it);
+        }
+        for (int pp = 0; pp < 8; ++pp)
+            for (int64_t g = 0; g < n_full; ++g) {
+                const uint32_t code = (uint32_t)g * 8u + (((uint32_t)pp - strata_rot((uint32_t)g, key)) & 7u);
+                up_rank_item[code] = part[(size_t)pp][(size_t)g];
+            }
+        for (int64_t it = 8 * n_full; it < ni; ++it) up_rank_item[(size_t)it] = (int32_t)it;
+        for (int64_t r = 0; r < ni; ++r) item_rank[(size_t)up_rank_item[(size_t)r]] = (int32_t)r;
+    }
+#endif
     h->item_rank.upload(item_rank.data(), (size_t)ni, h->stream);
-    h->rank_item.upload(h->h_rank_item.data(), (size_t)ni, h->stream);
+    h->rank_item.upload(up_rank_item.data(), (size_t)ni, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->strata_ranked = true;
     h->strata_built = false;
+    h->strata_code_waves = -1;
 }
 
 static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_population, int flags) {
@@ -1502,34 +1533,6 @@ static bool hogwild_uses_strata(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
 }
 
 // grid / ownership / rank tables of the strata kernel; returns the grid width
-// Where does the dispatcher put workgroup b of a `grid`-wide launch?  One tiny launch of the same shape records every
-// workgroup's HW_REG_XCC_ID; if all workgroups of a residue class b % 8 share one XCD and the 8 classes sit on 8
-// different XCDs, that permutation is what the strata kernel verifies against (the identity on most boxes, a rotation on
-// some); anything else keeps the identity, i.e. the kernel falls back to atomics wherever it is not met.
-static void strata_probe_placement(cornac_hip_bpr_t h, int grid) {
-    if (h->strata_probe_grid == grid) return;
-    h->strata_probe_grid = grid;
-    h->strata_xcd_map = 0x76543210u;
-    DevBuf<uint32_t> d;
-    d.ensure((size_t)grid);
-    hipLaunchKernelGGL(strata_xcd_probe_kernel, dim3(grid), dim3(kBlock), 0, h->stream, d.p);
-    HIP_CHECK(hipGetLastError());
-    std::vector<uint32_t> x((size_t)grid);
-    d.download(x.data(), (size_t)grid, h->stream);
-    HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (grid < 8) return;
-    uint32_t map = 0, seen = 0;
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t phys = x[(size_t)c] & 7u;
-        for (int b = c; b < grid; b += 8)
-            if ((x[(size_t)b] & 7u) != phys) return;   // a residue class spread over XCDs: no usable map
-        if (seen & (1u << phys)) return;               // two classes on one XCD
-        seen |= 1u << phys;
-        map |= phys << (4 * c);
-    }
-    h->strata_xcd_map = map;
-}
-
 static int strata_prepare(cornac_hip_bpr_t h) {
     const DeviceInfo &di = device_info(h->device);
     StrataKernel kern = pick_strata_kernel(h->k);
@@ -1547,7 +1550,8 @@ static int strata_prepare(cornac_hip_bpr_t h) {
     h->rec_u.ensure((size_t)h->nnz);
     h->rec_i.ensure((size_t)h->nnz);
     h->sptr.ensure((size_t)W * 8 + 1);
-    strata_probe_placement(h, grid);
+    REQUIRE(grid % 8 == 0, "the strata grid must be a multiple of the 8 XCDs");
+    h->strata_claim.ensure(8 * 16);
     return grid;
 }
 
@@ -1557,6 +1561,13 @@ static void strata_build_buckets(cornac_hip_bpr_t h, int grid, uint32_t key) {
     s.own_u = h->own_u.p; s.own_i = h->own_i.p; s.wave_ptr = h->wave_ptr.p; s.item_rank = h->item_rank.p;
     s.rec_u = h->rec_u.p; s.rec_i = h->rec_i.p; s.sptr = h->sptr.p;
     s.key = key; s.n_hot = h->strata_n_hot; s.n_waves = (int64_t)grid * kWavesPerBlock;
+    h->strata_own_code.ensure((size_t)h->nnz);
+    s.own_code = h->strata_own_code.p;
+    if (h->strata_code_waves != h->own_waves) {  // once per ownership layout
+        hipLaunchKernelGGL(strata_code_kernel, dim3((unsigned)std::min<int64_t>(4096, (h->nnz + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, h->stream, s, h->nnz);
+        h->strata_code_waves = h->own_waves;
+    }
     hipLaunchKernelGGL(strata_bucket_kernel, dim3(grid), dim3(kBlock), 0, h->stream, s);
     HIP_CHECK(hipGetLastError());
     h->strata_built = true;
@@ -1577,22 +1588,28 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
         const auto first_phase = [&](int64_t s) { return (int)((8 * (__int128)s + h->nnz - 1) / h->nnz); };
         const int p_lo = first_phase(h->hog_offset), p_hi = h->hog_offset + n >= h->nnz ? 8 : first_phase(h->hog_offset + n);
         if (p_hi > p_lo) {
-            const uint32_t key = strata_key(h->hog_seed, h->hog_epoch / (uint32_t)std::max(1, h->strata_rehash_period));
+            uint32_t key = strata_key(h->hog_seed, h->hog_epoch / (uint32_t)std::max(1, h->strata_rehash_period));
+            if (prof_env_int("CORNAC_HIP_STRATA_CONTIG", 0)) key = 0x12345u;  // (profile builds: the static contiguous deal)
             strata_build_buckets(h, grid, key);
             HogArgs a;
             fill_hog_args(h, a, h->nnz, lr, reg, use_bias, CORNAC_HIP_NEG_UNIFORM, flags);
-            a.B = h->Bpad.p;
-            a.bstride = kBiasStride;
+            const bool dense_bias = prof_env_int("CORNAC_HIP_STRATA_DENSE_BIAS", 0) != 0;  // (profile builds: experiment)
+            a.B = dense_bias ? h->B.p : h->Bpad.p;
+            a.bstride = dense_bias ? 1 : kBiasStride;
             a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
-            a.strata_key = key; a.n_hot = h->strata_n_hot; a.xcd_map = h->strata_xcd_map;
-            hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
+            a.strata_key = key; a.n_hot = h->strata_n_hot;
+            HIP_CHECK(hipMemsetAsync(h->strata_claim.p, 0, 8 * 16 * sizeof(uint32_t), h->stream));
+            if (!dense_bias)
+                hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
             for (int ph = p_lo; ph < p_hi; ++ph) {
                 a.phase = ph;
+                a.xcd_claim = h->strata_claim.p + 16 * ph;
                 h->ktimer.before(h->stream);
                 hipLaunchKernelGGL(h->strata_kernel, dim3(grid), dim3(kBlock), 0, h->stream, a);
                 h->ktimer.after(h->stream);
             }
-            hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
+            if (!dense_bias)
+                hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
             HIP_CHECK(hipGetLastError());
         }
         advance_hog_offset(h, n);
@@ -1676,11 +1693,27 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
                              share * h->lb_hot_x1000)
         ++n_hot;
     std::vector<int32_t> hot_u, hot_i;
-    for (int r = 0; r < n_hot; ++r) {
-        const int32_t it = h->h_rank_item[(size_t)r];
-        for (int32_t p = cptr[(size_t)it]; p < cptr[(size_t)it + 1]; ++p) {
-            hot_u.push_back(cusers[(size_t)p]);
-            hot_i.push_back(it);
+    {
+        // item-major list, then shuffled once (stable order of a hash of the list index): a bin draws a contiguous run
+        // of the list (ldsbin_level_kernel), and a run should spread over all hot items
+        std::vector<int32_t> lu, li;
+        for (int r = 0; r < n_hot; ++r) {
+            const int32_t it = h->h_rank_item[(size_t)r];
+            for (int32_t p = cptr[(size_t)it]; p < cptr[(size_t)it + 1]; ++p) {
+                lu.push_back(cusers[(size_t)p]);
+                li.push_back(it);
+            }
+        }
+        std::vector<uint32_t> order(lu.size());
+        for (size_t t = 0; t < order.size(); ++t) order[t] = (uint32_t)t;
+        std::stable_sort(order.begin(), order.end(), [](uint32_t x, uint32_t y) {
+            return ldsbin_mix(x * 0x9E3779B1u + 0x5BD1E995u) < ldsbin_mix(y * 0x9E3779B1u + 0x5BD1E995u);
+        });
+        hot_u.resize(lu.size());
+        hot_i.resize(lu.size());
+        for (size_t t = 0; t < order.size(); ++t) {
+            hot_u[t] = lu[order[t]];
+            hot_i[t] = li[order[t]];
         }
     }
     h->lb_cptr.ensure((size_t)ni + 1);
@@ -1710,7 +1743,33 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
     h->lb_n_hot = n_hot;
     h->lb_n_hot_inter = (int)hot_u.size();
     h->lb_lds_bytes = std::max(ldsbin_lds_bytes(h->lb_cap, h->k), kLbLdsExclusive);
+    const int n_groups = (int)((ni + bins - 1) / bins);
+    h->lb_n_strata = std::max(1, n_groups / std::max(1, h->lb_strata_groups));
+    h->lb_mass.ensure((size_t)bins);
+    h->lb_cold.ensure((size_t)bins);
+    h->lb_hot_off.ensure((size_t)bins + 1);
+    HIP_CHECK(hipMemsetAsync(h->lb_mass.p, 0, (size_t)bins * sizeof(uint32_t), h->stream));
+    h->lb_deal_valid = false;
     h->lb_built = true;
+}
+
+// the deal bookkeeping of (seed, epoch): cold masses per bin and the hot runs that level them (two small launches,
+// once per epoch: the chunks of an epoch share them)
+static void ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t epoch, uint32_t key) {
+    if (h->lb_deal_valid && h->lb_deal_seed == seed && h->lb_deal_epoch == epoch) return;
+    LdsDealArgs d;
+    d.cptr = h->lb_cptr.p; d.rank_item = h->rank_item.p;
+    d.mass = h->lb_mass.p; d.cold_out = h->lb_cold.p; d.hot_off = h->lb_hot_off.p;
+    d.key = key;
+    d.n_items = (int32_t)h->n_items; d.n_bins = h->lb_bins; d.n_hot = h->lb_n_hot; d.n_hot_inter = h->lb_n_hot_inter;
+    d.n_strata = h->lb_n_strata; d.hot_cost_x16 = h->lb_hot_cost_x16;
+    const unsigned grid = (unsigned)std::min<int64_t>(64, (h->n_items + kLbBlock - 1) / kLbBlock);
+    hipLaunchKernelGGL(ldsbin_mass_kernel, dim3(grid), dim3(kLbBlock), 0, h->stream, d);
+    hipLaunchKernelGGL(ldsbin_level_kernel, dim3(1), dim3(kLbBlock), 0, h->stream, d);
+    HIP_CHECK(hipGetLastError());
+    h->lb_deal_valid = true;
+    h->lb_deal_seed = seed;
+    h->lb_deal_epoch = epoch;
 }
 
 static uint32_t ldsbin_key(uint64_t seed, uint32_t epoch) {
@@ -1723,16 +1782,17 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
                              int flags) {
     a.neg_pop = neg_population == CORNAC_HIP_NEG_POPULARITY ? 1 : 0;
     a.cptr = h->lb_cptr.p; a.cusers = h->lb_cusers.p; a.rank_item = h->rank_item.p;
-    a.hot_u = h->lb_hot_u.p; a.hot_i = h->lb_hot_i.p;
+    a.hot_u = h->lb_hot_u.p; a.hot_i = h->lb_hot_i.p; a.hot_off = h->lb_hot_off.p;
     a.indptr = h->indptr.p; a.indices = h->indices.p;
     a.bitmap = h->lb_bm_words ? h->lb_bitmap.p : nullptr;
     a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
     a.counters = h->counters.p;
     a.seed = h->hog_seed; a.epoch = h->hog_epoch; a.key = ldsbin_key(h->hog_seed, h->hog_epoch);
     a.n_items = (int32_t)h->n_items; a.n_bins = h->lb_bins; a.n_hot = h->lb_n_hot; a.n_hot_inter = h->lb_n_hot_inter;
-    a.bm_words = h->lb_bm_words; a.cap = h->lb_cap;
+    a.bm_words = h->lb_bm_words; a.cap = h->lb_cap; a.n_strata = h->lb_n_strata;
     a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg;
     a.ablate = (flags >> 8) & 0xff;
+    a.wg_clock = nullptr;
 }
 
 // one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
@@ -1749,10 +1809,36 @@ static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
         a.s_begin = (uint64_t)h->hog_offset;
         a.n = (uint64_t)n;
         a.nnz = (uint64_t)h->nnz;
+        ldsbin_deal(h, a.seed, a.epoch, a.key);
+#ifdef CORNAC_PROFILE
+        const char *clock_path = getenv("CORNAC_HIP_LDSBIN_CLOCKS");
+        if (clock_path) {
+            h->lb_wg_clock.ensure((size_t)h->lb_bins * 2);
+            a.wg_clock = h->lb_wg_clock.p;
+        }
+#endif
         h->ktimer.before(h->stream);
         hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
         h->ktimer.after(h->stream);
         HIP_CHECK(hipGetLastError());
+#ifdef CORNAC_PROFILE
+        if (clock_path) {  // per-bin durations next to the bin's cold / hot draw counts (100 MHz wall clock)
+            std::vector<unsigned long long> clk((size_t)h->lb_bins * 2);
+            std::vector<uint32_t> cold((size_t)h->lb_bins), off((size_t)h->lb_bins + 1);
+            h->lb_wg_clock.download(clk.data(), clk.size(), h->stream);
+            h->lb_cold.download(cold.data(), cold.size(), h->stream);
+            h->lb_hot_off.download(off.data(), off.size(), h->stream);
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (FILE *f = fopen(clock_path, "a")) {
+                unsigned long long t0 = ~0ull;
+                for (int b = 0; b < h->lb_bins; ++b) t0 = std::min(t0, clk[2 * (size_t)b]);
+                for (int b = 0; b < h->lb_bins; ++b)
+                    fprintf(f, "%u %d %llu %llu %u %u\n", a.epoch, b, clk[2 * (size_t)b] - t0, clk[2 * (size_t)b + 1] - t0,
+                            cold[(size_t)b], off[(size_t)b + 1] - off[(size_t)b]);
+                fclose(f);
+            }
+        }
+#endif
         advance_hog_offset(h, n);
         left -= n;
     }
@@ -1991,6 +2077,44 @@ int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_cand
         h->lb_min_candidates = min_candidates;
         h->lb_max_rounds = max_rounds;
         h->lb_built = false;
+    });
+}
+
+int cornac_hip_bpr_ldsbin_deal_config(cornac_hip_bpr_t h, int strata_groups, int hot_cost_x16) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(strata_groups >= 1, "strata_groups must be >= 1");
+        REQUIRE(hot_cost_x16 >= 0 && hot_cost_x16 <= 4096, "hot_cost_x16 must be in [0, 4096]");
+        h->lb_strata_groups = strata_groups;
+        h->lb_hot_cost_x16 = hot_cost_x16;
+        h->lb_built = false;
+    });
+}
+
+int cornac_hip_bpr_debug_ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t epoch, int32_t *bin_of_item,
+                                     uint32_t *cold_mass, uint32_t *hot_off, int32_t *hot_u, int32_t *hot_i) {
+    return guarded([&] {
+        bpr_check(h);
+        const int bins = ldsbin_plan_bins(h);
+        REQUIRE(bins > 0, "this shape does not use the LDS-bin form");
+        ldsbin_build(h);
+        const uint32_t key = ldsbin_key(seed, epoch);
+        h->lb_deal_valid = false;
+        ldsbin_deal(h, seed, epoch, key);
+        h->lb_deal_valid = false;  // a test hook: the next epoch deals again
+        if (cold_mass) h->lb_cold.download(cold_mass, (size_t)bins, h->stream);
+        if (hot_off) h->lb_hot_off.download(hot_off, (size_t)bins + 1, h->stream);
+        if (hot_u && h->lb_n_hot_inter) h->lb_hot_u.download(hot_u, (size_t)h->lb_n_hot_inter, h->stream);
+        if (hot_i && h->lb_n_hot_inter) h->lb_hot_i.download(hot_i, (size_t)h->lb_n_hot_inter, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (bin_of_item) {  // the host's evaluation of the same deal functions the kernels use
+            const uint32_t nb = (uint32_t)bins, ni = (uint32_t)h->n_items, n_groups = (ni + nb - 1) / nb;
+            for (uint32_t p = 0; p < ni; ++p) {
+                const uint32_t g = p / nb, o = p - g * nb;
+                const uint32_t code = ldsbin_deal_rank(p, key, nb, ni, n_groups, (uint32_t)h->lb_n_strata);
+                bin_of_item[(size_t)h->h_rank_item[code]] = (int32_t)((o + ldsbin_rot(g, key, nb)) % nb);
+            }
+        }
     });
 }
 

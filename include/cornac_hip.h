@@ -153,7 +153,8 @@ int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t
  * popular ranks that are touched at least hot_min_mult_x100 / 100 times as often as the average row and together
  * receive at most hot_permille / 1000 of the item-row touches (defaults 200, 120); the item partitions are re-dealt
  * every rehash_period epochs (default 1).  strata_stats: out4 = {hot rows (-1: tables not built yet), workgroup
- * launches the dispatcher placed off their logical XCD since create (those fell back to atomics), bucket builds, grid
+ * launches that were surplus on their XCD since create (an XCD handed more than an eighth of a launch: those fell back
+ * to atomics; parts are claimed at run time from HW_REG_XCC_ID, so blockIdx placement does not matter), bucket builds, grid
  * width in waves (0: the strata form has not run)}.  debug_strata (test hook): deals the partitions of `epoch` and
  * returns the bucket offsets sptr[8 W + 1], the bucketed records rec_u / rec_i [nnz] (rec_i: bit 31 = hot row),
  * rank_item [n_items] (popularity rank -> item) and the epoch key; any pointer may be NULL. */
@@ -162,7 +163,7 @@ int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
 int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
                                 int32_t *rank_item, uint32_t *key);
 /* Tuning and inspection of the LDS-bin form.  ldsbin_config: an item is hot (rows in global memory under atomics, its
- * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 100);
+ * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 75);
  * the form is used when every bin holds at least min_candidates items (default 48: the negative of a draw comes from
  * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4).  ldsbin_stats: out7 =
  * {bins (0: the shape does not use the form), LDS rows per bin, hot items, their interactions, bitmap words per user
@@ -170,6 +171,17 @@ int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *spt
  * unless there is a bug: fetched with the epoch counters)}. */
 int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_candidates, int max_rounds);
 int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out7);
+/* The per-epoch deal of the LDS-bin form (csrc/bpr_ldsbin.inc, ldsbin_deal_rank).  deal_config: the popularity ranks
+ * are permuted (epoch-keyed) inside strata of ~strata_groups * bins consecutive ranks before they are cut into the
+ * groups of `bins` items that are dealt one item to each bin (default 16; 1 = the groups are cut from the static rank
+ * order, so two items of one group never share a bin); the hot interactions are dealt to the bins in runs that level
+ * the bins' work with a hot draw priced at hot_cost_x16 / 16 cold draws (default 32; 0 = an even split).
+ * debug_ldsbin_deal (test hook): deals epoch `epoch` of hogwild seed `seed` and returns bin_of_item [n_items],
+ * cold_mass [bins] (interactions of the bin's own items), hot_off [bins + 1] (the bin's run of the hot list) and the
+ * shuffled hot list hot_u / hot_i [hot interactions]; any pointer may be NULL. */
+int cornac_hip_bpr_ldsbin_deal_config(cornac_hip_bpr_t h, int strata_groups, int hot_cost_x16);
+int cornac_hip_bpr_debug_ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t epoch, int32_t *bin_of_item,
+                                     uint32_t *cold_mass, uint32_t *hot_off, int32_t *hot_u, int32_t *hot_i);
 /* HIP-event timing of the hogwild SGD kernel launches, recorded on the handle's
  * stream: returns the summed duration and count of the launches recorded since
  * the previous call, then enables/disables recording for the following ones. */

@@ -560,17 +560,99 @@ int64_t oracle_strata_sample(uint64_t seed, uint32_t epoch, uint32_t key, uint32
 }
 
 /* LDS-bin variant of the device sampler (csrc/bpr_ldsbin.inc; restates the HIP path's own integer arithmetic).
- * Bin b of n_bins holds, for every popularity-rank group g, the item of rank g * n_bins + (b - rot(g)) mod n_bins;
- * ranks < n_hot are hot (no local positives; their interactions hot_u/hot_i[h], h = b mod n_bins, belong to bin b).
+ * The deal of an epoch key: n_groups = ceil(n_items / n_bins) groups of n_bins positions; the groups are cut into
+ * n_strata strata [s n_groups / n_strata, (s + 1) n_groups / n_strata); position p of stratum s holds the item of
+ * popularity rank base_s + perm_s(p - base_s) (perm = a keyed Feistel bijection of the stratum's ranks, cycle-walked) and
+ * belongs to bin (p mod n_bins + rot(p / n_bins)) mod n_bins.  Ranks < n_hot are hot: no local positives; their
+ * interactions (a list shuffled once by the stable order of a hash of its index) are dealt to the bins in contiguous
+ * runs [hot_off[b], hot_off[b + 1]) whose lengths level the bins (oracle_ldsbin_deal).
  * Draw `local` of bin b: counter (local, b, epoch, 0x20); words (0,1) pick the positive among cold_mass + hot_share
  * interactions, words (2,3) the negative among the bin's OTHER slots (all slots for a hot positive).  Returns the number of draws whose negative is a
  * positive of the user (the device's skip counter for the epoch) and the total number of draws. */
-static uint32_t ldsbin_rot(uint32_t g, uint32_t key, uint32_t n_bins) {
-    uint32_t h = g * 0x9E3779B1u + key;
+static uint32_t ldsbin_mix(uint32_t h) {
     h ^= h >> 15; h *= 0x85EBCA77u;
     h ^= h >> 13; h *= 0xC2B2AE3Du;
     h ^= h >> 16;
-    return h % n_bins;
+    return h;
+}
+
+static uint32_t ldsbin_rot(uint32_t g, uint32_t key, uint32_t n_bins) { return ldsbin_mix(g * 0x9E3779B1u + key) % n_bins; }
+
+uint32_t oracle_ldsbin_hot_shuffle_key(uint32_t t) { return ldsbin_mix(t * 0x9E3779B1u + 0x5BD1E995u); }
+
+static uint32_t ldsbin_perm(uint32_t x, uint32_t n, uint32_t key) {
+    if (n <= 1u) return 0u;
+    int bits = 0;
+    while (bits < 32 && (n - 1u) >> bits) ++bits;
+    if (bits < 2) bits = 2;
+    const int lb = bits / 2, rb = bits - lb;
+    const uint32_t lm = (1u << lb) - 1u, rm = (1u << rb) - 1u;
+    do {
+        uint32_t l = x >> rb, r = x & rm;
+        for (uint32_t round = 0; round < 3u; ++round) {
+            l ^= (ldsbin_mix(r * 0x9E3779B1u + key + round * 0x7F4A7C15u) >> 7) & lm;
+            r ^= (ldsbin_mix(l * 0x85EBCA6Bu + (key ^ 0x5BD1E995u) + round * 0x165667B1u) >> 7) & rm;
+        }
+        x = (l << rb) | r;
+    } while (x >= n);
+    return x;
+}
+
+static uint32_t ldsbin_deal_rank(uint32_t p, uint32_t key, uint32_t n_bins, uint32_t n_items, uint32_t n_groups,
+                                 uint32_t n_strata) {
+    const uint32_t g = p / n_bins;
+    uint32_t s = (uint32_t)(((uint64_t)g * n_strata) / n_groups);
+    if ((uint32_t)(((uint64_t)(s + 1u) * n_groups) / n_strata) <= g) ++s;
+    const uint32_t g_lo = (uint32_t)(((uint64_t)s * n_groups) / n_strata);
+    const uint32_t g_hi = (uint32_t)(((uint64_t)(s + 1u) * n_groups) / n_strata);
+    const uint32_t base = g_lo * n_bins;
+    const uint64_t end = (uint64_t)g_hi * n_bins;
+    const uint32_t size = (uint32_t)(end < n_items ? end : n_items) - base;
+    return base + ldsbin_perm(p - base, size, key ^ ldsbin_mix(s * 0x27D4EB2Fu + 0x165667B1u));
+}
+
+static uint64_t level_share(uint64_t level, uint32_t cold, uint32_t c16) {
+    const uint64_t t = 16ull * cold;
+    return level > t ? (level - t) / c16 : 0ull;
+}
+
+/* The bookkeeping of one deal: bin_of_item [n_items] (may be NULL), cold_mass [n_bins], hot_off [n_bins + 1].  A cold
+ * draw costs 16, a hot one hot_cost_x16: level = the largest L with sum_b floor(max(0, L - 16 cold_b) / cost) <= H; the
+ * rest is dealt round robin from bin 0 (csrc/bpr_ldsbin.inc ldsbin_level_kernel). */
+void oracle_ldsbin_deal(uint32_t key, uint32_t n_bins, uint32_t n_items, uint32_t n_hot, uint32_t n_strata,
+                        uint32_t hot_cost_x16, const int32_t *rank_item, const int32_t *cptr, uint32_t n_hot_inter,
+                        int32_t *bin_of_item, uint32_t *cold_mass, uint32_t *hot_off) {
+    const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
+    for (uint32_t b = 0; b < n_bins; ++b) cold_mass[b] = 0;
+    for (uint32_t p = 0; p < n_items; ++p) {
+        const uint32_t g = p / n_bins, o = p % n_bins;
+        const uint32_t code = ldsbin_deal_rank(p, key, n_bins, n_items, n_groups, n_strata);
+        const uint32_t b = (o + ldsbin_rot(g, key, n_bins)) % n_bins;
+        const int32_t it = rank_item[code];
+        if (bin_of_item) bin_of_item[it] = (int32_t)b;
+        if (code >= n_hot) cold_mass[b] += (uint32_t)(cptr[it + 1] - cptr[it]);
+    }
+    uint64_t level = 0, given = 0;
+    if (hot_cost_x16 && n_hot_inter) {
+        uint64_t tot = 0;
+        for (uint32_t b = 0; b < n_bins; ++b) tot += cold_mass[b];
+        uint64_t lo = 0, hi = 16ull * tot + (uint64_t)hot_cost_x16 * ((uint64_t)n_hot_inter + 1ull);
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            uint64_t sum = 0;
+            for (uint32_t b = 0; b < n_bins; ++b) sum += level_share(mid, cold_mass[b], hot_cost_x16);
+            if (sum <= n_hot_inter) lo = mid; else hi = mid - 1;
+        }
+        level = lo;
+        for (uint32_t b = 0; b < n_bins; ++b) given += level_share(level, cold_mass[b], hot_cost_x16);
+    }
+    const uint64_t rest = (uint64_t)n_hot_inter - given;
+    hot_off[0] = 0;
+    for (uint32_t b = 0; b < n_bins; ++b) {
+        const uint32_t share = (uint32_t)((hot_cost_x16 && n_hot_inter) ? level_share(level, cold_mass[b], hot_cost_x16) : 0ull) +
+                               (uint32_t)(rest / n_bins) + (b < (uint32_t)(rest % n_bins) ? 1u : 0u);
+        hot_off[b + 1] = hot_off[b] + share;
+    }
 }
 
 uint32_t oracle_ldsbin_key(uint64_t seed, uint32_t epoch) {
@@ -589,11 +671,16 @@ static int csr_has(const int32_t *indices, int32_t lo, int32_t hi, int32_t col) 
 }
 
 int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
-                                  uint32_t n_hot, const int32_t *rank_item, const int32_t *cptr, const int32_t *cusers,
+                                  uint32_t n_hot, uint32_t n_strata, uint32_t hot_cost_x16, const int32_t *rank_item,
+                                  const int32_t *cptr, const int32_t *cusers,
                                   const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
                                   const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count,
                                   int neg_pop) {
     const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
+    uint32_t *cold_all = (uint32_t *)malloc(sizeof(uint32_t) * n_bins);
+    uint32_t *hot_off = (uint32_t *)malloc(sizeof(uint32_t) * (n_bins + 1));
+    oracle_ldsbin_deal(key, n_bins, n_items, n_hot, n_strata, hot_cost_x16, rank_item, cptr, n_hot_inter, NULL, cold_all,
+                       hot_off);
     int32_t *item = (int32_t *)malloc(sizeof(int32_t) * n_groups);
     int32_t *cp = (int32_t *)malloc(sizeof(int32_t) * n_groups);
     uint32_t *cum = (uint32_t *)malloc(sizeof(uint32_t) * (n_groups + 1));
@@ -603,10 +690,11 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
         uint32_t n_slots = n_groups;
         cum[0] = 0;
         for (uint32_t g = 0; g < n_groups; ++g) {
-            const uint32_t code = g * n_bins + (b + n_bins - ldsbin_rot(g, key, n_bins)) % n_bins;
+            const uint32_t pos = g * n_bins + (b + n_bins - ldsbin_rot(g, key, n_bins)) % n_bins;
             uint32_t d = 0;
             item[g] = -1; cp[g] = 0; hot[g] = 0;
-            if (code < n_items) {
+            if (pos < n_items) {
+                const uint32_t code = ldsbin_deal_rank(pos, key, n_bins, n_items, n_groups, n_strata);
                 item[g] = rank_item[code];
                 cp[g] = cptr[item[g]];
                 hot[g] = code < n_hot;
@@ -616,7 +704,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
         }
         if (n_groups && item[n_groups - 1] == -1) n_slots = n_groups - 1;
         const uint32_t cold_mass = cum[n_groups];
-        const uint32_t hot_share = n_hot_inter > b ? (n_hot_inter - b + n_bins - 1) / n_bins : 0u;
+        const uint32_t hot_lo = hot_off[b], hot_share = hot_off[b + 1] - hot_lo;
         const uint32_t n_draws = n_slots ? cold_mass + hot_share : 0u;
         if (!n_slots) skipped += cold_mass + hot_share;
         total += cold_mass + hot_share;
@@ -639,7 +727,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
                 excl_lo = cum[lo];
                 excl = cum[lo + 1] - excl_lo;
             } else {
-                const uint32_t h = b + n_bins * (r_pos - cold_mass);
+                const uint32_t h = hot_lo + (r_pos - cold_mass);
                 u = hot_u[h];
                 i = hot_i[h];
                 s_j = lemire_bounded2(w[2], w[3], n_slots);
@@ -659,7 +747,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
                     }
                     j = item[lo];
                 } else {
-                    j = hot_i[b + n_bins * (r_neg - cold_mass)];
+                    j = hot_i[hot_lo + (r_neg - cold_mass)];
                 }
             }
             if (csr_has(indices, indptr[u], indptr[u + 1], j)) { ++skipped; continue; }
@@ -667,7 +755,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
             if (neg_count) ++neg_count[j];
         }
     }
-    free(item); free(cp); free(cum); free(hot);
+    free(item); free(cp); free(cum); free(hot); free(cold_all); free(hot_off);
     if (n_draws_out) *n_draws_out = total;
     return skipped;
 }

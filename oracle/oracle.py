@@ -101,7 +101,12 @@ def _bind(L):
         L.oracle_strata_sample.restype = C.c_int64
         L.oracle_ldsbin_key.argtypes = [C.c_uint64, C.c_uint32]
         L.oracle_ldsbin_key.restype = C.c_uint32
-        L.oracle_ldsbin_epoch_skips.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i32p,
+        L.oracle_ldsbin_hot_shuffle_key.argtypes = [C.c_uint32]
+        L.oracle_ldsbin_hot_shuffle_key.restype = C.c_uint32
+        L.oracle_ldsbin_deal.argtypes = [C.c_uint32] * 6 + [i32p, i32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_ldsbin_deal.restype = None
+        L.oracle_ldsbin_epoch_skips.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, i32p,
                                                 i32p, i32p, i32p, i32p, C.c_uint32, i32p, i32p, C.POINTER(C.c_int64),
                                                 C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_ldsbin_epoch_skips.restype = C.c_int64
@@ -449,9 +454,18 @@ def strata_buckets(wave_ptr, own_u, own_i, deg, key, n_hot):
     return sptr, rec_u, rec_i, rank_item
 
 
-def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False, neg_pop=False):
-    """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
-    positive touches per item, negative touches per item])."""
+def _ldsbin_mix(h):
+    """murmur3 finaliser variant of csrc/bpr_ldsbin.inc ldsbin_mix on uint32 arrays."""
+    h = np.asarray(h, np.uint64) & 0xFFFFFFFF
+    h ^= h >> np.uint64(15); h = (h * np.uint64(0x85EBCA77)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE3D)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16)
+    return h.astype(np.uint32)
+
+
+def ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000):
+    """The static tables of the LDS-bin form (csrc/bpr.hip ldsbin_build): CSC, popularity ranks, hot items and their
+    interaction list in the shuffled order (stable order of a hash of the item-major list index)."""
     import scipy.sparse as sp
 
     indptr = np.ascontiguousarray(indptr, np.int32)
@@ -468,21 +482,56 @@ def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count
         n_hot += 1
     hot_u = np.concatenate([cusers[cptr[i]:cptr[i + 1]] for i in rank_item[:n_hot]] + [np.zeros(0, np.int32)]).astype(np.int32)
     hot_i = np.repeat(rank_item[:n_hot], deg[rank_item[:n_hot]]).astype(np.int32)
-    if len(hot_u) == 0:
-        hot_u = hot_i = np.zeros(1, np.int32)
-        n_hot_inter = 0
+    n_hot_inter = len(hot_u)
+    if n_hot_inter:
+        t = np.arange(n_hot_inter, dtype=np.uint64)
+        order = np.argsort(_ldsbin_mix((t * np.uint64(0x9E3779B1) + np.uint64(0x5BD1E995)) & 0xFFFFFFFF), kind="stable")
+        hot_u, hot_i = np.ascontiguousarray(hot_u[order]), np.ascontiguousarray(hot_i[order])
     else:
-        n_hot_inter = len(hot_u)
+        hot_u = hot_i = np.zeros(1, np.int32)
+    return dict(indptr=indptr, indices=indices, cptr=cptr, cusers=cusers, rank_item=rank_item, n_hot=n_hot, hot_u=hot_u,
+                hot_i=hot_i, n_hot_inter=n_hot_inter, deg=deg)
+
+
+def ldsbin_n_strata(n_items, n_bins, strata_groups):
+    return max(1, ((n_items + n_bins - 1) // n_bins) // max(1, strata_groups))
+
+
+def ldsbin_deal_key(key, n_bins, n_items, n_hot, n_strata, hot_cost_x16, rank_item, cptr, n_hot_inter):
+    """One deal by its 32-bit key: (bin_of_item, cold_mass, hot_off)."""
+    bin_of = np.empty(n_items, np.int32)
+    cold, off = np.empty(n_bins, np.uint32), np.empty(n_bins + 1, np.uint32)
+    lib().oracle_ldsbin_deal(int(key), int(n_bins), int(n_items), int(n_hot), int(n_strata), int(hot_cost_x16),
+                             np.ascontiguousarray(rank_item, np.int32), np.ascontiguousarray(cptr, np.int32),
+                             int(n_hot_inter), bin_of.ctypes.data, cold.ctypes.data, off.ctypes.data)
+    return bin_of, cold, off
+
+
+def ldsbin_deal(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, strata_groups=16, hot_cost_x16=32):
+    """CPU restatement of the deal of (seed, epoch): (bin_of_item, cold_mass, hot_off, hot_u, hot_i, n_hot)."""
+    t = ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000)
+    key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)))
+    bin_of, cold, off = ldsbin_deal_key(key, n_bins, n_items, t["n_hot"], ldsbin_n_strata(n_items, n_bins, strata_groups),
+                                        hot_cost_x16, t["rank_item"], t["cptr"], t["n_hot_inter"])
+    return bin_of, cold, off, t["hot_u"][:t["n_hot_inter"]], t["hot_i"][:t["n_hot_inter"]], t["n_hot"]
+
+
+def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False, neg_pop=False,
+                 strata_groups=16, hot_cost_x16=32, tables=None):
+    """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
+    positive touches per item, negative touches per item])."""
+    t = tables if tables is not None else ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000)
     key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)))
     draws = C.c_int64()
     pos = np.zeros(n_items, np.int64) if count_touches else None
     neg = np.zeros(n_items, np.int64) if count_touches else None
-    s = lib().oracle_ldsbin_epoch_skips(int(seed), int(epoch), key, int(n_bins), int(n_items), int(n_hot), rank_item,
-                                        cptr, cusers, np.ascontiguousarray(hot_u), np.ascontiguousarray(hot_i),
-                                        int(n_hot_inter), indptr, indices, C.byref(draws),
+    s = lib().oracle_ldsbin_epoch_skips(int(seed), int(epoch), key, int(n_bins), int(n_items), int(t["n_hot"]),
+                                        int(ldsbin_n_strata(n_items, n_bins, strata_groups)), int(hot_cost_x16),
+                                        t["rank_item"], t["cptr"], t["cusers"], t["hot_u"], t["hot_i"],
+                                        int(t["n_hot_inter"]), t["indptr"], t["indices"], C.byref(draws),
                                         pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None,
                                         int(bool(neg_pop)))
-    return (int(s), int(draws.value), n_hot) + ((pos, neg) if count_touches else ())
+    return (int(s), int(draws.value), t["n_hot"]) + ((pos, neg) if count_touches else ())
 
 
 def hogwild_sample_owned(seed, epoch, wave_id, length, n_neg, lo, hi):

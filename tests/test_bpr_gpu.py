@@ -293,15 +293,13 @@ def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
     c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
     st = tr.strata_stats()
     assert st["waves"] > 0 and st["bucket_builds"] == 2, "form 2 must run the strata kernel here: %r" % (st,)
-    # Placement is a property of the box, not of the code: on most boxes of the pool workgroup b sits on XCD b % 8 and
-    # nothing is misplaced; on some EVERY workgroup reads another HW_REG_XCC_ID (seen once, round 3).  A misplaced
-    # workgroup updates its item rows by atomics for that launch — slower, never wrong — so everything below must hold
-    # either way; the count is reported.
-    if st["misplaced_workgroups"]:
-        import warnings
-
-        warnings.warn("XCD strata: %d workgroups were not on XCD blockIdx %% 8 on this box (atomic fallback): %r"
-                      % (st["misplaced_workgroups"], st))
+    # A workgroup takes its part from the XCD it finds itself on (HW_REG_XCC_ID + a slot counter per XCD), so nothing
+    # depends on blockIdx -> XCD placement; only an XCD that is handed more than its eighth of a launch makes its surplus
+    # workgroups fall back to atomics (slower, never wrong — everything below holds either way).  More than 1 % of the
+    # workgroup launches on the fallback means the form is not running as designed on this box: fail, do not warn.
+    launches = 2 * 8 * (st["waves"] // 4)
+    assert st["misplaced_workgroups"] <= 0.01 * launches, \
+        "XCD strata: %d of %d workgroup launches fell back to atomics: %r" % (st["misplaced_workgroups"], launches, st)
     wave_ptr, own_u, own_i = tr.debug_ownership()
     W = len(wave_ptr) - 1
     deg = np.bincount(indices, minlength=n_items)
@@ -384,6 +382,27 @@ def test_ldsbin_sampler_matches_its_cpu_restatement(oracle):
     assert s2 == want and chunk > 5
 
 
+@pytest.mark.parametrize("groups,cost", [(16, 32), (4, 16), (1, 0)])
+def test_ldsbin_deal_matches_its_cpu_restatement(oracle, groups, cost):
+    """The per-epoch deal (ldsbin_deal_rank + ldsbin_mass_kernel + ldsbin_level_kernel): the bin of every item, the
+    bins' cold masses, the hot runs that level them and the shuffled hot list equal the oracle's restatement."""
+    n_users, n_items, indptr, indices = _ldsbin_case()
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, 32)
+    tr.ldsbin_config(hot_x1000=50, min_candidates=8)
+    tr.ldsbin_deal_config(strata_groups=groups, hot_cost_x16=cost)
+    assert tr.ldsbin_stats()["bins"] == 256
+    for seed, epoch in ((11, 0), (11, 5), (0xFFFFFFFFFF, 2)):
+        bin_of, cold, off, hu, hi = tr.debug_ldsbin_deal(seed, epoch)
+        w_bin, w_cold, w_off, w_hu, w_hi, n_hot = oracle.ldsbin_deal(seed, epoch, 256, 50, indptr, indices, n_items,
+                                                                      strata_groups=groups, hot_cost_x16=cost)
+        assert n_hot == tr.ldsbin_stats()["n_hot"] and n_hot > 0
+        assert np.array_equal(bin_of, w_bin)
+        assert np.array_equal(cold, w_cold)
+        assert np.array_equal(off, w_off)
+        assert np.array_equal(hu, w_hu) and np.array_equal(hi, w_hi)
+    tr.close()
+
+
 def test_ldsbin_updates_are_exact_and_learn_like_the_fused_kernel(oracle):
     """Every item-row update of the LDS-bin form is applied exactly once (LDS read-modify-write under the row lock, hot
     rows and user rows by atomics): with reg = 0 a triplet adds +d to row i and -d to row j, so the column sums of V and
@@ -437,7 +456,7 @@ def test_ldsbin_popularity_negatives_wbpr(oracle):
     tr.close()
     want, neg_tot = 0, np.zeros(n_items, np.int64)
     for epoch in range(2):
-        sk, draws, n_hot, pos, neg = oracle.ldsbin_epoch(seed, epoch, st["bins"], 100, indptr, indices, n_items,
+        sk, draws, n_hot, pos, neg = oracle.ldsbin_epoch(seed, epoch, st["bins"], 75, indptr, indices, n_items,
                                                          count_touches=True, neg_pop=True)
         assert draws == nnz and n_hot == st["n_hot"]
         want += sk

@@ -156,6 +156,74 @@ def test_hogwild_full_size_statistical_parity_with_cpu_threads(oracle, ml20m):
     assert abs(s_gpu - s_cpu) < 0.02 * s_cpu
 
 
+def test_hogwild_full_size_gate_against_the_reference_threads(ml20m):
+    """The default throughput form (LDS-bin) at BASELINE size against the REAL reference's threads: the compiled
+    `BPR._fit_sgd` of oracle/_ref (cornac/models/bpr/recom_bpr.pyx:231-267, OpenMP, 32 threads) driven with raw arrays as
+    `BPR.fit` drives it (recom_bpr.pyx:186-201).  Same data, init, hyper-parameters and epochs.  Two probes on fixed
+    samples: j uniform over all items (the reference's own negative population), and j among the 2 x 128
+    popularity-rank neighbours of i — the (positive, negative) pairs round 3's static rank groups could never draw; the
+    binned sampler has to have learned them as well as the reference's global draw did."""
+    from oracle import ref_loader
+
+    if not (ref_loader.available() or ref_loader.kernel_available()):
+        pytest.skip("oracle/_ref (the compiled reference kernel) is not built")
+    RNGVector, RefBPR = ref_loader.load_kernel_only()
+    n_users, n_items, indptr, indices, init_factors = ml20m
+    k, lr, reg, epochs = 64, 0.05, 0.01, 12  # (the rank-neighbour probe starts to move after ~8 epochs)
+    nnz = len(indices)
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+    deg = np.bincount(indices, minlength=n_items)
+    rank_item = np.argsort(-deg, kind="stable")
+    item_rank = np.empty(n_items, np.int64)
+    item_rank[rank_item] = np.arange(n_items)
+    rs = np.random.RandomState(1)
+    n = 300000
+    pick = rs.randint(nnz, size=n)
+    pu, pi = user_ids[pick], indices[pick]
+    pj_all = rs.randint(n_items, size=n)
+    delta = rs.randint(1, 129, size=n) * rs.choice([-1, 1], size=n)
+    pj_near = rank_item[np.clip(item_rank[pi] + delta, 0, n_items - 1)]
+    allk = np.sort(user_ids.astype(np.int64) * n_items + indices)
+    near_ok = (pj_near != pi) & ~np.isin(pu.astype(np.int64) * n_items + pj_near, allk)
+
+    def probes(U, V, B):
+        out = []
+        for j, ok in ((pj_all, None), (pj_near, near_ok)):
+            x = B[pi] - B[j] + np.einsum("nk,nk->n", U[pu], V[pi] - V[j])
+            x = x if ok is None else x[ok]
+            out += [float(np.mean(np.log1p(np.exp(-x)))), float(np.mean(x > 0))]
+        return out
+
+    U, V, B = init_factors(n_users, n_items, k, 3)
+    l0 = probes(U, V, B)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    assert tr.ldsbin_stats()["bins"] == 256
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(11)
+    tr.fit_epochs(epochs - 1, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c_gpu, s_gpu = tr.fit_epochs(1, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    g = probes(*tr.get_factors())
+    tr.close()
+    Ur, Vr, Br = init_factors(n_users, n_items, k, 3)
+    model = RefBPR(k=k, learning_rate=lr, lambda_reg=reg)
+    threads = min(32, os.cpu_count() or 1)
+    neg_item_ids = np.arange(n_items, dtype=np.int32)
+    ip, ix = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
+    for e in range(epochs):
+        c_ref, s_ref = model._fit_sgd(RNGVector(threads, nnz - 1, 100 + e), RNGVector(threads, n_items - 1, 200 + e), threads,
+                                      user_ids, ix, neg_item_ids, ip, Ur, Vr, Br)
+    r = probes(Ur, Vr, Br)
+    print("full-size gate vs the reference's %d threads after %d epochs: all-items probe loss %.4f -> gpu %.4f ref %.4f, acc "
+          "gpu %.4f ref %.4f | rank-neighbour probe loss %.4f -> gpu %.4f ref %.4f, acc gpu %.4f ref %.4f | correct gpu %.4f "
+          "ref %.4f | skipped gpu %d ref %d" % (threads, epochs, l0[0], g[0], r[0], g[1], r[1], l0[2], g[2], r[2], g[3], r[3],
+                                                 c_gpu / (nnz - s_gpu), c_ref / (nnz - s_ref), s_gpu, s_ref))
+    assert r[0] < 0.97 * l0[0] and r[2] < 0.98 * l0[2], "the task must be learnable on both probes for the gate to mean anything"
+    assert abs(g[0] - r[0]) < 0.03 * l0[0] and abs(g[1] - r[1]) < 0.015
+    assert abs(g[2] - r[2]) < 0.03 * l0[2] and abs(g[3] - r[3]) < 0.015
+    assert abs(c_gpu / (nnz - s_gpu) - c_ref / (nnz - s_ref)) < 0.015
+    assert abs(s_gpu - s_ref) < 0.02 * s_ref
+
+
 def test_mf_full_size_deterministic_and_hogwild(oracle, ml20m):
     """BASELINE configs[2] family at ML-20M size (20 M ratings, k = 128): one deterministic epoch against the
     sequential oracle (the reference's seeded loop), then the hogwild kernel's loss against the same oracle."""

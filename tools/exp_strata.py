@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the XCD-strata BPR epoch (csrc/bpr_strata.inc) against the fused atomic kernel at the ML-20M shape.
 
-An arm is a dash-separated spec: `atomic` (the fused kernel), `strata`, `ldsbin` (the form, hogwild_flags bits 16..19), then `uN` (LDS-bin triplets in flight, profile build), `xN` (LDS-bin hot_x1000),
+An arm is a dash-separated spec: `atomic` (the fused kernel), `strata`, `ldsbin` (the form, hogwild_flags bits 16..19), then `uN` (LDS-bin triplets in flight, profile build), `xN` (LDS-bin hot_x1000), `sgN` / `hcN` (LDS-bin deal: strata_groups, hot_cost_x16),
 `hN` (hot_permille), `mN` (hot_min_mult_x100), `rN` (rehash period), `vN` (kernel variant, profile build),
 `ablN` (ablation bits, profile build).  Run with CORNAC_HIP_PROFILE=1 for the v / abl tokens.
 Per arm: ms per epoch by HIP events (sum of the epoch's launches) and by wall clock, the 'correct' fraction of the last
@@ -56,6 +56,10 @@ def parse(spec):
             env["CORNAC_HIP_LDSBIN_UNR"] = tok[1:]
         elif tok.startswith("x"):
             cfg["hot_x1000"] = int(tok[1:])
+        elif tok.startswith("sg"):
+            cfg["strata_groups"] = int(tok[2:])
+        elif tok.startswith("hc"):
+            cfg["hot_cost_x16"] = int(tok[2:])
         elif tok.startswith("abl"):
             flags |= int(tok[3:]) << 8
         elif tok.startswith("h"):
@@ -76,8 +80,11 @@ def make(flags, cfg, env):
     os.environ.pop("CORNAC_HIP_LDSBIN_UNR", None)
     os.environ.update(env)
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    cfg = dict(cfg)
     if "hot_x1000" in cfg:
         tr.ldsbin_config(hot_x1000=cfg.pop("hot_x1000"))
+    if "strata_groups" in cfg or "hot_cost_x16" in cfg:
+        tr.ldsbin_deal_config(strata_groups=cfg.pop("strata_groups", 16), hot_cost_x16=cfg.pop("hot_cost_x16", 32))
     if cfg:
         tr.strata_config(**cfg)
     U, V, B = bench.init_factors(n_users, n_items, k, 100)
@@ -119,6 +126,11 @@ for name in args.arms.split(","):
     kms, launches = tr.kernel_timing(False)
     st = tr.strata_stats()
     lb = tr.ldsbin_stats() if (flags >> 16) in (0, 3) else None
+    if lb and lb["bins"]:
+        _, cold, off, _, _ = tr.debug_ldsbin_deal(0xC0FFEE, 3)
+        tot = cold.astype(np.int64) + np.diff(off.astype(np.int64))
+        lb["draws_max_over_mean"] = round(float(tot.max() / tot.mean()), 4)
+        lb["cold_max_over_mean"] = round(float(cold.max() / cold.mean()), 4)
     tr.close()
     n_ep = args.epochs - 1
     # lossless-ness: column sums of V under reg = 0
