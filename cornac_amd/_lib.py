@@ -281,6 +281,7 @@ class BprTrainer:
         self.shape = (int(total_users), int(total_items), int(k))
         self.nnz = len(self.indices)
         self.n_items = int(n_items)
+        self.device, self._stream = int(device), None
         self.h = _vp()
         check(lib().cornac_hip_bpr_create(C.byref(self.h), device, n_users, n_items, total_users, total_items, k,
                                           self.indptr, self.indices, self.nnz))
@@ -362,10 +363,12 @@ class BprTrainer:
 
     def set_stream(self, stream_ptr):
         check(lib().cornac_hip_bpr_set_stream(self.h, stream_ptr))
+        self._stream = stream_ptr
 
     def switch_stream(self, stream_ptr):
         """set_stream without waiting for the previous stream's queued work (the caller orders the streams)"""
         check(lib().cornac_hip_bpr_switch_stream(self.h, stream_ptr))
+        self._stream = stream_ptr
 
     # ---- row-sharded item table building blocks (device pointers; see cornac_amd/dist.py) -----------
     def sample_triplets(self, n_draws, d_u, d_i, d_j, neg_population=NEG_UNIFORM):
@@ -404,13 +407,25 @@ class BprTrainer:
     def scatter_diff_rows(self, d_table, d_ids, n, width, d_now, d_before, d_scale=None):
         check(lib().cornac_hip_bpr_scatter_diff_rows(self.h, d_table, d_ids, int(n), int(width), d_now, d_before, d_scale))
 
-    def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local):
+    # the replicated table's elementwise passes (ItemTableReplica); rule 0 = sqrt on the handle's stream, any other rule
+    # through the handle-free entry point on the stream handed to set_stream
+    def _delta(self, op, rule, *args):
+        assert getattr(self, "_stream", None), "set_stream() first: rule != 0 runs on the caller's stream"
+        check(lib().cornac_hip_table_delta(op | (int(rule) << 4), self.device, self._stream, *args))
+
+    def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local, rule=0):
+        if rule:
+            return self._delta(0, rule, d_flat, d_base, None, None, int(n_items), int(k), d_bucket, d_local)
         check(lib().cornac_hip_bpr_table_delta_begin(self.h, d_flat, d_base, int(n_items), int(k), d_bucket, d_local))
 
-    def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k):
+    def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k, rule=0):
+        if rule:
+            return self._delta(1, rule, d_flat, d_base, d_bucket, d_local, int(n_items), int(k), None, None)
         check(lib().cornac_hip_bpr_table_delta_finish(self.h, d_flat, d_base, d_bucket, d_local, int(n_items), int(k)))
 
-    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local):
+    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local, rule=0):
+        if rule:
+            return self._delta(2, rule, d_flat, d_base, d_bucket_prev, d_local_prev, int(n_items), int(k), d_bucket, d_local)
         check(lib().cornac_hip_bpr_table_delta_step(self.h, d_flat, d_base, d_bucket_prev, d_local_prev, int(n_items),
                                                     int(k), d_bucket, d_local))
 
@@ -569,18 +584,18 @@ class MfTrainer:
         check(lib().cornac_hip_mf_sync(self.h, C.byref(l)))
         return l.value
 
-    # the replicated table's elementwise passes (ItemTableReplica), on the stream of set_stream
-    def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local):
-        check(lib().cornac_hip_table_delta(0, self.device, self._stream, d_flat, d_base, None, None, int(n_items), int(k),
-                                           d_bucket, d_local))
-
-    def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k):
-        check(lib().cornac_hip_table_delta(1, self.device, self._stream, d_flat, d_base, d_bucket, d_local, int(n_items),
-                                           int(k), None, None))
-
-    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local):
-        check(lib().cornac_hip_table_delta(2, self.device, self._stream, d_flat, d_base, d_bucket_prev, d_local_prev,
+    # the replicated table's elementwise passes (ItemTableReplica), on the stream of set_stream; rule: dist.RULES
+    def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local, rule=0):
+        check(lib().cornac_hip_table_delta(0 | (int(rule) << 4), self.device, self._stream, d_flat, d_base, None, None,
                                            int(n_items), int(k), d_bucket, d_local))
+
+    def table_delta_finish(self, d_flat, d_base, d_bucket, d_local, n_items, k, rule=0):
+        check(lib().cornac_hip_table_delta(1 | (int(rule) << 4), self.device, self._stream, d_flat, d_base, d_bucket, d_local,
+                                           int(n_items), int(k), None, None))
+
+    def table_delta_step(self, d_flat, d_base, d_bucket_prev, d_local_prev, n_items, k, d_bucket, d_local, rule=0):
+        check(lib().cornac_hip_table_delta(2 | (int(rule) << 4), self.device, self._stream, d_flat, d_base, d_bucket_prev,
+                                           d_local_prev, int(n_items), int(k), d_bucket, d_local))
 
     OPTIMIZERS = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3}
 

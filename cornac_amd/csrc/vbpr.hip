@@ -8,24 +8,32 @@
 // moments still decay and move the parameter).  The (u, i, j) batches come from the host sampler
 // (Dataset.uij_iter, a Python-level iterator in the reference too) and are uploaded per fit call.
 //
-// Per Adam step t (batch of B triplets), on two streams of the handle:
+// Per Adam step t (batch of B triplets), on three streams of the handle.  The batches of a call are known up front, so
+// every step looks ONE batch ahead: the dense sweep of step t leaves out the rows of batch t AND of batch t + 1, and the
+// rows of batch t + 1 get their (gradient-free) step-t update from the small kernel that also updates batch t's rows.
+// The score of step t + 1 therefore never waits for sweep t — the sweeps run back to back on their own stream and the
+// small-kernel chain runs beside them (round 3: sweep t -> score t+1 -> ... -> touched t+1 -> sweep t+1 was ONE serial
+// chain, 54 + 24 us of a 94 us step).
+//   gather stream (one step ahead of the main stream; reads F and the index arrays only)
+//   vbpr_featdiff_kernel  DF[t & 1][b] = F[i_b] - F[j_b] (the "auxiliary-feature gather"); stamps batch t's rows
+//                         with t in stamp set t & 3 and clears proj[t & 1]
 //   main stream
-//   vbpr_featdiff_kernel  one workgroup per triplet: DF[b] = F[i_b] - F[j_b] (the "auxiliary-feature gather"),
-//                         v_b = DF[b] . b'; also stamps the batch's user / item rows with the step number and clears
-//                         proj[b]
 //   vbpr_proj_kernel      proj = DF E on the fp32 matrix cores (mfma_gemm.h), split over feature chunks
-//   vbpr_score_kernel     s_b from the gathered rows and proj_b (one wave per triplet)  [waits for sweep t-1]
-//   vbpr_pair_grad_kernel the reference's B x B broadcast objective -> gs_b, gv_b (one workgroup per b)
-//   vbpr_scatter_kernel   sparse row gradients scattered with fp32 atomics
-//   vbpr_touched_adam_kernel  Adam step of the rows the batch touched (each distinct row once; consumes and clears
-//                         its scattered gradient)
+//   vbpr_score_kernel     s_b from the gathered rows and proj_b, v_b = DF[b] . beta' (one wave per triplet)
+//   vbpr_pair_scatter_kernel  the reference's B x B broadcast objective -> gs_b, gv_b (one workgroup per b), which then
+//                         scatters b's sparse row gradients with fp32 atomics and writes b's row of W = [gs t_u | gv]
+//   vbpr_touched_adam_kernel  [waits for sweep t-1]  Adam step of the rows batch t touched (each distinct row once;
+//                         consumes and clears its scattered gradient) + the gradient-free step-t update of the rows of
+//                         batch t + 1 that batch t did not touch (each once)
 //   vbpr_feat_adam_kernel gradient of E / beta' (DF^T x [gs t_u | gv] on the matrix cores) fused with their Adam step
-//   sweep stream (starts as soon as the rows are stamped, runs beside everything above)
-//   adam_sweep_kernel     dense Adam over Bi, Gu, Gi, Tu for every row NOT stamped with t: their gradient is exactly
-//                         zero (the L2 terms only cover the batch rows, recom_vbpr.py:251-253), so the sweep reads and
-//                         writes p, m, v only — 24 bytes per parameter and step
-// HBM-bound by the dense Adam sweep (all parameters + two moments per step); the latency-bound chain of small
-// kernels hides behind it.
+//   sweep stream  [sweep t waits for touched t-1 and for the stamps of batch t + 1]
+//   adam_sweep_kernel     dense Adam over Bi, Gu, Gi, Tu for every row NOT stamped with t or t + 1: their gradient is
+//                         exactly zero (the L2 terms only cover the batch rows, recom_vbpr.py:251-253), so the sweep
+//                         reads and writes p, m, v only — 24 bytes per parameter and step
+// Why this is the reference's arithmetic: every row receives exactly one Adam update per step, computed from its state
+// after the previous step, with the step's own scalars — by the sweep, by the batch's own update, or by the look-ahead
+// update (the same adam_update(g = 0) as the sweep's) — and a row is only ever read for a score after its last update.
+// HBM-bound by the dense Adam sweep (all parameters + two moments per step).
 #include <algorithm>
 #include <cmath>
 
@@ -55,16 +63,23 @@ struct VbprTables {
 //   d loss / d s_b = gs_b = sum_a G[a, b]   (drives b_i, b_j, g_u, g_i, g_j, t_u and E)
 //   d loss / d v_a = gv_a = sum_b G[a, b]   (drives b')
 
-// stage 1a — kFeatSlices workgroups per triplet: feature difference DF[b, :] = F[i_b] - F[j_b] (coalesced row reads,
-// written once for the two feature GEMMs of the step) and the slice's part of v_b = DF[b] . b' (summed in a fixed
-// order by the consumer).  Slice 0 also stamps the batch's rows with the step number and clears proj[b].
+// Stamp sets.  Step s stamps its batch rows in set s & 3 with one of three codes, all of which mean "row of batch s":
+//   s            stamped by the gather (vbpr_featdiff_kernel)
+//   s | kStPre   the look-ahead update of step s - 1 ran (vbpr_touched_adam_kernel of step s - 1 claimed the row)
+//   -s           the batch's own update of step s ran (vbpr_touched_adam_kernel of step s claimed the row)
+// Four sets: the sweep of step s reads sets s & 3 and (s + 1) & 3 while batch s + 2 is being stamped.
+constexpr int32_t kStPre = 1 << 30;
+__device__ __forceinline__ bool stamp_is(int32_t v, int32_t s) { return v == s || v == (s | kStPre) || v == -s; }
+
+// stage 0 (gather stream, one step ahead) — kFeatSlices workgroups per triplet: feature difference
+// DF[b, :] = F[i_b] - F[j_b] (coalesced row reads, written once for the two feature GEMMs and the beta' product of the
+// step).  Slice 0 also stamps the batch's rows with the step number and clears proj[b].  Reads nothing that training
+// writes.
 constexpr int kFeatSlices = 4;
 __global__ __launch_bounds__(kVb) void vbpr_featdiff_kernel(const VbprTables t, const int32_t *__restrict__ bu,
                                                             const int32_t *__restrict__ bi,
                                                             const int32_t *__restrict__ bj, float *__restrict__ DF,
-                                                            float *__restrict__ v_part, float *__restrict__ proj,
-                                                            int32_t step) {
-    __shared__ float red[kVb / 64];
+                                                            float *__restrict__ proj, int32_t step) {
     const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
     if (sl == 0) {
         if (tid == 0) {  // (several triplets may name the same row: they all write the same value)
@@ -76,22 +91,15 @@ __global__ __launch_bounds__(kVb) void vbpr_featdiff_kernel(const VbprTables t, 
     }
     const float *fi = t.F + (int64_t)bi[b] * t.n_feat, *fj = t.F + (int64_t)bj[b] * t.n_feat;
     float *df = DF + (int64_t)b * t.n_feat;
-    const int per = (t.n_feat + kFeatSlices - 1) / kFeatSlices;
-    const int f_end = min(t.n_feat, (sl + 1) * per);
-    float vb = 0.f;
-    for (int f = sl * per + tid; f < f_end; f += kVb) {
-        const float d = fi[f] - fj[f];
-        df[f] = d;
-        vb = fmaf(d, t.Bp[f], vb);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vb += __shfl_xor(vb, o, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = vb;
-    __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int w = 0; w < kVb / 64; ++w) tot += red[w];
-        v_part[(size_t)b * kFeatSlices + sl] = tot;
+    const int per = (((t.n_feat + kFeatSlices - 1) / kFeatSlices) + 3) & ~3;
+    const int f_begin = sl * per, f_end = min(t.n_feat, (sl + 1) * per);
+    if ((t.n_feat & 3) == 0) {
+        for (int f = f_begin + 4 * tid; f < f_end; f += 4 * kVb) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(fi + f), y = *reinterpret_cast<const f32x4 *>(fj + f);
+            *reinterpret_cast<f32x4 *>(df + f) = x - y;
+        }
+    } else {
+        for (int f = f_begin + tid; f < f_end; f += kVb) df[f] = fi[f] - fj[f];
     }
 }
 
@@ -110,11 +118,12 @@ __global__ __launch_bounds__(kWb) void vbpr_proj_kernel(const float *__restrict_
     });
 }
 
-// stage 1c — s_b = b_i - b_j + <g_u, g_i - g_j> + <t_u, proj_b>: one wave per triplet
+// stage 1c — s_b = b_i - b_j + <g_u, g_i - g_j> + <t_u, proj_b> and v_b = DF[b] . beta': one wave per triplet
 __global__ __launch_bounds__(kVb) void vbpr_score_kernel(const VbprTables t, const int32_t *__restrict__ bu,
                                                          const int32_t *__restrict__ bi,
                                                          const int32_t *__restrict__ bj, int n,
-                                                         const float *__restrict__ proj, float *__restrict__ s_out) {
+                                                         const float *__restrict__ proj, const float *__restrict__ DF,
+                                                         float *__restrict__ s_out, float *__restrict__ v_out) {
     const int b = (blockIdx.x * kVb + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (b >= n) return;
     const int64_t u = bu[b], i = bi[b], j = bj[b];
@@ -122,30 +131,55 @@ __global__ __launch_bounds__(kVb) void vbpr_score_kernel(const VbprTables t, con
     float part = 0.f;
     for (int q = lane; q < t.k; q += 64) part = fmaf(gu[q], gi[q] - gj[q], part);
     for (int q = lane; q < t.k2; q += 64) part = fmaf(tu[q], proj[(size_t)b * t.k2 + q], part);
+    const float *df = DF + (int64_t)b * t.n_feat;
+    float vb = 0.f;
+    if ((t.n_feat & 3) == 0) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int f = 4 * lane; f < t.n_feat; f += 256) {
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(df + f), w = *reinterpret_cast<const f32x4 *>(t.Bp + f);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (lane == 0) s_out[b] = (t.Bi[i] - t.Bi[j]) + part;
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(d[e], w[e], acc[e]);
+        }
+        vb = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } else {
+        for (int f = lane; f < t.n_feat; f += 64) vb = fmaf(df[f], t.Bp[f], vb);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        part += __shfl_xor(part, o, 64);
+        vb += __shfl_xor(vb, o, 64);
+    }
+    if (lane == 0) {
+        s_out[b] = (t.Bi[i] - t.Bi[j]) + part;
+        v_out[b] = vb;
+    }
 }
 
-// stage 2 — the B x B broadcast objective: gs_b = sum_a G[a,b], gv_a = sum_b G[a,b], NLL = sum softplus(-X).
-// One workgroup per b, threads over a (strided): column b and row b of G in one pass.
-__global__ __launch_bounds__(kVb) void vbpr_pair_grad_kernel(const float *__restrict__ s, const float *__restrict__ v,
-                                                             int n, float *__restrict__ gs, float *__restrict__ gv,
-                                                             double *__restrict__ loss_acc) {
-    __shared__ float red_c[kVb / 64], red_r[kVb / 64];
+// stage 2 — the B x B broadcast objective and the sparse row gradients in one launch.  One workgroup per b, threads over
+// a (strided): column b and row b of G in one pass give gs_b = sum_a G[a,b] and gv_b = sum_b' G[b,b'] (NLL = sum
+// softplus(-X)) — both belong to triplet b, so the same workgroup goes on to scatter b's row gradients with fp32 atomics
+// (duplicates inside a batch accumulate, like autograd's index_put accumulate) and to write b's row of the right-hand
+// side of the E / beta' gradient GEMM, W[b, :] = [gs_b * t_u | gv_b | 0 padding].
+__global__ __launch_bounds__(kVb) void vbpr_pair_scatter_kernel(const VbprTables t, const int32_t *__restrict__ bu,
+                                                                const int32_t *__restrict__ bi,
+                                                                const int32_t *__restrict__ bj, int n,
+                                                                const float *__restrict__ s, const float *__restrict__ v,
+                                                                const float *__restrict__ proj, float lambda_w,
+                                                                float lambda_b, float *__restrict__ W, int ldw,
+                                                                double *__restrict__ loss_acc) {
+    __shared__ float red_c[kVb / 64], red_r[kVb / 64], sh_g[2];
     __shared__ double red_n[kVb / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
-    auto v_of = [&](int x) {  // the feature slices' parts of v_x, always summed in the same order
-        float tot = 0.f;
-#pragma unroll
-        for (int q = 0; q < kFeatSlices; ++q) tot += v[(size_t)x * kFeatSlices + q];
-        return tot;
-    };
-    const float sb = s[b], vb = v_of(b);
+    const int64_t u = bu[b], i = bi[b], j = bj[b];
+    const int k2 = t.k2;
+    // the batch rows this workgroup needs after the reduction: requested before it
+    const float *gu = t.Gu + u * t.k, *gi = t.Gi + i * t.k, *gj = t.Gi + j * t.k, *tu = t.Tu + u * k2;
+    const float sb = s[b], vb = v[b];
     float col = 0.f, row = 0.f;
     double nll = 0.0;
     for (int a = tid; a < n; a += kVb) {
-        const float X = sb + v_of(a);              // X[a, b]
+        const float X = sb + v[a];                 // X[a, b]
         col += -1.0f / (1.0f + expf(X));
         nll += (X > 0.f) ? log1p(exp(-(double)X)) : (-(double)X + log1p(exp((double)X)));
         const float Y = s[a] + vb;                 // X[b, a]
@@ -171,28 +205,14 @@ __global__ __launch_bounds__(kVb) void vbpr_pair_grad_kernel(const float *__rest
             r += red_r[w];
             l += red_n[w];
         }
-        gs[b] = c;
-        gv[b] = r;
+        sh_g[0] = c;
+        sh_g[1] = r;
         atomicAdd(loss_acc, l);
     }
-}
-
-// stage 3 — sparse row gradients (duplicates inside a batch accumulate, like autograd's index_put accumulate)
-__global__ __launch_bounds__(kVb) void vbpr_scatter_kernel(const VbprTables t, const int32_t *__restrict__ bu,
-                                                           const int32_t *__restrict__ bi,
-                                                           const int32_t *__restrict__ bj, int n,
-                                                           const float *__restrict__ gs,
-                                                           const float *__restrict__ gv,
-                                                           const float *__restrict__ proj, float lambda_w,
-                                                           float lambda_b, float *__restrict__ W, int ldw) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t u = bu[b], i = bi[b], j = bj[b];
-    const float g = gs[b];
-    const int k2 = t.k2;
-    // right-hand side of the E / beta' gradient GEMM: W[b, :] = [gs_b * t_u | gv_b | 0 padding]
+    __syncthreads();
+    const float g = sh_g[0], gvb = sh_g[1];
     for (int q = tid; q < ldw; q += kVb)
-        W[(size_t)b * ldw + q] = q < k2 ? g * t.Tu[u * k2 + q] : (q == k2 ? gv[b] : 0.f);
-    const float *gu = t.Gu + u * t.k, *gi = t.Gi + i * t.k, *gj = t.Gi + j * t.k, *tu = t.Tu + u * k2;
+        W[(size_t)b * ldw + q] = q < k2 ? g * tu[q] : (q == k2 ? gvb : 0.f);
     if (tid == 0) {
         atomicAdd(t.gBi + i, g + lambda_b * t.Bi[i]);
         atomicAdd(t.gBi + j, -g + (lambda_b / 10.f) * t.Bi[j]);
@@ -221,7 +241,7 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
 }
 
 // Gradient of E / beta' over the batch fused with their Adam step:
-//   [dE | dbeta'] = DF^T [gs_b t_u | gv_b]   ([n_feat, B] x [B, k2 + 1]; W is written by the scatter kernel)
+//   [dE | dbeta'] = DF^T [gs_b t_u | gv_b]   ([n_feat, B] x [B, k2 + 1]; W is written by vbpr_pair_scatter_kernel)
 // fpb (<= 8) features per workgroup, fpb * (k2 + 1) <= 4 outputs per thread.  This kernel runs BESIDE the dense Adam sweep, where every memory round trip
 // costs several microseconds: all its loads (its parameters and moments, its DF columns, W) are independent and issued
 // up front, and there are n_feat / 8 workgroups of them in flight; the 26 MFLOP of products come out of the LDS.
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(kVb) void vbpr_feat_adam_kernel(const float *__rest
 // and the parameter moves, torch.optim.Adam's dense semantics).  One launch over all tables; 16-byte accesses.
 struct SweepTable {
     float *p, *m, *v;
-    const int32_t *stamp;
+    const int32_t *stamp, *stamp_next;  // the row's stamps in the sets of step and step + 1 (the same set when there is no next batch)
     int64_t begin;       // first unit of this table in the launch's global index space
     int units_per_row;   // float4 units (width / 4) when vec, floats (width) otherwise
     int vec;
@@ -283,7 +303,7 @@ struct SweepTable {
 struct SweepArgs {
     SweepTable tab[4];
     int64_t total;
-    int32_t step;
+    int32_t step, step_next;  // step_next = step when the call has no further batch
 };
 
 __global__ __launch_bounds__(kVb) void adam_sweep_kernel(const SweepArgs s, const AdamScalars a) {
@@ -293,8 +313,9 @@ __global__ __launch_bounds__(kVb) void adam_sweep_kernel(const SweepArgs s, cons
         for (int c = 1; c < 4; ++c) q += i >= s.tab[c].begin ? 1 : 0;
         const SweepTable &tb = s.tab[q];
         const int64_t local = i - tb.begin;
-        const int32_t st = tb.stamp[local / tb.units_per_row];
-        if (st == s.step || st == -s.step) continue;  // the batch's rows: vbpr_touched_adam_kernel
+        const int64_t row = local / tb.units_per_row;
+        // rows of this step's batch and of the next one: vbpr_touched_adam_kernel
+        if (stamp_is(tb.stamp[row], s.step) || stamp_is(tb.stamp_next[row], s.step_next)) continue;
         if (tb.vec) {
             f32x4 p = reinterpret_cast<const f32x4 *>(tb.p)[local], m = reinterpret_cast<const f32x4 *>(tb.m)[local],
                   v = reinterpret_cast<const f32x4 *>(tb.v)[local];
@@ -315,42 +336,60 @@ __global__ __launch_bounds__(kVb) void adam_sweep_kernel(const SweepArgs s, cons
     }
 }
 
-// Adam step of the rows the batch touched, each distinct row exactly once: the first of the (up to 3 B) references
-// that flips the row's stamp from +step to -step owns it.  Reads and clears the scattered gradient.
+// Workgroups [0, n): Adam step of the rows batch `step` touched, each distinct row exactly once — the first of the
+// (up to 3 B) references that flips the row's stamp from step (or step | kStPre) to -step owns it; reads and clears the
+// scattered gradient.  Workgroups [n, n + n_next): the rows of batch step + 1 that batch `step` did not touch get this
+// step's gradient-free update here (the sweep of this step leaves them out), each once: claimed by flipping the stamp in
+// the next set from step + 1 to (step + 1) | kStPre.
+struct VbprMoments {
+    float *mBi, *vBi, *mGu, *vGu, *mGi, *vGi, *mTu, *vTu;
+};
 __global__ __launch_bounds__(kVb) void vbpr_touched_adam_kernel(const VbprTables t, const int32_t *__restrict__ bu,
                                                                 const int32_t *__restrict__ bi,
-                                                                const int32_t *__restrict__ bj, int32_t step,
-                                                                float *mBi, float *vBi, float *mGu, float *vGu, float *mGi,
-                                                                float *vGi, float *mTu, float *vTu, const AdamScalars a) {
+                                                                const int32_t *__restrict__ bj, int n, int32_t step,
+                                                                int32_t *stamp_u_next, int32_t *stamp_i_next,
+                                                                const VbprMoments mo, const AdamScalars a) {
     __shared__ int own[3];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool ahead = b >= n;  // (the index arrays of batch step + 1 follow batch step's: b indexes both)
     const int64_t u = bu[b], i = bi[b], j = bj[b];
-    if (tid == 0) own[0] = atomicCAS(t.stamp_u + u, step, -step) == step;
-    if (tid == 1) own[1] = atomicCAS(t.stamp_i + i, step, -step) == step;
+    auto claim = [&](int32_t *cur, int32_t *next, int64_t r) -> int {
+        if (!ahead) {
+            if (atomicCAS(cur + r, step, -step) == step) return 1;
+            return atomicCAS(cur + r, step | kStPre, -step) == (step | kStPre);
+        }
+        if (stamp_is(cur[r], step)) return 0;  // in this step's batch too: updated with its gradient above
+        return atomicCAS(next + r, step + 1, (step + 1) | kStPre) == step + 1;
+    };
+    if (tid == 0) own[0] = claim(t.stamp_u, stamp_u_next, u);
+    if (tid == 1) own[1] = claim(t.stamp_i, stamp_i_next, i);
     __syncthreads();  // (i == j cannot happen for a valid triplet, but stay exact if it does: j claims after i)
-    if (tid == 2) own[2] = atomicCAS(t.stamp_i + j, step, -step) == step;
+    if (tid == 2) own[2] = claim(t.stamp_i, stamp_i_next, j);
     __syncthreads();
     auto row = [&](float *P, float *M, float *V, float *G, int64_t r, int width) {
         for (int q = tid; q < width; q += kVb) {
             const int64_t o = r * width + q;
-            const float g = G[o];
+            float g = 0.f;
+            if (!ahead) {
+                g = G[o];
+                G[o] = 0.f;
+            }
             float p = P[o], m = M[o], v = V[o];
             adam_update(p, m, v, g, a);
             P[o] = p; M[o] = m; V[o] = v;
-            G[o] = 0.f;
         }
     };
     if (own[0]) {
-        row(t.Gu, mGu, vGu, t.gGu, u, t.k);
-        row(t.Tu, mTu, vTu, t.gTu, u, t.k2);
+        row(t.Gu, mo.mGu, mo.vGu, t.gGu, u, t.k);
+        row(t.Tu, mo.mTu, mo.vTu, t.gTu, u, t.k2);
     }
     if (own[1]) {
-        row(t.Gi, mGi, vGi, t.gGi, i, t.k);
-        row(t.Bi, mBi, vBi, t.gBi, i, 1);
+        row(t.Gi, mo.mGi, mo.vGi, t.gGi, i, t.k);
+        row(t.Bi, mo.mBi, mo.vBi, t.gBi, i, 1);
     }
     if (own[2]) {
-        row(t.Gi, mGi, vGi, t.gGi, j, t.k);
-        row(t.Bi, mBi, vBi, t.gBi, j, 1);
+        row(t.Gi, mo.mGi, mo.vGi, t.gGi, j, t.k);
+        row(t.Bi, mo.mBi, mo.vBi, t.gBi, j, 1);
     }
 }
 
@@ -395,15 +434,19 @@ struct cornac_hip_vbpr {
     int64_t n_users = 0, n_items = 0;
     int k = 0, k2 = 0, n_feat = 0;
     hipStream_t stream = nullptr;
-    hipStream_t sweep_stream = nullptr;           // the dense Adam sweep runs beside the step's small kernels
-    hipEvent_t ev_stamped = nullptr, ev_swept = nullptr;
+    hipStream_t sweep_stream = nullptr;           // the dense Adam sweeps, back to back beside the steps' small kernels
+    hipStream_t gather_stream = nullptr;          // feature gather + row stamps, one step ahead
+    // hand-overs (attached to the producing kernel's completion signal, hipExtLaunchKernelGGL): [step & 1]
+    hipEvent_t ev_df[2] = {nullptr, nullptr};     // featdiff of the step done: DF / proj / the stamps of its batch are ready
+    hipEvent_t ev_fa[2] = {nullptr, nullptr};     // feat_adam of the step done: its DF / proj buffers are free again
+    hipEvent_t ev_swept[2] = {nullptr, nullptr};  // sweep of the step done
+    hipEvent_t ev_touched = nullptr;              // the batch rows' own update of the step done
     DevBuf<float> F, Bi, Gu, Gi, Tu, E, Bp;
     DevBuf<float> gBi, gGu, gGi, gTu;
     DevBuf<int32_t> stamp_u, stamp_i;
-    bool sweep_pending = false;
     DevBuf<float> mBi, vBi, mGu, vGu, mGi, vGi, mTu, vTu, mE, vE, mBp, vBp;
     DevBuf<int32_t> bu, bi, bj;
-    DevBuf<float> sX, vX, gS, gV, proj, DF, W;
+    DevBuf<float> sX, vX, proj, DF, W;
     DevBuf<double> loss;
     int64_t step = 0;
 };
@@ -438,12 +481,14 @@ int cornac_hip_vbpr_create(cornac_hip_vbpr_t *out, int device, int64_t n_users, 
         h->device = device; h->n_users = n_users; h->n_items = n_items; h->k = k; h->k2 = k2; h->n_feat = n_feat;
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->sweep_stream, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&h->ev_stamped, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&h->ev_swept, hipEventDisableTiming));
-        h->stamp_u.alloc((size_t)2 * n_users);   // two sets, used by alternate steps: the sweep of step t still reads
-        h->stamp_i.alloc((size_t)2 * n_items);   // its set while step t+1's rows are being stamped
-        HIP_CHECK(hipMemsetAsync(h->stamp_u.p, 0, (size_t)2 * n_users * sizeof(int32_t), h->stream));
-        HIP_CHECK(hipMemsetAsync(h->stamp_i.p, 0, (size_t)2 * n_items * sizeof(int32_t), h->stream));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->gather_stream, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&h->ev_df[0], &h->ev_df[1], &h->ev_fa[0], &h->ev_fa[1], &h->ev_swept[0], &h->ev_swept[1],
+                              &h->ev_touched})
+            HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        h->stamp_u.alloc((size_t)4 * n_users);   // four sets, set s & 3 for step s (see kStPre)
+        h->stamp_i.alloc((size_t)4 * n_items);
+        HIP_CHECK(hipMemsetAsync(h->stamp_u.p, 0, (size_t)4 * n_users * sizeof(int32_t), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->stamp_i.p, 0, (size_t)4 * n_items * sizeof(int32_t), h->stream));
         h->F.alloc((size_t)n_items * n_feat);
         h->F.upload(features, (size_t)n_items * n_feat, h->stream);
         struct Tab { DevBuf<float> *p, *m, *v, *g; size_t n; };
@@ -470,16 +515,13 @@ int cornac_hip_vbpr_destroy(cornac_hip_vbpr_t h) {
     return guarded([&] {
         if (!h) return;
         (void)hipSetDevice(h->device);
-        if (h->sweep_stream) {
-            (void)hipStreamSynchronize(h->sweep_stream);
-            (void)hipStreamDestroy(h->sweep_stream);
+        for (hipStream_t st : {h->gather_stream, h->sweep_stream, h->stream}) {
+            if (!st) continue;
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
         }
-        if (h->stream) {
-            (void)hipStreamSynchronize(h->stream);
-            (void)hipStreamDestroy(h->stream);
-        }
-        if (h->ev_stamped) (void)hipEventDestroy(h->ev_stamped);
-        if (h->ev_swept) (void)hipEventDestroy(h->ev_swept);
+        for (hipEvent_t e : {h->ev_df[0], h->ev_df[1], h->ev_fa[0], h->ev_fa[1], h->ev_swept[0], h->ev_swept[1], h->ev_touched})
+            if (e) (void)hipEventDestroy(e);
         delete h;
     });
 }
@@ -527,16 +569,15 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         h->bu.upload(u, (size_t)n_total, h->stream);
         h->bi.upload(i, (size_t)n_total, h->stream);
         h->bj.upload(j, (size_t)n_total, h->stream);
-        h->sX.ensure((size_t)batch_size); h->vX.ensure((size_t)batch_size * kFeatSlices);
-        h->gS.ensure((size_t)batch_size); h->gV.ensure((size_t)batch_size);
-        h->proj.ensure((size_t)batch_size * h->k2);
+        h->sX.ensure((size_t)batch_size); h->vX.ensure((size_t)batch_size);
+        h->proj.ensure((size_t)2 * batch_size * h->k2);          // [step & 1]
         const int ldw = (h->k2 + 1 + 3) & ~3;
         const int fpb = std::max(1, std::min(kFeatPerBlock, 4 * kVb / (h->k2 + 1)));
         h->W.ensure((size_t)batch_size * ldw);
         HIP_CHECK(hipMemsetAsync(h->loss.p, 0, sizeof(double), h->stream));
         const VbprTables t0 = vb_tables(h);
         const DeviceInfo &di = device_info(h->device);
-        h->DF.ensure((size_t)batch_size * h->n_feat);
+        h->DF.ensure((size_t)2 * batch_size * h->n_feat);        // [step & 1]
         // feature chunks of the split-K projection GEMM: a multiple of the k tile, ~2 workgroups per CU
         // (two k-tiles per workgroup measured best: 16 / 32 / 64 / 128 features per chunk -> 63.1 / 61.0 / 64.5 / 72.1 us per
         // step of the small-kernel chain at n_feat = 4096)
@@ -556,7 +597,7 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             for (int q = 0; q < 4; ++q) {
                 const bool vec = tabs[q].width % 4 == 0;
                 sw.tab[q].p = tabs[q].p->p; sw.tab[q].m = tabs[q].m->p; sw.tab[q].v = tabs[q].v->p;
-                sw.tab[q].stamp = tabs[q].stamp->p;
+                sw.tab[q].stamp = sw.tab[q].stamp_next = tabs[q].stamp->p;
                 sw.tab[q].begin = at;
                 sw.tab[q].units_per_row = vec ? tabs[q].width / 4 : tabs[q].width;
                 sw.tab[q].vec = vec ? 1 : 0;
@@ -565,21 +606,47 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             sw.total = at;
         }
         // 7 of the 8 workgroup slots of a CU: the sweep is persistent (grid-stride) and would otherwise hold every wave
-        // slot of the chip until it ends, and the kernels of the main stream could not even start beside it
-        // (measured per step: 8 slots on ONE stream 99.8 us; two streams 7 slots 91.9, 6 slots 94.2, 5 slots 95.8)
+        // slot of the chip until it ends, and the kernels of the other streams could not even start beside it
         const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 7);
         const int sweep_grid = (int)std::min<int64_t>((sw.total + kVb - 1) / kVb, (int64_t)di.cus * sweep_wg_per_cu);
-        const bool one_stream = prof_env_set("CORNAC_HIP_VBPR_ONE_STREAM");  // A/B switch (profile builds): everything in stream order
-        const bool ext_events = !prof_env_set("CORNAC_HIP_VBPR_PLAIN_EVENTS");  // A/B switch (profile builds): hipEventRecord hand-overs
+        // A/B switch (profile builds): no look-ahead — the sweep leaves out its own batch only and the next score waits for it
+        const bool look_ahead = !prof_env_set("CORNAC_HIP_VBPR_NO_LOOKAHEAD");
+        const VbprMoments mo = {h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p, h->mTu.p, h->vTu.p};
+        const int64_t n_steps = (n_total + batch_size - 1) / batch_size;
+        REQUIRE(h->step + n_steps < (int64_t(1) << 30), "step counter exceeds 30 bits");
+        auto set_of = [&](VbprTables &t, int64_t step) {
+            t.stamp_u = h->stamp_u.p + (size_t)(step & 3) * h->n_users;
+            t.stamp_i = h->stamp_i.p + (size_t)(step & 3) * h->n_items;
+        };
+        // the gather of the batch at b0 (step number `step`): waits until the step that last used its buffers has let go
+        auto enqueue_gather = [&](int64_t b0, int64_t step, bool wait_free) {
+            const int n = (int)std::min<int64_t>(batch_size, n_total - b0), par = (int)(step & 1);
+            VbprTables t = t0;
+            set_of(t, step);
+            if (wait_free) HIP_CHECK(hipStreamWaitEvent(h->gather_stream, h->ev_fa[par], 0));
+            hipExtLaunchKernelGGL(vbpr_featdiff_kernel, dim3(n, kFeatSlices), dim3(kVb), 0, h->gather_stream, nullptr,
+                                  h->ev_df[par], 0, t, (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
+                                  (const int32_t *)(h->bj.p + b0), h->DF.p + (size_t)par * batch_size * h->n_feat,
+                                  h->proj.p + (size_t)par * batch_size * h->k2, (int32_t)step);
+        };
+        // the index arrays are read by all three streams: uploaded before anything is enqueued
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        // (the previous call ended with every stream drained and every row swept: nothing to wait for at the first step)
+        enqueue_gather(0, h->step + 1, false);
+        HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[(h->step + 1) & 1], 0));
+        int64_t first = h->step + 1;
         for (int64_t b0 = 0; b0 < n_total; b0 += batch_size) {
             const int n = (int)std::min<int64_t>(batch_size, n_total - b0);
             ++h->step;
-            REQUIRE(h->step < (int64_t(1) << 31), "step counter exceeds 31 bits");
             const int32_t step = (int32_t)h->step;
             const int par = (int)(h->step & 1);
-            VbprTables t = t0;
-            t.stamp_u = h->stamp_u.p + (size_t)par * h->n_users;
-            t.stamp_i = h->stamp_i.p + (size_t)par * h->n_items;
+            const bool has_next = b0 + batch_size < n_total;
+            const bool ahead = has_next && look_ahead;
+            const int n_next = ahead ? (int)std::min<int64_t>(batch_size, n_total - b0 - batch_size) : 0;
+            VbprTables t = t0, t_next = t0;
+            set_of(t, h->step);
+            set_of(t_next, ahead ? h->step + 1 : h->step);
+            float *DF = h->DF.p + (size_t)par * batch_size * h->n_feat, *proj = h->proj.p + (size_t)par * batch_size * h->k2;
             // torch computes these in Python doubles and hands float scalars to the kernels
             const double b1 = 0.9, b2 = 0.999;
             const double bc1 = 1.0 - std::pow(b1, (double)h->step), bc2 = 1.0 - std::pow(b2, (double)h->step);
@@ -589,62 +656,59 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             a.step_size = (float)((double)lr / bc1);
             a.bc2_sqrt = (float)std::sqrt(bc2);
             a.eps = 1e-8f;
-            // (these two only read F, E, beta' and the batch's indices: they run beside the PREVIOUS step's sweep)
-            hipLaunchKernelGGL(vbpr_featdiff_kernel, dim3(n, kFeatSlices), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, h->DF.p, h->vX.p, h->proj.p, step);
-            hipLaunchKernelGGL(vbpr_proj_kernel, dim3(n_chunks, (n + kBM - 1) / kBM, (h->k2 + kBN - 1) / kBN), dim3(kWb), 0,
-                               h->stream, h->DF.p, h->E.p, n, h->n_feat, h->k2, feat_chunk, h->proj.p);
-            // the score reads rows the previous step's sweep may still be updating
-            if (h->sweep_pending) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept, 0));
-            hipLaunchKernelGGL(vbpr_score_kernel, dim3((n * 64 + kVb - 1) / kVb), dim3(kVb), 0, h->stream, t, h->bu.p + b0,
-                               h->bi.p + b0, h->bj.p + b0, n, h->proj.p, h->sX.p);
-            hipLaunchKernelGGL(vbpr_pair_grad_kernel, dim3(n), dim3(kVb), 0, h->stream, h->sX.p, h->vX.p, n, h->gS.p,
-                               h->gV.p, h->loss.p);
-            hipLaunchKernelGGL(vbpr_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, n, h->gS.p, h->gV.p, h->proj.p, lambda_w, lambda_b, h->W.p, ldw);
-            // the batch rows' own Adam step: a latency chain (index -> claim -> row) that took 27 us beside the sweep and
-            // 7 us alone, so it runs before the sweep starts (W keeps the Tu rows the E / beta' step still needs)
-            // (hipExtLaunchKernelGGL attaches the hand-over event to the kernel's own completion signal: a separate
-            // hipEventRecord costs a barrier packet and ~7 us of idle stream per hand-over)
-            if (one_stream || !ext_events)
-                hipLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                                   h->bj.p + b0, step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p,
-                                   h->mTu.p, h->vTu.p, a);
-            else
-                hipExtLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n), dim3(kVb), 0, h->stream, nullptr, h->ev_stamped, 0,
-                                      t, (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
-                                      (const int32_t *)(h->bj.p + b0), step, h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p,
-                                      h->vGi.p, h->mTu.p, h->vTu.p, a);
-            // The sweep of this step starts here — behind the latency-bound score / gradient kernels, which a
-            // bandwidth-saturating neighbour slows several-fold — and runs beside the E / beta' step and the next step's
-            // feature gather and projection.
+            // gather stream: the next batch's feature rows and stamps (its buffers were last used by step - 1)
+            if (has_next) enqueue_gather(b0 + batch_size, h->step + 1, h->step > first);
+            // sweep stream: this step's sweep — behind the previous sweep, the previous batch rows' own update, and the
+            // stamps it tests (this batch's: gathered before the next batch's on the same stream)
             sw.step = step;
-            for (int q = 0; q < 4; ++q) sw.tab[q].stamp = (sw_user[q] ? t.stamp_u : t.stamp_i);
-            if (one_stream) {
-                hipLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->stream, sw, a);
-            } else {
-                if (!ext_events) HIP_CHECK(hipEventRecord(h->ev_stamped, h->stream));
-                HIP_CHECK(hipStreamWaitEvent(h->sweep_stream, h->ev_stamped, 0));
-                if (ext_events) {
-                    hipExtLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, nullptr,
-                                          h->ev_swept, 0, sw, a);
-                } else {
-                    hipLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, sw, a);
-                    HIP_CHECK(hipEventRecord(h->ev_swept, h->sweep_stream));
-                }
-                h->sweep_pending = true;
+            sw.step_next = ahead ? step + 1 : step;
+            for (int q = 0; q < 4; ++q) {
+                sw.tab[q].stamp = sw_user[q] ? t.stamp_u : t.stamp_i;
+                sw.tab[q].stamp_next = sw_user[q] ? t_next.stamp_u : t_next.stamp_i;
             }
-            hipLaunchKernelGGL(vbpr_feat_adam_kernel, dim3((h->n_feat + fpb - 1) / fpb), dim3(kVb),
-                               ((size_t)n * ldw + (size_t)fpb * n) * sizeof(float), h->stream, h->DF.p, h->W.p, n,
-                               h->n_feat, h->k2, ldw, fpb, h->E.p, h->mE.p, h->vE.p, h->Bp.p, h->mBp.p, h->vBp.p, lambda_e, a);
+            if (look_ahead) {
+                HIP_CHECK(hipStreamWaitEvent(h->sweep_stream, h->ev_df[has_next ? par ^ 1 : par], 0));
+                if (h->step > first) HIP_CHECK(hipStreamWaitEvent(h->sweep_stream, h->ev_touched, 0));
+                hipExtLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, nullptr,
+                                      h->ev_swept[par], 0, sw, a);
+            }
+            // main stream
+            hipLaunchKernelGGL(vbpr_proj_kernel, dim3(n_chunks, (n + kBM - 1) / kBM, (h->k2 + kBN - 1) / kBN), dim3(kWb), 0,
+                               h->stream, DF, h->E.p, n, h->n_feat, h->k2, feat_chunk, proj);
+            // without the look-ahead the score reads rows the previous step's sweep may still be updating
+            if (!look_ahead && h->step > first) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[par ^ 1], 0));
+            hipLaunchKernelGGL(vbpr_score_kernel, dim3((n * 64 + kVb - 1) / kVb), dim3(kVb), 0, h->stream, t, h->bu.p + b0,
+                               h->bi.p + b0, h->bj.p + b0, n, proj, DF, h->sX.p, h->vX.p);
+            hipLaunchKernelGGL(vbpr_pair_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
+                               h->bj.p + b0, n, h->sX.p, h->vX.p, proj, lambda_w, lambda_b, h->W.p, ldw, h->loss.p);
+            // the batch rows' own update + the look-ahead update of the next batch's rows: the latter were last written by
+            // the PREVIOUS step's sweep, and their stamps come from the next batch's gather
+            if (look_ahead) {
+                if (h->step > first) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[par ^ 1], 0));
+                if (has_next) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[par ^ 1], 0));
+            }
+            hipExtLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n + n_next), dim3(kVb), 0, h->stream, nullptr, h->ev_touched,
+                                  0, t, (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
+                                  (const int32_t *)(h->bj.p + b0), n, step, t_next.stamp_u, t_next.stamp_i, mo, a);
+            if (!look_ahead) {  // round 3's order: the sweep starts behind the batch rows' update, on its own stream
+                HIP_CHECK(hipStreamWaitEvent(h->sweep_stream, h->ev_touched, 0));
+                hipExtLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, nullptr,
+                                      h->ev_swept[par], 0, sw, a);
+            }
+            hipExtLaunchKernelGGL(vbpr_feat_adam_kernel, dim3((h->n_feat + fpb - 1) / fpb), dim3(kVb),
+                                  ((size_t)n * ldw + (size_t)fpb * n) * sizeof(float), h->stream, nullptr, h->ev_fa[par], 0,
+                                  (const float *)DF, (const float *)h->W.p, n, h->n_feat, h->k2, ldw, fpb, h->E.p, h->mE.p,
+                                  h->vE.p, h->Bp.p, h->mBp.p, h->vBp.p, lambda_e, a);
+            if (!look_ahead && has_next) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[par ^ 1], 0));
         }
         // everything the caller does next runs on the main stream: it must see the last sweep
-        if (h->sweep_pending) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept, 0));
-        h->sweep_pending = false;
+        HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[h->step & 1], 0));
         HIP_CHECK(hipGetLastError());
         double l = 0;
         HIP_CHECK(hipMemcpyAsync(&l, h->loss.p, sizeof l, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->gather_stream));
+        HIP_CHECK(hipStreamSynchronize(h->sweep_stream));
         if (sum_nll) *sum_nll = l;
     });
 }

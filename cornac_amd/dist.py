@@ -23,23 +23,49 @@ import torch
 import torch.distributed as dist
 
 
+RULES = {"sqrt": 0, "align": 1}
+
+
+def exchanges_per_epoch(nnz_per_rank, total_items, updates_per_row=93.5, at_most=64):
+    """Item-table exchanges per epoch of the replicated regime.  What makes a stale replica harmful is the number of
+    updates a row collects on a rank between two exchanges, not the fraction of an epoch that passes: the emulations
+    behind the default (tools/emulate_ranks.py) found 16 exchanges per epoch necessary and sufficient at the
+    ML-20M shape with up to 8 ranks — 2 x 20 000 263 / 26 744 / 16 = 93.5 item-row updates per row and exchange.  The rule
+    keeps that staleness: the ML-20M shape gets its 16, the configs[4] slice (62.5 M interactions per rank over 10 M item
+    rows: 12.5 updates per row and EPOCH) one exchange per epoch, overlapped with the next epoch."""
+    x = 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row))
+    return int(min(max(1, int(x + 0.5)), at_most))
+
+
 class ItemTableReplica:
     """Flat [V | B] buffer + base copy + exchange of the ranks' deltas.
 
-    Reconciliation rule: a row's new value is  base + (sum over ranks of the row's delta) / sqrt(c),  c = number of
-    ranks that touched the row since the last exchange.  Rows one rank touched keep that rank's SGD steps
+    Reconciliation rule "sqrt" (BPR): a row's new value is  base + (sum over ranks of the row's delta) / sqrt(c),
+    c = number of ranks that touched the row since the last exchange.  Rows one rank touched keep that rank's SGD steps
     unchanged.  For rows every rank touched (the popular items) plain summation applies R stale copies of nearly
     the same gradient and diverges with growing R; the plain average is stable but discounts the item side to one
     rank's worth of progress per epoch; 1/sqrt(c) with >= 16 exchanges per epoch keeps the consolidated model
-    within 0.01-0.02 pairwise accuracy of a single rank's at R = 2, 4, 8 (tools/emulate_ranks.py)."""
+    within 0.01-0.02 pairwise accuracy of a single rank's at R = 2, 4, 8 (tools/emulate_ranks.py).
 
-    def __init__(self, total_items, k, device, group=None, trainer=None, sparse_threshold=None):
+    Rule "align" (MF):  base + S * min(1, sum_r |d_r|^2 / |S|^2),  S = the summed delta of the row, d_r rank r's.  The
+    factor is 1 (plain sum) when the ranks' deltas are orthogonal — independent evidence — and 1 / c (their mean) when
+    they are c copies of one step: the hot-row case in which sum / sqrt(c) overshoots by sqrt(c) and MF's unbounded
+    squared-error steps diverge (round 3: NaN at R = 8 below 16 exchanges per epoch).  Always contractive where the mean
+    is, never slower than the mean, a row one rank touched keeps that rank's steps; no exchange count makes it diverge
+    in the emulation (tools/emulate_ranks_mf.py --rule align: held-out RMSE 0.445 / 0.434 / 0.431 at 8 / 16 / 32
+    exchanges per epoch and R = 8 against 0.428 for one process on all ratings; sqrt: NaN / 0.730 / 0.443).  The bucket's
+    per-row slots carry |d_r|^2 instead of the touched flag."""
+
+    def __init__(self, total_items, k, device, group=None, trainer=None, sparse_threshold=None, rule="sqrt"):
         self.total_items, self.k = int(total_items), int(k)
         n = self.total_items * self.k + self.total_items
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.base = torch.zeros(n, dtype=torch.float32, device=device)
         self.group = group
         self.trainer = trainer  # on a GPU the two elementwise passes are fused HIP kernels of libcornac_hip
+        if rule not in RULES:
+            raise ValueError("rule must be one of %r" % (sorted(RULES),))
+        self.rule = rule
         self._pending = None
         # sparse exchange (SURVEY.md 8e): when at most this fraction of the item rows was touched since the last
         # exchange ON EVERY RANK, the ranks all_gather (row id, delta row) records instead of all-reducing the dense
@@ -47,6 +73,19 @@ class ItemTableReplica:
         self.sparse_threshold = sparse_threshold
         self.exchanges = {"dense": 0, "sparse": 0, "sparse_rows": 0}
         self._count_host = None
+
+    def _factors(self, S, w):
+        """per-row factor the summed delta S [m, width] is multiplied with; w = the all-reduced per-row weights"""
+        if self.rule == "sqrt":
+            return w.clamp(min=1.0).sqrt().reciprocal()
+        n2 = (S * S).sum(dim=1) if S.dim() == 2 else S * S
+        return torch.where(n2 > 0, (w / n2.clamp(min=1e-38)).clamp(max=1.0), torch.ones_like(n2))
+
+    def _weights(self, dV, dB):
+        """this rank's per-row weights of its deltas dV [m, k], dB [m]"""
+        if self.rule == "sqrt":
+            return (dV != 0).any(dim=1).to(torch.float32), (dB != 0).to(torch.float32)
+        return (dV * dV).sum(dim=1), dB * dB
 
     @property
     def V(self):
@@ -83,11 +122,12 @@ class ItemTableReplica:
         if self.trainer is not None and self.flat.is_cuda:
             local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
             self.trainer.table_delta_begin(self.flat.data_ptr(), self.base.data_ptr(), n, k, bucket.data_ptr(),
-                                           local.data_ptr())
+                                           local.data_ptr(), rule=RULES[self.rule])
         else:
             torch.sub(self.flat, self.base, out=delta)
-            bucket[n * k + n: n * k + 2 * n] = (delta[: n * k].view(n, k) != 0).any(dim=1)   # V rows touched
-            bucket[n * k + 2 * n:] = delta[n * k:] != 0                                         # biases touched
+            wV, wB = self._weights(delta[: n * k].view(n, k), delta[n * k:])
+            bucket[n * k + n: n * k + 2 * n] = wV   # V rows: touched flag ("sqrt") or |d|^2 ("align")
+            bucket[n * k + 2 * n:] = wB             # biases likewise
             local = delta.clone()
         if self.sparse_threshold is not None and self._begin_sparse(bucket):
             return
@@ -143,12 +183,11 @@ class ItemTableReplica:
             return
         recs = all_rec[valid]
         S = torch.zeros((uniq.numel(), k + 1), dtype=torch.float32, device=self.flat.device).index_add_(0, inv, recs)
-        cV = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(
-            0, inv, (recs[:, :k] != 0).any(dim=1).to(torch.float32))
-        cB = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(
-            0, inv, (recs[:, k] != 0).to(torch.float32))
-        RV = S[:, :k] / cV.clamp_(min=1.0).sqrt_().unsqueeze(1)
-        RB = S[:, k] / cB.clamp_(min=1.0).sqrt_()
+        wV, wB = self._weights(recs[:, :k], recs[:, k])
+        cV = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(0, inv, wV)
+        cB = torch.zeros(uniq.numel(), dtype=torch.float32, device=self.flat.device).index_add_(0, inv, wB)
+        RV = S[:, :k] * self._factors(S[:, :k], cV).unsqueeze(1)
+        RB = S[:, k] * self._factors(S[:, k], cB)
         V, B = self.V, self.B
         baseV, baseB = self.base[: n * k].view(n, k), self.base[n * k:]
         # base' = base + R, flat' = base' + ((flat - base) - d_local) on the union of the touched rows (the dense form's
@@ -180,7 +219,7 @@ class ItemTableReplica:
         bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
         local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
         self.trainer.table_delta_step(self.flat.data_ptr(), self.base.data_ptr(), bucket_prev.data_ptr(),
-                                      local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr())
+                                      local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr(), rule=RULES[self.rule])
         self.exchanges["dense"] += 1
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, bucket, local)
@@ -200,11 +239,12 @@ class ItemTableReplica:
         n, k = self.total_items, self.k
         if self.trainer is not None and self.flat.is_cuda:
             self.trainer.table_delta_finish(self.flat.data_ptr(), self.base.data_ptr(), bucket.data_ptr(),
-                                            local.data_ptr(), n, k)
+                                            local.data_ptr(), n, k, rule=RULES[self.rule])
             return
         delta = bucket[: n * k + n]
-        delta[: n * k].view(n, k).div_(bucket[n * k + n: n * k + 2 * n].clamp_(min=1.0).sqrt_().unsqueeze(1))
-        delta[n * k:].div_(bucket[n * k + 2 * n:].clamp_(min=1.0).sqrt_())
+        dV = delta[: n * k].view(n, k)
+        dV.mul_(self._factors(dV, bucket[n * k + n: n * k + 2 * n]).unsqueeze(1))
+        delta[n * k:].mul_(self._factors(delta[n * k:], bucket[n * k + 2 * n:]))
         # base' = base + R, flat' = base' + ((flat - base) - local): a row nobody trained since begin_sync ends with
         # flat' == base' bit for bit (see table_delta_finish_kernel), so the next exchange sees it as untouched
         progress = (self.flat - self.base).sub_(local)
@@ -277,21 +317,24 @@ class ShardedMfTrainer:
     records when few rows moved).  An epoch of a rank = its own ratings once, enqueued in `parts_per_epoch` slices of the
     stored order; the exchange of slice p is in flight while slice p + 1 trains.  `mu` is the GLOBAL mean rating
     (global_mean_across_ranks).  The slices run the fused atomic kernel (the block rotation needs whole epochs:
-    parts_per_epoch = 1 picks it where cornac_hip_mf_fit would — for a single rank only: see the note on the default
-    below).  parts_per_epoch = None: 4 exchanges per rank and epoch, at least 16."""
+    parts_per_epoch = 1 picks it where cornac_hip_mf_fit would).  The item side is reconciled with the "align" rule
+    (ItemTableReplica); parts_per_epoch = None: 8 exchanges per epoch, 16 from 5 ranks on (see __init__)."""
 
-    def __init__(self, trainer, total_items, k, device, parts_per_epoch=None, group=None, sparse_threshold=None):
+    def __init__(self, trainer, total_items, k, device, parts_per_epoch=None, group=None, sparse_threshold=None,
+                 rule="align"):
         self.trainer = trainer
         if parts_per_epoch is None:
-            # MF's squared-error steps are not bounded like BPR's sigmoid: R stale copies of an item's update, summed and
-            # divided by sqrt(R), overshoot unless the exchanges are frequent.  Emulation of this algebra with the oracle's
-            # fit_sgd loop (tools/emulate_ranks_mf.py, profiles/r03_emulate_ranks_mf.log): at R = 8, <= 8 exchanges per
-            # epoch diverge, 16 is marginal, 32 reaches the held-out RMSE of ONE process training on all ratings
-            # (0.443 vs 0.428; 64: 0.436), at two rating densities.  Hence 4 R, at least 16.
+            # Emulation of this algebra with the oracle's fit_sgd loop (tools/emulate_ranks_mf.py,
+            # profiles/r04_emulate_ranks_mf.log).  Round 3's sum / sqrt(c) rule diverged at R = 8 below 16 exchanges per
+            # epoch (MF's squared-error steps are not bounded like BPR's sigmoid) and needed 4 R of them; the "align" rule
+            # (ItemTableReplica) cannot diverge that way — R copies of one step are averaged — and at R = 8 reaches the
+            # held-out RMSE of ONE process on all ratings within 0.017 at 8 exchanges per epoch and 0.006 at 16 (0.445 /
+            # 0.434 against 0.428; twice the ratings per user: 0.427 / 0.419 against 0.417).  Hence 8, and 16 from 5
+            # ranks on.  With rule="sqrt" the round-3 count is kept.
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-            parts_per_epoch = max(16, 4 * world)
+            parts_per_epoch = (8 if world <= 4 else 16) if rule == "align" else max(16, 4 * world)
         self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None,
-                                      sparse_threshold=sparse_threshold)
+                                      sparse_threshold=sparse_threshold, rule=rule)
         self.parts = max(1, int(parts_per_epoch))
         self.device = device
         self.stream = None
@@ -779,14 +822,18 @@ def _sum_over_ranks(values, device, group):
     return [float(x) for x in t.cpu()]
 
 
-def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=16, sparse_threshold=None,
-                    trainer_factory=None):
+def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
+                    trainer_factory=None, local_popularity=False):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
     calls it with a model built from the same arguments and the SAME train_set; the users are cut into contiguous ranges
     of equal interaction counts, rank r trains its range in hogwild mode against its replica of the item table
     (ShardedBprTrainer), and on return every rank's model holds the complete u_factors / i_factors / i_biases.
     The reference has no counterpart (single process); seeded SEQUENTIAL semantics do not shard, so the model must be in
     hogwild mode (`mode="hogwild"`, or no seed) — a seed then fixes the initial tables and the sample streams.
+    sync_per_epoch = None: exchanges_per_epoch() of the largest rank's interaction count (the same number on every rank).
+    WBPR draws its negatives from the rank's OWN interactions (recom_wbpr.pyx:135 reads X.indices: popularity-weighted) —
+    the popularity of the rank's users, not of all users; that approximation has to be asked for (local_popularity=True),
+    otherwise a WBPR model over more than one rank is refused.
     trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo)."""
     from . import _lib
     from .recommender import Recommender
@@ -794,6 +841,9 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=16
     if model.effective_mode != "hogwild":
         raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
     world, rank = _world(group)
+    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+        raise ValueError("WBPR's popularity-weighted negatives would follow each rank's own users, not the global item "
+                         "popularity of recom_wbpr.pyx:135: pass local_popularity=True to accept that")
     device = device if device is not None else torch.device("cpu")
     Recommender.fit(model, train_set)
     model._init()
@@ -810,6 +860,8 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=16
     u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
     n_local, nnz = u1 - u0, counts[rank]
+    if sync_per_epoch is None:
+        sync_per_epoch = exchanges_per_epoch(max(counts), model.total_items)
     parts = max(1, min(int(sync_per_epoch), min(counts)))
     if trainer_factory is None:
         trainer = _lib.BprTrainer(indptr, indices, n_local, train_set.num_items, n_local, model.total_items, model.k,
@@ -843,7 +895,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=16
 
 
 def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=None, sparse_threshold=None,
-                   trainer_factory=None):
+                   trainer_factory=None, rule="align"):
     """`model.fit(train_set)` for a cornac_amd MF (backend "hip", hogwild mode) over all ranks of the process group:
     users — with their ratings, in stored order — cut into contiguous ranges of equal rating counts, the item side
     replicated and reconciled (ShardedMfTrainer); every rank returns with the complete model.  Same calling convention
@@ -857,6 +909,10 @@ def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=No
         raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
     if getattr(model, "early_stop", False):
         raise ValueError("early_stop is not supported by the sharded fit")
+    if trainer_factory is None and getattr(model, "backend", "hip") != "hip":
+        raise ValueError("fit_mf_sharded drives the 'hip' backend (fit_sgd); this model was built with backend=%r" % (model.backend,))
+    if not getattr(model, "trainable", True):
+        raise ValueError("the model is not trainable (trainable=False): nothing to fit")
     world, rank = _world(group)
     device = device if device is not None else torch.device("cpu")
     Recommender.fit(model, train_set)
@@ -876,10 +932,10 @@ def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=No
     if trainer_factory is None:
         trainer = _lib.MfTrainer(rid_l, cid_l, val_l, n_local, model.num_items, model.k, device=device.index or 0)
         sh = ShardedMfTrainer(trainer, model.num_items, model.k, device, parts_per_epoch=parts_per_epoch, group=group,
-                              sparse_threshold=sparse_threshold)
+                              sparse_threshold=sparse_threshold, rule=rule)
     else:
         sh = ShardedMfTrainer(None, model.num_items, model.k, device, parts_per_epoch=parts_per_epoch, group=group,
-                              sparse_threshold=sparse_threshold)
+                              sparse_threshold=sparse_threshold, rule=rule)
         trainer = sh.trainer = trainer_factory(sh.table, rid_l, cid_l, val_l, n_local, model.num_items, model.k)
     try:
         trainer.set_factors(model.u_factors[u0:u1], None, model.u_biases[u0:u1], None)
@@ -888,6 +944,9 @@ def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=No
         for _ in range(model.max_iter):
             sh.run_epoch(model.learning_rate, model.lambda_reg, mu, model.use_bias)
             losses.append(0.5 * _sum_over_ranks([sh.finish()], device, group)[0])
+            if not np.isfinite(losses[-1]):  # (the sum is the same on every rank: all of them raise)
+                raise FloatingPointError("the sharded MF fit diverged: non-finite loss in epoch %d (learning rate %g too "
+                                         "large for the hottest item rows?)" % (len(losses), model.learning_rate))
         U_local, _, Bu_local, _ = trainer.get_factors()
         V, Bi = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
     finally:

@@ -250,8 +250,11 @@ int cornac_hip_bpr_table_delta_finish(cornac_hip_bpr_t h, float *d_flat, float *
 /* finish of the previous exchange followed by begin of the next one, in one pass (adjacent in the overlapped schedule) */
 int cornac_hip_bpr_table_delta_step(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket_prev,
                                     const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
-/* The same passes for a caller without a BPR handle (the MF driver): op 0 = begin, 1 = finish, 2 = step, on `hip_stream`
- * of `device`; begin ignores the *_prev pointers, finish the next-exchange pointers. */
+/* The same passes for a caller without a BPR handle (the MF driver): op & 15: 0 = begin, 1 = finish, 2 = step, on
+ * `hip_stream` of `device`; begin ignores the *_prev pointers, finish the next-exchange pointers.  op >> 4 selects the
+ * reconciliation rule: 0 = "sqrt" (the one above: per-row slots of the bucket = touched flags, R = S / sqrt(count)),
+ * 1 = "align" (per-row slots = |delta row|^2 of this rank, R = S * min(1, sum of the slots / |S|^2): the sum of
+ * orthogonal deltas, the mean of identical ones — MF's default, cornac_amd/dist.py ItemTableReplica). */
 int cornac_hip_table_delta(int op, int device, void *hip_stream, float *d_flat, float *d_base, const float *d_bucket_prev,
                            const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
 

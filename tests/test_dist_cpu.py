@@ -75,6 +75,82 @@ def test_item_table_allreduce_of_deltas_world2(sparse_threshold):
     assert np.allclose(B_a, 3 * (0.5 + 1.0) / np.sqrt(2.0))  # every bias touched by both ranks
 
 
+def _align_worker(rank, world, port, out, sparse_threshold):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = ItemTableReplica(5, 2, torch.device("cpu"), sparse_threshold=sparse_threshold, rule="align")
+        t.load(np.zeros((5, 2), np.float32), np.zeros(5, np.float32))
+        t.V[0] += torch.tensor([1.0, 0.0])                       # both ranks make the SAME step on row 0 ...
+        t.V[1] += torch.tensor([1.0, 0.0]) if rank == 0 else torch.tensor([0.0, 2.0])  # ... orthogonal steps on row 1
+        if rank == 1:
+            t.V[2] += torch.tensor([0.5, 0.5])                   # row 2: rank 1 alone; rows 3, 4: nobody
+        t.B[0] += 0.5 if rank == 0 else 1.5                      # biases: same direction, different sizes
+        t.B[1] += 1.0 if rank == 0 else -1.0                     # opposed and equal: they cancel
+        t.sync()
+        out[rank] = (t.V.numpy().copy(), t.B.numpy().copy(), t.base.numpy().copy(), dict(t.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sparse_threshold", [None, 1.0])
+def test_align_rule_world2(sparse_threshold):
+    """rule "align": R = S min(1, sum |d_r|^2 / |S|^2) — identical steps are averaged, orthogonal steps summed, a row one
+    rank touched keeps that rank's step; the dense bucket and the sparse records give the same table"""
+    out = mp.Manager().dict()
+    mp.spawn(_align_worker, args=(2, _free_port(), out, sparse_threshold), nprocs=2, join=True)
+    (V0, B0, base0, ex0), (V1, B1, base1, ex1) = out[0], out[1]
+    assert (ex0["sparse"], ex0["dense"]) == ((1, 0) if sparse_threshold else (0, 1))
+    assert np.array_equal(V0, V1) and np.array_equal(B0, B1) and np.array_equal(base0, base1)
+    assert np.allclose(V0[0], [1.0, 0.0])        # S = (2, 0), sum |d|^2 = 2, |S|^2 = 4: factor 1/2 = the mean
+    assert np.allclose(V0[1], [1.0, 2.0])        # orthogonal: |S|^2 = 5 = sum |d|^2: the plain sum
+    assert np.allclose(V0[2], [0.5, 0.5])        # one rank: its step
+    assert np.array_equal(V0[3:], np.zeros((2, 2), np.float32))
+    assert np.allclose(B0[0], 2.0 * (0.25 + 2.25) / 4.0)   # S = 2, sum d^2 = 2.5: factor 0.625
+    assert B0[1] == 0.0 and np.array_equal(base0, np.concatenate([V0.ravel(), B0]))
+
+
+def test_align_rule_is_stable_where_the_sqrt_rule_diverges():
+    """the advisor's round-3 case, emulated on the host: R = 8 ranks each hold their own ratings of ONE hot item (and
+    their own user rows), train a slice with MF's squared-error SGD steps and exchange the item row with the replica's
+    algebra, remote deltas one slice late.  Every rank nearly solves the row locally, so 8 deltas summed / sqrt(8)
+    overshoot by ~2.8x per exchange and the row oscillates out of range; the align rule averages the (aligned) deltas
+    and converges to the value one process reaches."""
+    def run(rule, R=8, n=400, exchanges=12, lr=0.05):
+        rs = np.random.RandomState(0)
+        target = 2.0                                   # every rank's ratings say: item bias = 2
+        b = np.zeros(R)                                # the replicas of the hot item's bias
+        base, pending = 0.0, None
+        t = ItemTableReplica(1, 1, torch.device("cpu"), rule=rule)
+        for _ in range(exchanges):
+            for r in range(R):
+                for _ in range(n):                     # a slice: n SGD steps on the squared error of the bias alone
+                    b[r] += lr * ((target + rs.normal(0, 0.1)) - b[r])
+            d = b - base
+            if pending is not None:                    # the previous exchange lands one slice late
+                Rp, dp = pending
+                b += Rp - dp
+                base += Rp
+                d = b - base
+            S = torch.tensor([[d.sum()]], dtype=torch.float32)
+            w = torch.tensor([float(R) if rule == "sqrt" else float((d * d).sum())])
+            pending = (float((S[:, 0] * t._factors(S, w))[0]), d.copy())
+            if not np.isfinite(b).all() or np.abs(b).max() > 1e6:
+                return np.inf
+        return float(np.abs((base + pending[0]) - target))
+    assert run("align") < 0.2    # (hovers around the target within the SGD noise: 2 +- 0.09 over 24 exchanges)
+    assert run("sqrt") > 10.0    # (the documented failure of the round-3 rule at this staleness: 5.6, -4.7, 14, -20, 43 ...)
+
+
+def test_exchanges_per_epoch_rule():
+    from cornac_amd.dist import exchanges_per_epoch
+
+    assert exchanges_per_epoch(20_000_263, 26_744) == 16          # the ML-20M shape: the emulated default
+    assert exchanges_per_epoch(62_500_000, 10_000_000) == 1       # the configs[4] slice: one overlapped exchange per epoch
+    assert exchanges_per_epoch(5_000_000, 26_744) == 4            # a quarter of ML-20M per rank (the emulation's own shape)
+    assert exchanges_per_epoch(10 ** 12, 1000) == 64 and exchanges_per_epoch(10, 1000) == 1
+
+
 def test_single_process_sync_is_a_rebase():
     t = ItemTableReplica(5, 3, torch.device("cpu"))
     t.load(np.ones((5, 3), np.float32), np.zeros(5, np.float32))
@@ -611,12 +687,12 @@ def _mf_uneven_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # rank 1 holds a tenth of rank 0's users, and with the default slicing (4 per rank, at least 16) most of its
-        # slices are a handful of ratings — some exchanges touch few rows (sparse records), some many (dense bucket)
+        # rank 1 holds a tenth of rank 0's users, and with the default slicing (8 exchanges per epoch up to 4 ranks) its
+        # slices are a few dozen ratings — some exchanges touch few rows (sparse records), some many (dense bucket)
         rid, cid, val, n_users, n_items = _mf_data(rank, n_users=200 if rank == 0 else 20)
         mu = global_mean_across_ranks(val)
         sh = ShardedMfTrainer(None, total_items=n_items, k=5, device=torch.device("cpu"), sparse_threshold=0.5)
-        assert sh.parts == 16
+        assert sh.parts == 8 and sh.table.rule == "align"
         init = np.random.RandomState(7)
         sh.load_items(init.normal(0, 0.01, (n_items, 5)).astype(np.float32), np.zeros(n_items, np.float32))
         sh.trainer = _OracleMfTrainer(sh.table, rid, cid, val, n_users, 5, seed=31 + rank)
@@ -631,13 +707,13 @@ def _mf_uneven_worker(rank, world, port, out):
 
 def test_mf_ranks_of_very_different_sizes_exchange_in_lockstep():
     """the number of exchanges per epoch is a property of the driver (parts_per_epoch), not of a rank's data: a rank with a
-    tenth of the ratings runs the same 16 collectives per epoch (no deadlock, no mismatch), the dense / sparse decision is
+    tenth of the ratings runs the same 8 collectives per epoch (no deadlock, no mismatch), the dense / sparse decision is
     taken collectively, and both ranks end on one item side"""
     out = mp.Manager().dict()
     mp.spawn(_mf_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     (base0, rmse0, ex0), (base1, rmse1, ex1) = out[0], out[1]
     assert np.array_equal(base0, base1) and np.isfinite(base0).all()
-    assert ex0["dense"] == ex1["dense"] and ex0["sparse"] == ex1["sparse"] and ex0["dense"] + ex0["sparse"] >= 6 * 16
+    assert ex0["dense"] == ex1["dense"] and ex0["sparse"] == ex1["sparse"] and ex0["dense"] + ex0["sparse"] >= 6 * 8
     assert rmse0 < 1.0 and rmse1 < 1.2
 
 

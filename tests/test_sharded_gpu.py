@@ -368,6 +368,79 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     tr.close()
 
 
+def test_fused_table_delta_kernels_align_rule_equal_the_torch_algebra():
+    """the "align" reconciliation rule (R = S min(1, sum |d_r|^2 / |S|^2), MF's default) as HIP kernels — begin, finish
+    and the fused step, through the handle-free entry point on the caller's stream — against ItemTableReplica's torch
+    formulation of the same rule, with a hand-made all-reduced bucket of 3 virtual ranks: rows where the ranks agree
+    (the mean), where they are orthogonal (the sum), where one rank alone moved (its step) and where nobody did."""
+    import torch
+
+    from cornac_amd.dist import RULES, ItemTableReplica
+
+    ds = synth_dataset(50, 40, 300, seed=1)
+    tr = _trainer(ds, 4)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    tr.set_stream(st.cuda_stream)
+    n, k = 37, 5
+    g = torch.Generator(device="cpu").manual_seed(3)
+    base = torch.randn(n * k + n, generator=g).to(dev)
+    flat = base.clone()
+    rows = torch.tensor([0, 3, 4, 20, 36])
+    flat[: n * k].view(n, k)[rows] += torch.randn(len(rows), k, generator=g).to(dev)
+    flat[n * k + 7] += 0.5
+    flat[n * k + 9] -= 0.25
+    host = ItemTableReplica(n, k, torch.device("cpu"), rule="align")  # the torch formulation (the gloo tests' path)
+    with torch.cuda.stream(st):
+        bucket = torch.empty(n * k + 3 * n, device=dev)
+        local = torch.empty(n * k + n, device=dev)
+        tr.table_delta_begin(flat.data_ptr(), base.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr(), rule=RULES["align"])
+        st.synchronize()
+        d = flat - base
+        assert torch.equal(bucket[: n * k + n], d) and torch.equal(local, d)
+        wV, wB = host._weights(d[: n * k].view(n, k).cpu(), d[n * k:].cpu())
+        assert torch.allclose(bucket[n * k + n: n * k + 2 * n].cpu(), wV, rtol=1e-6, atol=0)
+        assert torch.allclose(bucket[n * k + 2 * n:].cpu(), wB, rtol=1e-6, atol=0)
+        assert float(bucket[n * k + n + 1]) == 0.0 and float(bucket[n * k + n + 3]) > 0.0  # untouched row: weight exactly 0
+        # two more ranks: row 0 = two copies of this rank's own delta (aligned: the mean comes out), row 3 = an orthogonal
+        # delta (the sum comes out), row 1 = touched by another rank only, bias 7 aligned, bias 9 opposed
+        other = torch.zeros_like(bucket)
+        oV = other[: n * k].view(n, k)
+        dV = d[: n * k].view(n, k)
+        oV[0] = 2 * dV[0]
+        other[n * k + n + 0] = 2 * (dV[0] * dV[0]).sum()
+        orth = torch.zeros(k, device=dev)
+        orth[0], orth[1] = -dV[3, 1], dV[3, 0]
+        oV[3] = orth
+        other[n * k + n + 3] = (orth * orth).sum()
+        oV[1] = torch.randn(k, generator=g).to(dev)
+        other[n * k + n + 1] = (oV[1] * oV[1]).sum()
+        other[n * k + 7] = 0.5; other[n * k + 2 * n + 7] = 0.25
+        other[n * k + 9] = 0.5; other[n * k + 2 * n + 9] = 0.25
+        red = bucket + other
+        fV = host._factors(red[: n * k].view(n, k).cpu(), red[n * k + n: n * k + 2 * n].cpu()).to(dev)
+        fB = host._factors(red[n * k: n * k + n].cpu(), red[n * k + 2 * n:].cpu()).to(dev)
+        assert abs(float(fV[0]) - 1 / 3) < 1e-5 and abs(float(fV[3]) - 1.0) < 1e-5 and float(fV[1]) == 1.0 and float(fV[2]) == 1.0
+        assert abs(float(fB[7]) - 0.5) < 1e-6 and float(fB[9]) == 1.0  # (opposed deltas: the factor is capped at 1)
+        R = torch.cat([(red[: n * k].view(n, k) * fV.unsqueeze(1)).reshape(-1), red[n * k: n * k + n] * fB])
+        want_flat, want_base = (base + R) + ((flat - base) - local), base + R
+        flat2, base2 = flat.clone(), base.clone()
+        tr.table_delta_finish(flat.data_ptr(), base.data_ptr(), red.data_ptr(), local.data_ptr(), n, k, rule=RULES["align"])
+        st.synchronize()
+        assert torch.allclose(flat, want_flat, atol=1e-6) and torch.allclose(base, want_base, atol=1e-6)
+        assert torch.equal(flat[2 * k: 3 * k], base[2 * k: 3 * k])  # an untrained row ends bit-identical to its base
+        b_sep, l_sep = torch.empty_like(bucket), torch.empty_like(local)
+        tr.table_delta_begin(flat.data_ptr(), base.data_ptr(), n, k, b_sep.data_ptr(), l_sep.data_ptr(), rule=RULES["align"])
+        b_fus, l_fus = torch.empty_like(bucket), torch.empty_like(local)
+        tr.table_delta_step(flat2.data_ptr(), base2.data_ptr(), red.data_ptr(), local.data_ptr(), n, k, b_fus.data_ptr(),
+                            l_fus.data_ptr(), rule=RULES["align"])
+        st.synchronize()
+        assert torch.equal(flat2, flat) and torch.equal(base2, base)
+        assert torch.equal(b_fus, b_sep) and torch.equal(l_fus, l_sep)
+    tr.close()
+
+
 def _fresh_port():
     """a free TCP port for this test's rendezvous (several tests of this process create and destroy process groups)"""
     import socket

@@ -28,7 +28,7 @@ ap.add_argument("--per-user", type=int, default=60)
 ap.add_argument("--k", type=int, default=16)
 ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--reg", type=float, default=0.02)
-ap.add_argument("--rule", default="sqrt", help="sqrt | sum | avg | pX (divide by c^(X/100), e.g. p75)")
+ap.add_argument("--rule", default="sqrt", help="sqrt | sum | avg | align | pX (divide by c^(X/100), e.g. p75)")
 args = ap.parse_args()
 R, ni, k = args.ranks, args.items, args.k
 
@@ -102,6 +102,13 @@ def run(parts):
                 SV, SB = SV / np.sqrt(np.maximum(cV, 1))[:, None], SB / np.sqrt(np.maximum(cB, 1))
             elif args.rule == "avg":
                 SV, SB = SV / np.maximum(cV, 1)[:, None], SB / np.maximum(cB, 1)
+            elif args.rule == "align":
+                # Delta = S * min(1, sum_r |d_r|^2 / |S|^2): the plain sum when the ranks' deltas of a row are orthogonal,
+                # their mean when they are R copies of one step (ItemTableReplica rule="align")
+                QV, QB = sum((d * d).sum(1) for d in dV), sum(d * d for d in dB)
+                nV, nB = (SV * SV).sum(1), SB * SB
+                SV = SV * np.minimum(1.0, QV / np.maximum(nV, 1e-30))[:, None]
+                SB = SB * np.minimum(1.0, QB / np.maximum(nB, 1e-30))
             elif args.rule.startswith("p"):
                 a = float(args.rule[1:]) / 100.0
                 SV, SB = SV / (np.maximum(cV, 1) ** a)[:, None], SB / np.maximum(cB, 1) ** a
