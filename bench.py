@@ -268,54 +268,78 @@ def leg_traffic(name, **must_match):
 def leg_mf_netflix(args, _lib):
     """configs[2]: biased MF, k = 128, Netflix Prize shape (480 189 x 17 770, 100 480 507 ratings), hogwild mode.
     Algorithmic bytes per rating: U and V rows read + written (16 k), the two biases R+W (16), the COO
-    record (int64 rid, int64 cid, f32 val = 20)."""
+    record (int64 rid, int64 cid, f32 val = 20).  Item popularity: Zipf exponent 0.45 (the most-rated title holds 0.25 %
+    of the ratings, as in the real set: 232 944 of 100 480 507); SURVEY 8d's suggested 0.8 (2.8 % on one item row) is
+    measured beside it (`zipf_0.8`)."""
     from cornac_amd import synth
 
     n_users, n_items, nnz, zipf_a, seed = synth.CONFIGS["netflix"]
     k, lr, reg = 128, 0.01, 0.02
-    t0 = time.time()
-    users, items, val = synth_ratings(n_users, n_items, nnz, zipf_a, seed)
-    t_gen = time.time() - t0
-    rs = np.random.RandomState(1)
-    mu = float(val.mean())
-    t0 = time.time()
-    tr = _lib.MfTrainer(users, items, val, n_users, n_items, k)
-    U = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
-    V = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
-    tr.set_factors(U, V, np.zeros(n_users, np.float32), np.zeros(n_items, np.float32))
-    tr.fit(1, lr, reg, mu, True, False, _lib.MODE_HOGWILD)  # warm-up: builds the ownership tables
-    t_setup = time.time() - t0
-    epochs = 3
-    tr.kernel_timing(True)
-    t0 = time.perf_counter()
-    loss, _ = tr.fit(epochs, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
-    dt = time.perf_counter() - t0
-    kms, launches = tr.kernel_timing(False)
-    tr.close()
     b = 16 * k + 16 + 20
-    # an epoch is one launch of the fused kernel or 8 phase launches of the block rotation (csrc/mf_blocks.inc)
-    rotation = launches == 8 * epochs
-    kernel = ("mf_blocks_kernel<2,4> (8 launches = one epoch)" if rotation else "mf_hogwild_rowwise_kernel (one launch = one epoch)")
-    per_launch = nnz * epochs / max(launches, 1)
-    achieved = per_launch * b / (kms / max(launches, 1) / 1e3) / 1e9
-    out = {"metric": "mf_ratings_per_sec", "value": nnz * epochs / dt, "unit": "ratings/s", "steps": epochs,
-           "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
+
+    def run(a, epochs):
+        t0 = time.time()
+        users, items, val = synth_ratings(n_users, n_items, nnz, a, seed)
+        t_gen = time.time() - t0
+        rs = np.random.RandomState(1)
+        mu = float(val.mean())
+        t0 = time.time()
+        tr = _lib.MfTrainer(users, items, val, n_users, n_items, k)
+        U = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+        V = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+        tr.set_factors(U, V, np.zeros(n_users, np.float32), np.zeros(n_items, np.float32))
+        tr.fit(1, lr, reg, mu, True, False, _lib.MODE_HOGWILD)  # warm-up: builds the ownership tables
+        t_setup = time.time() - t0
+        tr.kernel_timing(True)
+        t0 = time.perf_counter()
+        loss, _ = tr.fit(epochs, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
+        dt = time.perf_counter() - t0
+        kms, launches = tr.kernel_timing(False)
+        tr.close()
+        # an epoch is one launch of the fused kernel or 8 phase launches of the block rotation (csrc/mf_blocks.inc)
+        rotation = launches == 8 * epochs
+        kernel = ("mf_blocks_kernel<2,4> (8 launches = one epoch)" if rotation else "mf_hogwild_rowwise_kernel (one launch = one epoch)")
+        per_launch = nnz * epochs / max(launches, 1)
+        achieved = per_launch * b / (kms / max(launches, 1) / 1e3) / 1e9
+        top = float(np.bincount(items, minlength=n_items).max()) / nnz
+        return dict(users=users, items=items, val=val, mu=mu, t_gen=t_gen, t_setup=t_setup, dt=dt, epochs=epochs, loss=loss,
+                    kms=kms, launches=launches, rotation=rotation, kernel=kernel, per_launch=per_launch, achieved=achieved,
+                    top=top)
+
+    r = run(zipf_a, 3)
+    out = {"metric": "mf_ratings_per_sec", "value": nnz * r["epochs"] / r["dt"], "unit": "ratings/s", "steps": r["epochs"],
+           "ms_per_step": 1e3 * r["dt"] / r["epochs"], "dtype": "f32", "data": "synthetic",
            "config": {"workload": "biased MF k=%d, Netflix-Prize-shaped synthetic ratings (%d users x %d items, %d "
-                                  "ratings, int64 COO as the reference's uir_tuple), hogwild mode" % (k, n_users, n_items, nnz),
-                      "lr": lr, "reg": reg, "form": "block rotation" if rotation else "fused atomic kernel"},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": leg_traffic("mf_netflix", kernel=kernel, ratings_per_launch=int(per_launch), k=int(k)),
-                        "kernel": kernel,
-                        "launches": launches, "avg_launch_ms": kms / max(launches, 1),
+                                  "ratings, int64 COO as the reference's uir_tuple), item popularity Zipf exponent %.2f "
+                                  "(hottest item row: %.2f %% of the ratings), hogwild mode"
+                                  % (k, n_users, n_items, nnz, zipf_a, 100 * r["top"]),
+                      "lr": lr, "reg": reg, "form": "block rotation" if r["rotation"] else "fused atomic kernel",
+                      "zipf_exponent": zipf_a},
+           "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": r["achieved"] / HBM_PEAK_GBS,
+                        "traffic": leg_traffic("mf_netflix", kernel=r["kernel"], ratings_per_launch=int(r["per_launch"]), k=int(k)),
+                        "kernel": r["kernel"],
+                        "launches": r["launches"], "avg_launch_ms": r["kms"] / max(r["launches"], 1),
                         "algorithmic_bytes_per_rating": b},
-           "train_stats": {"mse_per_epoch": [float(x) / nnz for x in loss]},
-           "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
+           "train_stats": {"mse_per_epoch": [float(x) / nnz for x in r["loss"]]},
+           "host_s": {"generate": r["t_gen"], "create_and_first_epoch": r["t_setup"]}}
     if args.cpu_baseline_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline_mf(users, items, val, n_users, n_items, k, lr, reg, mu,
+        out["cpu_baseline"] = cpu_baseline_mf(r["users"], r["items"], r["val"], n_users, n_items, k, lr, reg, r["mu"],
                                               args.cpu_baseline_seconds)
         if out["cpu_baseline"]:
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del r
+    if os.environ.get("CORNAC_BENCH_MF_ZIPF08", "1") != "0":
+        try:
+            z = run(0.8, 1)
+            out["zipf_0.8"] = {"value": nnz * z["epochs"] / z["dt"], "unit": "ratings/s", "ms_per_step": 1e3 * z["dt"] / z["epochs"],
+                               "hottest_item_row_share": z["top"], "form": "block rotation" if z["rotation"] else "fused atomic kernel",
+                               "frac": z["achieved"] / HBM_PEAK_GBS, "frac_of_step": nnz * b / (z["dt"] / z["epochs"]) / 1e9 / HBM_PEAK_GBS,
+                               "mse_per_epoch": [float(x) / nnz for x in z["loss"]],
+                               "note": "the same shape with SURVEY 8d's Zipf exponent: one item row holds 2.8 % of the ratings "
+                                       "and lives in an LDS bin under a lock (csrc/mf_blocks.inc)"}
+        except Exception as e:
+            out["zipf_0.8"] = {"error": repr(e)}
     return out
 
 
@@ -464,9 +488,12 @@ def leg_bpr_k128_scale(args, _lib):
            "config": {"workload": "BPR k=%d on one GPU's user slice of the 100 M x 10 M synthetic (%d users x %d items, "
                                   "%d interactions, U %.1f GB, V %.1f GB: beyond the Infinity Cache), hogwild mode"
                                   % (k, nu, ni, nnz, nu * k * 4 / 1e9, ni * k * 4 / 1e9)},
-           "roofline": {"bound": "hbm", "achieved": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9,
+           # `frac` is over the whole step (the per-epoch bucket deal and the bias pad / unpad passes included): the epoch's
+           # algorithmic bytes / ms_per_step; the 8 partition launches alone: frac_kernel_only
+           "roofline": {"bound": "hbm", "achieved": bytes_launch * launches / dt / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": bytes_launch * launches / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac_kernel_only": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
                         "kernel": "bpr_strata_kernel<2,2>" if strata else "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>",
                         "launches": launches,
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
@@ -558,7 +585,83 @@ def leg_wmf_netflix(args, _lib):
     return out
 
 
-LEGS = {"mf_netflix": leg_mf_netflix, "wmf_netflix": leg_wmf_netflix, "vbpr_tradesy": leg_vbpr_tradesy, "bpr_k128_scale": leg_bpr_k128_scale}
+def _one_rank_group():
+    """a process group of ONE rank over RCCL (the multi-GPU drivers on the only GPU of the box); returns a closer"""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return lambda: None
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+    return dist.destroy_process_group
+
+
+def leg_dist_tax(args, _lib):
+    """What the multi-GPU driver costs BEFORE a second GPU is involved: one rank through RCCL (process group of one, the
+    replicated item table bound to the handle, delta passes, all-reduce, overlapped schedule) next to the plain
+    fit_epochs call, same data, same tables, same kernel form, at the ML-20M shape and at the configs[4] slice.
+    tax = 1 - plain time / driver time.  Exchanges per epoch: cornac_amd.dist.exchanges_per_epoch (16 and 1)."""
+    import torch
+
+    from cornac_amd.dist import ShardedBprTrainer, exchanges_per_epoch
+
+    close = _one_rank_group()
+    dev = torch.device("cuda", 0)
+    out = {"metric": "one_rank_driver_tax", "unit": "fraction of the driver's time", "higher_is_better": False}
+    try:
+        for shape in [x for x in os.environ.get("CORNAC_BENCH_DIST_TAX_SHAPES", "ml20m,scale").split(",") if x]:
+            if shape == "scale":
+                nu, ni, indptr, indices = scale_slice(0)
+                k, epochs = SCALE["k"], 2
+                U, V, B = scale_factors(nu, ni, k, 0)
+            else:
+                nu, ni, indptr, indices = load_dataset("ml20m", 0, args.cache_dir)
+                k, epochs = 64, 10
+                U, V, B = init_factors(nu, ni, k, 100)
+            nnz = len(indices)
+            spe = exchanges_per_epoch(nnz, ni)
+            tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+            tr.set_factors(U, V, B)
+            tr.seed_hogwild(11)
+            tr.fit_epochs(1, args.lr, args.reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+            t0 = time.perf_counter()
+            tr.fit_epochs(epochs, args.lr, args.reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+            plain = (time.perf_counter() - t0) / epochs
+            tr.close()
+            tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+            tr.set_factors(U, V, B)
+            tr.seed_hogwild(11)
+            sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=(nnz + spe - 1) // spe, sparse_threshold=None)
+            sh.load_items(V, B)
+            sh.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0)
+            sh.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                sh.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0)
+            sh.finish()
+            torch.cuda.synchronize()
+            driven = (time.perf_counter() - t0) / epochs
+            tr.close()
+            del sh
+            torch.cuda.empty_cache()
+            out[shape] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven,
+                          "exchanges_per_epoch": spe, "tax": 1.0 - plain / driven,
+                          "triplets_per_s_plain": nnz / plain, "triplets_per_s_driver": nnz / driven,
+                          "workload": "%d users x %d items, %d interactions, k = %d" % (nu, ni, nnz, k)}
+        out["value"] = max(v["tax"] for v in out.values() if isinstance(v, dict))
+    finally:
+        close()
+    return out
+
+
+LEGS = {"dist_tax": leg_dist_tax, "mf_netflix": leg_mf_netflix, "wmf_netflix": leg_wmf_netflix, "vbpr_tradesy": leg_vbpr_tradesy, "bpr_k128_scale": leg_bpr_k128_scale}
 
 
 def self_launch(args):
@@ -632,7 +735,9 @@ def main():
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--reg", type=float, default=0.01)
     ap.add_argument("--flags", type=int, default=0, help="hogwild_flags of cornac_hip_bpr_fit_epochs")
-    ap.add_argument("--sync-per-epoch", type=int, default=16, help="item-table exchanges per epoch (N > 1)")
+    ap.add_argument("--sync-per-epoch", type=int, default=0,
+                    help="item-table exchanges per epoch (N > 1); 0 = cornac_amd.dist.exchanges_per_epoch of the rank's "
+                         "interaction count (16 at the ML-20M shape, 1 at the configs[4] slice)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-rank", action="store_true")
     ap.add_argument("--rank-users", type=int, default=0, help="users ranked in the scoring leg (0 = all)")
@@ -644,7 +749,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=2_000_000, help="draws per exchange with --sharded-items")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
-    ap.add_argument("--legs", default="mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale",
+    ap.add_argument("--legs", default="mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale,dist_tax",
                     help="extra single-GPU legs reported under `legs` at N = 1 (comma list; empty = none)")
     ap.add_argument("--no-legs", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launcher / timing scaffolding only, gloo, no GPU")
@@ -716,7 +821,13 @@ def main():
     elif distributed:
         from cornac_amd.dist import ShardedBprTrainer
 
-        sparse = args.sparse_threshold if args.sparse_threshold >= 0 else (0.5 if scale else None)
+        from cornac_amd.dist import exchanges_per_epoch
+
+        if args.sync_per_epoch <= 0:
+            args.sync_per_epoch = exchanges_per_epoch(nnz, n_items)
+        # (sparse records pay off when a rank touches a small part of the table per exchange; with one exchange per epoch
+        # at the configs[4] density every row is touched: dense, which also keeps the fused finish + begin pass)
+        sparse = args.sparse_threshold if args.sparse_threshold >= 0 else (0.5 if scale and args.sync_per_epoch > 4 else None)
         sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
                                     // args.sync_per_epoch, sparse_threshold=sparse)
         sharded.load_items(V, B)

@@ -346,6 +346,74 @@ def test_mf_netflix_shape_deterministic_and_hogwild(oracle):
 
 
 @pytest.mark.timeout(900)
+def test_mf_netflix_shape_hogwild_gate_against_the_reference_threads():
+    """The throughput form of MF (block rotation: exact row updates, its own visiting order) against the REAL reference's
+    racy threads at the Netflix shape: 3 epochs of `backend_cpu.fit_sgd(num_threads=32)` (backend_cpu.pyx:62-88, the
+    compiled extension in oracle/_ref; the oracle's C port with the same thread count where that is absent) and 3 hogwild
+    epochs on the device, the SAME 100 480 507-rating COO, start tables and hyper-parameters.  Both are order-dependent
+    stochastic runs of one optimisation, so the gate is on what they optimise: the mean squared error of the trained
+    model over a fixed 10 M-rating sample of the training set, evaluated in float64 — within 1 % of each other — and the
+    learned item side pointing the same way."""
+    import time
+
+    from bench import synth_ratings
+    from cornac_amd import synth
+
+    n_users, n_items, nnz, zipf_a, seed = synth.CONFIGS["netflix"]
+    rid, cid, val = synth_ratings(n_users, n_items, nnz, zipf_a, seed)
+    k, lr, reg, epochs, threads = 128, 0.01, 0.02, 3, 32
+    mu = float(val.mean(dtype=np.float64))
+    rs = np.random.RandomState(11)
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    sample = np.sort(rs.choice(nnz, 10_000_000, replace=False))
+    rs_, cs_, vs_ = rid[sample], cid[sample], val[sample].astype(np.float64)
+
+    def mse(U, V, Bu, Bi):
+        tot = 0.0
+        for a in range(0, len(vs_), 1 << 21):
+            b = min(a + (1 << 21), len(vs_))
+            p = mu + Bu[rs_[a:b]].astype(np.float64) + Bi[cs_[a:b]] + np.einsum("nk,nk->n", U[rs_[a:b]], V[cs_[a:b]], dtype=np.float64)
+            tot += float(np.sum((vs_[a:b] - p) ** 2))
+        return tot / len(vs_)
+
+    Ur, Vr = U0.copy(), V0.copy()
+    Bur, Bir = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    t0 = time.perf_counter()
+    try:
+        from oracle import ref_loader
+
+        ref_loader.load_mf_kernel()(rid, cid, val, Ur, Vr, Bur, Bir, lr, reg, mu, epochs, threads, True, False, False)
+        who = "the reference's compiled fit_sgd"
+    except Exception as e:  # oracle/_ref not built on this box: the C port's threads
+        from oracle import oracle as orc
+
+        loss = np.zeros(epochs, np.float32)
+        orc.lib().oracle_mf_fit(rid, cid, val, nnz, Ur, Vr, Bur, Bir, k, lr, reg, mu, epochs, threads, 1, 0, loss.ctypes.data)
+        who = "the oracle's C port (%r)" % (e,)
+    t_cpu = time.perf_counter() - t0
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.set_factors(U0, V0, np.zeros(n_users, np.float32), np.zeros(n_items, np.float32))
+    t0 = time.perf_counter()
+    tr.fit(epochs, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
+    t_dev = time.perf_counter() - t0
+    Uh, Vh, Buh, Bih = tr.get_factors()
+    tr.close()
+    m0 = mse(U0, V0, np.zeros(n_users, np.float32), np.zeros(n_items, np.float32))
+    m_ref, m_dev = mse(Ur, Vr, Bur, Bir), mse(Uh, Vh, Buh, Bih)
+    dv_h, dv_r = (Vh - V0).ravel().astype(np.float64), (Vr - V0).ravel().astype(np.float64)
+    cos = float(dv_h @ dv_r) / (np.linalg.norm(dv_h) * np.linalg.norm(dv_r))
+    cos_b = float((Bih.astype(np.float64) @ Bir) / (np.linalg.norm(Bih) * np.linalg.norm(Bir)))
+    print("Netflix-shape hogwild MF, %d epochs: training MSE on a 10 M sample %.5f untrained -> %s, %d threads: %.5f (%.1f s); "
+          "device: %.5f (%.2f s); relative difference %.3f %%; cosine of the item-factor moves %.3f, of the item biases %.3f"
+          % (epochs, m0, who, threads, m_ref, t_cpu, m_dev, t_dev, 100 * abs(m_dev - m_ref) / m_ref, cos, cos_b))
+    assert np.isfinite(Uh).all() and np.isfinite(Vh).all()
+    assert m_ref < 0.8 * m0, "the reference run itself must have learned something"
+    assert abs(m_dev - m_ref) <= 0.01 * m_ref, (m_dev, m_ref)
+    assert cos_b > 0.98 and cos > 0.5, (cos, cos_b)
+
+
+@pytest.mark.timeout(900)
 def test_vbpr_tradesy_shape_matches_the_torch_oracle():
     """configs[3] at its real size (19 243 users x 165 906 items, 4096-d features, k = k2 = 64, batch 100): 40 minibatch
     steps on the device — stamped batch rows, gradient-free dense sweep on the second stream, E / beta' step — against
