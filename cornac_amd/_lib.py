@@ -35,7 +35,7 @@ SYMBOLS = [
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
-    "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_hogwild_form",
+    "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_fit_epochs_f64", "cornac_hip_vebpr_hogwild_form",
     "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
     "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
     "cornac_hip_bpr_ldsbin_deal_config", "cornac_hip_bpr_debug_ldsbin_deal",
@@ -155,6 +155,8 @@ def lib():
         L.cornac_hip_vebpr_hogwild_form.argtypes = [_vp, C.POINTER(C.c_int)]
         L.cornac_hip_vebpr_fit_epochs.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cornac_hip_vebpr_fit_epochs_f64.argtypes = [_vp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_sample_triplets.argtypes = [_vp, C.c_int64, C.c_int, _vp, _vp, _vp]
         L.cornac_hip_bpr_apply_triplets.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_float,
                                                     C.c_float, C.c_int]
@@ -333,6 +335,13 @@ class BprTrainer:
         check(lib().cornac_hip_bpr_get_factors(self.h, U.ctypes.data, None, None))
         return U
 
+    def get_item_factors(self):
+        """(V, B) only"""
+        _, ti, k = self.shape
+        V, B = np.empty((ti, k), np.float32), np.empty(ti, np.float32)
+        check(lib().cornac_hip_bpr_get_factors(self.h, None, V.ctypes.data, B.ctypes.data))
+        return V, B
+
     def seed_mt19937(self, seed_pos, seed_neg, shared_stream=False):
         check(lib().cornac_hip_bpr_seed_mt19937(self.h, seed_pos, seed_neg, int(shared_stream)))
 
@@ -454,6 +463,13 @@ class BprTrainer:
         c, s = C.c_int64(), C.c_int64()
         check(lib().cornac_hip_vebpr_fit_epochs(self.h, n_epochs, lr, reg, alpha, mode | (0 if ownership else VEBPR_NO_OWNERSHIP),
                                                 C.byref(c), C.byref(s)))
+        return c.value, s.value
+
+    def fit_epochs_vebpr_f64(self, n_epochs, lr, reg, alpha):
+        """float64 tables (set_factors_f64): sequential semantics, everything in double (recom_vebpr.pyx:219)"""
+        c, s = C.c_int64(), C.c_int64()
+        check(lib().cornac_hip_vebpr_fit_epochs_f64(self.h, n_epochs, float(lr), float(reg), float(alpha), C.byref(c),
+                                                    C.byref(s)))
         return c.value, s.value
 
     def vebpr_hogwild_owned(self):

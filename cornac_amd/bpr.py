@@ -244,9 +244,13 @@ class VEBPR(Recommender):
             self.u_factor = (_uniform((n_users, self.k), self.rng) - 0.5) / self.k
         if self.i_factor is None:
             self.i_factor = (_uniform((n_items, self.k), self.rng) - 0.5) / self.k
-        if np.asarray(self.u_factor).dtype != DTYPE or np.asarray(self.i_factor).dtype != DTYPE:
-            raise ValueError("VEBPR on the HIP backend trains float32 tables (recom_vebpr.pyx:219's float64 "
-                             "instantiation is not provided)")
+        # _fit_sgd_viewloss is a fused-type function (recom_vebpr.pyx:219): float32 tables train in float, two float64
+        # tables (both given through init_params) in double; a mix fails its buffer check (ValueError) before anything moves
+        kinds = {np.asarray(self.u_factor).dtype, np.asarray(self.i_factor).dtype}
+        if len(kinds) != 1 or next(iter(kinds)) not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("Buffer dtype mismatch: U and V must both be float32 or both be float64 (got %s)"
+                             % sorted(str(x) for x in kinds))
+        f64 = next(iter(kinds)) == np.dtype(np.float64)
         if not self.trainable:
             return self
         X, Vw = train_set.matrix, train_set.view_matrix
@@ -256,8 +260,14 @@ class VEBPR(Recommender):
                                   self.k, device=self.device)
         try:
             trainer.set_views(Vw.indptr, Vw.indices)
-            trainer.set_factors(self.u_factor, self.i_factor, None)
-            if self.effective_mode == "deterministic":
+            if f64:
+                # float64 tables: the sequential engine in double, whatever the mode (as for BPR: there is no float64
+                # throughput kernel, and the reference's unseeded float64 run is its racy loop, to which the sequential
+                # order is one admissible interleaving)
+                trainer.set_factors_f64(self.u_factor, self.i_factor, np.zeros(n_items, np.float64))
+            else:
+                trainer.set_factors(self.u_factor, self.i_factor, None)
+            if self.effective_mode == "deterministic" or f64:
                 # recom_vebpr.pyx:191-193: rng_pos, rng_view, rng_neg drawn in this order
                 sp = rngvector_mt_seed(self.rng.randint(2 ** 31))
                 sv = rngvector_mt_seed(self.rng.randint(2 ** 31))
@@ -269,9 +279,13 @@ class VEBPR(Recommender):
                 lo, hi = int(self.rng.randint(2 ** 31)), int(self.rng.randint(2 ** 31))
                 trainer.seed_hogwild((hi << 32) | lo)
                 mode = _lib.MODE_HOGWILD
-            self.fit_stats = [trainer.fit_epochs_vebpr(self.max_iter, self.learning_rate, self.lambda_reg,
-                                                       self.alpha, mode)]
-            U, V, _ = trainer.get_factors()
+            if f64:
+                self.fit_stats = [trainer.fit_epochs_vebpr_f64(self.max_iter, self.learning_rate, self.lambda_reg, self.alpha)]
+                U, V, _ = trainer.get_factors_f64()
+            else:
+                self.fit_stats = [trainer.fit_epochs_vebpr(self.max_iter, self.learning_rate, self.lambda_reg,
+                                                           self.alpha, mode)]
+                U, V, _ = trainer.get_factors()
             self.u_factor[...] = U
             self.i_factor[...] = V
         finally:
@@ -282,10 +296,19 @@ class VEBPR(Recommender):
     def _scoring_tables(self):
         return self.u_factor, self.i_factor, None, None
 
+    @property
+    def trains_float64(self):
+        return self.u_factor is not None and np.asarray(self.u_factor).dtype == np.float64
+
     def _scorer_row_count(self):
-        return len(self.u_factor)
+        # (a float64 model takes the per-user flow over score(), like BPR's: the batched kernels are float32)
+        return 0 if self.trains_float64 else len(self.u_factor)
 
     def score(self, user_idx, item_idx=None):
         if item_idx is None:
+            if self.trains_float64:
+                # the reference allocates a float32 output here whatever the tables' type and its fast_dot then refuses the
+                # float64 tables (recom_vebpr.pyx:356-357): a float64 VEBPR trains and serves score(user, item), not this
+                raise ValueError("Buffer dtype mismatch, expected 'double' but got 'float'")
             return self._get_scorer().score_user(user_idx)
         return np.dot(self.u_factor[user_idx], self.i_factor[item_idx])

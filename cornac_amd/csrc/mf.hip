@@ -1199,6 +1199,7 @@ int cornac_hip_mf_sync(cornac_hip_mf_t h, double *sq_err_sum) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->enqueue_open = false;
         if (sq_err_sum) *sq_err_sum = l;
+        REQUIRE(std::isfinite(l), "the enqueued MF slices diverged: non-finite sum of squared errors (lower the learning rate)");
     });
 }
 
@@ -1237,10 +1238,21 @@ int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, floa
         }
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->timing[2] = t_k.ms();
-        if (loss_per_epoch && e > 0) {
+        if (e > 0) {
             std::vector<double> l((size_t)e);
             HIP_CHECK(hipMemcpy(l.data(), h->loss.p, sizeof(double) * (size_t)e, hipMemcpyDeviceToHost));
-            for (int t = 0; t < e; ++t) loss_per_epoch[t] = (float)(0.5 * l[(size_t)t]);
+            if (loss_per_epoch)
+                for (int t = 0; t < e; ++t) loss_per_epoch[t] = (float)(0.5 * l[(size_t)t]);
+            if (epochs_run) *epochs_run = e;
+            h->timing[3] = total.ms();
+            // The racy form has no sequential counterpart to stay faithful to: a non-finite loss means the run diverged
+            // (a very popular row under the atomic kernel takes many stale steps at once: profiles/r03_mf_zipf.log), and a
+            // NaN model must not be returned silently.  (The sequential mode reproduces the reference, NaNs included.)
+            if (mode == CORNAC_HIP_MODE_HOGWILD)
+                for (int t = 0; t < e; ++t)
+                    REQUIRE(std::isfinite(l[(size_t)t]),
+                            "the hogwild MF fit diverged: non-finite loss in epoch %d of %d (learning rate %g; the tables now hold "
+                            "non-finite values — lower the learning rate or use mode = deterministic)", t + 1, e, (double)lr);
         }
         if (epochs_run) *epochs_run = e;
         h->timing[3] = total.ms();

@@ -298,6 +298,7 @@ struct SweepTable {
     const int32_t *stamp, *stamp_next;  // the row's stamps in the sets of step and step + 1 (the same set when there is no next batch)
     int64_t begin;       // first unit of this table in the launch's global index space
     int units_per_row;   // float4 units (width / 4) when vec, floats (width) otherwise
+    int row_shift;       // log2(units_per_row) when that is a power of two, else -1 (a 64-bit division per unit otherwise)
     int vec;
 };
 struct SweepArgs {
@@ -306,32 +307,58 @@ struct SweepArgs {
     int32_t step, step_next;  // step_next = step when the call has no further batch
 };
 
+// Two units per thread and iteration, all six loads of both issued before the arithmetic: the sweep needs bytes in
+// flight, not waves — with half the waves it leaves the other half of the CU's wave slots (and issue cycles) to the
+// latency-bound kernels of the other streams (measured per step with one unit per thread: 8 workgroups per CU 90.8 us,
+// 7: 80.8, 6: 76.7, 5: 72.4 — every workgroup taken from the sweep sped the chain up more than it slowed the sweep).
 __global__ __launch_bounds__(kVb) void adam_sweep_kernel(const SweepArgs s, const AdamScalars a) {
-    for (int64_t i = (int64_t)blockIdx.x * kVb + threadIdx.x; i < s.total; i += (int64_t)gridDim.x * kVb) {
-        int q = 0;
+    constexpr int UN = 2;
+    const int64_t stride = (int64_t)gridDim.x * kVb;
+    for (int64_t i0 = (int64_t)blockIdx.x * kVb + threadIdx.x; i0 < s.total; i0 += UN * stride) {
+        int q[UN];
+        int64_t local[UN];
+        bool live[UN];
+        f32x4 p[UN], m[UN], v[UN];
+        float ps[UN], ms[UN], vs[UN];
 #pragma unroll
-        for (int c = 1; c < 4; ++c) q += i >= s.tab[c].begin ? 1 : 0;
-        const SweepTable &tb = s.tab[q];
-        const int64_t local = i - tb.begin;
-        const int64_t row = local / tb.units_per_row;
-        // rows of this step's batch and of the next one: vbpr_touched_adam_kernel
-        if (stamp_is(tb.stamp[row], s.step) || stamp_is(tb.stamp_next[row], s.step_next)) continue;
-        if (tb.vec) {
-            f32x4 p = reinterpret_cast<const f32x4 *>(tb.p)[local], m = reinterpret_cast<const f32x4 *>(tb.m)[local],
-                  v = reinterpret_cast<const f32x4 *>(tb.v)[local];
+        for (int un = 0; un < UN; ++un) {
+            const int64_t i = i0 + un * stride;
+            live[un] = i < s.total;
+            q[un] = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pe = p[e], me = m[e], ve = v[e];
-                adam_update(pe, me, ve, 0.f, a);
-                p[e] = pe; m[e] = me; v[e] = ve;
+            for (int c = 1; c < 4; ++c) q[un] += (live[un] && i >= s.tab[c].begin) ? 1 : 0;
+            const SweepTable &tb = s.tab[q[un]];
+            local[un] = live[un] ? i - tb.begin : 0;
+            const int64_t row = tb.row_shift >= 0 ? local[un] >> tb.row_shift : local[un] / tb.units_per_row;
+            // rows of this step's batch and of the next one: vbpr_touched_adam_kernel
+            if (live[un] && (stamp_is(tb.stamp[row], s.step) || stamp_is(tb.stamp_next[row], s.step_next))) live[un] = false;
+            if (!live[un]) continue;
+            if (tb.vec) {
+                p[un] = reinterpret_cast<const f32x4 *>(tb.p)[local[un]];
+                m[un] = reinterpret_cast<const f32x4 *>(tb.m)[local[un]];
+                v[un] = reinterpret_cast<const f32x4 *>(tb.v)[local[un]];
+            } else {
+                ps[un] = tb.p[local[un]]; ms[un] = tb.m[local[un]]; vs[un] = tb.v[local[un]];
             }
-            reinterpret_cast<f32x4 *>(tb.p)[local] = p;
-            reinterpret_cast<f32x4 *>(tb.m)[local] = m;
-            reinterpret_cast<f32x4 *>(tb.v)[local] = v;
-        } else {
-            float pe = tb.p[local], me = tb.m[local], ve = tb.v[local];
-            adam_update(pe, me, ve, 0.f, a);
-            tb.p[local] = pe; tb.m[local] = me; tb.v[local] = ve;
+        }
+#pragma unroll
+        for (int un = 0; un < UN; ++un) {
+            if (!live[un]) continue;
+            const SweepTable &tb = s.tab[q[un]];
+            if (tb.vec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = p[un][e], me = m[un][e], ve = v[un][e];
+                    adam_update(pe, me, ve, 0.f, a);
+                    p[un][e] = pe; m[un][e] = me; v[un][e] = ve;
+                }
+                reinterpret_cast<f32x4 *>(tb.p)[local[un]] = p[un];
+                reinterpret_cast<f32x4 *>(tb.m)[local[un]] = m[un];
+                reinterpret_cast<f32x4 *>(tb.v)[local[un]] = v[un];
+            } else {
+                adam_update(ps[un], ms[un], vs[un], 0.f, a);
+                tb.p[local[un]] = ps[un]; tb.m[local[un]] = ms[un]; tb.v[local[un]] = vs[un];
+            }
         }
     }
 }
@@ -361,10 +388,11 @@ __global__ __launch_bounds__(kVb) void vbpr_touched_adam_kernel(const VbprTables
         if (stamp_is(cur[r], step)) return 0;  // in this step's batch too: updated with its gradient above
         return atomicCAS(next + r, step + 1, (step + 1) | kStPre) == step + 1;
     };
+    // the three claims are independent atomics (one round trip, not three: this kernel is a latency chain beside the
+    // bandwidth-saturating sweep); i == j cannot happen for a valid triplet, and if it does the row is claimed once
     if (tid == 0) own[0] = claim(t.stamp_u, stamp_u_next, u);
-    if (tid == 1) own[1] = claim(t.stamp_i, stamp_i_next, i);
-    __syncthreads();  // (i == j cannot happen for a valid triplet, but stay exact if it does: j claims after i)
-    if (tid == 2) own[2] = claim(t.stamp_i, stamp_i_next, j);
+    if (tid == 64) own[1] = claim(t.stamp_i, stamp_i_next, i);
+    if (tid == 128) own[2] = j != i ? claim(t.stamp_i, stamp_i_next, j) : 0;
     __syncthreads();
     auto row = [&](float *P, float *M, float *V, float *G, int64_t r, int width) {
         for (int q = tid; q < width; q += kVb) {
@@ -436,6 +464,8 @@ struct cornac_hip_vbpr {
     hipStream_t stream = nullptr;
     hipStream_t sweep_stream = nullptr;           // the dense Adam sweeps, back to back beside the steps' small kernels
     hipStream_t gather_stream = nullptr;          // feature gather + row stamps, one step ahead
+    hipStream_t row_stream = nullptr;             // the batch rows' own update, beside the E / beta' step of the main stream
+    hipEvent_t ev_pair = nullptr;                 // pair-gradient + scatter of the step done
     // hand-overs (attached to the producing kernel's completion signal, hipExtLaunchKernelGGL): [step & 1]
     hipEvent_t ev_df[2] = {nullptr, nullptr};     // featdiff of the step done: DF / proj / the stamps of its batch are ready
     hipEvent_t ev_fa[2] = {nullptr, nullptr};     // feat_adam of the step done: its DF / proj buffers are free again
@@ -482,8 +512,9 @@ int cornac_hip_vbpr_create(cornac_hip_vbpr_t *out, int device, int64_t n_users, 
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->sweep_stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->gather_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->row_stream, hipStreamNonBlocking));
         for (hipEvent_t *e : {&h->ev_df[0], &h->ev_df[1], &h->ev_fa[0], &h->ev_fa[1], &h->ev_swept[0], &h->ev_swept[1],
-                              &h->ev_touched})
+                              &h->ev_touched, &h->ev_pair})
             HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         h->stamp_u.alloc((size_t)4 * n_users);   // four sets, set s & 3 for step s (see kStPre)
         h->stamp_i.alloc((size_t)4 * n_items);
@@ -515,12 +546,13 @@ int cornac_hip_vbpr_destroy(cornac_hip_vbpr_t h) {
     return guarded([&] {
         if (!h) return;
         (void)hipSetDevice(h->device);
-        for (hipStream_t st : {h->gather_stream, h->sweep_stream, h->stream}) {
+        for (hipStream_t st : {h->gather_stream, h->sweep_stream, h->row_stream, h->stream}) {
             if (!st) continue;
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
-        for (hipEvent_t e : {h->ev_df[0], h->ev_df[1], h->ev_fa[0], h->ev_fa[1], h->ev_swept[0], h->ev_swept[1], h->ev_touched})
+        for (hipEvent_t e : {h->ev_df[0], h->ev_df[1], h->ev_fa[0], h->ev_fa[1], h->ev_swept[0], h->ev_swept[1], h->ev_touched,
+                             h->ev_pair})
             if (e) (void)hipEventDestroy(e);
         delete h;
     });
@@ -600,6 +632,10 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
                 sw.tab[q].stamp = sw.tab[q].stamp_next = tabs[q].stamp->p;
                 sw.tab[q].begin = at;
                 sw.tab[q].units_per_row = vec ? tabs[q].width / 4 : tabs[q].width;
+                {
+                    const int upr = sw.tab[q].units_per_row;
+                    sw.tab[q].row_shift = (upr & (upr - 1)) == 0 ? __builtin_ctz((unsigned)upr) : -1;
+                }
                 sw.tab[q].vec = vec ? 1 : 0;
                 at += vec ? (int64_t)tabs[q].p->n / 4 : (int64_t)tabs[q].p->n;
             }
@@ -607,10 +643,11 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         }
         // 7 of the 8 workgroup slots of a CU: the sweep is persistent (grid-stride) and would otherwise hold every wave
         // slot of the chip until it ends, and the kernels of the other streams could not even start beside it
-        const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 7);
+        const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 3);
         const int sweep_grid = (int)std::min<int64_t>((sw.total + kVb - 1) / kVb, (int64_t)di.cus * sweep_wg_per_cu);
         // A/B switch (profile builds): no look-ahead — the sweep leaves out its own batch only and the next score waits for it
         const bool look_ahead = !prof_env_set("CORNAC_HIP_VBPR_NO_LOOKAHEAD");
+        const bool split_rows = !prof_env_set("CORNAC_HIP_VBPR_ROWS_ON_MAIN");  // A/B switch: the batch rows' update in stream order
         const VbprMoments mo = {h->mBi.p, h->vBi.p, h->mGu.p, h->vGu.p, h->mGi.p, h->vGi.p, h->mTu.p, h->vTu.p};
         const int64_t n_steps = (n_total + batch_size - 1) / batch_size;
         REQUIRE(h->step + n_steps < (int64_t(1) << 30), "step counter exceeds 30 bits");
@@ -672,22 +709,33 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
                 hipExtLaunchKernelGGL(adam_sweep_kernel, dim3(sweep_grid), dim3(kVb), 0, h->sweep_stream, nullptr,
                                       h->ev_swept[par], 0, sw, a);
             }
-            // main stream
+            // main stream: the E / beta' chain  proj -> score -> pair gradient + scatter -> E / beta' step -> next proj
+            if (h->step > first) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[par], 0));  // (the first step waited above)
             hipLaunchKernelGGL(vbpr_proj_kernel, dim3(n_chunks, (n + kBM - 1) / kBM, (h->k2 + kBN - 1) / kBN), dim3(kWb), 0,
                                h->stream, DF, h->E.p, n, h->n_feat, h->k2, feat_chunk, proj);
-            // without the look-ahead the score reads rows the previous step's sweep may still be updating
-            if (!look_ahead && h->step > first) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[par ^ 1], 0));
+            // the score reads the batch's rows: after the previous step's update of them (row stream); without the look-ahead
+            // also after the previous step's sweep, which may still be updating them
+            if (h->step > first) {
+                if (split_rows) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_touched, 0));
+                if (!look_ahead) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[par ^ 1], 0));
+            }
             hipLaunchKernelGGL(vbpr_score_kernel, dim3((n * 64 + kVb - 1) / kVb), dim3(kVb), 0, h->stream, t, h->bu.p + b0,
                                h->bi.p + b0, h->bj.p + b0, n, proj, DF, h->sX.p, h->vX.p);
-            hipLaunchKernelGGL(vbpr_pair_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, t, h->bu.p + b0, h->bi.p + b0,
-                               h->bj.p + b0, n, h->sX.p, h->vX.p, proj, lambda_w, lambda_b, h->W.p, ldw, h->loss.p);
-            // the batch rows' own update + the look-ahead update of the next batch's rows: the latter were last written by
-            // the PREVIOUS step's sweep, and their stamps come from the next batch's gather
+            hipExtLaunchKernelGGL(vbpr_pair_scatter_kernel, dim3(n), dim3(kVb), 0, h->stream, nullptr, h->ev_pair, 0, t,
+                                  (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
+                                  (const int32_t *)(h->bj.p + b0), n, (const float *)h->sX.p, (const float *)h->vX.p,
+                                  (const float *)proj, lambda_w, lambda_b, h->W.p, ldw, h->loss.p);
+            // row stream (or the main stream): the batch rows' own update + the look-ahead update of the next batch's rows —
+            // the latter were last written by the PREVIOUS step's sweep, and their stamps come from the next batch's gather.
+            // It is a latency chain (index -> claim -> row) that takes 22 us beside the sweep: on its own stream it runs
+            // beside the E / beta' step instead of in front of it.
+            hipStream_t rs = split_rows ? h->row_stream : h->stream;
+            if (split_rows) HIP_CHECK(hipStreamWaitEvent(rs, h->ev_pair, 0));
             if (look_ahead) {
-                if (h->step > first) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[par ^ 1], 0));
-                if (has_next) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[par ^ 1], 0));
+                if (h->step > first) HIP_CHECK(hipStreamWaitEvent(rs, h->ev_swept[par ^ 1], 0));
+                if (has_next) HIP_CHECK(hipStreamWaitEvent(rs, h->ev_df[par ^ 1], 0));
             }
-            hipExtLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n + n_next), dim3(kVb), 0, h->stream, nullptr, h->ev_touched,
+            hipExtLaunchKernelGGL(vbpr_touched_adam_kernel, dim3(n + n_next), dim3(kVb), 0, rs, nullptr, h->ev_touched,
                                   0, t, (const int32_t *)(h->bu.p + b0), (const int32_t *)(h->bi.p + b0),
                                   (const int32_t *)(h->bj.p + b0), n, step, t_next.stamp_u, t_next.stamp_i, mo, a);
             if (!look_ahead) {  // round 3's order: the sweep starts behind the batch rows' update, on its own stream
@@ -699,9 +747,9 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
                                   ((size_t)n * ldw + (size_t)fpb * n) * sizeof(float), h->stream, nullptr, h->ev_fa[par], 0,
                                   (const float *)DF, (const float *)h->W.p, n, h->n_feat, h->k2, ldw, fpb, h->E.p, h->mE.p,
                                   h->vE.p, h->Bp.p, h->mBp.p, h->vBp.p, lambda_e, a);
-            if (!look_ahead && has_next) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_df[par ^ 1], 0));
         }
-        // everything the caller does next runs on the main stream: it must see the last sweep
+        // everything the caller does next runs on the main stream: it must see the last row update and the last sweep
+        HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_touched, 0));
         HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_swept[h->step & 1], 0));
         HIP_CHECK(hipGetLastError());
         double l = 0;
@@ -709,6 +757,7 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
         HIP_CHECK(hipStreamSynchronize(h->stream));
         HIP_CHECK(hipStreamSynchronize(h->gather_stream));
         HIP_CHECK(hipStreamSynchronize(h->sweep_stream));
+        HIP_CHECK(hipStreamSynchronize(h->row_stream));
         if (sum_nll) *sum_nll = l;
     });
 }

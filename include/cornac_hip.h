@@ -272,6 +272,11 @@ int cornac_hip_bpr_set_views(cornac_hip_bpr_t h, const int32_t *view_indptr, con
 int cornac_hip_bpr_seed_view_stream(cornac_hip_bpr_t h, uint32_t mt_seed_view);
 int cornac_hip_vebpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, float alpha, int mode,
                                 int64_t *correct, int64_t *skipped);
+/* The float64 instantiation of the same fused-type function (recom_vebpr.pyx:219 `floating[:, :] U, floating[:, :] V`,
+ * reached by float64 init_params): tables set with cornac_hip_bpr_set_factors_f64 (its bias table is not used), all
+ * locals of the step in double, sequential semantics (the three mt19937 streams) only, like cornac_hip_bpr_fit_epochs_f64. */
+int cornac_hip_vebpr_fit_epochs_f64(cornac_hip_bpr_t h, int n_epochs, double lr, double reg, double alpha, int64_t *correct,
+                                    int64_t *skipped);
 /* Hogwild mode (the reference's prange over samples, recom_vebpr.pyx:211-337) gives every wave of the grid a fixed set of
  * users (k > 32 and enough interactions for one 64-sample tile per wave): positives come from the wave's own users, so
  * an exclusive user's row has one writer and is updated by plain load / store; the three item rows keep fp32 atomics.

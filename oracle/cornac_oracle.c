@@ -344,6 +344,70 @@ int oracle_vebpr_epoch_seq(oracle_mt19937 *rng_pos, oracle_mt19937 *rng_view, or
     return 0;
 }
 
+/* The float64 instantiation of the same fused-type function (recom_vebpr.pyx:219: `floating[:, :] U, V`; reached by
+ * float64 init_params): every local of the step is a double, so are the clamps and 1.0 / (1.0 + exp(x)). */
+static inline double clamp50d(double x) { return x > 50.0 ? 50.0 : (x < -50.0 ? -50.0 : x); }
+
+int oracle_vebpr_epoch_seq_f64(oracle_mt19937 *rng_pos, oracle_mt19937 *rng_view, oracle_mt19937 *rng_neg,
+                               int64_t num_samples, int32_t n_items, const int32_t *user_ids, const int32_t *p_indices,
+                               const int32_t *p_indptr, const int32_t *v_indices, const int32_t *v_indptr, double *U,
+                               double *V, int k, double lr, double reg, double alpha, int64_t *correct_out,
+                               int64_t *skipped_out) {
+    int64_t correct = 0, skipped = 0;
+    const uint64_t pos_hi = (uint64_t)num_samples - 1, item_hi = (uint64_t)n_items - 1;
+    for (int64_t s = 0; s < num_samples; ++s) {
+        int64_t i_index = oracle_boost_uniform(rng_pos, pos_hi) % num_samples;
+        int32_t u_id = user_ids[i_index], i_id = p_indices[i_index];
+        int32_t num_view = v_indptr[u_id + 1] - v_indptr[u_id];
+        double *user = U + (int64_t)u_id * k, *item_i = V + (int64_t)i_id * k;
+        if (num_view == 0) {
+            int32_t j_id = (int32_t)oracle_boost_uniform(rng_neg, item_hi);
+            if (has_non_zero(p_indptr, p_indices, u_id, j_id)) { ++skipped; continue; }
+            double *item_j = V + (int64_t)j_id * k;
+            double x_uij = 0.0;
+            for (int f = 0; f < k; ++f) x_uij = x_uij + user[f] * (item_i[f] - item_j[f]);
+            x_uij = clamp50d(x_uij);
+            double delta_ij = 1.0 / (1.0 + exp(x_uij));
+            if (delta_ij < 0.5) ++correct;
+            for (int f = 0; f < k; ++f) {
+                double u_old = user[f], i_old = item_i[f], j_old = item_j[f];
+                user[f] -= lr * (-delta_ij * (i_old - j_old) + reg * u_old);
+                item_i[f] -= lr * (-delta_ij * u_old + reg * i_old);
+                item_j[f] -= lr * (delta_ij * u_old + reg * j_old);
+            }
+            continue;
+        }
+        int64_t v_index = v_indptr[u_id] + (oracle_boost_uniform(rng_view, item_hi) % num_view);
+        int32_t v_id = v_indices[v_index];
+        int32_t j_id = (int32_t)oracle_boost_uniform(rng_neg, item_hi);
+        if (has_non_zero(p_indptr, p_indices, u_id, j_id) || has_non_zero(v_indptr, v_indices, u_id, j_id)) {
+            ++skipped;
+            continue;
+        }
+        double *item_v = V + (int64_t)v_id * k, *item_j = V + (int64_t)j_id * k;
+        double x_uij = 0.0, x_uiv = 0.0, x_uvj = 0.0;
+        for (int f = 0; f < k; ++f) {
+            x_uij = x_uij + user[f] * (item_i[f] - item_j[f]);
+            x_uiv = x_uiv + user[f] * (item_i[f] - item_v[f]);
+            x_uvj = x_uvj + user[f] * (item_v[f] - item_j[f]);
+        }
+        x_uij = clamp50d(x_uij); x_uiv = clamp50d(x_uiv); x_uvj = clamp50d(x_uvj);
+        double delta_ij = 1.0 / (1.0 + exp(x_uij)), delta_iv = 1.0 / (1.0 + exp(x_uiv)), delta_vj = 1.0 / (1.0 + exp(x_uvj));
+        if (delta_ij < 0.5 && delta_iv < 0.5 && delta_vj < 0.5) ++correct;
+        for (int f = 0; f < k; ++f) {
+            double u_old = user[f], i_old = item_i[f], v_old = item_v[f], j_old = item_j[f];
+            user[f] -= lr * (-delta_ij * (i_old - j_old) - alpha * delta_iv * (i_old - v_old)
+                             - (1.0 - alpha) * delta_vj * (v_old - j_old) + reg * u_old);
+            item_i[f] -= lr * (-delta_ij * u_old - alpha * delta_iv * u_old + reg * i_old);
+            item_v[f] -= lr * (alpha * delta_iv * u_old - (1.0 - alpha) * delta_vj * u_old + reg * v_old);
+            item_j[f] -= lr * (delta_ij * u_old + (1.0 - alpha) * delta_vj * u_old + reg * j_old);
+        }
+    }
+    *correct_out = correct;
+    *skipped_out = skipped;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- *
  * backend_cpu.fit_sgd (cornac/models/mf/backend_cpu.pyx:35-97): all epochs in
  * one call, COO order, in-place SGD; loss_per_epoch[e] = 0.5*sum(err^2) with

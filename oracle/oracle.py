@@ -81,6 +81,9 @@ def _bind(L):
         L.oracle_vebpr_epoch_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, i32p, i32p, i32p,
                                              i32p, i32p, f32p, f32p, C.c_int, C.c_float, C.c_float, C.c_float,
                                              C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.oracle_vebpr_epoch_seq_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, i32p, i32p, i32p,
+                                                 i32p, i32p, f64p, f64p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.oracle_mf_fit.argtypes = [i64p, i64p, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_fast_dot.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int, C.c_int]
@@ -272,8 +275,11 @@ class VEBPROracle:
             self.u_factor = (_uniform((nu, self.k), self.rng) - 0.5) / self.k
         if self.i_factor is None:
             self.i_factor = (_uniform((ni, self.k), self.rng) - 0.5) / self.k
-        self.u_factor = np.ascontiguousarray(self.u_factor, np.float32)
-        self.i_factor = np.ascontiguousarray(self.i_factor, np.float32)
+        # float64 tables (both given through init_params) train in double: recom_vebpr.pyx:219 is a fused-type function
+        f64 = np.asarray(self.u_factor).dtype == np.float64 and np.asarray(self.i_factor).dtype == np.float64
+        dt = np.float64 if f64 else np.float32
+        self.u_factor = np.ascontiguousarray(self.u_factor, dt)
+        self.i_factor = np.ascontiguousarray(self.i_factor, dt)
         indptr, indices, user_ids = csr_arrays(train_set)
         Vw = train_set.view_matrix
         v_indptr = np.ascontiguousarray(Vw.indptr, np.int32)
@@ -286,9 +292,9 @@ class VEBPROracle:
         self.correct, self.skipped = [], []
         for _ in range(self.max_iter):
             c, s = C.c_int64(), C.c_int64()
-            L.oracle_vebpr_epoch_seq(gp.ptr, gv.ptr, gn.ptr, len(user_ids), train_set.num_items, user_ids, indices,
-                                     indptr, v_indices, v_indptr, self.u_factor, self.i_factor, self.k, self.lr,
-                                     self.reg, self.alpha, C.byref(c), C.byref(s))
+            (L.oracle_vebpr_epoch_seq_f64 if f64 else L.oracle_vebpr_epoch_seq)(
+                gp.ptr, gv.ptr, gn.ptr, len(user_ids), train_set.num_items, user_ids, indices, indptr, v_indices, v_indptr,
+                self.u_factor, self.i_factor, self.k, self.lr, self.reg, self.alpha, C.byref(c), C.byref(s))
             self.correct.append(c.value)
             self.skipped.append(s.value)
         return self

@@ -100,6 +100,17 @@ class FakeBprTrainer:
             correct, skipped = correct + c.value, skipped + s.value
         return correct, skipped
 
+    def fit_epochs_vebpr_f64(self, n_epochs, lr, reg, alpha):
+        assert self.U.dtype == np.float64
+        correct = skipped = 0
+        for _ in range(n_epochs):
+            c, s = C.c_int64(), C.c_int64()
+            orc.lib().oracle_vebpr_epoch_seq_f64(self.gp.ptr, self.gv.ptr, self.gn.ptr, len(self.user_ids), self.n_items,
+                                                 self.user_ids, self.indices, self.indptr, self.v_indices, self.v_indptr,
+                                                 self.U, self.V, self.k, lr, reg, alpha, C.byref(c), C.byref(s))
+            correct, skipped = correct + c.value, skipped + s.value
+        return correct, skipped
+
     def last_timing(self):
         return {}
 

@@ -631,6 +631,50 @@ def test_vebpr_deterministic_matches_oracle_and_reference_golden(oracle, name):
     assert np.abs(m.score(0) - fx["score0"]).max() < 2e-5
 
 
+def test_vebpr_float64_tables_train_in_double(oracle):
+    """VEBPR's float64 instantiation (recom_vebpr.pyx:219, reached by float64 init_params): the 4-row level kernel in
+    double against the oracle's double loop and the REAL reference's float64 run (tests/golden/vebpr_f64.npz), counters
+    included; the float32 run of the same problem differs; score(user) fails like the reference's, score(user, item) works;
+    the raw handle refuses the float32 entry point on float64 tables and continues its streams across calls"""
+    fx = load_golden("vebpr_f64")
+    ds = _vebpr_dataset(fx)
+    kw = dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]), lambda_reg=float(fx["reg"]),
+              alpha=float(fx["alpha"]), seed=int(fx["seed"]))
+    init = lambda: {"U": fx["init_U"].copy(), "V": fx["init_V"].copy()}  # noqa: E731
+    ip = init()
+    m = VEBPR(init_params=ip, **kw).fit(ds)
+    o = oracle.VEBPROracle(init_params=init(), **kw).fit(ds)
+    assert m.u_factor is ip["U"] and m.u_factor.dtype == np.float64
+    assert m.fit_stats[0] == (sum(o.correct), sum(o.skipped))
+    assert np.abs(m.u_factor - o.u_factor).max() <= 1e-12 and np.abs(m.i_factor - o.i_factor).max() <= 1e-12
+    assert np.abs(m.u_factor - fx["U"]).max() <= 1e-12 and np.abs(m.i_factor - fx["V"]).max() <= 1e-12
+    f32 = VEBPR(init_params={n: a.astype(np.float32) for n, a in init().items()}, **kw).fit(ds)
+    assert 1e-9 < np.abs(f32.u_factor - m.u_factor).max() < 1e-4
+    assert abs(m.score(0, 3) - float(fx["score_0_3"])) <= 1e-12
+    with pytest.raises(ValueError, match="Buffer dtype mismatch"):
+        m.score(0)
+    # the raw handle: 1 + 2 epochs == 3 epochs (the three mt19937 streams persist), float32 entry point refused
+    X, Vw = ds.matrix, ds.view_matrix
+    outs = []
+    for split in ((3,), (1, 2)):
+        tr = _lib.BprTrainer(X.indptr, X.indices, ds.num_users, ds.num_items, ds.num_users, ds.num_items, int(fx["k"]))
+        tr.set_views(Vw.indptr, Vw.indices)
+        tr.set_factors_f64(fx["init_U"], fx["init_V"], np.zeros(ds.num_items))
+        tr.seed_mt19937(11, 12, shared_stream=False)
+        tr.seed_view_stream(13)
+        if split == (3,):
+            with pytest.raises(_lib.HipError):
+                tr.fit_epochs_vebpr(1, 0.05, 0.01, 0.4, _lib.MODE_DETERMINISTIC)
+        tot = (0, 0)
+        for n in split:
+            c, s_ = tr.fit_epochs_vebpr_f64(n, 0.05, 0.01, 0.4)
+            tot = (tot[0] + c, tot[1] + s_)
+        outs.append((tr.get_factors_f64()[:2], tot))
+        tr.close()
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][0][0], outs[1][0][0]) and np.array_equal(outs[0][0][1], outs[1][0][1])
+
+
 def test_vebpr_hogwild_learns_like_the_sequential_oracle(oracle):
     rs = np.random.RandomState(0)
 

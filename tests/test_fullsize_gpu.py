@@ -352,8 +352,8 @@ def test_mf_netflix_shape_hogwild_gate_against_the_reference_threads():
     compiled extension in oracle/_ref; the oracle's C port with the same thread count where that is absent) and 3 hogwild
     epochs on the device, the SAME 100 480 507-rating COO, start tables and hyper-parameters.  Both are order-dependent
     stochastic runs of one optimisation, so the gate is on what they optimise: the mean squared error of the trained
-    model over a fixed 10 M-rating sample of the training set, evaluated in float64 — within 1 % of each other — and the
-    learned item side pointing the same way."""
+    model over a fixed 10 M-rating sample of the training set, evaluated in float64 — within 0.25 % of each other (measured:
+    0.52901 against 0.52899, 0.004 %) — and the learned item side pointing the same way (cosines 0.983 / 0.988)."""
     import time
 
     from bench import synth_ratings
@@ -409,8 +409,8 @@ def test_mf_netflix_shape_hogwild_gate_against_the_reference_threads():
           % (epochs, m0, who, threads, m_ref, t_cpu, m_dev, t_dev, 100 * abs(m_dev - m_ref) / m_ref, cos, cos_b))
     assert np.isfinite(Uh).all() and np.isfinite(Vh).all()
     assert m_ref < 0.8 * m0, "the reference run itself must have learned something"
-    assert abs(m_dev - m_ref) <= 0.01 * m_ref, (m_dev, m_ref)
-    assert cos_b > 0.98 and cos > 0.5, (cos, cos_b)
+    assert abs(m_dev - m_ref) <= 0.0025 * m_ref, (m_dev, m_ref)
+    assert cos_b > 0.97 and cos > 0.9, (cos, cos_b)
 
 
 @pytest.mark.timeout(900)

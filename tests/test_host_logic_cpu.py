@@ -178,6 +178,29 @@ def test_vebpr_host_class_reproduces_the_reference_goldens(device_double, name):
         VEBPR(k=4, seed=1).fit(golden_dataset(load_golden("tiny")))   # needs the view matrix
 
 
+def test_vebpr_float64_host_class_reproduces_the_references_float64_run(device_double):
+    """float64 init_params through cornac_amd.VEBPR (device double = the oracle's double loop): the reference's own
+    float64 result; the tables stay the caller's float64 arrays; score(user, item) works and score(user) fails exactly as
+    the reference's does (it allocates a float32 output for float64 tables, recom_vebpr.pyx:356-357); a float32 / float64
+    mix is refused before anything is trained"""
+    from cornac_amd import VEBPR, PurchaseViewDataset
+
+    fx = load_golden("vebpr_f64")
+    ds = PurchaseViewDataset.build([(int(a), int(b), 1.0) for a, b in zip(fx["pu"], fx["pi"])],
+                                   [(int(a), int(b), 1.0) for a, b in zip(fx["vu"], fx["vi"])], seed=1)
+    kw = dict(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]), lambda_reg=float(fx["reg"]),
+              alpha=float(fx["alpha"]), seed=int(fx["seed"]))
+    ip = {"U": fx["init_U"].copy(), "V": fx["init_V"].copy()}
+    m = VEBPR(init_params=ip, **kw).fit(ds)
+    assert m.u_factor is ip["U"] and m.u_factor.dtype == np.float64
+    assert np.abs(m.u_factor - fx["U"]).max() <= 1e-13 and np.abs(m.i_factor - fx["V"]).max() <= 1e-13
+    assert abs(m.score(0, 3) - float(fx["score_0_3"])) <= 1e-13
+    with pytest.raises(ValueError, match="Buffer dtype mismatch"):
+        m.score(0)
+    with pytest.raises(ValueError, match="Buffer dtype mismatch"):
+        VEBPR(init_params={"U": fx["init_U"].copy(), "V": fx["init_V"].astype(np.float32)}, **kw).fit(ds)
+
+
 @pytest.mark.parametrize("use_bias", [True, False])
 @pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])
 def test_mf_minibatch_host_class_reproduces_the_reference_goldens(device_double, opt, use_bias):

@@ -111,6 +111,21 @@ def test_errors():
         _lib.MfTrainer(rid + 1000, cid, val, ds.num_users, ds.num_items, 4)
 
 
+def test_hogwild_divergence_is_reported_not_returned():
+    """a learning rate far too large drives the racy run to non-finite values: the call fails loudly (advisor r3) instead
+    of returning a NaN model; the same tables in sequential mode reproduce the reference, NaNs and all, without an error"""
+    rid, cid, val = _coo(400, 60, 40_000, 3)
+    rs = np.random.RandomState(0)
+    U, V = rs.normal(0, 0.5, (400, 8)).astype(np.float32), rs.normal(0, 0.5, (60, 8)).astype(np.float32)
+    tr = _lib.MfTrainer(rid, cid, val, 400, 60, 8)
+    tr.set_factors(U, V, np.zeros(400, np.float32), np.zeros(60, np.float32))
+    with pytest.raises(_lib.HipError, match="diverged"):
+        tr.fit(4, 5.0, 0.0, 3.5, True, False, _lib.MODE_HOGWILD)
+    tr.set_factors(U, V, np.zeros(400, np.float32), np.zeros(60, np.float32))
+    tr.fit(4, 5.0, 0.0, 3.5, True, False, _lib.MODE_DETERMINISTIC)  # (no error: parity with the reference's seeded loop)
+    tr.close()
+
+
 def _coo(n_users, n_items, nnz, seed):
     rs = np.random.RandomState(seed)
     act = rs.lognormal(0, 1.0, n_users)

@@ -138,6 +138,24 @@ def test_vebpr_oracle_matches_reference_golden(oracle, name):
     assert_close(o.i_factor, fx["V"])
 
 
+def test_vebpr_float64_oracle_matches_the_references_float64_run(oracle):
+    """float64 init_params: `_fit_sgd_viewloss` is a fused-type function (recom_vebpr.pyx:219), so the reference trains in
+    double; the oracle's double restatement against what the REAL reference learned (tests/golden/vebpr_f64.npz,
+    tests/golden/make_f64_golden.py)"""
+    from cornac_amd import PurchaseViewDataset
+
+    fx = load_golden("vebpr_f64")
+    ds = PurchaseViewDataset.build([(int(a), int(b), 1.0) for a, b in zip(fx["pu"], fx["pi"])],
+                                   [(int(a), int(b), 1.0) for a, b in zip(fx["vu"], fx["vi"])], seed=1)
+    assert (np.diff(ds.view_matrix.indptr) == 0).any()   # users without views: the plain-BPR fallback branch runs too
+    o = oracle.VEBPROracle(k=int(fx["k"]), max_iter=int(fx["epochs"]), learning_rate=float(fx["lr"]),
+                           lambda_reg=float(fx["reg"]), alpha=float(fx["alpha"]), seed=int(fx["seed"]),
+                           init_params={"U": fx["init_U"].copy(), "V": fx["init_V"].copy()}).fit(ds)
+    assert o.u_factor.dtype == np.float64
+    assert np.abs(o.u_factor - fx["U"]).max() <= 1e-13 and np.abs(o.i_factor - fx["V"]).max() <= 1e-13
+    assert np.abs(fx["U"] - fx["init_U"]).max() > 1e-3
+
+
 def _vbpr_case():
     from cornac_amd.data import Dataset, ImageFeatures
 

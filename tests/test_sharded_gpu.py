@@ -317,15 +317,17 @@ def test_row_sharded_trainer_single_rank_through_rccl():
     assert abs(float(B2.astype(np.float64).sum())) <= 1e-4 * np.abs(B2).sum() + 1e-3
 
 
-def test_fused_table_delta_kernels_equal_the_torch_algebra():
+@pytest.mark.parametrize("k", [5, 8])
+def test_fused_table_delta_kernels_equal_the_torch_algebra(k):
     """ItemTableReplica's two elementwise passes as HIP kernels vs the torch formulation (the gloo tests' path),
-    with a hand-made 'all-reduced' bucket in between: summed deltas of 3 virtual ranks and their touch counts."""
+    with a hand-made 'all-reduced' bucket in between: summed deltas of 3 virtual ranks and their touch counts.
+    k = 5: the scalar form of the kernels; k = 8: the 16-byte form (k % 4 == 0)."""
     import torch
 
     ds = synth_dataset(50, 40, 300, seed=1)
     tr = _trainer(ds, 4)
     dev = torch.device("cuda", 0)
-    n, k = 37, 5
+    n = 37
     g = torch.Generator(device="cpu").manual_seed(0)
     base = torch.randn(n * k + n, generator=g).to(dev)
     flat = base.clone()
@@ -368,7 +370,8 @@ def test_fused_table_delta_kernels_equal_the_torch_algebra():
     tr.close()
 
 
-def test_fused_table_delta_kernels_align_rule_equal_the_torch_algebra():
+@pytest.mark.parametrize("k", [5, 8])
+def test_fused_table_delta_kernels_align_rule_equal_the_torch_algebra(k):
     """the "align" reconciliation rule (R = S min(1, sum |d_r|^2 / |S|^2), MF's default) as HIP kernels — begin, finish
     and the fused step, through the handle-free entry point on the caller's stream — against ItemTableReplica's torch
     formulation of the same rule, with a hand-made all-reduced bucket of 3 virtual ranks: rows where the ranks agree
@@ -383,7 +386,7 @@ def test_fused_table_delta_kernels_align_rule_equal_the_torch_algebra():
     st = torch.cuda.Stream(dev)
     torch.cuda.synchronize()
     tr.set_stream(st.cuda_stream)
-    n, k = 37, 5
+    n = 37
     g = torch.Generator(device="cpu").manual_seed(3)
     base = torch.randn(n * k + n, generator=g).to(dev)
     flat = base.clone()
