@@ -443,7 +443,7 @@ struct cornac_hip_mf {
     DevBuf<int64_t> c_wrow_ptr, c_row_beg, c_row_end, c_row_cur;
     DevBuf<unsigned int> uver, chain_abort;
     // hogwild block rotation (mf_blocks.inc): ratings grouped by (phase, xcd, slot, sub-round), tiles of whole user runs
-    bool blocks_built = false, blocks_failed = false;
+    bool blocks_built = false, blocks_failed = false, blocks_probed = false;
     int hog_form = 0, hog_form_used = 0;  // 0 automatic, 1 fused atomic kernel, 2 block rotation
     int mb_cap = 0;
     size_t mb_lds = 0;
@@ -997,12 +997,29 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     return true;
 }
 
-// returns false when the launch had to give up (placement / barrier bound): the caller re-runs the epoch's REMAINING
-// work with the fused kernel?  No — an aborted epoch is reported as an error; the handle then stays on the fused kernel.
+// returns false when the form cannot be used (its tables do not fit, or the placement probe did not see 32 workgroups on
+// every XCD): the caller runs the epoch with the fused kernel.  A launch that gives up in the middle of an epoch (a
+// barrier bound: another kernel held CUs) is reported as an error — part of the epoch has been applied — and the handle
+// then stays on the fused kernel.
 static bool mf_epoch_blocks(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
     if (!mf_build_blocks(h)) return false;
     MfBlocksKernel kern = pick_blocks_kernel(h->k);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mb_lds));
+    if (!h->blocks_probed) {  // once per handle: does a launch of this shape put 32 workgroups on every XCD?
+        HIP_CHECK(hipFuncSetAttribute((const void *)mf_blocks_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)h->mb_lds));
+        HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 24 * sizeof(unsigned int), h->stream));
+        hipLaunchKernelGGL(mf_blocks_probe_kernel, dim3(256), dim3(kMbBlock), h->mb_lds, h->stream, h->mb_sync.p);
+        unsigned int per[8];
+        HIP_CHECK(hipMemcpyAsync(per, h->mb_sync.p, sizeof per, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->blocks_probed = true;
+        for (int x = 0; x < 8; ++x)
+            if (per[x] != 32u) {
+                h->blocks_failed = true;   // this device / partition mode: the fused kernel, from the first epoch on
+                return false;
+            }
+    }
     MfBlockArgs a;
     a.blk_tile_ptr = h->mb_blk_tile_ptr.p; a.tile_ptr = h->mb_tile_ptr.p;
     a.b_u = h->mb_u.p; a.b_slot = h->mb_slot.p; a.b_r = h->mb_r.p;

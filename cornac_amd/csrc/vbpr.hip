@@ -307,58 +307,36 @@ struct SweepArgs {
     int32_t step, step_next;  // step_next = step when the call has no further batch
 };
 
-// Two units per thread and iteration, all six loads of both issued before the arithmetic: the sweep needs bytes in
-// flight, not waves — with half the waves it leaves the other half of the CU's wave slots (and issue cycles) to the
-// latency-bound kernels of the other streams (measured per step with one unit per thread: 8 workgroups per CU 90.8 us,
-// 7: 80.8, 6: 76.7, 5: 72.4 — every workgroup taken from the sweep sped the chain up more than it slowed the sweep).
+// One 16-byte unit per thread and iteration.  (Two units per thread with half the workgroups — the same bytes in flight
+// from half the waves — was measured: the sweep alone slows from 52 to 70 us at 3 workgroups per CU and the step is no
+// faster at any workgroup count, profiles/r04_vbpr_ab_sweep2unit.log: the sweep and the latency-bound kernels of the
+// other streams share one memory system, and what one gains the other loses.)
 __global__ __launch_bounds__(kVb) void adam_sweep_kernel(const SweepArgs s, const AdamScalars a) {
-    constexpr int UN = 2;
-    const int64_t stride = (int64_t)gridDim.x * kVb;
-    for (int64_t i0 = (int64_t)blockIdx.x * kVb + threadIdx.x; i0 < s.total; i0 += UN * stride) {
-        int q[UN];
-        int64_t local[UN];
-        bool live[UN];
-        f32x4 p[UN], m[UN], v[UN];
-        float ps[UN], ms[UN], vs[UN];
+    for (int64_t i = (int64_t)blockIdx.x * kVb + threadIdx.x; i < s.total; i += (int64_t)gridDim.x * kVb) {
+        int q = 0;
 #pragma unroll
-        for (int un = 0; un < UN; ++un) {
-            const int64_t i = i0 + un * stride;
-            live[un] = i < s.total;
-            q[un] = 0;
+        for (int c = 1; c < 4; ++c) q += i >= s.tab[c].begin ? 1 : 0;
+        const SweepTable &tb = s.tab[q];
+        const int64_t local = i - tb.begin;
+        const int64_t row = tb.row_shift >= 0 ? local >> tb.row_shift : local / tb.units_per_row;
+        // rows of this step's batch and of the next one: vbpr_touched_adam_kernel
+        if (stamp_is(tb.stamp[row], s.step) || stamp_is(tb.stamp_next[row], s.step_next)) continue;
+        if (tb.vec) {
+            f32x4 p = reinterpret_cast<const f32x4 *>(tb.p)[local], m = reinterpret_cast<const f32x4 *>(tb.m)[local],
+                  v = reinterpret_cast<const f32x4 *>(tb.v)[local];
 #pragma unroll
-            for (int c = 1; c < 4; ++c) q[un] += (live[un] && i >= s.tab[c].begin) ? 1 : 0;
-            const SweepTable &tb = s.tab[q[un]];
-            local[un] = live[un] ? i - tb.begin : 0;
-            const int64_t row = tb.row_shift >= 0 ? local[un] >> tb.row_shift : local[un] / tb.units_per_row;
-            // rows of this step's batch and of the next one: vbpr_touched_adam_kernel
-            if (live[un] && (stamp_is(tb.stamp[row], s.step) || stamp_is(tb.stamp_next[row], s.step_next))) live[un] = false;
-            if (!live[un]) continue;
-            if (tb.vec) {
-                p[un] = reinterpret_cast<const f32x4 *>(tb.p)[local[un]];
-                m[un] = reinterpret_cast<const f32x4 *>(tb.m)[local[un]];
-                v[un] = reinterpret_cast<const f32x4 *>(tb.v)[local[un]];
-            } else {
-                ps[un] = tb.p[local[un]]; ms[un] = tb.m[local[un]]; vs[un] = tb.v[local[un]];
+            for (int e = 0; e < 4; ++e) {
+                float pe = p[e], me = m[e], ve = v[e];
+                adam_update(pe, me, ve, 0.f, a);
+                p[e] = pe; m[e] = me; v[e] = ve;
             }
-        }
-#pragma unroll
-        for (int un = 0; un < UN; ++un) {
-            if (!live[un]) continue;
-            const SweepTable &tb = s.tab[q[un]];
-            if (tb.vec) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pe = p[un][e], me = m[un][e], ve = v[un][e];
-                    adam_update(pe, me, ve, 0.f, a);
-                    p[un][e] = pe; m[un][e] = me; v[un][e] = ve;
-                }
-                reinterpret_cast<f32x4 *>(tb.p)[local[un]] = p[un];
-                reinterpret_cast<f32x4 *>(tb.m)[local[un]] = m[un];
-                reinterpret_cast<f32x4 *>(tb.v)[local[un]] = v[un];
-            } else {
-                adam_update(ps[un], ms[un], vs[un], 0.f, a);
-                tb.p[local[un]] = ps[un]; tb.m[local[un]] = ms[un]; tb.v[local[un]] = vs[un];
-            }
+            reinterpret_cast<f32x4 *>(tb.p)[local] = p;
+            reinterpret_cast<f32x4 *>(tb.m)[local] = m;
+            reinterpret_cast<f32x4 *>(tb.v)[local] = v;
+        } else {
+            float pe = tb.p[local], me = tb.m[local], ve = tb.v[local];
+            adam_update(pe, me, ve, 0.f, a);
+            tb.p[local] = pe; tb.m[local] = me; tb.v[local] = ve;
         }
     }
 }
@@ -641,9 +619,11 @@ int cornac_hip_vbpr_fit_batches(cornac_hip_vbpr_t h, const int32_t *u, const int
             }
             sw.total = at;
         }
-        // 7 of the 8 workgroup slots of a CU: the sweep is persistent (grid-stride) and would otherwise hold every wave
-        // slot of the chip until it ends, and the kernels of the other streams could not even start beside it
-        const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 3);
+        // 5 of the 8 workgroup slots of a CU: the sweep is persistent (grid-stride) and would otherwise hold every wave
+        // slot of the chip until it ends, and the kernels of the other streams could not even start beside it; every slot
+        // it gives up speeds the latency-bound chain up more than it slows the sweep, down to 5 (per step: 8 slots 90.8 us,
+        // 7: 80.8, 6: 76.7, 5: 72.4; profiles/r04_vbpr_ab_rowstream.log)
+        const int sweep_wg_per_cu = prof_env_int("CORNAC_HIP_VBPR_SWEEP_WGS", 5);
         const int sweep_grid = (int)std::min<int64_t>((sw.total + kVb - 1) / kVb, (int64_t)di.cus * sweep_wg_per_cu);
         // A/B switch (profile builds): no look-ahead — the sweep leaves out its own batch only and the next score waits for it
         const bool look_ahead = !prof_env_set("CORNAC_HIP_VBPR_NO_LOOKAHEAD");
