@@ -438,6 +438,7 @@ struct cornac_hip_mf {
     // deterministic dataflow ("chain") kernel: ratings grouped by the wave that owns their item, per-user sequence numbers
     bool chain_built = false, chain_own_user = false;
     int chain_grid = 0;
+    bool chain_refused = false;  // a cooperative launch of the dataflow kernel was refused: level schedule from then on
     DevBuf<int32_t> c_row_id, c_sid, c_seq;
     DevBuf<float> c_r;
     DevBuf<int64_t> c_wrow_ptr, c_row_beg, c_row_end, c_row_cur;
@@ -658,7 +659,9 @@ static void mf_build_chain(cornac_hip_mf_t h) {
     h->timing[1] += t.ms();
 }
 
-static void mf_epoch_chain(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
+// returns false when the runtime refuses the launch (the whole grid cannot be co-resident): nothing has run, the caller
+// takes the level schedule
+static bool mf_epoch_chain(cornac_hip_mf_t h, float lr, float reg, float mu, int use_bias, double *loss_slot) {
     mf_build_chain(h);
     HIP_CHECK(hipMemsetAsync(h->uver.p, 0, h->uver.n * sizeof(unsigned int), h->stream));
     HIP_CHECK(hipMemsetAsync(h->chain_abort.p, 0, 8 * sizeof(unsigned int), h->stream));
@@ -670,13 +673,24 @@ static void mf_epoch_chain(cornac_hip_mf_t h, float lr, float reg, float mu, int
     a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p; a.Bi = h->Bi.p; a.loss_acc = loss_slot;
     a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
     a.wait_bound_ticks = (long long)prof_env_int("CORNAC_HIP_MF_CHAIN_WAIT_S", 120) * 100000000ll;
-    hipLaunchKernelGGL(pick_chain_kernel(h->k, h->chain_own_user), dim3(h->chain_grid), dim3(kBlock), 0, h->stream, a);
-    HIP_CHECK(hipGetLastError());
+    // The waves wait for each other (per-row hand-over counters): every workgroup of the grid has to be resident.  A
+    // cooperative launch makes that the runtime's business — it refuses a grid that cannot be co-resident instead of
+    // letting the resident half spin on the other half until the time bound (advisor r3).
+    {
+        void *kargs[] = {(void *)&a};
+        const hipError_t st = hipLaunchCooperativeKernel((const void *)pick_chain_kernel(h->k, h->chain_own_user),
+                                                         dim3(h->chain_grid), dim3(kBlock), kargs, 0, h->stream);
+        if (st != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
     unsigned int ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(ab, h->chain_abort.p, sizeof ab, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (ab[0])
         fail(CORNAC_HIP_ERR_HIP, "deterministic MF dataflow kernel: wave %u made no progress for its time bound (internal error)", ab[1]);
+    return true;
 }
 
 typedef void (*MfHogKernel)(const MfHogArgs);
@@ -1230,7 +1244,8 @@ int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, floa
         Timer total;
         h->loss.ensure((size_t)std::max(max_iter, 1));
         HIP_CHECK(hipMemsetAsync(h->loss.p, 0, h->loss.n * sizeof(double), h->stream));
-        const bool chain = mode == CORNAC_HIP_MODE_DETERMINISTIC && mf_uses_chain(h) && !prof_env_set("CORNAC_HIP_MF_LEVELS");
+        bool chain = mode == CORNAC_HIP_MODE_DETERMINISTIC && mf_uses_chain(h) && !h->chain_refused &&
+                     !prof_env_set("CORNAC_HIP_MF_LEVELS");
         if (mode == CORNAC_HIP_MODE_DETERMINISTIC) {
             if (chain) mf_build_chain(h); else mf_build_schedule(h);
         }
@@ -1238,9 +1253,15 @@ int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, floa
         float loss = 0.f, last_loss = 0.f;
         int e = 0;
         for (; e < max_iter; ++e) {
-            if (chain) mf_epoch_chain(h, lr, reg, mu, use_bias, h->loss.p + e);
-            else if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
-            else mf_epoch_hogwild(h, lr, reg, mu, use_bias, h->loss.p + e);
+            if (chain && !mf_epoch_chain(h, lr, reg, mu, use_bias, h->loss.p + e)) {
+                chain = false;              // the dataflow launch was refused before anything ran: the level schedule,
+                h->chain_refused = true;    // for this and every later fit of the handle
+                mf_build_schedule(h);
+                mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
+            } else if (!chain) {
+                if (mode == CORNAC_HIP_MODE_DETERMINISTIC) mf_epoch_deterministic(h, lr, reg, mu, use_bias, h->loss.p + e);
+                else mf_epoch_hogwild(h, lr, reg, mu, use_bias, h->loss.p + e);
+            }
             if (early_stop) {  // needs this epoch's loss on the host (backend_cpu.pyx:89-93)
                 double l;
                 HIP_CHECK(hipMemcpyAsync(&l, h->loss.p + e, sizeof l, hipMemcpyDeviceToHost, h->stream));
