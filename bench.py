@@ -708,9 +708,11 @@ def dry_run(args):
 
 SAMPLING = {
     "ldsbin": "every draw picks an interaction with the reference's probability 1 / nnz (nnz draws per epoch); the negative is "
-              "uniform over the ~n_items / bins items dealt to the positive's LDS bin in that epoch (bins re-dealt every epoch by "
-              "popularity-rank groups, so every bin carries the same popularity mass) instead of uniform over all items; item "
-              "updates exact (LDS read-modify-write under a row lock), user rows and hot item rows by fp32 atomics",
+              "uniform over the ~n_items / bins items dealt to the positive's LDS bin in that epoch instead of uniform over all "
+              "items; bins are re-dealt every epoch from popularity strata permuted by an epoch-keyed bijection, so every bin "
+              "carries the same popularity mass and ANY two items share a bin with probability ~1 / bins per epoch (no pair is "
+              "excluded: tests/test_ldsbin_deal_cpu.py); item updates exact (LDS read-modify-write under a row lock), user rows "
+              "and hot item rows by fp32 atomics",
     "strata": "stratified by user ownership (every wave draws its positives i.i.d. from its own users' interactions) and by XCD "
               "item partition (8 partitions re-dealt every epoch; the negative is uniform inside the positive's partition); "
               "item rows by plain read-modify-write inside one XCD (racy like the reference's threads)",
@@ -808,7 +810,10 @@ def main():
     # the form a whole-epoch call with these flags takes (include/cornac_hip.h: hogwild_flags bits 16..19)
     trainer_stats = {"ldsbin": trainer.ldsbin_stats()}
     sel = (args.flags >> 16) & 15
-    form = ("fused" if (args.flags & 0xffff) or sel == 1 or (distributed and args.sharded_items) else
+    # (profile builds honour the ablation bits 8..15 inside the LDS-bin / strata forms; the shipped library takes the fused
+    # kernel for any non-zero low flag)
+    low = args.flags & (0xff if os.environ.get("CORNAC_HIP_PROFILE") == "1" else 0xffff)
+    form = ("fused" if low or sel == 1 or (distributed and args.sharded_items) else
             "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
             "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 

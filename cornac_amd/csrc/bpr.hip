@@ -168,6 +168,7 @@ struct HogArgs {
     int64_t own_tmax;  // tiles of 64 samples of the longest wave slice
     int64_t nnz;
     int bstride;  // element stride of the (padded) bias table handed to the hogwild kernels
+    int vpitch;   // element pitch of the item table (k, or the record pitch of the strata form's packed table)
     int ablate;  // profiling-only switches (hogwild_flags bits 8..): see DESIGN.md "ablations"
     // row-sharded item table (sharded.inc): the owned kernel in its EMIT / STAGED forms exchanges the triplets of
     // tile t of wave w through trip_*[((trip_tile0 + t) * total_waves + w) * 64 + lane]
@@ -674,6 +675,12 @@ struct cornac_hip_bpr {
     bool f64 = false;  // float64 tables (set_factors_f64): deterministic mode only, like the reference's fused-type loop
     DevBuf<double> U64, V64, B64;
     DevBuf<float> Bpad;  // hogwild-mode view of B, one bias per 128-byte line
+    // XCD-strata form inside fit_epochs: ONE record per item — the row (padded to whole 128-byte lines) with its bias line
+    // behind it — so that a triplet names 3 random locations instead of 5.  While strata_packed is set the records are
+    // authoritative and the dense V / B are stale; every other entry point unpacks first (bpr_check).
+    DevBuf<float> VB;
+    bool strata_packed = false, strata_allow_pack = false;
+    int vb_pitch = 0, vb_kp = 0;
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped, [2] strata workgroups placed off their logical XCD
     // deterministic sampler state
     DevBuf<uint32_t> mt_state;  // 2 x 624
@@ -751,7 +758,15 @@ struct cornac_hip_bpr {
 
 static constexpr int64_t kDetChunk = int64_t(1) << 24;
 
+static void strata_unpack(cornac_hip_bpr_t h);
+// every entry point that may read or write the dense tables goes through here: packed strata records are written back
 static void bpr_check(cornac_hip_bpr_t h) {
+    REQUIRE(h != nullptr, "BPR handle is NULL");
+    HIP_CHECK(hipSetDevice(h->device));
+    if (h->strata_packed) strata_unpack(h);
+}
+// ... except the epoch loop of fit_epochs, which keeps them across calls
+static void bpr_check_keep_packed(cornac_hip_bpr_t h) {
     REQUIRE(h != nullptr, "BPR handle is NULL");
     HIP_CHECK(hipSetDevice(h->device));
 }
@@ -927,7 +942,7 @@ int cornac_hip_bpr_seed_mt19937(cornac_hip_bpr_t h, uint32_t mt_seed_pos, uint32
 
 int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed) {
     return guarded([&] {
-        bpr_check(h);
+        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay)
         h->hog_seed = seed;
         h->hog_epoch = 0;
         h->hog_offset = 0;
@@ -1359,6 +1374,7 @@ static void fill_hog_args(cornac_hip_bpr_t h, HogArgs &a, int64_t n, float lr, f
     a.user_ids = h->user_ids.p; a.indices = h->indices.p; a.indptr = h->indptr.p;
     a.U = h->U.p; a.V = h->V.p; a.B = h->B.p;
     a.bstride = 1;
+    a.vpitch = h->k;
     a.counters = h->counters.p;
     a.n = n;
     a.s_begin = (uint64_t)h->hog_offset;
@@ -1578,9 +1594,34 @@ static void strata_build_buckets(cornac_hip_bpr_t h, int grid, uint32_t key) {
 // 8 phase launches per epoch, buckets re-dealt when the epoch key changes.  A chunk of an epoch (the multi-GPU driver's
 // exchange points) runs the phases whose nominal start p * nnz / 8 lies inside it, so consecutive chunks run every
 // phase of the epoch exactly once.
+static void strata_pack(cornac_hip_bpr_t h) {
+    if (h->strata_packed) return;
+    h->vb_kp = (h->k + kBiasStride - 1) / kBiasStride * kBiasStride;
+    h->vb_pitch = h->vb_kp + kBiasStride;
+    h->VB.ensure((size_t)h->total_items * h->vb_pitch);
+    const int64_t n = (int64_t)h->total_items * h->vb_pitch;
+    hipLaunchKernelGGL(strata_pack_kernel, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 65536)), dim3(kBlock), 0,
+                       h->stream, h->V.p, h->B.p, h->total_items, h->k, h->vb_kp, h->vb_pitch, h->VB.p);
+    HIP_CHECK(hipGetLastError());
+    h->strata_packed = true;
+}
+
+static void strata_unpack(cornac_hip_bpr_t h) {
+    if (!h->strata_packed) return;
+    const int64_t n = (int64_t)h->total_items * h->k;
+    hipLaunchKernelGGL(strata_unpack_kernel, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 65536)), dim3(kBlock), 0,
+                       h->stream, h->VB.p, h->total_items, h->k, h->vb_kp, h->vb_pitch, h->V.p, h->B.p);
+    HIP_CHECK(hipGetLastError());
+    h->strata_packed = false;
+}
+
 static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int flags) {
     const int grid = strata_prepare(h);
-    h->Bpad.ensure((size_t)h->total_items * kBiasStride);
+    // packed records only inside fit_epochs (strata_allow_pack) and only for tables the handle owns: the multi-GPU
+    // drivers train into a caller-owned dense table and read it between chunks
+    const bool packed = h->strata_allow_pack && h->V.owned && h->B.owned && !prof_env_set("CORNAC_HIP_STRATA_NO_PACK");
+    if (packed) strata_pack(h); else strata_unpack(h);
+    if (!packed) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
     const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
     int64_t left = n_samples;
     while (left > 0) {
@@ -1593,13 +1634,19 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
             strata_build_buckets(h, grid, key);
             HogArgs a;
             fill_hog_args(h, a, h->nnz, lr, reg, use_bias, CORNAC_HIP_NEG_UNIFORM, flags);
-            const bool dense_bias = prof_env_int("CORNAC_HIP_STRATA_DENSE_BIAS", 0) != 0;  // (profile builds: experiment)
+            const bool dense_bias = !packed && prof_env_int("CORNAC_HIP_STRATA_DENSE_BIAS", 0) != 0;  // (profile builds: experiment)
             a.B = dense_bias ? h->B.p : h->Bpad.p;
             a.bstride = dense_bias ? 1 : kBiasStride;
+            if (packed) {
+                a.V = h->VB.p;
+                a.vpitch = h->vb_pitch;
+                a.B = h->VB.p + h->vb_kp;
+                a.bstride = h->vb_pitch;
+            }
             a.rec_u = h->rec_u.p; a.rec_i = h->rec_i.p; a.rank_item = h->rank_item.p; a.sptr = h->sptr.p;
             a.strata_key = key; a.n_hot = h->strata_n_hot;
             HIP_CHECK(hipMemsetAsync(h->strata_claim.p, 0, 8 * 16 * sizeof(uint32_t), h->stream));
-            if (!dense_bias)
+            if (!dense_bias && !packed)
                 hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->B.p, h->Bpad.p, h->total_items);
             for (int ph = p_lo; ph < p_hi; ++ph) {
                 a.phase = ph;
@@ -1608,7 +1655,7 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
                 hipLaunchKernelGGL(h->strata_kernel, dim3(grid), dim3(kBlock), 0, h->stream, a);
                 h->ktimer.after(h->stream);
             }
-            if (!dense_bias)
+            if (!dense_bias && !packed)
                 hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bpad.p, h->B.p, h->total_items);
             HIP_CHECK(hipGetLastError());
         }
@@ -1902,12 +1949,22 @@ extern "C" {
 int cornac_hip_bpr_fit_epochs(cornac_hip_bpr_t h, int n_epochs, float lr, float reg, int use_bias, int neg_population,
                               int mode, int hogwild_flags, int64_t *correct, int64_t *skipped) {
     return guarded([&] {
-        bpr_check(h);
+        bpr_check_keep_packed(h);
         REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
                 "unknown neg_population %d", neg_population);
         REQUIRE(mode == CORNAC_HIP_MODE_DETERMINISTIC || mode == CORNAC_HIP_MODE_HOGWILD, "unknown mode %d", mode);
         REQUIRE(!h->f64, "the handle holds float64 tables: use cornac_hip_bpr_fit_epochs_f64 (sequential semantics only)");
+        // the strata form keeps its packed item records from one fit_epochs call to the next; any other form (and any
+        // other entry point: bpr_check) gets the dense tables back first
+        struct AllowPack {
+            cornac_hip_bpr_t h;
+            ~AllowPack() { h->strata_allow_pack = false; }
+        } allow_guard{h};
+        h->strata_allow_pack = mode == CORNAC_HIP_MODE_HOGWILD && h->hog_seeded &&
+                               !hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags) &&
+                               hogwild_uses_strata(h, h->nnz, neg_population, hogwild_flags);
+        if (!h->strata_allow_pack) strata_unpack(h);
         if (correct) *correct = 0;
         if (skipped) *skipped = 0;
         for (double &t : h->timing) t = 0;
@@ -1960,7 +2017,7 @@ int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float 
 
 int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped) {
     return guarded([&] {
-        bpr_check(h);
+        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay)
         if (correct) *correct = 0;
         if (skipped) *skipped = 0;
         fetch_counters(h, correct, skipped);
@@ -2015,7 +2072,7 @@ int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t
 
 int cornac_hip_bpr_kernel_timing(cornac_hip_bpr_t h, int enable, double *total_ms, int64_t *launches) {
     return guarded([&] {
-        bpr_check(h);
+        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay)
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->ktimer.collect(total_ms, launches);
         h->ktimer.enabled = enable != 0;
@@ -2038,7 +2095,7 @@ int cornac_hip_bpr_strata_config(cornac_hip_bpr_t h, int hot_permille, int hot_m
 
 int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4) {
     return guarded([&] {
-        bpr_check(h);
+        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay)
         REQUIRE(out4 != nullptr, "out4 is NULL");
         HIP_CHECK(hipStreamSynchronize(h->stream));
         out4[0] = h->strata_ranked ? (int64_t)h->strata_n_hot : -1;
