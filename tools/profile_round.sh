@@ -5,7 +5,7 @@
 #   2. hardware-counter passes of the headline SGD kernel (counters in their own runs, only --kernel-trace beside them):
 #      atomics received by the L2s / forwarded to the fabric, stalls, wave-state breakdown;
 #   3. FETCH_SIZE / WRITE_SIZE passes (separate runs) over the headline kernel and the legs' kernels.
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$ROUND
