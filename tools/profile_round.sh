@@ -11,7 +11,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$ROUND
 mkdir -p $O
 if [ "${SKIP_STATS:-0}" != 1 ]; then
-rocprofv3 --kernel-trace --stats -d $O/bench -o b -- python $R/bench.py > $O/bench.log 2>&1
+# (BENCH_ARGS: round 4 profiles the default line without the dist_tax leg — an RCCL process group under the tracer —
+# `--legs mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale`; every kernel of the line is in that run)
+rocprofv3 --kernel-trace --stats -d $O/bench -o b -- python $R/bench.py $BENCH_ARGS > $O/bench.log 2>&1
 ( cd $R && python tools/rocpd_summary.py stats $O/bench/b_results.db > gpurun_out/${ROUND}_bench_kernel_stats.csv
   grep '^{' $O/bench.log | tail -1 > gpurun_out/${ROUND}_bench_profiled.json.log
   head -14 gpurun_out/${ROUND}_bench_kernel_stats.csv | cut -c1-200 )
@@ -30,6 +32,6 @@ if [ "${SKIP_LEGS:-0}" != 1 ]; then
 CMD="env CORNAC_BENCH_VBPR_FEEDBACK=30000 python $R/bench.py --steps 2 --warmup 1 --cpu-baseline-seconds 0 --legs ${LEGS:-mf_netflix,wmf_netflix,vbpr_tradesy} --rank-full-users 0"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-( cd $R && for p in fetch write; do python tools/rocpd_summary.py pmc $O/$p/p_results.db | grep -E "^kernel|mf_hogwild|mf_blocks|mf_det_chain|wmf_user_step|adam_sweep|rank_fused|feat_adam|touched|$KPAT"; done > gpurun_out/${ROUND}_legs_pmc.csv
+( cd $R && for p in fetch write; do python tools/rocpd_summary.py pmc $O/$p/p_results.db | grep -E "^kernel|mf_hogwild|mf_blocks|mf_det_chain|wmf_user_step|adam_sweep|rank_fused|feat_adam|touched|vbpr_|$KPAT"; done > gpurun_out/${ROUND}_legs_pmc.csv
   cut -c1-220 gpurun_out/${ROUND}_legs_pmc.csv )
 fi
