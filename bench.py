@@ -1034,8 +1034,26 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    emit_json_line(out if rank == 0 else None)
+
+
+def emit_json_line(out):
+    """ONE JSON line on stdout, and nothing else: native libraries (RCCL prints a version banner through C stdio when a
+    communicator is created) hold text in their own stdout buffer that would otherwise be flushed AFTER the line at process
+    exit.  Their pending text goes to stderr before the line, and stdout is pointed at stderr afterwards."""
+    import ctypes
+
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    libc.fflush(None)
+    os.dup2(keep, 1)
+    os.close(keep)
+    if out is not None:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
+    os.dup2(2, 1)
 
 
 if __name__ == "__main__":

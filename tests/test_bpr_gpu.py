@@ -330,6 +330,112 @@ def test_strata_buckets_and_sampler_match_their_cpu_restatement(oracle):
     assert 0 < st["n_hot"] < n_items // 4
 
 
+@pytest.mark.parametrize("k", [64, 100])
+def test_strata_packed_item_records_round_trip_and_stay_coherent(k):
+    """Inside fit_epochs the XCD-strata form trains on ONE record per item (row padded to whole 128-byte lines + the bias's
+    own line, csrc/bpr_strata.inc strata_pack_kernel); the records stay authoritative from one fit_epochs call to the next
+    and every other entry point gets the dense tables back first.  lr = 0: the tables come back bit-identical (pack ->
+    8 x 2 launches -> unpack; k = 100: a padded row); set_factors after a packed call is what the next call trains on; the
+    chunk API (the multi-GPU drivers' path, two-table layout) and fit_epochs interleave on one handle and both learn."""
+    from cornac_amd import synth
+
+    n_users, n_items = 6000, 3003
+    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.8, 3)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    rs = np.random.RandomState(1)
+    U0 = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    B0 = rs.normal(0, 0.1, n_items).astype(np.float32)
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    tr.set_factors(U0, V0, B0)
+    tr.seed_hogwild(5)
+    tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
+    assert tr.strata_stats()["bucket_builds"] >= 1
+    U1, V1, B1 = tr.get_factors()
+    assert np.array_equal(V1, V0) and np.array_equal(B1, B0) and np.array_equal(U1, U0)
+    # a new table handed over while the records were packed is what the next call trains on (not the old records)
+    tr.fit_epochs(1, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
+    V2 = (V0 * 2).astype(np.float32)
+    tr.set_factors(None, V2, None)
+    tr.fit_epochs(1, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
+    assert np.array_equal(tr.get_factors()[1], V2)
+    # real training, fit_epochs (packed records) and the chunk API (dense tables) taking turns: every call continues
+    # from what the previous one left, the model learns, and the table really moves in both kinds of call
+    tr.set_factors(U0, V0, B0)
+    c1, s1 = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
+    Va = tr.get_factors()[1]
+    tr.hogwild_enqueue(len(indices), 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.FORM_STRATA)
+    c2, s2 = tr.sync()
+    Vb = tr.get_factors()[1]
+    c3, s3 = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=_lib.FORM_STRATA)
+    Vc, Bc = tr.get_factors()[1:]
+    tr.close()
+    n = len(indices)
+    assert np.abs(Va - V0).max() > 1e-3 and np.abs(Vb - Va).max() > 1e-3 and np.abs(Vc - Vb).max() > 1e-3
+    assert np.abs(Bc - B0).max() > 1e-3 and np.isfinite(Vc).all() and np.isfinite(Bc).all()
+    acc = [c / float(n - s_) for c, s_ in ((c1, s1), (c2, s2), (c3, s3))]
+    assert acc[2] > acc[0] > 0.45, acc
+
+
+def test_ldsbin_ranking_metrics_match_the_global_negative_draw(capsys):
+    """Advisor r3: judge the binned negatives by a RANKING metric, not only by the pairwise loss.  One held-out positive
+    per user; BPR trained from the same start tables for the same epochs by (a) the LDS-bin form — negatives from the
+    positive's bin, bins re-dealt every epoch from permuted popularity strata — and (b) the fused kernel, whose negatives
+    are uniform over ALL items like the reference's (recom_bpr.pyx:235-238); Recall@20 / NDCG@20 of the held-out item with
+    the training positives excluded (the evaluation protocol, on the device top-k kernel).  The data is popularity-driven
+    (Zipf items), so the metric is decided by the order among the popular items — exactly the comparisons the round-3
+    deal could not make."""
+    from cornac_amd import synth
+
+    n_users, n_items, k = 8000, 12800, 64
+    users, items = synth.zipf_interactions(n_users, n_items, 800_000, 0.9, 17)
+    rs = np.random.RandomState(3)
+    # hold out one interaction of every user with at least 5
+    order = np.lexsort((rs.random_sample(len(users)), users))
+    users, items = users[order], items[order]
+    first = np.concatenate([[True], users[1:] != users[:-1]])
+    deg = np.bincount(users, minlength=n_users)
+    held = first & (deg[users] >= 5)
+    tu, ti = users[held], items[held]
+    keep = ~held
+    o2 = np.lexsort((items[keep], users[keep]))
+    tr_u, tr_i = users[keep][o2], items[keep][o2]
+    indptr, indices = synth.csr_from_sorted(tr_u, tr_i, n_users)
+    U0 = ((rs.random_sample((n_users, k)) - 0.5) / k).astype(np.float32)
+    V0 = ((rs.random_sample((n_items, k)) - 0.5) / k).astype(np.float32)
+    excl = (np.concatenate([[0], np.cumsum(np.diff(indptr)[tu])]).astype(np.int64),          # the listed users' training
+            np.concatenate([indices[indptr[u]:indptr[u + 1]] for u in tu]).astype(np.int32))  # positives, CSR per listed user
+    out = {}
+    for name, flags in (("ldsbin", _lib.FORM_AUTO), ("fused", _lib.FORM_FUSED)):
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        if name == "ldsbin":
+            assert tr.ldsbin_stats()["bins"] == 256
+        tr.set_factors(U0, V0, np.zeros(n_items, np.float32))
+        tr.seed_hogwild(99)
+        tr.fit_epochs(25, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        U, V, B = tr.get_factors()
+        tr.close()
+        sc = _lib.Scorer(U, V, B, None)
+        top, _ = sc.rank_topk(tu.astype(np.int32), 20, exclude=excl)
+        sc.close()
+        hit = top == ti[:, None].astype(np.int32)
+        rank = np.where(hit.any(1), hit.argmax(1), -1)
+        recall = float((rank >= 0).mean())
+        ndcg = float(np.where(rank >= 0, 1.0 / np.log2(rank + 2.0), 0.0).mean())
+        out[name] = (recall, ndcg)
+    pop = np.argsort(-np.bincount(indices, minlength=n_items), kind="stable")[:40]
+    pop_recall = float(np.mean([ti[t] in set(pop[~np.isin(pop, indices[indptr[u]:indptr[u + 1]])][:20].tolist())
+                                for t, u in enumerate(tu)]))
+    with capsys.disabled():
+        print("\nheld-out Recall@20 / NDCG@20 over %d users: LDS-bin negatives %.4f / %.4f, global negatives (fused kernel) "
+              "%.4f / %.4f; most-popular baseline Recall@20 %.4f" % ((len(tu),) + out["ldsbin"] + out["fused"] + (pop_recall,)))
+    (ra, na), (rb, nb) = out["ldsbin"], out["fused"]
+    se = np.sqrt(max(rb, 1e-3) * (1 - rb) / len(tu))
+    assert rb > 0.5 * pop_recall and ra > 0.5 * pop_recall, (out, pop_recall)   # both really rank
+    assert abs(ra - rb) <= 4 * se + 0.05 * rb, (out, se)
+    assert abs(na - nb) <= 4 * se + 0.05 * nb, (out, se)
+
+
 def _ldsbin_case(n_users=6000, n_items=3003, nnz=700_000, zipf=0.8, seed=3):
     from cornac_amd import synth
 
