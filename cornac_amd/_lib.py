@@ -36,7 +36,7 @@ SYMBOLS = [
     "cornac_hip_bpr_last_timing", "cornac_hip_bpr_kernel_timing", "cornac_hip_mf_kernel_timing",
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_fit_epochs_f64", "cornac_hip_vebpr_hogwild_form",
-    "cornac_hip_bpr_strata_config", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
+    "cornac_hip_bpr_strata_config", "cornac_hip_bpr_chunk_records", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
     "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
     "cornac_hip_bpr_ldsbin_deal_config", "cornac_hip_bpr_debug_ldsbin_deal",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
@@ -176,6 +176,7 @@ def lib():
         L.cornac_hip_table_delta.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+        L.cornac_hip_bpr_chunk_records.argtypes = [_vp, C.c_int]
         L.cornac_hip_bpr_strata_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_strata.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
         L.cornac_hip_bpr_ldsbin_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
@@ -515,6 +516,11 @@ class BprTrainer:
 
     def strata_config(self, hot_permille=120, hot_min_mult_x100=200, rehash_period=1):
         check(lib().cornac_hip_bpr_strata_config(self.h, int(hot_permille), int(hot_min_mult_x100), int(rehash_period)))
+
+    def chunk_records(self, enable=True):
+        """let hogwild_enqueue keep the strata form's packed item records from call to call (see include/cornac_hip.h:
+        the caller touches the bound dense table only through table_delta_* until sync())"""
+        check(lib().cornac_hip_bpr_chunk_records(self.h, int(bool(enable))))
 
     def strata_stats(self):
         o = (C.c_int64 * 4)()

@@ -680,6 +680,7 @@ struct cornac_hip_bpr {
     // authoritative and the dense V / B are stale; every other entry point unpacks first (bpr_check).
     DevBuf<float> VB;
     bool strata_packed = false, strata_allow_pack = false;
+    bool chunk_records = false;  // cornac_hip_bpr_chunk_records: the chunk API may keep the records too (multi-GPU driver)
     int vb_pitch = 0, vb_kp = 0;
     DevBuf<unsigned long long> counters;  // [0] correct, [1] skipped, [2] strata workgroups placed off their logical XCD
     // deterministic sampler state
@@ -1617,9 +1618,11 @@ static void strata_unpack(cornac_hip_bpr_t h) {
 
 static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int flags) {
     const int grid = strata_prepare(h);
-    // packed records only inside fit_epochs (strata_allow_pack) and only for tables the handle owns: the multi-GPU
-    // drivers train into a caller-owned dense table and read it between chunks
-    const bool packed = h->strata_allow_pack && h->V.owned && h->B.owned && !prof_env_set("CORNAC_HIP_STRATA_NO_PACK");
+    // packed records only inside fit_epochs (strata_allow_pack) and only for tables the handle owns — or, in the chunk
+    // API, when the caller said so (cornac_hip_bpr_chunk_records: the multi-GPU driver, which touches its dense replica
+    // only through cornac_hip_bpr_table_delta_* between chunks and reads it after cornac_hip_bpr_sync)
+    const bool packed = h->strata_allow_pack && ((h->V.owned && h->B.owned) || h->chunk_records) &&
+                        !prof_env_set("CORNAC_HIP_STRATA_NO_PACK");
     if (packed) strata_pack(h); else strata_unpack(h);
     if (!packed) h->Bpad.ensure((size_t)h->total_items * kBiasStride);
     const unsigned bgrid = (unsigned)((h->total_items + kBlock - 1) / kBlock);
@@ -2008,16 +2011,31 @@ int cornac_hip_bpr_fit_epochs_f64(cornac_hip_bpr_t h, int n_epochs, double lr, d
 int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
                                    int neg_population, int hogwild_flags) {
     return guarded([&] {
-        bpr_check(h);
+        if (h && h->chunk_records) bpr_check_keep_packed(h); else bpr_check(h);
         REQUIRE(n_samples >= 0, "n_samples must be >= 0");
         REQUIRE(!h->f64, "the handle holds float64 tables: use cornac_hip_bpr_fit_epochs_f64 (sequential semantics only)");
+        struct AllowPack {
+            cornac_hip_bpr_t h;
+            ~AllowPack() { h->strata_allow_pack = false; }
+        } allow_guard{h};
+        h->strata_allow_pack = h->chunk_records && h->hog_seeded && !hogwild_uses_ldsbin(h, n_samples, neg_population, hogwild_flags) &&
+                               hogwild_uses_strata(h, n_samples, neg_population, hogwild_flags);
+        if (!h->strata_allow_pack) strata_unpack(h);
         hogwild_enqueue(h, n_samples, lr, reg, use_bias, neg_population, hogwild_flags);
+    });
+}
+
+int cornac_hip_bpr_chunk_records(cornac_hip_bpr_t h, int enable) {
+    return guarded([&] {
+        bpr_check(h);  // (dense tables current: the mode starts and ends with them)
+        h->chunk_records = enable != 0;
     });
 }
 
 int cornac_hip_bpr_sync(cornac_hip_bpr_t h, int64_t *correct, int64_t *skipped) {
     return guarded([&] {
-        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay)
+        bpr_check_keep_packed(h);  // (touches no table: packed strata records stay ...
+        if (!h->V.owned || !h->B.owned) strata_unpack(h);  // ... unless the dense table is the caller's: it reads it after this call)
         if (correct) *correct = 0;
         if (skipped) *skipped = 0;
         fetch_counters(h, correct, skipped);

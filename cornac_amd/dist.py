@@ -73,6 +73,19 @@ class ItemTableReplica:
         self.sparse_threshold = sparse_threshold
         self.exchanges = {"dense": 0, "sparse": 0, "sparse_rows": 0}
         self._count_host = None
+        # the dense exchange's buffers, two sets used in turn (exchange c is in flight while c + 1 is being filled): at the
+        # configs[4] size a bucket is 5.3 GB — allocated once, not per exchange
+        self._sets = [None, None]
+        self._turn = 0
+
+    def _next_buffers(self):
+        """(bucket [n k + 3 n], local [n k + n]) of the next exchange"""
+        n, k = self.total_items, self.k
+        self._turn ^= 1
+        if self._sets[self._turn] is None:
+            self._sets[self._turn] = (torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device),
+                                      torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device))
+        return self._sets[self._turn]
 
     def _factors(self, S, w):
         """per-row factor the summed delta S [m, width] is multiplied with; w = the all-reduced per-row weights"""
@@ -117,10 +130,9 @@ class ItemTableReplica:
             self._pending = (None, None, None)
             return
         n, k = self.total_items, self.k
-        bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
+        bucket, local = self._next_buffers()
         delta = bucket[: n * k + n]
         if self.trainer is not None and self.flat.is_cuda:
-            local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
             self.trainer.table_delta_begin(self.flat.data_ptr(), self.base.data_ptr(), n, k, bucket.data_ptr(),
                                            local.data_ptr(), rule=RULES[self.rule])
         else:
@@ -128,7 +140,7 @@ class ItemTableReplica:
             wV, wB = self._weights(delta[: n * k].view(n, k), delta[n * k:])
             bucket[n * k + n: n * k + 2 * n] = wV   # V rows: touched flag ("sqrt") or |d|^2 ("align")
             bucket[n * k + 2 * n:] = wB             # biases likewise
-            local = delta.clone()
+            local.copy_(delta)
         if self.sparse_threshold is not None and self._begin_sparse(bucket):
             return
         self.exchanges["dense"] += 1
@@ -216,8 +228,7 @@ class ItemTableReplica:
         self._pending = None
         work.wait()
         n, k = self.total_items, self.k
-        bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
-        local = torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device)
+        bucket, local = self._next_buffers()
         self.trainer.table_delta_step(self.flat.data_ptr(), self.base.data_ptr(), bucket_prev.data_ptr(),
                                       local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr(), rule=RULES[self.rule])
         self.exchanges["dense"] += 1
@@ -268,6 +279,11 @@ class ShardedBprTrainer:
                 torch.cuda.synchronize(device)
                 trainer.bind_device(None, self.table.V.data_ptr(), self.table.B.data_ptr())
                 trainer.set_stream(self.stream.cuda_stream)
+                # dense exchange: the replica is touched between chunks only by the handle's own table passes, so the XCD-strata
+                # form may keep its packed item records (row + bias line in one place) from chunk to chunk; the passes then
+                # work on the records and sync() writes them back.  The sparse exchange indexes the dense replica from torch.
+                if sparse_threshold is None and hasattr(trainer, "chunk_records") and dist.is_available() and dist.is_initialized():
+                    trainer.chunk_records(True)
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()

@@ -159,6 +159,13 @@ int cornac_hip_bpr_debug_ownership(cornac_hip_bpr_t h, int64_t *n_waves, int64_t
  * returns the bucket offsets sptr[8 W + 1], the bucketed records rec_u / rec_i [nnz] (rec_i: bit 31 = hot row),
  * rank_item [n_items] (popularity rank -> item) and the epoch key; any pointer may be NULL. */
 int cornac_hip_bpr_strata_config(cornac_hip_bpr_t h, int hot_permille, int hot_min_mult_x100, int rehash_period);
+/* Inside cornac_hip_bpr_fit_epochs the XCD-strata form trains on packed item records (row + its bias line = one random
+ * location per item, csrc/bpr_strata.inc); every other entry point gets the dense V / B back first.  enable = 1 lets the
+ * chunk API (cornac_hip_bpr_hogwild_enqueue) keep the records from call to call as well — for a caller that touches the
+ * (bound) dense table between chunks only through cornac_hip_bpr_table_delta_begin / _step / _finish, which then work on
+ * the records, and reads it after cornac_hip_bpr_sync, which writes the records back (the multi-GPU driver of
+ * cornac_amd/dist.py with the dense exchange).  Default 0. */
+int cornac_hip_bpr_chunk_records(cornac_hip_bpr_t h, int enable);
 int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
 int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
                                 int32_t *rank_item, uint32_t *key);

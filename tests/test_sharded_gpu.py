@@ -453,6 +453,73 @@ def _fresh_port():
         return str(sk.getsockname()[1])
 
 
+def test_sharded_trainer_keeps_packed_records_between_chunks_through_rccl():
+    """The multi-GPU BPR driver over the XCD-strata form (forced here; automatic for item tables of >= 2^20 rows, i.e. the
+    configs[4] slices): with the dense exchange the handle keeps its packed item records from chunk to chunk
+    (cornac_hip_bpr_chunk_records), the driver's table passes work on the records, and finish() -> sync() writes them
+    back into the torch-owned replica.  One rank through RCCL, 4 exchanges per epoch:
+    * lr = 0: records -> passes -> records -> replica is the identity, bit for bit (any mis-addressed row or bias would show);
+    * lr > 0: the same seed with and without the records trains the same model in aggregate (the sampler and the
+      arithmetic are the same; the form itself is racy, so not row by row) and the replica is rebased after finish()."""
+    import torch
+    import torch.distributed as dist
+
+    from cornac_amd import synth
+    from cornac_amd.dist import ShardedBprTrainer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = _fresh_port()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    # 2^20 item rows: the size from which the form is automatic; k = 100: padded rows in the records, scalar table passes
+    n_users, n_items, k = 20000, 1 << 20, 100
+    users, items = synth.zipf_interactions(n_users, n_items, 700_000, 0.5, 11)   # (>= 524 288: user-row ownership)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    nnz = len(indices)
+    rs = np.random.RandomState(2)
+    U0 = rs.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    B0 = rs.normal(0, 0.1, n_items).astype(np.float32)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        def drive(lr, records, epochs=1):
+            tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+            tr.set_factors(U0, None, None)
+            tr.seed_hogwild(21)
+            sh = ShardedBprTrainer(tr, n_items, k, dev, sync_every=(nnz + 3) // 4)
+            if not records:
+                tr.chunk_records(False)
+            sh.load_items(V0, B0)
+            for _ in range(epochs):
+                sh.run(nnz, lr, 0.01, True, _lib.NEG_UNIFORM, _lib.FORM_STRATA)
+            c, s_ = sh.finish()
+            st = tr.strata_stats()
+            V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
+            rebased = np.array_equal(sh.table.base.cpu().numpy(), sh.table.flat.cpu().numpy())
+            ex = dict(sh.table.exchanges)
+            U = tr.get_user_factors()
+            tr.close()
+            assert st["bucket_builds"] >= 1 and ex["dense"] == 4 * epochs and rebased, (st, ex, rebased)
+            return U, V, B, c / float(nnz * epochs - s_)
+
+        U, V, B, _ = drive(0.0, True)
+        assert np.array_equal(V, V0) and np.array_equal(B, B0) and np.array_equal(U, U0)
+        Ua, Va, Ba, acc_a = drive(0.05, True, epochs=2)
+        Ub, Vb, Bb, acc_b = drive(0.05, False, epochs=2)
+        assert np.abs(Va - V0).max() > 1e-3 and np.abs(Ba - B0).max() > 1e-3
+        # the form is racy (a read-modify-write lost inside an XCD differs from run to run, and its effect spreads through
+        # the users that touch the row), so the two tables agree in aggregate, not row by row: the same moves, the same
+        # 'correct' fraction
+        dva, dvb = (Va - V0).ravel().astype(np.float64), (Vb - V0).ravel().astype(np.float64)
+        cos = float(dva @ dvb) / (np.linalg.norm(dva) * np.linalg.norm(dvb))
+        dba, dbb = (Ba - B0).astype(np.float64), (Bb - B0).astype(np.float64)
+        cos_b = float(dba @ dbb) / (np.linalg.norm(dba) * np.linalg.norm(dbb))
+        assert cos > 0.995 and cos_b > 0.995, (cos, cos_b)
+        assert abs(np.linalg.norm(dva) / np.linalg.norm(dvb) - 1.0) < 0.01 and abs(acc_a - acc_b) < 0.01, (acc_a, acc_b)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sharded_mf_trainer_single_rank_through_rccl():
     """the multi-GPU MF driver (ShardedMfTrainer: item side [V | Bi] in a torch-owned replica, epochs enqueued in slices on
     the driver's stream, the replica's delta passes through cornac_hip_table_delta, a real RCCL group of size 1) against
