@@ -639,13 +639,16 @@ def leg_dist_tax(args, _lib):
             tr.seed_hogwild(11)
             sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=(nnz + spe - 1) // spe, sparse_threshold=None)
             sh.load_items(V, B)
+            # the resident exchange (ONE launch per epoch, the exchange points inside it) where the handle takes the LDS-bin
+            # form, chunk launches with the overlapped exchange between them otherwise: ShardedBprTrainer.run_epoch decides
+            resident = os.environ.get("CORNAC_BENCH_DIST_CHUNKS") is None and 1 <= spe <= 32 and sh.resident_bins() > 0
             for _ in range(2):   # warm-up with the timed region's own pattern (begin, step, finish: both buffer sets exist)
-                sh.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0)
+                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident)
             sh.finish()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(epochs):
-                sh.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0)
+                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident)
             sh.finish()
             torch.cuda.synchronize()
             driven = (time.perf_counter() - t0) / epochs
@@ -654,6 +657,7 @@ def leg_dist_tax(args, _lib):
             torch.cuda.empty_cache()
             out[shape] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven,
                           "exchanges_per_epoch": spe, "tax": 1.0 - plain / driven,
+                          "protocol": "resident exchange (one launch per epoch)" if resident else "chunk launches",
                           "triplets_per_s_plain": nnz / plain, "triplets_per_s_driver": nnz / driven,
                           "workload": "%d users x %d items, %d interactions, k = %d" % (nu, ni, nnz, k)}
         out["value"] = max(v["tax"] for v in out.values() if isinstance(v, dict))
@@ -750,6 +754,9 @@ def main():
                     help="multi-GPU regime 2: item table sharded by row, all-to-all of the touched rows "
                          "(default for N > 1 is regime 1: replicated item table + all-reduce of deltas)")
     ap.add_argument("--micro-batch", type=int, default=2_000_000, help="draws per exchange with --sharded-items")
+    ap.add_argument("--dist-chunks", action="store_true",
+                    help="multi-GPU regime 1: cut the epoch into chunk launches with the overlapped exchange between them "
+                         "even where the resident exchange (one launch per epoch) is available")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
     ap.add_argument("--legs", default="mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale,dist_tax",
@@ -818,7 +825,7 @@ def main():
             "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
             "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 
-    sharded = None
+    sharded, resident_mode = None, False
     if distributed and args.sharded_items:
         from cornac_amd.dist import RowShardedBprTrainer
 
@@ -837,6 +844,8 @@ def main():
         sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
                                     // args.sync_per_epoch, sparse_threshold=sparse)
         sharded.load_items(V, B)
+        resident_mode = (not args.dist_chunks and sparse is None and 1 <= args.sync_per_epoch <= 32
+                         and sharded.resident_bins(_lib.NEG_UNIFORM, args.flags) > 0)
 
     def step():
         if sharded is None:
@@ -844,7 +853,10 @@ def main():
         if args.sharded_items:
             sharded.run(nnz, args.lr, args.reg, True)
         else:
-            sharded.run(nnz, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags)
+            # the resident exchange (one launch per epoch, the exchange points inside it) where the handle takes the LDS-bin
+            # form; chunk launches with the overlapped exchange between them otherwise or with --dist-chunks
+            sharded.run_epoch(nnz, args.sync_per_epoch, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags,
+                              resident=resident_mode)
         return (0, 0)
 
     for _ in range(args.warmup):
@@ -890,8 +902,9 @@ def main():
                    "parallelism": "1 gpu" if world == 1 and not distributed else
                                   ("user-partitioned dp%d, item table sharded by row, all-to-all every %d draws"
                                    % (world, args.micro_batch)) if args.sharded_items else
-                                  ("user-partitioned dp%d, item table all-reduce x%d/epoch"
-                                   % (world, args.sync_per_epoch))},
+                                  ("user-partitioned dp%d, item table all-reduce x%d/epoch%s"
+                                   % (world, args.sync_per_epoch, " from inside one launch per epoch (resident exchange)"
+                                      if resident_mode else ", chunk launches"))},
     }
     if rank == 0 and sharded is None:
         out["step_ms"] = {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)), "max": float(np.max(step_ms))}

@@ -45,6 +45,8 @@ SYMBOLS = [
     "cornac_hip_bpr_scatter_diff_rows", "cornac_hip_bpr_switch_stream",
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
     "cornac_hip_bpr_table_delta_step", "cornac_hip_table_delta",
+    "cornac_hip_bpr_resident_exchange_bins", "cornac_hip_bpr_epoch_resident_enqueue", "cornac_hip_bpr_resident_flush",
+    "cornac_hip_stream_wait_counter", "cornac_hip_stream_set_flag",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
@@ -174,6 +176,13 @@ def lib():
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
         L.cornac_hip_bpr_table_delta_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_table_delta.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
+        L.cornac_hip_bpr_resident_exchange_bins.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.cornac_hip_bpr_epoch_resident_enqueue.argtypes = [_vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                            C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp,
+                                                            C.POINTER(C.c_int)]
+        L.cornac_hip_bpr_resident_flush.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]
+        L.cornac_hip_stream_wait_counter.argtypes = [C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_int]
+        L.cornac_hip_stream_set_flag.argtypes = [C.c_int, _vp, _vp, C.c_uint32]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_chunk_records.argtypes = [_vp, C.c_int]
@@ -243,6 +252,15 @@ def lib():
 def check(rc):
     if rc != 0:
         raise HipError(rc, lib().cornac_hip_last_error().decode("utf-8", "replace"))
+
+
+def stream_wait_counter(device, stream, d_counter, target, d_error, timeout_ms=5000):
+    """enqueue on `stream` (a hipStream_t as int): wait until *d_counter >= target; after timeout_ms *d_error = 1"""
+    check(lib().cornac_hip_stream_wait_counter(int(device), stream, d_counter, int(target), d_error, int(timeout_ms)))
+
+
+def stream_set_flag(device, stream, d_flag, value=1):
+    check(lib().cornac_hip_stream_set_flag(int(device), stream, d_flag, int(value)))
 
 
 def device_count():
@@ -438,6 +456,26 @@ class BprTrainer:
             return self._delta(2, rule, d_flat, d_base, d_bucket_prev, d_local_prev, int(n_items), int(k), d_bucket, d_local)
         check(lib().cornac_hip_bpr_table_delta_step(self.h, d_flat, d_base, d_bucket_prev, d_local_prev, int(n_items),
                                                     int(k), d_bucket, d_local))
+
+    # ---- resident exchange (multi-GPU regime 1 inside one launch per epoch; include/cornac_hip.h) ----
+    def resident_exchange_bins(self, neg_population=NEG_UNIFORM, flags=0):
+        """workgroups of the resident-exchange launch (= arrivals per exchange); 0: this shape / these flags do not take
+        the LDS-bin form and the driver has to cut the epoch into chunk launches"""
+        n = C.c_int()
+        check(lib().cornac_hip_bpr_resident_exchange_bins(self.h, neg_population, flags, C.byref(n)))
+        return n.value
+
+    def epoch_resident_enqueue(self, lr, reg, use_bias, neg_population, flags, n_exchanges, rule, d_base, d_buckets,
+                               bucket_stride, d_keeps, keep_stride, d_arrive, d_landed, d_applied):
+        n = C.c_int()
+        check(lib().cornac_hip_bpr_epoch_resident_enqueue(self.h, lr, reg, int(use_bias), neg_population, flags,
+                                                          int(n_exchanges), int(rule), d_base, d_buckets, int(bucket_stride),
+                                                          d_keeps, int(keep_stride), d_arrive, d_landed, d_applied, C.byref(n)))
+        return n.value
+
+    def resident_flush(self, n_exchanges, rule, d_base, d_buckets, bucket_stride, d_keeps, keep_stride, d_applied):
+        check(lib().cornac_hip_bpr_resident_flush(self.h, int(n_exchanges), int(rule), d_base, d_buckets, int(bucket_stride),
+                                                  d_keeps, int(keep_stride), d_applied))
 
     def gather_rows(self, d_table, d_ids, n, width, d_out):
         check(lib().cornac_hip_bpr_gather_rows(self.h, d_table, d_ids, int(n), int(width), d_out))

@@ -1669,7 +1669,19 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
 
 // ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
 typedef void (*LdsBinKernel)(const LdsBinArgs);
-static LdsBinKernel pick_ldsbin_kernel(int k, bool pop) {
+static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false) {
+    if (exch) {  // resident exchange (multi-GPU regime 1 inside one launch per epoch)
+        if (pop) {
+            if (k <= 64) return bpr_ldsbin_kernel<1, 4, true, true>;
+            if (k <= 128) return bpr_ldsbin_kernel<2, 2, true, true>;
+            if (k <= 192) return bpr_ldsbin_kernel<3, 2, true, true>;
+            return bpr_ldsbin_kernel<4, 1, true, true>;
+        }
+        if (k <= 64) return bpr_ldsbin_kernel<1, 4, false, true>;
+        if (k <= 128) return bpr_ldsbin_kernel<2, 2, false, true>;
+        if (k <= 192) return bpr_ldsbin_kernel<3, 2, false, true>;
+        return bpr_ldsbin_kernel<4, 1, false, true>;
+    }
     if (pop) {
         if (k <= 64) return bpr_ldsbin_kernel<1, 4, true>;
         if (k <= 128) return bpr_ldsbin_kernel<2, 2, true>;
@@ -1843,6 +1855,7 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
     a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg;
     a.ablate = (flags >> 8) & 0xff;
     a.wg_clock = nullptr;
+    a.ex = LdsBinExchange{};
 }
 
 // one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
@@ -1892,6 +1905,27 @@ static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
         advance_hog_offset(h, n);
         left -= n;
     }
+}
+
+// One whole epoch in ONE launch with the item-table exchanges of multi-GPU regime 1 inside it (bpr_ldsbin.inc, "resident
+// exchange"): the launch publishes its rows' deltas at n_ex points and applies the landed sums itself.
+static void ldsbin_resident_enqueue(cornac_hip_bpr_t h, float lr, float reg, int use_bias, int neg_population, int flags,
+                                    const LdsBinExchange &ex) {
+    ldsbin_build(h);
+    LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, true);
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
+    LdsBinArgs a;
+    ldsbin_fill_args(h, a, lr, reg, use_bias, neg_population, flags);
+    a.s_begin = 0;
+    a.n = (uint64_t)h->nnz;
+    a.nnz = (uint64_t)h->nnz;
+    a.ex = ex;
+    ldsbin_deal(h, a.seed, a.epoch, a.key);
+    h->ktimer.before(h->stream);
+    hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
+    h->ktimer.after(h->stream);
+    HIP_CHECK(hipGetLastError());
+    advance_hog_offset(h, h->nnz);
 }
 
 static void hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias,
@@ -2022,6 +2056,93 @@ int cornac_hip_bpr_hogwild_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float 
                                hogwild_uses_strata(h, n_samples, neg_population, hogwild_flags);
         if (!h->strata_allow_pack) strata_unpack(h);
         hogwild_enqueue(h, n_samples, lr, reg, use_bias, neg_population, hogwild_flags);
+    });
+}
+
+static LdsBinExchange resident_exchange_args(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, float *d_buckets,
+                                             int64_t bucket_stride, float *d_keeps, int64_t keep_stride,
+                                             uint32_t *d_arrive, const uint32_t *d_landed, uint32_t *d_applied) {
+    REQUIRE(n_exchanges >= 1 && n_exchanges <= kLbMaxExchanges, "n_exchanges must be in [1, %d]", kLbMaxExchanges);
+    REQUIRE(rule == 0 || rule == 1, "rule must be 0 (sqrt) or 1 (align)");
+    REQUIRE(d_base && d_buckets && d_keeps && d_arrive && d_landed && d_applied, "NULL device pointer");
+    const int64_t nt = h->total_items, width = nt * h->k + nt;
+    REQUIRE(bucket_stride >= width + 2 * nt && keep_stride >= width,
+            "a bucket holds [dV | dB | wV | wB] = %lld floats, a keep buffer [dV | dB] = %lld", (long long)(width + 2 * nt),
+            (long long)width);
+    LdsBinExchange ex;
+    ex.base = d_base; ex.bucket = d_buckets; ex.keep = d_keeps;
+    ex.arrive = d_arrive; ex.landed = d_landed; ex.applied = d_applied;
+    ex.bucket_stride = bucket_stride; ex.keep_stride = keep_stride; ex.nt = nt;
+    ex.n_ex = n_exchanges; ex.rule = rule;
+    return ex;
+}
+
+int cornac_hip_bpr_resident_exchange_bins(cornac_hip_bpr_t h, int neg_population, int hogwild_flags, int *n_bins) {
+    return guarded([&] {
+        bpr_check_keep_packed(h);
+        REQUIRE(n_bins != nullptr, "n_bins is NULL");
+        *n_bins = (h->hog_seeded && !h->f64 && hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags)) ? ldsbin_plan_bins(h) : 0;
+    });
+}
+
+int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float reg, int use_bias, int neg_population,
+                                          int hogwild_flags, int n_exchanges, int rule, float *d_base, float *d_buckets,
+                                          int64_t bucket_stride, float *d_keeps, int64_t keep_stride, uint32_t *d_arrive,
+                                          const uint32_t *d_landed, uint32_t *d_applied, int *n_arrivals) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+        REQUIRE(!h->f64, "the handle holds float64 tables");
+        REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
+                "unknown neg_population %d", neg_population);
+        REQUIRE(hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags),
+                "the resident exchange lives in the LDS-bin form, which this shape / these flags do not take "
+                "(cornac_hip_bpr_resident_exchange_bins tells): use cornac_hip_bpr_hogwild_enqueue chunks");
+        REQUIRE(h->hog_offset == 0, "an epoch is under way (%lld of its samples drawn): the resident launch covers whole epochs",
+                (long long)h->hog_offset);
+        const LdsBinExchange ex = resident_exchange_args(h, n_exchanges, rule, d_base, d_buckets, bucket_stride, d_keeps,
+                                                         keep_stride, d_arrive, d_landed, d_applied);
+        ldsbin_resident_enqueue(h, lr, reg, use_bias, neg_population, hogwild_flags, ex);
+        if (n_arrivals) *n_arrivals = h->lb_bins;
+    });
+}
+
+int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, const float *d_buckets,
+                                  int64_t bucket_stride, const float *d_keeps, int64_t keep_stride,
+                                  const uint32_t *d_applied) {
+    return guarded([&] {
+        bpr_check(h);
+        static uint32_t unused_flag = 0;
+        const LdsBinExchange ex = resident_exchange_args(h, n_exchanges, rule, d_base, const_cast<float *>(d_buckets), bucket_stride,
+                                                         const_cast<float *>(d_keeps), keep_stride, &unused_flag, &unused_flag,
+                                                         const_cast<uint32_t *>(d_applied));
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((h->n_items + kWavesPerBlock - 1) / kWavesPerBlock, 4096));
+        hipLaunchKernelGGL(ldsbin_exchange_flush_kernel, dim3(grid), dim3(kBlock), 0, h->stream, ex, h->V.p, h->B.p,
+                           (int32_t)h->n_items, h->k);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// The communication stream's two steps of the hand-shake (no handle: they run on the caller's stream): wait until
+// *d_counter >= target (gives up after timeout_ms and sets *d_error = 1), and set a flag.
+int cornac_hip_stream_wait_counter(int device, void *hip_stream, const uint32_t *d_counter, uint32_t target,
+                                   uint32_t *d_error, int timeout_ms) {
+    return guarded([&] {
+        REQUIRE(d_counter && d_error, "NULL device pointer");
+        REQUIRE(timeout_ms > 0, "timeout_ms must be positive");
+        use_device(device);
+        hipLaunchKernelGGL(stream_wait_counter_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)hip_stream, d_counter, target, d_error,
+                           (long long)timeout_ms * 100000ll);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value) {
+    return guarded([&] {
+        REQUIRE(d_flag != nullptr, "NULL device pointer");
+        use_device(device);
+        hipLaunchKernelGGL(stream_set_flag_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)hip_stream, d_flag, value);
+        HIP_CHECK(hipGetLastError());
     });
 }
 

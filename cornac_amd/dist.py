@@ -216,6 +216,45 @@ class ItemTableReplica:
         V[uniq] = bV + pV
         B[uniq] = bB + pB
 
+    # ---- resident protocol (ShardedBprTrainer.run_epoch_resident): several exchanges may be in flight --------------------
+    # publish: d = flat - base (this rank's steps since the last publication), base = flat, all-reduce [d | weights];
+    # apply (any time after the sum has landed): c = rule(S) - d_own, flat += c, base += c.  flat - base stays "steps not
+    # yet published" throughout, whatever the number of exchanges in flight; with every exchange applied exactly one
+    # boundary after its publication the tables are those of begin_sync / finish_sync.  On a GPU the bins' own workgroups
+    # do both per row inside the epoch's launch (csrc/bpr_ldsbin.inc); this torch form is the gloo path and the
+    # statement the device tests compare with.
+    def resident_publish(self):
+        n, k = self.total_items, self.k
+        bucket = torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device)
+        delta = bucket[: n * k + n]
+        torch.sub(self.flat, self.base, out=delta)
+        self.base.copy_(self.flat)
+        wV, wB = self._weights(delta[: n * k].view(n, k), delta[n * k:])
+        bucket[n * k + n: n * k + 2 * n] = wV
+        bucket[n * k + 2 * n:] = wB
+        keep = delta.clone()
+        work = None
+        if dist.is_available() and dist.is_initialized():
+            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.exchanges["dense"] += 1
+        return work, bucket, keep
+
+    def resident_correction(self, bucket, keep):
+        """c = rule(S) - keep for an all-reduced bucket [S | weights]"""
+        n, k = self.total_items, self.k
+        c = torch.empty(n * k + n, dtype=torch.float32, device=bucket.device)
+        S = bucket[: n * k].view(n, k)
+        torch.mul(S, self._factors(S, bucket[n * k + n: n * k + 2 * n]).unsqueeze(1), out=c[: n * k].view(n, k))
+        torch.mul(bucket[n * k: n * k + n], self._factors(bucket[n * k: n * k + n], bucket[n * k + 2 * n:]), out=c[n * k:])
+        return c.sub_(keep)
+
+    def resident_apply(self, work, bucket, keep):
+        if work is not None:
+            work.wait()
+        c = self.resident_correction(bucket, keep)
+        self.flat.add_(c)
+        self.base.add_(c)
+
     def step_sync(self):
         """finish_sync() of the pending exchange followed by begin_sync() of the next one; on a GPU the two table
         passes are one fused kernel"""
@@ -273,6 +312,12 @@ class ShardedBprTrainer:
         self.sync_every = int(sync_every)
         self.device = device
         self.stream = None
+        self._resident = None            # buffers of the resident exchange (device path), allocated at first use
+        self.resident_timeout_ms = 20000
+        self.resident_lag = 1            # host path: an exchange is applied this many boundaries after its publication
+        # emulation / test hook: called as hook(e, bucket) on the communication stream where the all-reduce of exchange e
+        # sits (after it, when there is one) — e.g. `bucket *= 2` plays a twin rank on a single GPU
+        self.resident_bucket_hook = None
         if device.type == "cuda":
             self.stream = torch.cuda.Stream(device)
             if trainer is not None:
@@ -317,12 +362,121 @@ class ShardedBprTrainer:
                     self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
                 self.table.step_sync()
 
+    # ---- resident exchange: ONE launch per epoch, the exchange points inside it (csrc/bpr_ldsbin.inc) ----------------------
+    def resident_bins(self, neg_population=0, flags=0):
+        """arrivals per exchange of the resident launch, 0 when this trainer / table cannot take it (not the LDS-bin form,
+        sparse exchange asked for, a host stand-in without the entry point)"""
+        if (self.table.sparse_threshold is not None or self.device.type != "cuda"
+                or not hasattr(self.trainer, "resident_exchange_bins")):
+            return 0
+        return int(self.trainer.resident_exchange_bins(neg_population, flags))
+
+    def _resident_buffers(self, n_ex):
+        st = self._resident
+        if st is None or st["n_ex"] != n_ex:
+            n, k, dev = self.table.total_items, self.table.k, self.device
+            st = self._resident = {
+                "n_ex": n_ex,
+                # every exchange of an epoch has its own bucket and keep buffer (n_ex x 2 x the table: 230 MB at the ML-20M
+                # shape with 16 exchanges — nothing on a 288 GB part): the launch never has to wait for a buffer
+                "buckets": torch.zeros((n_ex, n * k + 3 * n), dtype=torch.float32, device=dev),
+                "keeps": torch.zeros((n_ex, n * k + n), dtype=torch.float32, device=dev),
+                "signals": torch.zeros(2 * n_ex + 1, dtype=torch.int32, device=dev),   # arrive | landed | error
+                "applied": torch.zeros(n, dtype=torch.int32, device=dev),
+                "comm": torch.cuda.Stream(dev),
+            }
+            torch.cuda.synchronize(dev)
+        return st
+
+    def run_epoch_resident(self, n_exchanges, lr, reg, use_bias=True, neg_population=0, flags=0):
+        """one epoch as ONE launch that publishes the item-table deltas at `n_exchanges` points and applies the landed sums
+        itself; this side only feeds the collectives: on the communication stream, per exchange, wait for the launch's
+        arrivals -> all-reduce the bucket in place -> raise the landed flag.  The launch never waits, so nothing here can
+        deadlock it; a wait that does not end within resident_timeout_ms is reported by finish()."""
+        from . import _lib
+
+        t, n_ex = self.table, int(n_exchanges)
+        st = self._resident_buffers(n_ex)
+        sig, comm, dev_index = st["signals"], st["comm"], self.device.index or 0
+        p_arrive, p_landed, p_err = sig.data_ptr(), sig.data_ptr() + 4 * n_ex, sig.data_ptr() + 8 * n_ex
+        stride_b, stride_k = st["buckets"].stride(0), st["keeps"].stride(0)
+        with self._on_stream():
+            if t._pending is not None:
+                t.finish_sync()            # (an exchange of the chunk protocol still in flight)
+            sig[: 2 * n_ex].zero_()
+            zeroed = torch.cuda.Event()
+            zeroed.record()
+            arrivals = self.trainer.epoch_resident_enqueue(lr, reg, use_bias, neg_population, flags, n_ex, RULES[t.rule],
+                                                           t.base.data_ptr(), st["buckets"].data_ptr(), stride_b,
+                                                           st["keeps"].data_ptr(), stride_k, p_arrive, p_landed,
+                                                           st["applied"].data_ptr())
+        comm.wait_event(zeroed)
+        collective = dist.is_available() and dist.is_initialized()
+        with torch.cuda.stream(comm):
+            for e in range(n_ex):
+                _lib.stream_wait_counter(dev_index, comm.cuda_stream, p_arrive + 4 * e, arrivals, p_err, self.resident_timeout_ms)
+                if collective:
+                    dist.all_reduce(st["buckets"][e], op=dist.ReduceOp.SUM, group=t.group, async_op=True).wait()
+                if self.resident_bucket_hook is not None:
+                    self.resident_bucket_hook(e, st["buckets"][e])
+                _lib.stream_set_flag(dev_index, comm.cuda_stream, p_landed + 4 * e, 1)
+            landed = torch.cuda.Event()
+            landed.record()
+        with self._on_stream():
+            self.stream.wait_event(landed)
+            self.trainer.resident_flush(n_ex, RULES[t.rule], t.base.data_ptr(), st["buckets"].data_ptr(), stride_b,
+                                        st["keeps"].data_ptr(), stride_k, st["applied"].data_ptr())
+        t.exchanges["dense"] += n_ex
+        t.exchanges["resident"] = t.exchanges.get("resident", 0) + n_ex
+
+    def _run_epoch_resident_host(self, nnz, n_exchanges, lr, reg, use_bias, neg_population, flags):
+        """the same protocol on a host (gloo): the stand-in trains chunk by chunk, the table does for all rows at once
+        what the device's duty waves do row by row"""
+        t, pending = self.table, []
+        if t._pending is not None:
+            t.finish_sync()
+        for e in range(n_exchanges):
+            n = nnz * (e + 1) // n_exchanges - nnz * e // n_exchanges
+            if n:
+                self.trainer.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
+            while pending and pending[0][0] <= e - self.resident_lag:
+                t.resident_apply(*pending.pop(0)[1])
+            ex = t.resident_publish()
+            if self.resident_bucket_hook is not None:
+                if ex[0] is not None:
+                    ex[0].wait()
+                self.resident_bucket_hook(e, ex[1])
+                ex = (None, ex[1], ex[2])
+            pending.append((e, ex))
+        for _, ex in pending:              # (the device's flush)
+            t.resident_apply(*ex)
+        t.exchanges["resident"] = t.exchanges.get("resident", 0) + n_exchanges
+
+    def run_epoch(self, nnz, parts, lr, reg, use_bias=True, neg_population=0, flags=0, resident=None):
+        """one epoch of `nnz` samples with `parts` item-table exchanges.  resident = None: the resident exchange (one
+        launch) where the trainer has it, else `parts` chunk launches with the overlapped exchange between them
+        (run_epoch_in_parts); True / False force one or the other (True on a host stand-in: the torch form)."""
+        parts = int(parts)
+        if resident is None:
+            resident = 1 <= parts <= 32 and self.resident_bins(neg_population, flags) > 0
+        if not resident:
+            return self.run_epoch_in_parts(nnz, parts, lr, reg, use_bias, neg_population, flags)
+        if self.device.type == "cuda" and hasattr(self.trainer, "epoch_resident_enqueue"):
+            return self.run_epoch_resident(parts, lr, reg, use_bias, neg_population, flags)
+        return self._run_epoch_resident_host(int(nnz), parts, lr, reg, use_bias, neg_population, flags)
+
     def finish(self):
         with self._on_stream():
             self.table.finish_sync()
         out = self.trainer.sync()
         if self.stream is not None:
             self.stream.synchronize()
+        if self._resident is not None:
+            self._resident["comm"].synchronize()
+            if int(self._resident["signals"][-1].item()) != 0:
+                raise RuntimeError("resident exchange: the communication stream gave up waiting for the epoch launch's "
+                                   "arrivals (%d ms) — the exchange of that epoch was all-reduced incomplete"
+                                   % self.resident_timeout_ms)
         return out
 
 
@@ -894,8 +1048,13 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
         lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
         trainer.seed_hogwild((((hi << 32) | lo) + 7919 * rank) & 0xFFFFFFFFFFFFFFFF)
         sh.load_items(model.i_factors, model.i_biases)
+        # every rank must take the same protocol (the same number of collectives in the same order): the resident
+        # exchange only when every rank's trainer has it for its slice
+        resident = bool(_sum_over_ranks([0 if 1 <= parts <= 32 and sh.resident_bins(model._neg_population) > 0 else 1],
+                                        device, group)[0] == 0)
         for _ in range(model.max_iter):
-            sh.run_epoch_in_parts(nnz, parts, model.learning_rate, model.lambda_reg, model.use_bias, model._neg_population)
+            sh.run_epoch(nnz, parts, model.learning_rate, model.lambda_reg, model.use_bias, model._neg_population,
+                         resident=resident)
         correct, skipped = sh.finish()
         U_local = trainer.get_user_factors()
         V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()

@@ -264,6 +264,34 @@ int cornac_hip_bpr_table_delta_step(cornac_hip_bpr_t h, float *d_flat, float *d_
  * orthogonal deltas, the mean of identical ones — MF's default, cornac_amd/dist.py ItemTableReplica). */
 int cornac_hip_table_delta(int op, int device, void *hip_stream, float *d_flat, float *d_base, const float *d_bucket_prev,
                            const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
+/* Resident exchange: multi-GPU regime 1 for the LDS-bin form WITHOUT chunk launches (the reference has no counterpart:
+ * BPR._fit_sgd, recom_bpr.pyx:208-269, is one process; the update it distributes is :252-265).  ONE launch per epoch
+ * publishes the item-table deltas of this rank at n_exchanges points and applies the all-reduced sums of the earlier
+ * points as soon as their `landed` flag is set — the launch never waits for the collective (csrc/bpr_ldsbin.inc).
+ *   d_base     [nt k + nt], nt = total_items: as in the table_delta passes; table - base = steps not yet published
+ *   d_buckets  exchange e at + e * bucket_stride floats: [dV (nt k) | dB (nt) | wV (nt) | wB (nt)], all-reduced in place by
+ *              the caller; d_keeps exchange e at + e * keep_stride: this rank's own [dV | dB]
+ *   d_arrive   [n_exchanges] zero on entry; reaches *n_arrivals (the launch's workgroups) when bucket e is complete
+ *   d_landed   [n_exchanges] zero on entry; the caller sets [e] != 0 after the all-reduce of bucket e (in order)
+ *   d_applied  [n_items] out: row i has applied the exchanges [0, d_applied[i])
+ * The caller's communication stream runs, for e = 0 .. n_exchanges-1: cornac_hip_stream_wait_counter(d_arrive + e,
+ * *n_arrivals) -> all-reduce of bucket e -> cornac_hip_stream_set_flag(d_landed + e); when the last one has landed,
+ * cornac_hip_bpr_resident_flush (on the handle's stream) applies what the launch did not.  The bound tables
+ * (cornac_hip_bpr_bind_device) are the replica.  cornac_hip_bpr_resident_exchange_bins: *n_bins = the launch's
+ * workgroup count, 0 when this shape / these flags do not take the LDS-bin form (use hogwild_enqueue chunks then). */
+int cornac_hip_bpr_resident_exchange_bins(cornac_hip_bpr_t h, int neg_population, int hogwild_flags, int *n_bins);
+int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float reg, int use_bias, int neg_population,
+                                          int hogwild_flags, int n_exchanges, int rule, float *d_base, float *d_buckets,
+                                          int64_t bucket_stride, float *d_keeps, int64_t keep_stride, uint32_t *d_arrive,
+                                          const uint32_t *d_landed, uint32_t *d_applied, int *n_arrivals);
+int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, const float *d_buckets,
+                                  int64_t bucket_stride, const float *d_keeps, int64_t keep_stride,
+                                  const uint32_t *d_applied);
+/* on `hip_stream` of `device`: wait until *d_counter >= target (after timeout_ms: *d_error = 1 and the stream moves on);
+ * set *d_flag = value */
+int cornac_hip_stream_wait_counter(int device, void *hip_stream, const uint32_t *d_counter, uint32_t target,
+                                   uint32_t *d_error, int timeout_ms);
+int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value);
 
 /* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.

@@ -816,3 +816,88 @@ def test_model_level_sharded_fits_return_one_complete_model_on_every_rank():
     assert rmse < 0.9 * rmse_mean_only, (rmse, rmse_mean_only)
     for lo, hi in ((0, 20), (ds.num_users - 20, ds.num_users)):     # users of both ranks' ranges were trained and gathered
         assert np.abs(a["mBu"][lo:hi]).max() > 1e-3 and np.abs(a["bU"][lo:hi]).max() > 0.02
+
+
+# ---- resident exchange (ShardedBprTrainer.run_epoch, the protocol of csrc/bpr_ldsbin.inc's EXCH kernels) -------------
+def _resident_worker(rank, world, port, out, resident, lag, epochs, parts):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        indptr, indices, n_items = _popularity_data(rank)
+        k, nnz = 8, len(indices)
+        sh = ShardedBprTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"), sync_every=nnz)
+        sh.resident_lag = lag
+        init = np.random.RandomState(7)
+        sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
+        sh.trainer = _OracleTrainer(sh.table, indptr, indices, n_items, k, seed=11 + rank)
+        for _ in range(epochs):
+            sh.run_epoch(nnz, parts, 0.05, 0.01, resident=resident)
+        sh.finish()
+        acc = _pairwise_accuracy(sh.trainer.U, sh.table.V.numpy(), sh.table.B.numpy(), indptr, indices, n_items)
+        out[rank] = (sh.table.V.numpy().copy(), sh.table.B.numpy().copy(), sh.table.base.numpy().copy(), acc,
+                     dict(sh.table.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+def _resident_run(resident, lag=1, epochs=1, parts=8):
+    out = mp.Manager().dict()
+    mp.spawn(_resident_worker, args=(2, _free_port(), out, resident, lag, epochs, parts), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_resident_exchange_equals_the_chunk_protocol_within_an_epoch():
+    """The resident protocol (publish d = flat - base, base = flat; apply c = rule(S) - d_own to flat AND base whenever the
+    sum has landed) with every exchange applied one boundary after its publication is the overlapped chunk protocol
+    (begin_sync / finish_sync) in other words: two gloo ranks, real BPR arithmetic, one epoch of 8 exchanges -> the same
+    consolidated table to fp32 rounding, the same number of collectives, replicas rebased."""
+    (Va, Ba, base_a, _, ex_a), (Va1, Ba1, base_a1, _, _) = _resident_run(True)
+    (Vb, Bb, base_b, _, ex_b), _ = _resident_run(False)
+    assert ex_a["dense"] == ex_b["dense"] == 8 and ex_a["resident"] == 8, (ex_a, ex_b)
+    assert np.abs(Va - Vb).max() < 2e-6 and np.abs(Ba - Bb).max() < 2e-6, (np.abs(Va - Vb).max(), np.abs(Ba - Bb).max())
+    # one consolidated table on both ranks; nothing unpublished is left after the epoch's flush
+    assert np.allclose(Va, Va1, rtol=0, atol=1e-6) and np.allclose(Ba, Ba1, rtol=0, atol=1e-6)
+    assert np.array_equal(np.concatenate([Va.ravel(), Ba]), base_a) and np.allclose(base_a, base_a1, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("lag", [1, 3])
+def test_resident_exchange_learns_with_late_landing_sums(lag):
+    """several exchanges in flight (a sum applied three boundaries after its publication, the rest by the epoch's flush):
+    the accounting stays exact — both ranks end with one table — and the consolidated model is as good as the chunk
+    protocol's"""
+    (V0, B0, base0, acc0, _), (V1, B1, _, acc1, _) = _resident_run(True, lag=lag, epochs=6)
+    (_, _, _, ref0, _), (_, _, _, ref1, _) = _resident_run(False, epochs=6)
+    assert np.isfinite(V0).all() and np.allclose(V0, V1, rtol=0, atol=1e-5) and np.allclose(B0, B1, rtol=0, atol=1e-5)
+    assert np.array_equal(np.concatenate([V0.ravel(), B0]), base0)
+    assert acc0 > 0.75 and acc1 > 0.75 and acc0 > ref0 - 0.03 and acc1 > ref1 - 0.03, (acc0, acc1, ref0, ref1)
+
+
+def test_resident_exchange_of_one_process_keeps_its_own_steps_bit_for_bit():
+    """no process group: S = d and one touching rank -> c = 1 * d - d = 0 exactly; the table evolves as if nothing were
+    exchanged; with a twin rank played by the bucket hook (S = 2 d, two touching ranks) every published delta is
+    amplified to sqrt(2) d — checked in closed form on a stand-in with known steps"""
+    dev = torch.device("cpu")
+    sh = ShardedBprTrainer(None, total_items=6, k=4, device=dev, sync_every=100)
+    sh.trainer = _FakeTrainer(sh.table, 0)
+    V0 = np.arange(24, dtype=np.float32).reshape(6, 4)
+    sh.load_items(V0, np.zeros(6, np.float32))
+    sh.run_epoch(300, 3, lr=0.01, reg=0.0, resident=True)
+    sh.finish()
+    want = V0.copy()
+    want[0::2] += 0.01 * 300
+    want[0] += 3.0
+    assert np.array_equal(sh.table.V.numpy(), want) and np.array_equal(sh.table.B.numpy(), np.full(6, 1.5, np.float32))
+    assert torch.equal(sh.table.flat, sh.table.base)
+    # twin rank: every bucket doubled, weights doubled
+    sh2 = ShardedBprTrainer(None, total_items=6, k=4, device=dev, sync_every=100)
+    sh2.trainer = _FakeTrainer(sh2.table, 0)
+    sh2.load_items(V0, np.zeros(6, np.float32))
+    sh2.resident_bucket_hook = lambda e, bucket: bucket.mul_(2.0)
+    sh2.run_epoch(300, 3, lr=0.01, reg=0.0, resident=True)
+    sh2.finish()
+    r2 = np.float32(np.sqrt(2.0))
+    want2 = V0.copy()
+    want2[0::2] += r2 * np.float32(0.01 * 300)
+    want2[0] += r2 * 3.0
+    assert np.allclose(sh2.table.V.numpy(), want2, rtol=0, atol=1e-5)
+    assert np.allclose(sh2.table.B.numpy(), r2 * 1.5, atol=1e-6) and torch.equal(sh2.table.flat, sh2.table.base)

@@ -626,3 +626,141 @@ def test_model_level_sharded_fits_single_rank_through_rccl():
         assert abs(m.loss_history[-1] - p.loss_history[-1]) < 0.15 * p.loss_history[-1], (m.loss_history, p.loss_history)
     finally:
         dist.destroy_process_group()
+
+
+# ---- resident exchange: regime 1 inside ONE launch per epoch (csrc/bpr_ldsbin.inc EXCH kernels, dist.run_epoch_resident) ----
+def _ldsbin_problem(k, nnz=300_000, seed=9):
+    from cornac_amd import synth
+
+    nu, ni = 4000, 12800
+    users, items = synth.zipf_interactions(nu, ni, nnz, 0.6, seed)
+    indptr, indices = synth.csr_from_sorted(users, items, nu)
+    rs = np.random.RandomState(seed)
+    return (nu, ni, indptr, indices, rs.normal(0, 0.1, (nu, k)).astype(np.float32),
+            rs.normal(0, 0.1, (ni, k)).astype(np.float32), rs.normal(0, 0.1, ni).astype(np.float32))
+
+
+@pytest.mark.parametrize("k,n_ex,twin", [(64, 4, True), (64, 16, True), (100, 32, True), (64, 8, False), (128, 5, True)])
+def test_resident_exchange_publishes_and_applies_every_row_exactly_once(k, n_ex, twin):
+    """The accounting of the resident exchange, made deterministic: lr = 0 (no step changes a row) and a base that differs
+    from the table by a known D0, so exchange 0 carries d = D0 for EVERY row — cold rows from their bins' LDS, hot rows
+    from the global table — and all later exchanges carry exact zeros.  A twin rank is played on the communication stream
+    (bucket *= 2: S = 2 d, two touching ranks), so each row must end at table + (sqrt(2) - 1) D0 with base == table bit
+    for bit: a row published twice, never, or corrected twice (in the launch AND by the flush) would show.  Without the
+    twin the correction is exactly zero and the table must not change by a bit.  All n_ex arrival counters reach the
+    launch's workgroup count, every landed flag is up, the wait never timed out."""
+    import torch
+
+    from cornac_amd.dist import ShardedBprTrainer
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    nu, ni, indptr, indices, U0, V0, B0 = _ldsbin_problem(k)
+    tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+    try:
+        tr.set_factors(U0, None, None)
+        tr.seed_hogwild(77)
+        sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=len(indices))
+        sh.load_items(V0, B0)
+        bins = sh.resident_bins()
+        assert bins == 256, bins
+        rs = np.random.RandomState(k + n_ex)
+        D0 = rs.normal(0, 0.05, ni * k + ni).astype(np.float32)
+        flat0 = np.concatenate([V0.ravel(), B0])
+        base0 = flat0 - D0
+        with sh._on_stream():
+            sh.table.base.copy_(torch.as_tensor(base0))
+        sh.stream.synchronize()
+        if twin:
+            sh.resident_bucket_hook = lambda e, bucket: bucket.mul_(2.0)
+        sh.run_epoch(len(indices), n_ex, 0.0, 0.01, resident=None)
+        c, s = sh.finish()
+        assert sh.table.exchanges.get("resident") == n_ex, sh.table.exchanges
+        sig = sh._resident["signals"].cpu().numpy()
+        assert (sig[:n_ex] == bins).all() and (sig[n_ex:2 * n_ex] == 1).all() and sig[2 * n_ex] == 0, sig
+        flat, base = sh.table.flat.cpu().numpy(), sh.table.base.cpu().numpy()
+        assert np.array_equal(flat, base), "table and base took the same corrections"
+        buckets = sh._resident["buckets"].cpu().numpy()
+        keeps = sh._resident["keeps"].cpu().numpy()
+        d0 = flat0 - base0                                    # the pending delta (fp32, as the kernel computes it)
+        # every element's delta is published by exactly ONE exchange — the row's first duty: exchange 0, or a later one
+        # where a bin holds so few tiles that two boundaries' duties of one part overtake each other — and every other
+        # exchange carries an exact zero for it (row == base bit for bit)
+        assert ((keeps != 0).sum(0) <= 1).all() and np.array_equal(keeps.sum(0, dtype=np.float32), d0)
+        first = (keeps[0] != 0).mean()
+        assert first > (0.99 if n_ex <= 8 else 0.5), first
+        width = ni * k + ni
+        if twin:
+            assert np.array_equal(buckets[:, :width], 2.0 * keeps)
+            wV, wB = buckets[:, width: width + ni], buckets[:, width + ni:]
+            assert np.array_equal(wV, 2.0 * (keeps[:, : ni * k].reshape(n_ex, ni, k) != 0).any(2))
+            assert np.array_equal(wB, 2.0 * (keeps[:, ni * k:] != 0))
+            f = np.float32(1.0) / np.sqrt(np.float32(2.0))
+            want = flat0 + ((2.0 * d0) * f - d0)
+            assert np.abs(flat - want).max() < 1e-6, np.abs(flat - want).max()
+        else:
+            assert np.array_equal(flat, flat0), "one rank alone: the exchange is the identity"
+        assert np.array_equal(tr.get_user_factors(), U0) and 0 < s < len(indices) // 4
+    finally:
+        tr.close()
+
+
+def test_resident_exchange_trains_like_the_plain_launch_through_rccl():
+    """One rank through a real RCCL group: the epoch with 16 exchange points inside ONE launch against the plain call on
+    the same seed (the LDS-bin sample stream is a pure function of (seed, epoch, bin, draw), so both draw the same
+    triplets; only the hogwild interleaving differs).  A single rank's correction is exactly zero, so the tables must
+    move alike; the collectives really ran (16 per epoch) and nothing is left unpublished on cold rows."""
+    import torch
+    import torch.distributed as dist
+
+    from cornac_amd.dist import ShardedBprTrainer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = _fresh_port()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    k, epochs = 64, 3
+    nu, ni, indptr, indices, U0, V0, B0 = _ldsbin_problem(k, nnz=600_000, seed=4)
+    nnz = len(indices)
+    def plain_run():
+        plain = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+        plain.set_factors(U0, V0, B0)
+        plain.seed_hogwild(5)
+        cs = plain.fit_epochs(epochs, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+        out = plain.get_factors()
+        plain.close()
+        return cs, out
+
+    def moves_alike(got, ref, init):
+        dg, dr = (got - init).ravel().astype(np.float64), (ref - init).ravel().astype(np.float64)
+        return float(dg @ dr) / (np.linalg.norm(dg) * np.linalg.norm(dr)), np.linalg.norm(dg) / np.linalg.norm(dr)
+
+    (c_p, s_p), (Up, Vp, Bp) = plain_run()
+    _, (Uq, Vq, Bq) = plain_run()     # the same call again: how far two hogwild interleavings of the same draws are apart
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+        tr.set_factors(U0, None, None)
+        tr.seed_hogwild(5)
+        sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=nnz)
+        sh.load_items(V0, B0)
+        assert sh.resident_bins() == 256
+        for _ in range(epochs):
+            sh.run_epoch(nnz, 16, 0.05, 0.01)
+        c, s = sh.finish()
+        V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
+        base = sh.table.base.cpu().numpy()
+        U = tr.get_user_factors()
+        st = tr.ldsbin_stats()
+        tr.close()
+        assert sh.table.exchanges["resident"] == 16 * epochs and s == s_p, (sh.table.exchanges, s, s_p)
+        assert abs(c - c_p) < 0.005 * nnz * epochs, (c, c_p)
+        unpublished = np.abs(np.concatenate([V.ravel(), B]) - base).reshape(-1)
+        rows_left = np.unique(np.nonzero(unpublished[: ni * k])[0] // k)
+        assert len(rows_left) <= st["n_hot"], (len(rows_left), st)   # only hot rows can move after their last publication
+        for got, ref, again, init in ((V, Vp, Vq, V0), (B, Bp, Bq, B0), (U, Up, Uq, U0)):
+            cos, ratio = moves_alike(got, ref, init)
+            cos_pp, _ = moves_alike(again, ref, init)
+            assert cos > cos_pp - 0.01 and abs(ratio - 1.0) < 0.02, (cos, cos_pp, ratio)
+    finally:
+        dist.destroy_process_group()
