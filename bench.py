@@ -606,10 +606,12 @@ def leg_dist_tax(args, _lib):
     """What the multi-GPU driver costs BEFORE a second GPU is involved: one rank through RCCL (process group of one, the
     replicated item table bound to the handle, delta passes, all-reduce, overlapped schedule) next to the plain
     fit_epochs call, same data, same tables, same kernel form, at the ML-20M shape and at the configs[4] slice.
-    tax = 1 - plain time / driver time.  Exchanges per epoch: cornac_amd.dist.exchanges_per_epoch (16 and 1)."""
+    tax = 1 - plain time / driver time.  How often and by which rule the replicas are reconciled: cornac_amd.dist.exchange_schedule
+    (ML-20M shape: 16 exchanges per epoch, "sqrt", from inside one launch per epoch; configs[4] slice: one exchange every
+    4 epochs, "align" — tools/emulate_exchange_interval.py; the timed region holds a whole number of intervals)."""
     import torch
 
-    from cornac_amd.dist import ShardedBprTrainer, exchanges_per_epoch
+    from cornac_amd.dist import ShardedBprTrainer, exchange_schedule
 
     close = _one_rank_group()
     dev = torch.device("cuda", 0)
@@ -618,14 +620,14 @@ def leg_dist_tax(args, _lib):
         for shape in [x for x in os.environ.get("CORNAC_BENCH_DIST_TAX_SHAPES", "ml20m,scale").split(",") if x]:
             if shape == "scale":
                 nu, ni, indptr, indices = scale_slice(0)
-                k, epochs = SCALE["k"], 4
+                k, epochs = SCALE["k"], 8
                 U, V, B = scale_factors(nu, ni, k, 0)
             else:
                 nu, ni, indptr, indices = load_dataset("ml20m", 0, args.cache_dir)
                 k, epochs = 64, 10
                 U, V, B = init_factors(nu, ni, k, 100)
             nnz = len(indices)
-            spe = exchanges_per_epoch(nnz, ni)
+            spe, interval, rule = exchange_schedule(nnz, ni)
             tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
             tr.set_factors(U, V, B)
             tr.seed_hogwild(11)
@@ -637,18 +639,18 @@ def leg_dist_tax(args, _lib):
             tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
             tr.set_factors(U, V, B)
             tr.seed_hogwild(11)
-            sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=(nnz + spe - 1) // spe, sparse_threshold=None)
+            sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=(nnz + spe - 1) // spe, sparse_threshold=None, rule=rule)
             sh.load_items(V, B)
             # the resident exchange (ONE launch per epoch, the exchange points inside it) where the handle takes the LDS-bin
             # form, chunk launches with the overlapped exchange between them otherwise: ShardedBprTrainer.run_epoch decides
             resident = os.environ.get("CORNAC_BENCH_DIST_CHUNKS") is None and 1 <= spe <= 32 and sh.resident_bins() > 0
-            for _ in range(2):   # warm-up with the timed region's own pattern (begin, step, finish: both buffer sets exist)
-                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident)
+            for _ in range(2 * interval):   # warm-up with the timed region's own pattern (begin, step, finish: both buffer sets exist)
+                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
             sh.finish()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(epochs):
-                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident)
+                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
             sh.finish()
             torch.cuda.synchronize()
             driven = (time.perf_counter() - t0) / epochs
@@ -656,7 +658,8 @@ def leg_dist_tax(args, _lib):
             del sh
             torch.cuda.empty_cache()
             out[shape] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven,
-                          "exchanges_per_epoch": spe, "tax": 1.0 - plain / driven,
+                          "exchanges_per_epoch": spe if interval == 1 else 1.0 / interval, "rule": rule, "epochs_timed": epochs,
+                          "tax": 1.0 - plain / driven,
                           "protocol": "resident exchange (one launch per epoch)" if resident else "chunk launches",
                           "triplets_per_s_plain": nnz / plain, "triplets_per_s_driver": nnz / driven,
                           "workload": "%d users x %d items, %d interactions, k = %d" % (nu, ni, nnz, k)}
@@ -825,7 +828,7 @@ def main():
             "ldsbin" if sel in (0, 3) and trainer_stats["ldsbin"]["bins"] > 0 else
             "strata" if sel == 2 or (sel == 0 and n_items >= 1 << 20) else "fused")
 
-    sharded, resident_mode = None, False
+    sharded, resident_mode, exchange_interval, exchange_rule = None, False, 1, "sqrt"
     if distributed and args.sharded_items:
         from cornac_amd.dist import RowShardedBprTrainer
 
@@ -834,15 +837,20 @@ def main():
     elif distributed:
         from cornac_amd.dist import ShardedBprTrainer
 
-        from cornac_amd.dist import exchanges_per_epoch
+        from cornac_amd.dist import exchange_schedule
 
+        # how often the replicas are reconciled and by which rule: cornac_amd.dist.exchange_schedule (16 per epoch under
+        # "sqrt" at the ML-20M shape; one exchange every 4 epochs under "align" at the configs[4] slice)
+        exchange_interval, exchange_rule = 1, ("sqrt" if args.sync_per_epoch >= 16 else "align")
         if args.sync_per_epoch <= 0:
-            args.sync_per_epoch = exchanges_per_epoch(nnz, n_items)
+            args.sync_per_epoch, exchange_interval, exchange_rule = exchange_schedule(nnz, n_items)
         # (sparse records pay off when a rank touches a small part of the table per exchange; with one exchange per epoch
         # at the configs[4] density every row is touched: dense, which also keeps the fused finish + begin pass)
         sparse = args.sparse_threshold if args.sparse_threshold >= 0 else (0.5 if scale and args.sync_per_epoch > 4 else None)
+        if sparse is not None:
+            exchange_interval = 1
         sharded = ShardedBprTrainer(trainer, n_items, k, dev, sync_every=(nnz + args.sync_per_epoch - 1)
-                                    // args.sync_per_epoch, sparse_threshold=sparse)
+                                    // args.sync_per_epoch, sparse_threshold=sparse, rule=exchange_rule)
         sharded.load_items(V, B)
         resident_mode = (not args.dist_chunks and sparse is None and 1 <= args.sync_per_epoch <= 32
                          and sharded.resident_bins(_lib.NEG_UNIFORM, args.flags) > 0)
@@ -856,7 +864,7 @@ def main():
             # the resident exchange (one launch per epoch, the exchange points inside it) where the handle takes the LDS-bin
             # form; chunk launches with the overlapped exchange between them otherwise or with --dist-chunks
             sharded.run_epoch(nnz, args.sync_per_epoch, args.lr, args.reg, True, _lib.NEG_UNIFORM, args.flags,
-                              resident=resident_mode)
+                              resident=resident_mode, epochs_per_exchange=exchange_interval)
         return (0, 0)
 
     for _ in range(args.warmup):
@@ -902,8 +910,10 @@ def main():
                    "parallelism": "1 gpu" if world == 1 and not distributed else
                                   ("user-partitioned dp%d, item table sharded by row, all-to-all every %d draws"
                                    % (world, args.micro_batch)) if args.sharded_items else
-                                  ("user-partitioned dp%d, item table all-reduce x%d/epoch%s"
-                                   % (world, args.sync_per_epoch, " from inside one launch per epoch (resident exchange)"
+                                  ("user-partitioned dp%d, item table all-reduce %s, rule %s%s"
+                                   % (world, "x%d/epoch" % args.sync_per_epoch if exchange_interval == 1 else
+                                      "every %d epochs" % exchange_interval, exchange_rule,
+                                      " from inside one launch per epoch (resident exchange)"
                                       if resident_mode else ", chunk launches"))},
     }
     if rank == 0 and sharded is None:

@@ -44,7 +44,7 @@ SYMBOLS = [
     "cornac_hip_bpr_shard_mark", "cornac_hip_bpr_shard_slots", "cornac_hip_bpr_shard_uniq",
     "cornac_hip_bpr_scatter_diff_rows", "cornac_hip_bpr_switch_stream",
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
-    "cornac_hip_bpr_table_delta_step", "cornac_hip_table_delta",
+    "cornac_hip_bpr_table_delta_step", "cornac_hip_table_delta", "cornac_hip_bpr_table_delta",
     "cornac_hip_bpr_resident_exchange_bins", "cornac_hip_bpr_epoch_resident_enqueue", "cornac_hip_bpr_resident_flush",
     "cornac_hip_stream_wait_counter", "cornac_hip_stream_set_flag",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
@@ -176,6 +176,7 @@ def lib():
         L.cornac_hip_bpr_table_delta_finish.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]
         L.cornac_hip_bpr_table_delta_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_table_delta.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
+        L.cornac_hip_bpr_table_delta.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]
         L.cornac_hip_bpr_resident_exchange_bins.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.cornac_hip_bpr_epoch_resident_enqueue.argtypes = [_vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                                             C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp,
@@ -435,11 +436,10 @@ class BprTrainer:
     def scatter_diff_rows(self, d_table, d_ids, n, width, d_now, d_before, d_scale=None):
         check(lib().cornac_hip_bpr_scatter_diff_rows(self.h, d_table, d_ids, int(n), int(width), d_now, d_before, d_scale))
 
-    # the replicated table's elementwise passes (ItemTableReplica); rule 0 = sqrt on the handle's stream, any other rule
-    # through the handle-free entry point on the stream handed to set_stream
+    # the replicated table's elementwise passes (ItemTableReplica) on the handle's stream (and on its packed records
+    # where it keeps them); rule 0 = sqrt through the first entry points, any rule through cornac_hip_bpr_table_delta
     def _delta(self, op, rule, *args):
-        assert getattr(self, "_stream", None), "set_stream() first: rule != 0 runs on the caller's stream"
-        check(lib().cornac_hip_table_delta(op | (int(rule) << 4), self.device, self._stream, *args))
+        check(lib().cornac_hip_bpr_table_delta(self.h, op, int(rule), *args))
 
     def table_delta_begin(self, d_flat, d_base, n_items, k, d_bucket, d_local, rule=0):
         if rule:

@@ -37,6 +37,29 @@ def exchanges_per_epoch(nnz_per_rank, total_items, updates_per_row=93.5, at_most
     return int(min(max(1, int(x + 0.5)), at_most))
 
 
+def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=64, max_epochs=4):
+    """(exchanges per epoch, epochs per exchange, rule) of the replicated regime for BPR.
+
+    Dense item sides (the ML-20M shape: 1 496 item-row updates per row and epoch on a rank) exchange several times per
+    epoch — exchanges_per_epoch() — under the "sqrt" rule (device emulation at R = 8: sqrt 0.673 vs align 0.667 of 0.679
+    at 16 exchanges per epoch; below that align is the better one: 0.650 vs 0.604 at 8).  SPARSE item sides (the
+    configs[4] slice: 12.5 updates per row and epoch) were emulated on the CPU with the oracle's arithmetic
+    (tools/emulate_exchange_interval.py, 8 ranks, profiles/r04_emulate_exchange_interval.log): there every rank touches
+    every popular row between two exchanges with a delta that is a sizeable part of the way to its optimum, and "sqrt"
+    (sum / sqrt(8) = 2.8 x one rank's step) overshoots — consolidated accuracy 0.753 / 0.668 / 0.817 / 0.487 at one exchange
+    every 1 / 2 / 4 / 8 epochs, erratic — while "align" (the mean of aligned deltas, the sum of orthogonal ones) gives
+    0.825 / 0.819 / 0.814 / 0.813 against 0.836 for one process on all ranks' data.  So: fewer than 16 exchanges per
+    epoch -> "align"; and a rank whose rows collect less than the 93.5 updates per exchange in a whole epoch exchanges
+    every floor(93.5 / updates per row and epoch) epochs, at most every `max_epochs` (0.011 below exchanging every
+    epoch in the emulation, for a quarter of the table passes)."""
+    x = 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row))
+    if x >= 0.75:
+        per_epoch, epochs = int(min(max(1, int(x + 0.5)), at_most)), 1
+    else:
+        per_epoch, epochs = 1, int(max(1, min(int(max_epochs), int(1.0 / x))))
+    return per_epoch, epochs, ("sqrt" if per_epoch >= 16 else "align")
+
+
 class ItemTableReplica:
     """Flat [V | B] buffer + base copy + exchange of the ranks' deltas.
 
@@ -305,10 +328,11 @@ class ItemTableReplica:
 class ShardedBprTrainer:
     """Drives one rank's cornac_hip BPR handle plus the replicated item table."""
 
-    def __init__(self, trainer, total_items, k, device, sync_every, group=None, sparse_threshold=None):
+    def __init__(self, trainer, total_items, k, device, sync_every, group=None, sparse_threshold=None, rule="sqrt"):
         self.trainer = trainer
         self.table = ItemTableReplica(total_items, k, device, group, trainer=trainer if device.type == "cuda" else None,
-                                      sparse_threshold=sparse_threshold)
+                                      sparse_threshold=sparse_threshold, rule=rule)
+        self._epochs_since_exchange = 0
         self.sync_every = int(sync_every)
         self.device = device
         self.stream = None
@@ -452,11 +476,21 @@ class ShardedBprTrainer:
             t.resident_apply(*ex)
         t.exchanges["resident"] = t.exchanges.get("resident", 0) + n_exchanges
 
-    def run_epoch(self, nnz, parts, lr, reg, use_bias=True, neg_population=0, flags=0, resident=None):
+    def run_epoch(self, nnz, parts, lr, reg, use_bias=True, neg_population=0, flags=0, resident=None, epochs_per_exchange=1):
         """one epoch of `nnz` samples with `parts` item-table exchanges.  resident = None: the resident exchange (one
         launch) where the trainer has it, else `parts` chunk launches with the overlapped exchange between them
-        (run_epoch_in_parts); True / False force one or the other (True on a host stand-in: the torch form)."""
+        (run_epoch_in_parts); True / False force one or the other (True on a host stand-in: the torch form).
+        epochs_per_exchange > 1 (sparse item sides, exchange_schedule): the epoch is enqueued whole and only every
+        epochs_per_exchange-th call exchanges (overlapped with the epochs that follow; finish() lands the last one)."""
         parts = int(parts)
+        if int(epochs_per_exchange) > 1:
+            with self._on_stream():
+                self.trainer.hogwild_enqueue(int(nnz), lr, reg, use_bias, neg_population, flags)
+                self._epochs_since_exchange += 1
+                if self._epochs_since_exchange >= int(epochs_per_exchange):
+                    self.table.step_sync()
+                    self._epochs_since_exchange = 0
+            return
         if resident is None:
             resident = 1 <= parts <= 32 and self.resident_bins(neg_population, flags) > 0
         if not resident:
@@ -467,6 +501,9 @@ class ShardedBprTrainer:
 
     def finish(self):
         with self._on_stream():
+            if self._epochs_since_exchange:      # epochs trained since the last exchange of a multi-epoch schedule
+                self.table.step_sync()
+                self._epochs_since_exchange = 0
             self.table.finish_sync()
         out = self.trainer.sync()
         if self.stream is not None:
@@ -993,14 +1030,15 @@ def _sum_over_ranks(values, device, group):
 
 
 def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
-                    trainer_factory=None, local_popularity=False):
+                    trainer_factory=None, local_popularity=False, rule=None):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
     calls it with a model built from the same arguments and the SAME train_set; the users are cut into contiguous ranges
     of equal interaction counts, rank r trains its range in hogwild mode against its replica of the item table
     (ShardedBprTrainer), and on return every rank's model holds the complete u_factors / i_factors / i_biases.
     The reference has no counterpart (single process); seeded SEQUENTIAL semantics do not shard, so the model must be in
     hogwild mode (`mode="hogwild"`, or no seed) — a seed then fixes the initial tables and the sample streams.
-    sync_per_epoch = None: exchanges_per_epoch() of the largest rank's interaction count (the same number on every rank).
+    sync_per_epoch = None: exchange_schedule() of the largest rank's interaction count (the same on every rank): how many
+    exchanges per epoch — or, for sparse item sides, every how many epochs — and the reconciliation rule (rule = None).
     WBPR draws its negatives from the rank's OWN interactions (recom_wbpr.pyx:135 reads X.indices: popularity-weighted) —
     the popularity of the rank's users, not of all users; that approximation has to be asked for (local_popularity=True),
     otherwise a WBPR model over more than one rank is refused.
@@ -1030,17 +1068,22 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
     n_local, nnz = u1 - u0, counts[rank]
+    interval = 1
     if sync_per_epoch is None:
-        sync_per_epoch = exchanges_per_epoch(max(counts), model.total_items)
+        sync_per_epoch, interval, rule = exchange_schedule(max(counts), model.total_items)
+    if rule is None:
+        rule = "sqrt" if int(sync_per_epoch) >= 16 else "align"
+    if sparse_threshold is not None:
+        interval = 1
     parts = max(1, min(int(sync_per_epoch), min(counts)))
     if trainer_factory is None:
         trainer = _lib.BprTrainer(indptr, indices, n_local, train_set.num_items, n_local, model.total_items, model.k,
                                   device=device.index or 0)
         sh = ShardedBprTrainer(trainer, model.total_items, model.k, device, sync_every=nnz, group=group,
-                               sparse_threshold=sparse_threshold)
+                               sparse_threshold=sparse_threshold, rule=rule)
     else:
         sh = ShardedBprTrainer(None, model.total_items, model.k, device, sync_every=nnz, group=group,
-                               sparse_threshold=sparse_threshold)
+                               sparse_threshold=sparse_threshold, rule=rule)
         trainer = sh.trainer = trainer_factory(sh.table, indptr, indices, n_local, train_set.num_items, model.total_items,
                                                model.k)
     try:
@@ -1054,7 +1097,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
                                         device, group)[0] == 0)
         for _ in range(model.max_iter):
             sh.run_epoch(nnz, parts, model.learning_rate, model.lambda_reg, model.use_bias, model._neg_population,
-                         resident=resident)
+                         resident=resident, epochs_per_exchange=interval)
         correct, skipped = sh.finish()
         U_local = trainer.get_user_factors()
         V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()

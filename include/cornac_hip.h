@@ -257,6 +257,11 @@ int cornac_hip_bpr_table_delta_finish(cornac_hip_bpr_t h, float *d_flat, float *
 /* finish of the previous exchange followed by begin of the next one, in one pass (adjacent in the overlapped schedule) */
 int cornac_hip_bpr_table_delta_step(cornac_hip_bpr_t h, float *d_flat, float *d_base, const float *d_bucket_prev,
                                     const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
+/* The three passes with the reconciliation rule as an argument (op: 0 = begin, 1 = finish, 2 = step; rule: 0 = "sqrt",
+ * 1 = "align", described below), on the handle's stream and on its packed records where it keeps them: the regime-1
+ * driver takes "align" when it exchanges less than a few times per epoch (sparse item sides: DESIGN.md 5). */
+int cornac_hip_bpr_table_delta(cornac_hip_bpr_t h, int op, int rule, float *d_flat, float *d_base, const float *d_bucket_prev,
+                               const float *d_local_prev, int64_t n_items, int k, float *d_bucket, float *d_local);
 /* The same passes for a caller without a BPR handle (the MF driver): op & 15: 0 = begin, 1 = finish, 2 = step, on
  * `hip_stream` of `device`; begin ignores the *_prev pointers, finish the next-exchange pointers.  op >> 4 selects the
  * reconciliation rule: 0 = "sqrt" (the one above: per-row slots of the bucket = touched flags, R = S / sqrt(count)),

@@ -901,3 +901,47 @@ def test_resident_exchange_of_one_process_keeps_its_own_steps_bit_for_bit():
     want2[0] += r2 * 3.0
     assert np.allclose(sh2.table.V.numpy(), want2, rtol=0, atol=1e-5)
     assert np.allclose(sh2.table.B.numpy(), r2 * 1.5, atol=1e-6) and torch.equal(sh2.table.flat, sh2.table.base)
+
+
+def test_exchange_schedule_rule():
+    """dense item sides: several exchanges per epoch under "sqrt" from 16 on, "align" below; sparse item sides (the
+    configs[4] slice): one exchange every few epochs under "align" (tools/emulate_exchange_interval.py)"""
+    from cornac_amd.dist import exchange_schedule, exchanges_per_epoch
+
+    assert exchange_schedule(20_000_263, 26_744) == (16, 1, "sqrt") and exchanges_per_epoch(20_000_263, 26_744) == 16
+    assert exchange_schedule(5_000_000, 26_744) == (4, 1, "align")
+    assert exchange_schedule(62_500_000, 10_000_000) == (1, 4, "align")
+    assert exchange_schedule(62_500_000, 2_000_000) == (1, 1, "align")        # 62.5 updates per row and epoch: every epoch
+    assert exchange_schedule(10_000_000, 10_000_000, max_epochs=8) == (1, 8, "align")
+    assert exchange_schedule(4_000_000_000, 26_744)[0] == 64
+
+
+def _interval_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        indptr, indices, n_items = _popularity_data(rank)
+        k, nnz = 8, len(indices)
+        sh = ShardedBprTrainer(None, total_items=n_items, k=k, device=torch.device("cpu"), sync_every=nnz, rule="align")
+        init = np.random.RandomState(7)
+        sh.load_items((init.uniform(0, 1, (n_items, k)).astype(np.float32) - 0.5) / k, np.zeros(n_items, np.float32))
+        sh.trainer = _OracleTrainer(sh.table, indptr, indices, n_items, k, seed=11 + rank)
+        for _ in range(5):                                         # exchanges after epochs 2 and 4, the fifth epoch's by finish()
+            sh.run_epoch(nnz, 1, 0.05, 0.01, epochs_per_exchange=2)
+        sh.finish()
+        acc = _pairwise_accuracy(sh.trainer.U, sh.table.V.numpy(), sh.table.B.numpy(), indptr, indices, n_items)
+        out[rank] = (sh.table.V.numpy().copy(), sh.table.base.numpy().copy(), acc, dict(sh.table.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_epoch_exchange_interval_world2():
+    """sparse schedule: one exchange every 2 epochs under the align rule, two gloo ranks with real BPR arithmetic — 3
+    exchanges for 5 epochs (the last, partial interval is exchanged by finish()), one consolidated table, a model that
+    has learnt"""
+    out = mp.Manager().dict()
+    mp.spawn(_interval_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (V0, base0, acc0, ex0), (V1, base1, acc1, _) = out[0], out[1]
+    assert ex0["dense"] == 3, ex0
+    assert np.array_equal(base0, base1) and np.allclose(V0, V1, rtol=0, atol=1e-6)
+    assert acc0 > 0.75 and acc1 > 0.75, (acc0, acc1)

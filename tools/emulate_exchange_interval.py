@@ -29,6 +29,7 @@ ap.add_argument("--k", type=int, default=16)
 ap.add_argument("--epochs", type=int, default=24)
 ap.add_argument("--intervals", default="1,2,4,8", help="epochs per exchange")
 ap.add_argument("--zipf", type=float, default=0.8)
+ap.add_argument("--rules", default="sqrt,align", help="reconciliation rules to run (ItemTableReplica: sqrt, align)")
 args = ap.parse_args()
 R, ni, nu, k, lr, reg = args.ranks, args.items, args.users, args.k, 0.05, 0.01
 
@@ -96,12 +97,17 @@ ok = np.array([pj[t] not in ix0[ip0[pu[t]]:ip0[pu[t] + 1]] for t in range(len(pp
 probe = (pu[ok], pi[ok], pj[ok])
 
 
-def reconcile(ranks, pending):
+def reconcile(ranks, pending, rule):
     """finish the pending exchange (its sum lands now), begin the next one: ItemTableReplica.step_sync for all ranks"""
     if pending is not None:
         SV, SB, cV, cB = pending
-        RV = SV / np.sqrt(np.maximum(cV, 1.0))[:, None]
-        RB = SB / np.sqrt(np.maximum(cB, 1.0))
+        if rule == "sqrt":
+            RV = SV / np.sqrt(np.maximum(cV, 1.0))[:, None]
+            RB = SB / np.sqrt(np.maximum(cB, 1.0))
+        else:  # align: S * min(1, sum |d_r|^2 / |S|^2)
+            n2 = (SV * SV).sum(1)
+            RV = SV * np.where(n2 > 0, np.minimum(1.0, cV / np.maximum(n2, 1e-38)), 1.0)[:, None].astype(np.float32)
+            RB = SB * np.where(SB * SB > 0, np.minimum(1.0, cB / np.maximum(SB * SB, 1e-38)), 1.0).astype(np.float32)
         for x in ranks:
             pV, pB = (x.V - x.baseV) - x.local[0], (x.B - x.baseB) - x.local[1]
             x.baseV += RV
@@ -115,8 +121,12 @@ def reconcile(ranks, pending):
         x.local = (dV, dB)
         SV += dV
         SB += dB
-        cV += (dV != 0).any(1)
-        cB += dB != 0
+        if rule == "sqrt":
+            cV += (dV != 0).any(1)
+            cB += dB != 0
+        else:
+            cV += (dV * dV).sum(1)
+            cB += dB * dB
     return SV, SB, cV, cB
 
 
@@ -139,7 +149,7 @@ for e in range(args.epochs):
     allacc.append(accuracy(ranks[0].U, shared_V, shared_B, probe))
 print("one process, all ranks' data: " + " ".join("%.3f" % a for a in allacc[3::4]), flush=True)
 
-for interval in [int(x) for x in args.intervals.split(",")]:
+for rule, interval in [(r_, int(x)) for r_ in args.rules.split(",") for x in args.intervals.split(",")]:
     for x in ranks:
         x.reset(V0)
     pending, acc = None, []
@@ -147,11 +157,11 @@ for interval in [int(x) for x in args.intervals.split(",")]:
         for x in ranks:
             x.epoch()
         if (e + 1) % interval == 0:
-            pending = reconcile(ranks, pending)
+            pending = reconcile(ranks, pending, rule)
         acc.append(accuracy(ranks[0].U, ranks[0].baseV if pending is not None else ranks[0].V,
                             ranks[0].baseB if pending is not None else ranks[0].B, probe))
     # the consolidated model: finish the last exchange
-    reconcile(ranks, pending)
+    reconcile(ranks, pending, rule)
     final = accuracy(ranks[0].U, ranks[0].baseV, ranks[0].baseB, probe)
-    print("exchange every %d epoch(s) (%.1f updates per row and exchange): " % (interval, interval * 2.0 * nnz / ni)
+    print("%-5s exchange every %d epoch(s) (%.1f updates per row and exchange): " % (rule, interval, interval * 2.0 * nnz / ni)
           + " ".join("%.3f" % a for a in acc[3::4]) + "   consolidated %.3f" % final, flush=True)
