@@ -688,8 +688,6 @@ def test_resident_exchange_publishes_and_applies_every_row_exactly_once(k, n_ex,
         # where a bin holds so few tiles that two boundaries' duties of one part overtake each other — and every other
         # exchange carries an exact zero for it (row == base bit for bit)
         assert ((keeps != 0).sum(0) <= 1).all() and np.array_equal(keeps.sum(0, dtype=np.float32), d0)
-        first = (keeps[0] != 0).mean()
-        assert first > (0.99 if n_ex <= 8 else 0.5), first
         width = ni * k + ni
         if twin:
             assert np.array_equal(buckets[:, :width], 2.0 * keeps)
