@@ -55,7 +55,7 @@ SYMBOLS = [
     "cornac_hip_mf_fit", "cornac_hip_mf_bind_items", "cornac_hip_mf_set_stream", "cornac_hip_mf_epoch_enqueue",
     "cornac_hip_mf_sync", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_mf_hogwild_form", "cornac_hip_mf_hogwild_stats",
-    "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_reset_optimizer",
+    "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_fit_minibatch_dropout", "cornac_hip_mf_reset_optimizer",
     "cornac_hip_scorer_create", "cornac_hip_scorer_destroy", "cornac_hip_scorer_set", "cornac_hip_score_user",
     "cornac_hip_scorer_set_f64", "cornac_hip_score_user_f64",
     "cornac_hip_score_block", "cornac_hip_rank_topk", "cornac_hip_rank_topk_device", "cornac_hip_score_pairs",
@@ -204,6 +204,8 @@ def lib():
         L.cornac_hip_vbpr_item_tables.argtypes = [_vp, _f32, _f32]
         L.cornac_hip_mf_fit_minibatch.argtypes = [_vp, _i64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                                   C.c_float, C.c_int, C.POINTER(C.c_double)]
+        L.cornac_hip_mf_fit_minibatch_dropout.argtypes = [_vp, _i64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                          C.c_float, C.c_int, _vp, _vp, C.c_float, C.POINTER(C.c_double)]
         L.cornac_hip_mf_reset_optimizer.argtypes = [_vp]
         L.cornac_hip_wmf_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int64, C.c_int64, C.c_int, _i64, _i32, _f32,
                                             C.c_int64]
@@ -659,11 +661,24 @@ class MfTrainer:
 
     OPTIMIZERS = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3}
 
-    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True):
+    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True, keep_u=None, keep_i=None,
+                      keep_scale=1.0):
         """one optimiser step per consecutive slice of `batch_size` entries of `order` (indices into the
-        rating arrays); returns the summed squared error over all visited ratings"""
+        rating arrays); returns the summed squared error over all visited ratings.  keep_u / keep_i: the dropout keep
+        masks of the gathered user / item rows, uint8 [len(order), k] (row b belongs to order[b]; kept factors are scaled
+        by keep_scale); None = no dropout"""
         order = np.ascontiguousarray(order, np.int64)
         loss = C.c_double()
+        if keep_u is not None:
+            keep_u, keep_i = np.ascontiguousarray(keep_u, np.uint8), np.ascontiguousarray(keep_i, np.uint8)
+            if keep_u.shape != (len(order), self.shape[2]) or keep_i.shape != keep_u.shape:
+                raise ValueError("keep masks must be [len(order), k] = %r, got %r / %r"
+                                 % ((len(order), self.shape[2]), keep_u.shape, keep_i.shape))
+            check(lib().cornac_hip_mf_fit_minibatch_dropout(self.h, order, len(order), int(batch_size),
+                                                            self.OPTIMIZERS[optimizer], lr, reg, mu, int(use_bias),
+                                                            keep_u.ctypes.data, keep_i.ctypes.data, float(keep_scale),
+                                                            C.byref(loss)))
+            return loss.value
         check(lib().cornac_hip_mf_fit_minibatch(self.h, order, len(order), int(batch_size), self.OPTIMIZERS[optimizer],
                                                 lr, reg, mu, int(use_bias), C.byref(loss)))
         return loss.value

@@ -464,6 +464,7 @@ struct cornac_hip_mf {
     // minibatch path (mf_minibatch.inc): dense gradients and optimiser state of [U, V, Bu, Bi]
     DevBuf<float> opt_g[4], opt_s1[4], opt_s2[4];
     DevBuf<int64_t> opt_order;
+    DevBuf<uint8_t> opt_keep;  // dropout keep masks of a fit_minibatch_dropout call: [2][n_total][k]
     int64_t opt_step = 0;
     int opt_kind = -1;
     bool enqueue_open = false;  // epoch_enqueue has accumulated into loss[0] since the last cornac_hip_mf_sync

@@ -6,7 +6,9 @@ attributes (`u_factors, i_factors, u_biases, i_biases, global_mean`) of the refe
   * `backend="hip"`            replaces `backend_cpu.fit_sgd` (recom_mf.py:189-209) by `cornac_hip_mf_fit`;
   * `backend="hip-minibatch"`  replaces `backend_pt.learn` (recom_mf.py:211-252, backend_pt.py:67-106: batches of
                                `batch_size` ratings, `optimizer` in {sgd, adam, rmsprop, adagrad} with
-                               weight_decay = lambda_reg over the dense tables) by `cornac_hip_mf_fit_minibatch`.
+                               weight_decay = lambda_reg over the dense tables) by `cornac_hip_mf_fit_minibatch`;
+                               `dropout > 0` (backend_pt.py:42,59) by `cornac_hip_mf_fit_minibatch_dropout` with the keep
+                               masks drawn on the host as the reference's CPU run draws them (`_DropoutMasks`).
 """
 import numpy as np
 
@@ -19,6 +21,36 @@ DTYPE = np.float32
 def _normal(shape, rng, std):
     # cornac/utils/init_utils.py:60-82 `normal(shape, mean=0, std, dtype=float32)`
     return rng.normal(0.0, std, shape).astype(DTYPE)
+
+
+class _DropoutMasks:
+    """The keep masks of `nn.Dropout(p)` on a batch's gathered user rows and item rows (backend_pt.py:42,59), drawn as the
+    reference's run on the CPU draws them: `_fit_pt` seeds torch's generator (recom_mf.py:221-222), the model's two — with
+    biases four — nn.Embedding tables consume it with their normal_ initialisation before their weights are replaced
+    (backend_pt.py:45-53), then every batch draws bernoulli_(1 - p) for the user rows and again for the item rows, kept
+    entries scaled by 1 / (1 - p) in float32.  torch is the generator here, nothing else of it is used; the arithmetic of
+    the step stays on the device (cornac_hip_mf_fit_minibatch_dropout)."""
+
+    def __init__(self, p, seed, n_users, n_items, k, use_bias):
+        import torch
+
+        self.torch, self.p, self.k = torch, float(p), int(k)
+        if seed is not None:
+            torch.manual_seed(seed)
+        for shape in [(n_users, k), (n_items, k)] + ([(n_users, 1), (n_items, 1)] if use_bias else []):
+            torch.empty(shape).normal_()
+        # p = 1: F.dropout multiplies by zero without drawing (nothing kept, no scale)
+        self.scale = float(np.float32(1.0) / np.float32(1.0 - self.p)) if self.p < 1.0 else 0.0
+
+    def epoch(self, n, batch_size):
+        """keyword arguments of MfTrainer.fit_minibatch for an epoch of n ratings in consecutive batches"""
+        keep_u, keep_i = np.zeros((n, self.k), np.uint8), np.zeros((n, self.k), np.uint8)
+        if self.p < 1.0:
+            for b0 in range(0, n, batch_size):
+                b = min(batch_size, n - b0)
+                keep_u[b0:b0 + b] = self.torch.empty(b, self.k).bernoulli_(1.0 - self.p).numpy()
+                keep_i[b0:b0 + b] = self.torch.empty(b, self.k).bernoulli_(1.0 - self.p).numpy()
+        return {"keep_u": keep_u, "keep_i": keep_i, "keep_scale": self.scale}
 
 
 class MF(Recommender):
@@ -106,8 +138,10 @@ class MF(Recommender):
     def _fit_minibatch(self, train_set, val_set):
         if self.optimizer not in _lib.MfTrainer.OPTIMIZERS:
             raise KeyError(self.optimizer)  # OPTIMIZER_DICT[optimizer], backend_pt.py:79
-        if self.dropout != 0.0:
-            raise ValueError("dropout is not supported by the HIP backend (it would consume torch's RNG stream)")
+        if self.dropout < 0.0 or self.dropout > 1.0:  # nn.Dropout.__init__ (backend_pt.py:42)
+            raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(self.dropout))
+        masks = _DropoutMasks(self.dropout, self.seed, self.num_users, self.num_items, self.k, self.use_bias) \
+            if self.dropout != 0.0 else None
         rid, cid, val = train_set.uir_tuple
         trainer = _lib.MfTrainer(rid, cid, val.astype(DTYPE), self.num_users, self.num_items, self.k,
                                  device=self.device)
@@ -118,8 +152,9 @@ class MF(Recommender):
             for _ in range(self.max_iter):
                 # backend_pt.py:85-88: uir_iter(batch_size, shuffle=True) = consecutive slices of one shuffle
                 order = np.concatenate(list(train_set.idx_iter(len(val), self.batch_size, shuffle=True)))
+                keep = masks.epoch(len(order), self.batch_size) if masks is not None else {}
                 sse = trainer.fit_minibatch(order, self.batch_size, self.optimizer, self.learning_rate,
-                                            self.lambda_reg, float(self.global_mean), self.use_bias)
+                                            self.lambda_reg, float(self.global_mean), self.use_bias, **keep)
                 self.loss_history.append(sse / len(val))
             U, V, Bu, Bi = trainer.get_factors()
             self.u_factors, self.i_factors = U, V

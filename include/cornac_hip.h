@@ -374,7 +374,7 @@ int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 /* Minibatch path with dense optimisers on the same handle.
  * Replaces: backend_pt.learn(model, train_set, n_epochs, batch_size, learning_rate, reg, optimizer)
  *           cornac/models/mf/backend_pt.py:67-106 and the forward of backend_pt.MF (:56-65), selected by
- *           MF(backend="pytorch", optimizer=...) (cornac/models/mf/recom_mf.py:211-252); dropout = 0 only.
+ *           MF(backend="pytorch", optimizer=...) (cornac/models/mf/recom_mf.py:211-252).
  * order: indices into the handle's rating arrays in visiting order (the concatenated batches of
  * Dataset.uir_iter(batch_size, shuffle=True), cornac/data/dataset.py:445-488); consecutive slices of batch_size
  * form the optimiser steps (the last one may be shorter).  Optimiser state persists across calls. */
@@ -384,6 +384,13 @@ int cornac_hip_mf_last_timing(cornac_hip_mf_t h, double *ms4);
 #define CORNAC_HIP_OPT_ADAGRAD 3
 int cornac_hip_mf_fit_minibatch(cornac_hip_mf_t h, const int64_t *order, int64_t n_total, int batch_size,
                                 int optimizer, float lr, float reg, float mu, int use_bias, double *loss_sum);
+/* The same with the reference's dropout on the gathered rows (backend_pt.py:42,59: nn.Dropout(p) on the user rows and on
+ * the item rows of a batch): keep_u / keep_i are [n_total][k] bytes, row b belongs to order[b], non-zero = the factor is
+ * kept and scaled by keep_scale = 1 / (1 - p).  The masks are an input: the host draws them as the reference's run
+ * draws them from torch's CPU generator (cornac_amd/mf.py). */
+int cornac_hip_mf_fit_minibatch_dropout(cornac_hip_mf_t h, const int64_t *order, int64_t n_total, int batch_size,
+                                        int optimizer, float lr, float reg, float mu, int use_bias, const uint8_t *keep_u,
+                                        const uint8_t *keep_i, float keep_scale, double *loss_sum);
 int cornac_hip_mf_reset_optimizer(cornac_hip_mf_t h);
 
 /* ------------------------------------------------------------------------- *

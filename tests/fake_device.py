@@ -143,8 +143,10 @@ class FakeMfTrainer:
 
     def reset_optimizer(self):
         self.steps = []
+        self.keeps = None
 
-    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True):
+    def fit_minibatch(self, order, batch_size, optimizer, lr, reg, mu, use_bias=True, keep_u=None, keep_i=None,
+                      keep_scale=1.0):
         """the double re-runs the torch optimiser from the initial parameters over every batch seen so far (optimiser
         state has no other home here); returns the last epoch's sum of squared errors like the device call"""
         from oracle import mf_minibatch_oracle
@@ -154,8 +156,12 @@ class FakeMfTrainer:
         order = np.asarray(order)
         batches = [order[b:b + batch_size] for b in range(0, len(order), batch_size)]
         self.steps += batches
+        if keep_u is not None:
+            self.keeps = (getattr(self, "keeps", None) or []) + [(keep_u[b:b + batch_size], keep_i[b:b + batch_size])
+                                                       for b in range(0, len(order), batch_size)]
         U, V, Bu, Bi, losses = mf_minibatch_oracle.fit(*self.start, mu, self.rid, self.cid, self.val, self.steps, optimizer,
-                                                       lr, reg, use_bias)
+                                                       lr, reg, use_bias, keep=getattr(self, "keeps", None),
+                                                       keep_scale=keep_scale)
         self.U, self.V, self.Bu, self.Bi = U, V, Bu, Bi
         return float(np.sum(losses[-len(batches):]))
 

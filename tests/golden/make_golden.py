@@ -204,12 +204,34 @@ def make_mf_minibatch_fixture():
     print("wrote mf_minibatch")
 
 
+def make_mf_dropout_fixture():
+    """MF(backend="pytorch", dropout=p) of the REAL reference on CPU torch: the dropout masks come from torch's CPU
+    generator (seeded by recom_mf.py:221-222), so the fixture also pins how cornac_amd/mf.py restates their draw."""
+    build_ref.build()
+    ns = ref_loader.load()
+    u, i, r = synth_pairs(90, 50, 1100, 0.7, 21)
+    ds = dataset(ns, u, i, r)
+    fx = {"users": u, "items": i, "ratings": r, "k": np.int64(6), "epochs": np.int64(3), "batch_size": np.int64(64),
+          "lr": np.float64(0.02), "reg": np.float64(0.03), "seed": np.int64(5)}
+    for opt, use_bias, p in (("sgd", True, 0.3), ("adam", True, 0.5), ("rmsprop", False, 0.2), ("adagrad", True, 0.1)):
+        m = ns.MF(k=6, backend="pytorch", optimizer=opt, max_iter=3, batch_size=64, learning_rate=0.02, lambda_reg=0.03,
+                  use_bias=use_bias, dropout=p, seed=5, verbose=False).fit(ds)
+        tag = "%s_p%d%s" % (opt, round(100 * p), "" if use_bias else "_nobias")
+        fx[tag + "_U"], fx[tag + "_V"] = m.u_factors.copy(), m.i_factors.copy()
+        fx[tag + "_Bu"], fx[tag + "_Bi"] = np.asarray(m.u_biases).copy(), np.asarray(m.i_biases).copy()
+    np.savez_compressed(os.path.join(OUT, "mf_minibatch_dropout.npz"), **fx)
+    print("wrote mf_minibatch_dropout")
+
+
 if __name__ == "__main__":
-    if "--wmf-only" in sys.argv:
+    if "--mf-dropout-only" in sys.argv:
+        make_mf_dropout_fixture()
+    elif "--wmf-only" in sys.argv:
         make_wmf_fixture()
     elif "--mf-minibatch-only" in sys.argv:
         make_mf_minibatch_fixture()
     else:
         main()
         make_mf_minibatch_fixture()
+        make_mf_dropout_fixture()
         make_wmf_fixture()

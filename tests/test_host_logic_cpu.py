@@ -201,6 +201,29 @@ def test_vebpr_float64_host_class_reproduces_the_references_float64_run(device_d
         VEBPR(init_params={"U": fx["init_U"].copy(), "V": fx["init_V"].astype(np.float32)}, **kw).fit(ds)
 
 
+DROPOUT_CASES = [("sgd", True, 0.3), ("adam", True, 0.5), ("rmsprop", False, 0.2), ("adagrad", True, 0.1)]
+
+
+@pytest.mark.parametrize("opt,use_bias,p", DROPOUT_CASES)
+def test_mf_minibatch_dropout_host_class_reproduces_the_reference_goldens(device_double, opt, use_bias, p):
+    """MF(backend="pytorch", dropout=p) of the real reference (goldens made by tests/golden/make_golden.py) against the
+    host class over the device double: the keep masks cornac_amd/mf.py draws from torch's CPU generator are the
+    reference's (seed, the embedding initialisations that consume the generator first, user rows then item rows of
+    every batch), and the step applies them as nn.Dropout does"""
+    from cornac_amd import MF
+
+    fx = load_golden("mf_minibatch_dropout")
+    m = MF(k=int(fx["k"]), backend="hip-minibatch", optimizer=opt, max_iter=int(fx["epochs"]),
+           batch_size=int(fx["batch_size"]), learning_rate=float(fx["lr"]), lambda_reg=float(fx["reg"]),
+           use_bias=use_bias, dropout=p, seed=int(fx["seed"])).fit(golden_dataset(fx))
+    tag = "%s_p%d%s" % (opt, round(100 * p), "" if use_bias else "_nobias")
+    for got, key in ((m.u_factors, "_U"), (m.i_factors, "_V"), (m.u_biases, "_Bu"), (m.i_biases, "_Bi")):
+        # (Adam divides by sqrt(v): a last-bit difference of a nearly dropped-out row's tiny gradient is amplified)
+        assert np.abs(np.asarray(got) - fx[tag + key]).max() <= 2e-5, tag + key
+    with pytest.raises(ValueError, match="dropout probability"):
+        MF(k=4, backend="hip-minibatch", dropout=1.5).fit(golden_dataset(fx))
+
+
 @pytest.mark.parametrize("use_bias", [True, False])
 @pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad"])
 def test_mf_minibatch_host_class_reproduces_the_reference_goldens(device_double, opt, use_bias):

@@ -81,7 +81,52 @@ def test_hip_minibatch_ragged_duplicates_and_errors():
         for a, b in zip(got, want[:4]):
             assert np.abs(a - b).max() <= 2e-5, (opt, np.abs(a - b).max())
         assert abs(sse - sum(want[4])) <= 1e-4 * sum(want[4])
-    with pytest.raises(ValueError):
-        MF(backend="hip-minibatch", dropout=0.1).fit(golden_dataset(load_golden("tiny")))
+    with pytest.raises(ValueError, match="dropout probability"):
+        MF(backend="hip-minibatch", dropout=1.1).fit(golden_dataset(load_golden("tiny")))
     with pytest.raises(KeyError):
         MF(backend="hip-minibatch", optimizer="lbfgs").fit(golden_dataset(load_golden("tiny")))
+
+
+DROPOUT_CASES = [("sgd", True, 0.3), ("adam", True, 0.5), ("rmsprop", False, 0.2), ("adagrad", True, 0.1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt,use_bias,p", DROPOUT_CASES)
+def test_hip_minibatch_dropout_matches_reference_golden_and_oracle(opt, use_bias, p):
+    """cornac_hip_mf_fit_minibatch_dropout: the model against the goldens the real reference produced with dropout = p
+    (the masks come from torch's CPU generator on this box exactly as on the box that made the goldens), and the raw
+    call against the oracle on ragged batches with duplicate rows and arbitrary masks (k = 5 and 20: a 16-lane group
+    covers a row in one and in two passes)"""
+    from cornac_amd import MF, _lib
+
+    fx = load_golden("mf_minibatch_dropout")
+    m = MF(k=int(fx["k"]), backend="hip-minibatch", optimizer=opt, max_iter=int(fx["epochs"]),
+           batch_size=int(fx["batch_size"]), learning_rate=float(fx["lr"]), lambda_reg=float(fx["reg"]),
+           use_bias=use_bias, dropout=p, seed=int(fx["seed"])).fit(golden_dataset(fx))
+    tag = "%s_p%d%s" % (opt, round(100 * p), "" if use_bias else "_nobias")
+    for got, key in ((m.u_factors, "_U"), (m.i_factors, "_V"), (m.u_biases, "_Bu"), (m.i_biases, "_Bi")):
+        assert np.abs(np.asarray(got) - fx[tag + key]).max() <= 2e-5, (tag + key, np.abs(np.asarray(got) - fx[tag + key]).max())
+    for k in (5, 20):
+        rs = np.random.RandomState(k)
+        nu, ni, n = 40, 30, 333
+        rid, cid = rs.randint(0, nu, n).astype(np.int64), rs.randint(0, ni, n).astype(np.int64)
+        val = rs.randint(1, 6, n).astype(np.float32)
+        U, V = rs.normal(0, .1, (nu, k)).astype(np.float32), rs.normal(0, .1, (ni, k)).astype(np.float32)
+        Bu, Bi = rs.normal(0, .1, nu).astype(np.float32), rs.normal(0, .1, ni).astype(np.float32)
+        order = rs.permutation(n)
+        batches = [order[s:s + 50] for s in range(0, n, 50)]
+        keep_u, keep_i = (rs.rand(n, k) > p).astype(np.uint8), (rs.rand(n, k) > p).astype(np.uint8)
+        scale = float(np.float32(1.0) / np.float32(1.0 - p))
+        tr = _lib.MfTrainer(rid, cid, val, nu, ni, k)
+        tr.set_factors(U, V, Bu, Bi)
+        sse = tr.fit_minibatch(order, 50, opt, 0.01, 0.05, 3.0, use_bias, keep_u=keep_u, keep_i=keep_i, keep_scale=scale)
+        got = tr.get_factors()
+        with pytest.raises(ValueError):
+            tr.fit_minibatch(order, 50, opt, 0.01, 0.05, 3.0, use_bias, keep_u=keep_u[:-1], keep_i=keep_i[:-1])
+        tr.close()
+        keep = [(keep_u[s:s + 50], keep_i[s:s + 50]) for s in range(0, n, 50)]
+        want = mf_minibatch_oracle.fit(U, V, Bu, Bi, 3.0, rid, cid, val, batches, opt, 0.01, 0.05, use_bias, keep=keep,
+                                       keep_scale=scale)
+        for a, b in zip(got[:4] if use_bias else got[:2], want[:4]):
+            assert np.abs(a - b).max() <= 2e-5, (opt, k, np.abs(a - b).max())
+        assert abs(sse - sum(want[4])) <= 1e-4 * sum(want[4])

@@ -221,6 +221,39 @@ def test_mf_minibatch_oracle_matches_live_reference(opt):
         assert_close(a, np.asarray(b))
 
 
+@pytest.mark.parametrize("opt,use_bias,p", [("sgd", True, 0.3), ("adam", True, 0.5), ("adagrad", False, 0.2), ("rmsprop", True, 0.9),
+                                            ("sgd", True, 1.0)])
+def test_mf_minibatch_dropout_matches_live_reference(opt, use_bias, p):
+    """MF(backend="pytorch", dropout=p) of the real reference on a fresh random case vs the oracle fed with the masks
+    `mf_minibatch_oracle.dropout_masks` restates (torch's CPU generator after manual_seed and the embedding
+    initialisations; user rows, then item rows, per batch).  p = 1 drops everything without drawing."""
+    from cornac_amd import Dataset
+    from oracle import mf_minibatch_oracle
+
+    ns = ref_loader.load()
+    data = _pairs(70, 45, 700, 9)
+    ref_ds = ns.Dataset.from_uir(data, seed=11)
+    m = ns.MF(k=7, backend="pytorch", optimizer=opt, max_iter=2, batch_size=48, learning_rate=0.03, lambda_reg=0.01,
+              use_bias=use_bias, dropout=p, seed=4, verbose=False).fit(ref_ds)
+    ds = Dataset.from_uir(data, seed=11)
+    ds.reset()
+    rng = np.random.RandomState(4)
+    U = rng.normal(0.0, 0.01, (ds.num_users, 7)).astype(np.float32)
+    V = rng.normal(0.0, 0.01, (ds.num_items, 7)).astype(np.float32)
+    rid, cid, val = ds.uir_tuple
+    batches = []
+    for _ in range(2):
+        batches += list(ds.idx_iter(len(val), 48, shuffle=True))
+    if p < 1.0:
+        keep, scale = mf_minibatch_oracle.dropout_masks(p, 4, ds.num_users, ds.num_items, 7, use_bias, [len(b) for b in batches])
+    else:
+        keep, scale = [(np.zeros((len(b), 7), np.uint8),) * 2 for b in batches], 0.0
+    got = mf_minibatch_oracle.fit(U, V, np.zeros(ds.num_users), np.zeros(ds.num_items), np.float32(ds.global_mean), rid, cid,
+                                  val.astype(np.float32), batches, opt, 0.03, 0.01, use_bias, keep=keep, keep_scale=scale)
+    for a, b in zip(got[:4] if use_bias else got[:2], (m.u_factors, m.i_factors, m.u_biases, m.i_biases)):
+        assert_close(a, np.asarray(b))
+
+
 def _f64_init(nu, ni, k, seed):
     rs = np.random.RandomState(seed)
     return {"U": (rs.rand(nu, k) - 0.5) / k, "V": (rs.rand(ni, k) - 0.5) / k, "Bi": 0.01 * rs.randn(ni)}
