@@ -11,6 +11,12 @@ described first; (2) sharded by row with all-to-all exchanges of the touched row
   * RCCL runs over xGMI via torch.distributed (backend "nccl"); on CPU-only hosts the same code
     path runs over gloo with a host stand-in for the trainer (tests/test_dist_cpu.py).
 
+Two protocols drive regime 1 (ShardedBprTrainer.run_epoch picks): CHUNK LAUNCHES with the overlapped exchange between
+them (begin_sync / finish_sync / step_sync), and — where the handle takes the LDS-bin form — the RESIDENT EXCHANGE: one
+launch per epoch whose workgroups publish their rows' deltas at the exchange points and apply the landed sums
+themselves, fed from a communication stream (run_epoch_resident; csrc/bpr_ldsbin.inc).  exchange_schedule() says how
+often and by which rule the replicas are reconciled.
+
 The trainer kernels, the delta computation and the collective all run on ONE dedicated torch stream
 (handed to the library with cornac_hip_bpr_set_stream), so chunk -> delta -> all-reduce -> rebase ->
 next chunk is stream-ordered without host syncs.  (torch's default stream is the NULL stream, which
