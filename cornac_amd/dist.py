@@ -1076,7 +1076,8 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     n_local, nnz = u1 - u0, counts[rank]
     interval = 1
     if sync_per_epoch is None:
-        sync_per_epoch, interval, rule = exchange_schedule(max(counts), model.total_items)
+        sync_per_epoch, interval, scheduled_rule = exchange_schedule(max(counts), model.total_items)
+        rule = rule if rule is not None else scheduled_rule
     if rule is None:
         rule = "sqrt" if int(sync_per_epoch) >= 16 else "align"
     if sparse_threshold is not None:
