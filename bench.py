@@ -955,6 +955,13 @@ def main():
             # what bounds the LDS-bin kernel: item rows never leave the LDS, every processed triplet still
             # issues the 64-byte fp32 atomic requests of its user row (k / 16) plus those of the hot item rows
             lb = trainer_stats["ldsbin"]
+            # `frac` prices a triplet with SURVEY 8d's 24k + 48 bytes; this kernel moves neither the indptr pair nor the
+            # log2(d) CSR probes of that figure (one user id, one item slot, one bitmap word instead): the same rate by the
+            # bytes the kernel itself needs
+            own_full, own_skip = 24 * k + 16 + 4 + 4 + 4, 4 + 4 + 4
+            out["roofline"]["frac_by_the_kernels_own_bytes"] = (out["roofline"]["frac"] * ((1.0 - skip_frac) * own_full + skip_frac * own_skip)
+                                                                / ((1.0 - skip_frac) * b_full + skip_frac * b_skip))
+            out["roofline"]["own_bytes_per_triplet"] = own_full
             req_per = k / 16.0 + (lb["hot_interactions"] / float(nnz)) * (k / 16.0 + 1.0)
             req = (n_draws - skipped) / max(launches, 1) * req_per / avg_launch_s / 1e9
             out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules) of the user rows and the hot item rows",
