@@ -470,6 +470,7 @@ def leg_bpr_k128_scale(args, _lib):
     tr.seed_hogwild(7)
     tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)  # warm-up: builds ownership tables
     t_setup = time.time() - t0
+    lb = tr.ldsbin_stats()
     epochs = 2
     tr.kernel_timing(True)
     t0 = time.perf_counter()
@@ -479,23 +480,36 @@ def leg_bpr_k128_scale(args, _lib):
     tr.close()
     b_full, b_skip = algorithmic_bytes_per_triplet(k, d)
     skip = sk / float(nnz * epochs)
-    # an epoch is one launch of the fused kernel or 8 partition launches of the XCD-strata form (the automatic choice for
-    # item tables of >= 2^20 rows): bytes per launch = the epoch's bytes x epochs / launches recorded
+    # an epoch is one launch (LDS-bin form with passing bins — the automatic choice when an epoch draws >= 2 interactions
+    # per item row —, or the fused kernel) or 8 partition launches of the XCD-strata form: bytes per launch = the epoch's
+    # bytes x epochs / launches recorded
     bytes_launch = nnz * ((1 - skip) * b_full + skip * b_skip) * epochs / max(launches, 1)
     strata = launches == 8 * epochs
+    passing = lb["bins"] > 0 and not strata
+    kernel = ("bpr_ldsbin_kernel<2,4> (passing bins: %d bins of <= %d item rows, %d threads, %d B of LDS each)"
+              % (lb["bins"], lb["rows_per_bin"], lb["block_threads"], lb["lds_bytes"]) if passing
+              else "bpr_strata_kernel<2,2>" if strata else "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>")
     out = {"metric": "bpr_triplets_per_sec", "value": nnz * epochs / dt, "unit": "triplets/s", "steps": epochs,
            "ms_per_step": 1e3 * dt / epochs, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BPR k=%d on one GPU's user slice of the 100 M x 10 M synthetic (%d users x %d items, "
                                   "%d interactions, U %.1f GB, V %.1f GB: beyond the Infinity Cache), hogwild mode"
-                                  % (k, nu, ni, nnz, nu * k * 4 / 1e9, ni * k * 4 / 1e9)},
+                                  % (k, nu, ni, nnz, nu * k * 4 / 1e9, ni * k * 4 / 1e9),
+                      "form": "ldsbin (passing bins)" if passing else "strata" if strata else "fused",
+                      "sampling": ("every draw picks an interaction with probability 1 / nnz (nnz draws per epoch); the "
+                                   "negative is uniform over the ~%d items sharing the positive's LDS bin in that epoch, bins "
+                                   "re-dealt every epoch (every item pair can meet: csrc/bpr_ldsbin.inc); item-row updates "
+                                   "exact (LDS read-modify-write under a row lock), user rows by fp32 atomics"
+                                   % lb["rows_per_bin"]) if passing else
+                                  "XCD strata: the negative is uniform over the eighth of the items dealt to the positive's "
+                                  "partition in that epoch; plain read-modify-write of item rows inside one XCD" if strata else
+                                  "global uniform negatives, fp32 atomics"},
            # `frac` is over the whole step (the per-epoch bucket deal and the bias pad / unpad passes included): the epoch's
            # algorithmic bytes / ms_per_step; the 8 partition launches alone: frac_kernel_only
            "roofline": {"bound": "hbm", "achieved": bytes_launch * launches / dt / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch * launches / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "frac_kernel_only": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
-                        "kernel": "bpr_strata_kernel<2,2>" if strata else "bpr_hogwild_rowwise_kernel<64,2,2,atomic,owned>",
-                        "launches": launches,
+                        "kernel": kernel, "launches": launches,
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
            "train_stats": {"correct_frac": c / max(nnz * epochs - sk, 1), "skipped_frac": skip},
            "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}

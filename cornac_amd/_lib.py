@@ -37,7 +37,7 @@ SYMBOLS = [
     "cornac_hip_bpr_debug_ownership", "cornac_hip_bpr_set_views", "cornac_hip_bpr_seed_view_stream",
     "cornac_hip_vebpr_fit_epochs", "cornac_hip_vebpr_fit_epochs_f64", "cornac_hip_vebpr_hogwild_form",
     "cornac_hip_bpr_strata_config", "cornac_hip_bpr_chunk_records", "cornac_hip_bpr_strata_stats", "cornac_hip_bpr_debug_strata",
-    "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_stats",
+    "cornac_hip_bpr_ldsbin_config", "cornac_hip_bpr_ldsbin_pass_config", "cornac_hip_bpr_ldsbin_stats",
     "cornac_hip_bpr_ldsbin_deal_config", "cornac_hip_bpr_debug_ldsbin_deal",
     "cornac_hip_bpr_sample_triplets", "cornac_hip_bpr_apply_triplets", "cornac_hip_bpr_gather_rows",
     "cornac_hip_bpr_staged_slots", "cornac_hip_bpr_emit_triplets", "cornac_hip_bpr_apply_staged",
@@ -181,15 +181,16 @@ def lib():
         L.cornac_hip_bpr_epoch_resident_enqueue.argtypes = [_vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                                             C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp,
                                                             C.POINTER(C.c_int)]
-        L.cornac_hip_bpr_resident_flush.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]
+        L.cornac_hip_bpr_resident_flush.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp]
         L.cornac_hip_stream_wait_counter.argtypes = [C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_int]
-        L.cornac_hip_stream_set_flag.argtypes = [C.c_int, _vp, _vp, C.c_uint32]
+        L.cornac_hip_stream_set_flag.argtypes = [C.c_int, _vp, _vp, C.c_uint32, _vp]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_chunk_records.argtypes = [_vp, C.c_int]
         L.cornac_hip_bpr_strata_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_debug_strata.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
         L.cornac_hip_bpr_ldsbin_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+        L.cornac_hip_bpr_ldsbin_pass_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_ldsbin_stats.argtypes = [_vp, C.POINTER(C.c_int64)]
         L.cornac_hip_bpr_ldsbin_deal_config.argtypes = [_vp, C.c_int, C.c_int]
         L.cornac_hip_bpr_debug_ldsbin_deal.argtypes = [_vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp]
@@ -262,8 +263,9 @@ def stream_wait_counter(device, stream, d_counter, target, d_error, timeout_ms=5
     check(lib().cornac_hip_stream_wait_counter(int(device), stream, d_counter, int(target), d_error, int(timeout_ms)))
 
 
-def stream_set_flag(device, stream, d_flag, value=1):
-    check(lib().cornac_hip_stream_set_flag(int(device), stream, d_flag, int(value)))
+def stream_set_flag(device, stream, d_flag, value=1, d_unless=None):
+    """*d_flag = value on `stream` — unless d_unless is given and *d_unless != 0 (an earlier stream_wait_counter gave up)"""
+    check(lib().cornac_hip_stream_set_flag(int(device), stream, d_flag, int(value), d_unless))
 
 
 def device_count():
@@ -475,9 +477,9 @@ class BprTrainer:
                                                           d_keeps, int(keep_stride), d_arrive, d_landed, d_applied, C.byref(n)))
         return n.value
 
-    def resident_flush(self, n_exchanges, rule, d_base, d_buckets, bucket_stride, d_keeps, keep_stride, d_applied):
+    def resident_flush(self, n_exchanges, rule, d_base, d_buckets, bucket_stride, d_keeps, keep_stride, d_applied, d_landed=None):
         check(lib().cornac_hip_bpr_resident_flush(self.h, int(n_exchanges), int(rule), d_base, d_buckets, int(bucket_stride),
-                                                  d_keeps, int(keep_stride), d_applied))
+                                                  d_keeps, int(keep_stride), d_applied, d_landed))
 
     def gather_rows(self, d_table, d_ids, n, width, d_out):
         check(lib().cornac_hip_bpr_gather_rows(self.h, d_table, d_ids, int(n), int(width), d_out))
@@ -548,11 +550,16 @@ class BprTrainer:
                                                      off.ctypes.data, hu.ctypes.data, hi.ctypes.data))
         return bin_of, cold, off, hu[:nh], hi[:nh]
 
+    def ldsbin_pass_config(self, enable=True, waves=8, lds_kb=64, min_draws_x100=200):
+        """the "passing bins" regime of the LDS-bin form (item tables that need more than max_rounds rounds): see
+        include/cornac_hip.h"""
+        check(lib().cornac_hip_bpr_ldsbin_pass_config(self.h, int(bool(enable)), int(waves), int(lds_kb), int(min_draws_x100)))
+
     def ldsbin_stats(self):
-        o = (C.c_int64 * 7)()
+        o = (C.c_int64 * 8)()
         check(lib().cornac_hip_bpr_ldsbin_stats(self.h, o))
         return {"bins": o[0], "rows_per_bin": o[1], "n_hot": o[2], "hot_interactions": o[3], "bitmap_words": o[4],
-                "lds_bytes": o[5], "lock_timeouts": o[6]}
+                "lds_bytes": o[5], "lock_timeouts": o[6], "block_threads": o[7]}
 
     def strata_config(self, hot_permille=120, hot_min_mult_x100=200, rehash_period=1):
         check(lib().cornac_hip_bpr_strata_config(self.h, int(hot_permille), int(hot_min_mult_x100), int(rehash_period)))

@@ -733,6 +733,9 @@ struct cornac_hip_bpr {
     DevBuf<uint32_t> lb_bitmap;
     int lb_bins = 0, lb_cap = 0, lb_n_hot = 0, lb_n_hot_inter = 0, lb_bm_words = 0;
     int lb_hot_x1000 = 75, lb_min_candidates = 48, lb_max_rounds = 4;
+    int lb_pass_enable = 1, lb_pass_waves = 8, lb_pass_kb = 64, lb_pass_min_draws_x100 = 200;  // passing bins (ldsbin_plan)
+    int lb_block = kLbBlock;
+    bool lb_passing = false;
     int lb_strata_groups = 16, lb_hot_cost_x16 = 32;  // the deal: stratum width in groups, price of a hot draw
     int lb_n_strata = 1;
     DevBuf<uint32_t> lb_mass, lb_cold, lb_hot_off;
@@ -1669,7 +1672,16 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
 
 // ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
 typedef void (*LdsBinKernel)(const LdsBinArgs);
-static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false) {
+static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false, bool passing = false) {
+    // passing bins (8-wave workgroups, two per CU): 4 triplets in flight per wave at k in 65..128 — measured on the
+    // configs[4] slice (profiles/r05_exp_scale_passing.log): 2 in flight 38.1 ms, 3: 35.1, 4: 33.8 per epoch; with the
+    // rows of a bin loaded 4 at a time 30.5; requesting the user rows two steps ahead instead of one: no gain (31.0)
+    if (passing && !exch && k > 64 && k <= 128) {
+#ifdef CORNAC_PROFILE
+        if (prof_env_int("CORNAC_HIP_LDSBIN_UNR", 0) == 0)
+#endif
+            return pop ? bpr_ldsbin_kernel<2, 4, true> : bpr_ldsbin_kernel<2, 4>;
+    }
     if (exch) {  // resident exchange (multi-GPU regime 1 inside one launch per epoch)
         if (pop) {
             if (k <= 64) return bpr_ldsbin_kernel<1, 4, true, true>;
@@ -1695,6 +1707,14 @@ static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false) {
         case 8: return bpr_ldsbin_kernel<1, 8>;
         default: break;
     }
+    else if (k <= 128) switch (prof_env_int("CORNAC_HIP_LDSBIN_UNR", 0)) {
+        case 3: return bpr_ldsbin_kernel<2, 3>;
+        case 4: return bpr_ldsbin_kernel<2, 4>;
+        case 22: return bpr_ldsbin_kernel<2, 2, false, false, 2>;
+        case 32: return bpr_ldsbin_kernel<2, 3, false, false, 2>;
+        case 42: return bpr_ldsbin_kernel<2, 4, false, false, 2>;
+        default: break;
+    }
 #endif
     if (k <= 64) return bpr_ldsbin_kernel<1, 4>;
     if (k <= 128) return bpr_ldsbin_kernel<2, 2>;
@@ -1704,23 +1724,60 @@ static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false) {
 
 constexpr size_t kLbLdsBudget = 96 * 1024;   // of the 160 KiB per CU
 constexpr size_t kLbLdsExclusive = 82 * 1024;  // requested at least: two workgroups never share a CU's LDS
-static size_t ldsbin_lds_bytes(int cap, int k) {
+static size_t ldsbin_lds_bytes(int cap, int k, int waves = kLbWaves) {
     const int kp = ((k + kWave - 1) / kWave) * kWave;
-    return ((size_t)cap * (kp + 5) + 1) * sizeof(float) + (size_t)kLbWaves * 3 * kWave * sizeof(int32_t);
+    return ((size_t)cap * (kp + 5) + 1) * sizeof(float) + (size_t)waves * 3 * kWave * sizeof(int32_t);
 }
 
-// bins = the smallest multiple of the CU count whose rows fit the LDS budget; 0 = this shape does not use the form
-static int ldsbin_plan_bins(cornac_hip_bpr_t h) {
+// Two regimes of the form (bpr_ldsbin.inc):
+//   * resident bins — the whole item table fits the chip's LDS in <= lb_max_rounds (4) rounds of one 16-wave workgroup
+//     per CU: a bin owns its CU for the epoch (>= kLbLdsExclusive requested so that no second workgroup joins it);
+//   * passing bins — a large item table (configs[4]: 10 M x 128) passes through the LDS once per epoch in hundreds of
+//     rounds: 8-wave workgroups with <= lb_pass_kb of LDS each, so that two of them share a CU and one loads / stores
+//     its rows while the other trains.  An item row then costs ONE read and ONE write of HBM per epoch however often it
+//     is drawn, and its updates are exact LDS read-modify-writes; worth it when a row is drawn a few times per epoch
+//     (nnz >= lb_pass_min_draws_x100 / 100 x n_items), else the row traffic would exceed what the triplets need.
+struct LbPlan {
+    int bins = 0, block = kLbBlock, cap = 0;
+    size_t lds = 0;
+    bool passing = false;
+};
+static LbPlan ldsbin_plan(cornac_hip_bpr_t h) {
+    LbPlan pl;
     const int cus = device_info(h->device).cus;
-    if (h->k > 256 || h->nnz < (int64_t)cus * kLbWaves * kWave) return 0;
+    if (h->k > 256 || h->nnz < (int64_t)cus * kLbWaves * kWave) return pl;
     for (int rounds = 1; rounds <= h->lb_max_rounds; ++rounds) {
         const int64_t bins = (int64_t)cus * rounds;
         const int64_t cap = (h->n_items + bins - 1) / bins;
-        if (cap < h->lb_min_candidates) return 0;  // negatives would be drawn from too few items
-        if (ldsbin_lds_bytes((int)cap, h->k) <= kLbLdsBudget) return (int)bins;
+        if (cap < h->lb_min_candidates) return pl;  // negatives would be drawn from too few items
+        if (ldsbin_lds_bytes((int)cap, h->k) <= (size_t)prof_env_int("CORNAC_HIP_LDSBIN_BUDGET_KB", (int)(kLbLdsBudget >> 10)) << 10) {
+            pl.bins = (int)bins;
+            pl.cap = (int)cap;
+            pl.lds = std::max(ldsbin_lds_bytes((int)cap, h->k), kLbLdsExclusive);
+            return pl;
+        }
     }
-    return 0;
+    if (!h->lb_pass_enable || (double)h->nnz * 100.0 < (double)h->n_items * h->lb_pass_min_draws_x100) return pl;
+    const int waves = prof_env_int("CORNAC_HIP_LDSBIN_PASS_WAVES", h->lb_pass_waves);
+    const size_t budget = (size_t)prof_env_int("CORNAC_HIP_LDSBIN_PASS_KB", h->lb_pass_kb) << 10;
+    const int kp = ((h->k + kWave - 1) / kWave) * kWave;
+    const size_t fixed = sizeof(float) + (size_t)waves * 3 * kWave * sizeof(int32_t);
+    if (budget <= fixed) return pl;
+    int64_t cap = (int64_t)((budget - fixed) / ((size_t)(kp + 5) * sizeof(float)));
+    if (cap < h->lb_min_candidates) return pl;
+    int64_t bins = (h->n_items + cap - 1) / cap;
+    bins = ((bins + cus - 1) / cus) * cus;
+    cap = (h->n_items + bins - 1) / bins;
+    if (cap < h->lb_min_candidates || bins > (int64_t(1) << 22)) return pl;
+    pl.bins = (int)bins;
+    pl.cap = (int)cap;
+    pl.block = waves * kWave;
+    pl.lds = ldsbin_lds_bytes((int)cap, h->k, waves);
+    pl.passing = true;
+    return pl;
 }
+// bins = a multiple of the CU count; 0 = this shape does not use the form
+static int ldsbin_plan_bins(cornac_hip_bpr_t h) { return ldsbin_plan(h).bins; }
 
 static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_population, int flags) {
     const int form = (flags >> 16) & 15;
@@ -1728,14 +1785,17 @@ static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
     flags &= ~0xff00;
 #endif
     if (!(form == 0 || form == 3) || (flags & 0xffff) != 0) return false;
-    (void)n_samples;  // any chunk of an epoch: a launch takes its share of every bin's draws
     (void)neg_population;  // uniform (BPR) and popularity-weighted (WBPR) negatives both have a binned form
-    return ldsbin_plan_bins(h) > 0;
+    // any chunk of an epoch: a launch takes its share of every bin's draws — but a launch of passing bins moves the whole
+    // item table through the LDS, so only launches of at least a quarter of an epoch take that regime
+    const LbPlan pl = ldsbin_plan(h);
+    return pl.bins > 0 && (!pl.passing || n_samples * 4 >= h->nnz);
 }
 
 static void ldsbin_build(cornac_hip_bpr_t h) {
-    const int bins = ldsbin_plan_bins(h);
-    if (h->lb_built && h->lb_bins == bins) return;
+    const LbPlan plan = ldsbin_plan(h);
+    const int bins = plan.bins;
+    if (h->lb_built && h->lb_bins == bins && h->lb_block == plan.block && h->lb_lds_bytes == plan.lds) return;
     build_item_ranks(h);
     const int64_t ni = h->n_items, nnz = h->nnz, nu = h->n_users;
     // CSC: users of every item, in user order
@@ -1748,8 +1808,10 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
             for (int32_t p = h->h_indptr[(size_t)u]; p < h->h_indptr[(size_t)u + 1]; ++p)
                 cusers[(size_t)cur[(size_t)h->h_indices[(size_t)p]]++] = (int32_t)u;
     }
-    // hot items: degree above hot_x1000 / 1000 of a bin's share of the interactions (they would serialise their bin)
-    const double share = (double)nnz / bins;
+    // hot items: degree above hot_x1000 / 1000 of a bin's share of the interactions (they would serialise their bin).
+    // Passing bins are scheduled dynamically over 2 x CUs slots, so what a heavy item costs is the tail its bin adds to the
+    // epoch: the share that counts is a slot's, priced at a quarter (hot_x1000 = 75: degree > nnz / 13 653 at 256 CUs)
+    const double share = plan.passing ? (double)nnz / (4.0 * device_info(h->device).cus) : (double)nnz / bins;
     int n_hot = 0;
     while (n_hot < ni && (double)(cptr[(size_t)h->h_rank_item[(size_t)n_hot] + 1] - cptr[(size_t)h->h_rank_item[(size_t)n_hot]]) * 1000.0 >
                              share * h->lb_hot_x1000)
@@ -1801,10 +1863,12 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
     }
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->lb_bins = bins;
-    h->lb_cap = (int)((ni + bins - 1) / bins);
+    h->lb_cap = plan.cap;
+    h->lb_block = plan.block;
+    h->lb_passing = plan.passing;
     h->lb_n_hot = n_hot;
     h->lb_n_hot_inter = (int)hot_u.size();
-    h->lb_lds_bytes = std::max(ldsbin_lds_bytes(h->lb_cap, h->k), kLbLdsExclusive);
+    h->lb_lds_bytes = plan.lds;
     const int n_groups = (int)((ni + bins - 1) / bins);
     h->lb_n_strata = std::max(1, n_groups / std::max(1, h->lb_strata_groups));
     h->lb_mass.ensure((size_t)bins);
@@ -1862,7 +1926,7 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
 static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int neg_population,
                            int flags) {
     ldsbin_build(h);
-    LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY);
+    LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, false, h->lb_passing);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
     int64_t left = n_samples;
     while (left > 0) {
@@ -1881,7 +1945,7 @@ static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
         }
 #endif
         h->ktimer.before(h->stream);
-        hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
+        hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(h->lb_block), h->lb_lds_bytes, h->stream, a);
         h->ktimer.after(h->stream);
         HIP_CHECK(hipGetLastError());
 #ifdef CORNAC_PROFILE
@@ -1922,7 +1986,7 @@ static void ldsbin_resident_enqueue(cornac_hip_bpr_t h, float lr, float reg, int
     a.ex = ex;
     ldsbin_deal(h, a.seed, a.epoch, a.key);
     h->ktimer.before(h->stream);
-    hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(kLbBlock), h->lb_lds_bytes, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3(h->lb_bins), dim3(h->lb_block), h->lb_lds_bytes, h->stream, a);
     h->ktimer.after(h->stream);
     HIP_CHECK(hipGetLastError());
     advance_hog_offset(h, h->nnz);
@@ -2064,7 +2128,7 @@ static LdsBinExchange resident_exchange_args(cornac_hip_bpr_t h, int n_exchanges
                                              uint32_t *d_arrive, const uint32_t *d_landed, uint32_t *d_applied) {
     REQUIRE(n_exchanges >= 1 && n_exchanges <= kLbMaxExchanges, "n_exchanges must be in [1, %d]", kLbMaxExchanges);
     REQUIRE(rule == 0 || rule == 1, "rule must be 0 (sqrt) or 1 (align)");
-    REQUIRE(d_base && d_buckets && d_keeps && d_arrive && d_landed && d_applied, "NULL device pointer");
+    REQUIRE(d_base && d_buckets && d_keeps && d_applied, "NULL device pointer");  // (arrive / landed: the launch checks its own)
     const int64_t nt = h->total_items, width = nt * h->k + nt;
     REQUIRE(bucket_stride >= width + 2 * nt && keep_stride >= width,
             "a bucket holds [dV | dB | wV | wB] = %lld floats, a keep buffer [dV | dB] = %lld", (long long)(width + 2 * nt),
@@ -2081,7 +2145,8 @@ int cornac_hip_bpr_resident_exchange_bins(cornac_hip_bpr_t h, int neg_population
     return guarded([&] {
         bpr_check_keep_packed(h);
         REQUIRE(n_bins != nullptr, "n_bins is NULL");
-        *n_bins = (h->hog_seeded && !h->f64 && hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags)) ? ldsbin_plan_bins(h) : 0;
+        *n_bins = (h->hog_seeded && !h->f64 && hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags) && !ldsbin_plan(h).passing)
+                      ? ldsbin_plan_bins(h) : 0;
     });
 }
 
@@ -2098,8 +2163,11 @@ int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float re
         REQUIRE(hogwild_uses_ldsbin(h, h->nnz, neg_population, hogwild_flags),
                 "the resident exchange lives in the LDS-bin form, which this shape / these flags do not take "
                 "(cornac_hip_bpr_resident_exchange_bins tells): use cornac_hip_bpr_hogwild_enqueue chunks");
+        REQUIRE(!ldsbin_plan(h).passing, "the resident exchange needs resident bins (the item table in <= %d rounds); this table "
+                "passes through the LDS in many rounds: exchange between whole-epoch launches", h->lb_max_rounds);
         REQUIRE(h->hog_offset == 0, "an epoch is under way (%lld of its samples drawn): the resident launch covers whole epochs",
                 (long long)h->hog_offset);
+        REQUIRE(d_arrive && d_landed, "NULL device pointer");
         const LdsBinExchange ex = resident_exchange_args(h, n_exchanges, rule, d_base, d_buckets, bucket_stride, d_keeps,
                                                          keep_stride, d_arrive, d_landed, d_applied);
         ldsbin_resident_enqueue(h, lr, reg, use_bias, neg_population, hogwild_flags, ex);
@@ -2109,12 +2177,13 @@ int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float re
 
 int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, const float *d_buckets,
                                   int64_t bucket_stride, const float *d_keeps, int64_t keep_stride,
-                                  const uint32_t *d_applied) {
+                                  const uint32_t *d_applied, const uint32_t *d_landed) {
     return guarded([&] {
         bpr_check(h);
-        static uint32_t unused_flag = 0;
+        // d_landed (may be NULL = all landed): an exchange whose flag is still 0 — the communication stream gave up waiting
+        // for its arrivals — is left unapplied
         const LdsBinExchange ex = resident_exchange_args(h, n_exchanges, rule, d_base, const_cast<float *>(d_buckets), bucket_stride,
-                                                         const_cast<float *>(d_keeps), keep_stride, &unused_flag, &unused_flag,
+                                                         const_cast<float *>(d_keeps), keep_stride, nullptr, d_landed,
                                                          const_cast<uint32_t *>(d_applied));
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((h->n_items + kWavesPerBlock - 1) / kWavesPerBlock, 4096));
         hipLaunchKernelGGL(ldsbin_exchange_flush_kernel, dim3(grid), dim3(kBlock), 0, h->stream, ex, h->V.p, h->B.p,
@@ -2137,11 +2206,11 @@ int cornac_hip_stream_wait_counter(int device, void *hip_stream, const uint32_t 
     });
 }
 
-int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value) {
+int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value, const uint32_t *d_unless) {
     return guarded([&] {
         REQUIRE(d_flag != nullptr, "NULL device pointer");
         use_device(device);
-        hipLaunchKernelGGL(stream_set_flag_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)hip_stream, d_flag, value);
+        hipLaunchKernelGGL(stream_set_flag_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)hip_stream, d_flag, value, d_unless);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -2276,6 +2345,20 @@ int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_cand
     });
 }
 
+int cornac_hip_bpr_ldsbin_pass_config(cornac_hip_bpr_t h, int enable, int waves, int lds_kb, int min_draws_x100) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(waves == 4 || waves == 8 || waves == 16, "waves per workgroup must be 4, 8 or 16");
+        REQUIRE(lds_kb >= 16 && lds_kb <= 156, "lds_kb must be in [16, 156]");
+        REQUIRE(min_draws_x100 >= 0, "min_draws_x100 must be >= 0");
+        h->lb_pass_enable = enable != 0;
+        h->lb_pass_waves = waves;
+        h->lb_pass_kb = lds_kb;
+        h->lb_pass_min_draws_x100 = min_draws_x100;
+        h->lb_built = false;
+    });
+}
+
 int cornac_hip_bpr_ldsbin_deal_config(cornac_hip_bpr_t h, int strata_groups, int hot_cost_x16) {
     return guarded([&] {
         bpr_check(h);
@@ -2317,7 +2400,7 @@ int cornac_hip_bpr_debug_ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t
 int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6) {
     return guarded([&] {
         bpr_check(h);
-        REQUIRE(out6 != nullptr, "out7 is NULL");
+        REQUIRE(out6 != nullptr, "out8 is NULL");
         out6[6] = h->lb_lock_timeouts;
         const int bins = ldsbin_plan_bins(h);
         if (bins > 0) ldsbin_build(h);
@@ -2327,6 +2410,7 @@ int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out6) {
         out6[3] = bins ? h->lb_n_hot_inter : 0;
         out6[4] = bins ? h->lb_bm_words : 0;
         out6[5] = bins ? (int64_t)h->lb_lds_bytes : 0;
+        out6[7] = bins ? h->lb_block : 0;
     });
 }
 

@@ -452,6 +452,10 @@ struct cornac_hip_mf {
     DevBuf<int32_t> mb_u, mb_slot, mb_bin_ptr, mb_bin_items;
     DevBuf<float> mb_r;
     DevBuf<unsigned int> mb_sync;  // [8 slot counters | 8 barrier counters | abort]
+    // split items (mf_blocks.inc): copies of their rows, the items, the copies of each
+    DevBuf<float> mb_vx, mb_bix;
+    DevBuf<int32_t> mb_split_item, mb_split_ptr;
+    int mb_n_split = 0, mb_n_virtual = 0;
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
     DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
@@ -888,16 +892,32 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     // They stay in global memory under atomics and take no bin.
     std::vector<int64_t> cnt_cold(cnt_i);
     std::vector<char> hot((size_t)ni, 0);
-    // ... unless the row is so popular (> 0.5 % of ALL ratings) that thousands of atomic updates computed from one stale
-    // copy would be in flight at once: summed, they overshoot and the factorisation diverges (measured at SURVEY 8d's
-    // Zipf(0.8): one row with 3.2 % of the ratings, loss = nan in this form AND in the fused kernel).  Such a row keeps a
-    // bin (alone, LPT) and its lock: at most the workgroup's 64 ratings in flight see a stale copy, like the reference's
-    // threads do, at the price of serialising that row.
+    // ... and a row so popular (> 0.1 % of ALL ratings) that more than ~16 of the ~16 000 ratings in flight at any time name
+    // it is SPLIT into W = ceil(share / 0.1 %) virtual rows: summed, hundreds of atomic updates computed from one stale copy
+    // overshoot and the factorisation diverges (measured at SURVEY 8d's Zipf(0.8): one row with 3.2 % of the ratings, loss
+    // = nan in this form AND in the fused kernel).  The copies are hot rows of their own (ids n_items + v, a side table),
+    // merged after every phase (mf_virtual_merge_kernel); a rating takes the copy a hash of its position names.
+    std::vector<int32_t> split_item, split_ptr(1, 0), split_of((size_t)ni, -1);
     for (int64_t i = 0; i < ni; ++i)
-        if (cnt_i[(size_t)i] * 10 * 256 > n && cnt_i[(size_t)i] * 200 <= n) {
+        if (cnt_i[(size_t)i] * 10 * 256 > n) {
             hot[(size_t)i] = 1;
             cnt_cold[(size_t)i] = 0;
+            if (cnt_i[(size_t)i] * 1000 > n) {
+                const int64_t W = std::min<int64_t>(256, (cnt_i[(size_t)i] * 1000 + n - 1) / n);
+                split_of[(size_t)i] = (int32_t)split_item.size();
+                split_item.push_back((int32_t)i);
+                split_ptr.push_back(split_ptr.back() + (int32_t)W);
+            }
         }
+    auto hot_id = [&](int64_t s) -> int32_t {  // the row a hot rating updates: the item, or one of its copies
+        const int64_t it = h->host_cid[(size_t)s];
+        const int32_t j = split_of[(size_t)it];
+        if (j < 0) return (int32_t)it;
+        uint32_t x = (uint32_t)s * 0x85EBCA6Bu + 0x165667B1u;
+        x ^= x >> 16; x *= 0x9E3779B1u; x ^= x >> 13;
+        const uint32_t W = (uint32_t)(split_ptr[(size_t)j + 1] - split_ptr[(size_t)j]);
+        return (int32_t)(ni + split_ptr[(size_t)j] + (int32_t)(x % W));
+    };
     int cap = 0;
     const std::vector<int32_t> ibin = mf_lpt_256(cnt_cold, &cap), ublk = mf_lpt_256(cnt_u, nullptr);
     cap = std::max(cap, 1);
@@ -980,7 +1000,7 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
                 for (const auto &e : L) {
                     const int64_t sidx = e.second;
                     b_u[(size_t)pos] = (int32_t)h->host_rid[(size_t)sidx];
-                    b_slot[(size_t)pos] = hot[(size_t)h->host_cid[(size_t)sidx]] ? (int32_t)(h->host_cid[(size_t)sidx] | 0x80000000ll)
+                    b_slot[(size_t)pos] = hot[(size_t)h->host_cid[(size_t)sidx]] ? (int32_t)((int64_t)hot_id(sidx) | 0x80000000ll)
                                                                                  : slot[(size_t)h->host_cid[(size_t)sidx]];
                     b_r[(size_t)pos] = h->host_val[(size_t)sidx];
                     ++pos;
@@ -1004,6 +1024,16 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     h->mb_r.upload(b_r.data(), (size_t)n, h->stream);
     h->mb_bin_ptr.upload(bin_ptr.data(), 257, h->stream);
     h->mb_bin_items.upload(bin_items.data(), bin_items.size(), h->stream);
+    h->mb_n_split = (int)split_item.size();
+    h->mb_n_virtual = split_ptr.back();
+    if (h->mb_n_split) {
+        h->mb_split_item.alloc(split_item.size());
+        h->mb_split_ptr.alloc(split_ptr.size());
+        h->mb_split_item.upload(split_item.data(), split_item.size(), h->stream);
+        h->mb_split_ptr.upload(split_ptr.data(), split_ptr.size(), h->stream);
+        h->mb_vx.alloc((size_t)h->mb_n_virtual * (size_t)h->k);
+        h->mb_bix.alloc((size_t)h->mb_n_virtual * kBiasStride);
+    }
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->mb_cap = cap;
     h->mb_lds = std::max(mf_blocks_lds(cap, h->k), (size_t)82 * 1024);  // >= 82 KB: one workgroup per CU
@@ -1043,13 +1073,25 @@ static bool mf_epoch_blocks(cornac_hip_mf_t h, float lr, float reg, float mu, in
     a.slot_cnt = h->mb_sync.p; a.bar = h->mb_sync.p + 8; a.abort = h->mb_sync.p + 16;
     a.wait_bound_ticks = (long long)prof_env_int("CORNAC_HIP_MF_BLOCKS_WAIT_S", 20) * 100000000ll;
     a.cap = h->mb_cap; a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
+    a.Vx = h->mb_vx.p; a.Bix = h->mb_bix.p; a.n_items = (int32_t)h->n_items;
+    MfVirtArgs va;
+    va.V = h->V.p; va.Bi = h->Bi.p; va.Vx = h->mb_vx.p; va.Bix = h->mb_bix.p;
+    va.item = h->mb_split_item.p; va.ptr = h->mb_split_ptr.p; va.n_split = h->mb_n_split; va.k = h->k;
     HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 24 * sizeof(unsigned int), h->stream));
     for (int ph = 0; ph < 8; ++ph) {
         a.phase = ph;
         if (ph) HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 16 * sizeof(unsigned int), h->stream));  // (the abort word stays)
+        if (h->mb_n_split && ph == 0) {  // the copies start the epoch equal to their rows (the tables may have been set since)
+            va.merge = 0;
+            hipLaunchKernelGGL(mf_virtual_merge_kernel, dim3(h->mb_n_split), dim3(kWave), 0, h->stream, va);
+        }
         h->ktimer.before(h->stream);
         hipLaunchKernelGGL(kern, dim3(256), dim3(kMbBlock), h->mb_lds, h->stream, a);
         h->ktimer.after(h->stream);
+        if (h->mb_n_split) {
+            va.merge = 1;
+            hipLaunchKernelGGL(mf_virtual_merge_kernel, dim3(h->mb_n_split), dim3(kWave), 0, h->stream, va);
+        }
     }
     HIP_CHECK(hipGetLastError());
     unsigned int aborted = 0;

@@ -343,6 +343,7 @@ class ShardedBprTrainer:
         self.device = device
         self.stream = None
         self._resident = None            # buffers of the resident exchange (device path), allocated at first use
+        self._resident_open = False      # resident launches since the last closing exchange (finish())
         self.resident_timeout_ms = 20000
         self.resident_lag = 1            # host path: an exchange is applied this many boundaries after its publication
         # emulation / test hook: called as hook(e, bucket) on the communication stream where the all-reduce of exchange e
@@ -449,15 +450,20 @@ class ShardedBprTrainer:
                     dist.all_reduce(st["buckets"][e], op=dist.ReduceOp.SUM, group=t.group, async_op=True).wait()
                 if self.resident_bucket_hook is not None:
                     self.resident_bucket_hook(e, st["buckets"][e])
-                _lib.stream_set_flag(dev_index, comm.cuda_stream, p_landed + 4 * e, 1)
+                # a wait that gave up (p_err set) leaves this and every later flag of the epoch down: a bucket that was
+                # all-reduced incomplete is applied neither by the launch nor by the flush; finish() raises on every rank
+                _lib.stream_set_flag(dev_index, comm.cuda_stream, p_landed + 4 * e, 1, p_err)
             landed = torch.cuda.Event()
             landed.record()
         with self._on_stream():
             self.stream.wait_event(landed)
             self.trainer.resident_flush(n_ex, RULES[t.rule], t.base.data_ptr(), st["buckets"].data_ptr(), stride_b,
-                                        st["keeps"].data_ptr(), stride_k, st["applied"].data_ptr())
+                                        st["keeps"].data_ptr(), stride_k, st["applied"].data_ptr(), p_landed)
         t.exchanges["dense"] += n_ex
         t.exchanges["resident"] = t.exchanges.get("resident", 0) + n_ex
+        # the hot rows live in the global table: their owner bin publishes them when IT has finished, and bins that train
+        # on add steps afterwards — table - base still holds those on this rank only.  finish() closes with one exchange.
+        self._resident_open = True
 
     def _run_epoch_resident_host(self, nnz, n_exchanges, lr, reg, use_bias, neg_population, flags):
         """the same protocol on a host (gloo): the stand-in trains chunk by chunk, the table does for all rows at once
@@ -511,15 +517,26 @@ class ShardedBprTrainer:
                 self.table.step_sync()
                 self._epochs_since_exchange = 0
             self.table.finish_sync()
+            if self._resident_open:
+                # closing exchange of the resident protocol: the steps taken on the hot rows after their last in-launch
+                # publication (table - base = steps not yet published, the invariant the chunk protocol's passes share)
+                # reach the other ranks, so that every rank leaves with the same item table
+                self.table.begin_sync()
+                self.table.finish_sync()
+                self._resident_open = False
         out = self.trainer.sync()
         if self.stream is not None:
             self.stream.synchronize()
         if self._resident is not None:
             self._resident["comm"].synchronize()
-            if int(self._resident["signals"][-1].item()) != 0:
-                raise RuntimeError("resident exchange: the communication stream gave up waiting for the epoch launch's "
-                                   "arrivals (%d ms) — the exchange of that epoch was all-reduced incomplete"
-                                   % self.resident_timeout_ms)
+            err = self._resident["signals"][-1:].clone()
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(err, op=dist.ReduceOp.MAX, group=self.table.group)   # every rank raises together
+            if int(err.item()) != 0:
+                self._resident["signals"][-1:].zero_()
+                raise RuntimeError("resident exchange: a communication stream gave up waiting for its epoch launch's "
+                                   "arrivals (%d ms) — that exchange and the later ones of the epoch were left unapplied "
+                                   "on every rank; the item tables of the ranks no longer agree" % self.resident_timeout_ms)
         return out
 
 

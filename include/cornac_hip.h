@@ -170,14 +170,22 @@ int cornac_hip_bpr_strata_stats(cornac_hip_bpr_t h, int64_t *out4);
 int cornac_hip_bpr_debug_strata(cornac_hip_bpr_t h, uint32_t epoch, int64_t *sptr, int32_t *rec_u, int32_t *rec_i,
                                 int32_t *rank_item, uint32_t *key);
 /* Tuning and inspection of the LDS-bin form.  ldsbin_config: an item is hot (rows in global memory under atomics, its
- * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 75);
+ * interactions dealt to all bins) when its degree exceeds hot_x1000 / 1000 of a bin's share nnz / bins (default 75;
+ * passing bins: of nnz / (4 x CUs) — a quarter of what one of the 2 x CUs concurrent slots draws per epoch);
  * the form is used when every bin holds at least min_candidates items (default 48: the negative of a draw comes from
- * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4).  ldsbin_stats: out7 =
+ * the positive's bin) and the table fits in max_rounds rounds of one bin per CU (default 4: "resident bins", a bin owns
+ * its CU for the epoch).  ldsbin_pass_config: "passing bins" for item tables beyond that — the table passes through the
+ * LDS once per epoch in as many rounds as it takes, `waves` waves (4 / 8 / 16; default 8) and at most lds_kb KiB
+ * (default 64: two workgroups per CU) per bin, used when an epoch draws at least min_draws_x100 / 100 interactions per
+ * item row (default 200) and for launches of at least a quarter of an epoch; enable = 0 switches the regime off
+ * (automatic then falls through to XCD strata / the fused kernel).  ldsbin_stats: out8 =
  * {bins (0: the shape does not use the form), LDS rows per bin, hot items, their interactions, bitmap words per user
  * (0: CSR binary search), dynamic LDS bytes per workgroup, row-lock spins that hit their bound since create (0
- * unless there is a bug: fetched with the epoch counters)}. */
+ * unless there is a bug: fetched with the epoch counters; the resident exchange's row duties count here too), threads
+ * per workgroup (1024 resident bins, 64 x waves passing bins)}. */
 int cornac_hip_bpr_ldsbin_config(cornac_hip_bpr_t h, int hot_x1000, int min_candidates, int max_rounds);
-int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out7);
+int cornac_hip_bpr_ldsbin_pass_config(cornac_hip_bpr_t h, int enable, int waves, int lds_kb, int min_draws_x100);
+int cornac_hip_bpr_ldsbin_stats(cornac_hip_bpr_t h, int64_t *out8);
 /* The per-epoch deal of the LDS-bin form (csrc/bpr_ldsbin.inc, ldsbin_deal_rank).  deal_config: the popularity ranks
  * are permuted (epoch-keyed) inside strata of ~strata_groups * bins consecutive ranks before they are cut into the
  * groups of `bins` items that are dealt one item to each bin (default 16; 1 = the groups are cut from the static rank
@@ -281,7 +289,7 @@ int cornac_hip_table_delta(int op, int device, void *hip_stream, float *d_flat, 
  *   d_applied  [n_items] out: row i has applied the exchanges [0, d_applied[i])
  * The caller's communication stream runs, for e = 0 .. n_exchanges-1: cornac_hip_stream_wait_counter(d_arrive + e,
  * *n_arrivals) -> all-reduce of bucket e -> cornac_hip_stream_set_flag(d_landed + e); when the last one has landed,
- * cornac_hip_bpr_resident_flush (on the handle's stream) applies what the launch did not.  The bound tables
+ * cornac_hip_bpr_resident_flush (on the handle's stream) applies what the launch did not (d_landed: the landed exchanges only).  The bound tables
  * (cornac_hip_bpr_bind_device) are the replica.  cornac_hip_bpr_resident_exchange_bins: *n_bins = the launch's
  * workgroup count, 0 when this shape / these flags do not take the LDS-bin form (use hogwild_enqueue chunks then). */
 int cornac_hip_bpr_resident_exchange_bins(cornac_hip_bpr_t h, int neg_population, int hogwild_flags, int *n_bins);
@@ -291,12 +299,14 @@ int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float re
                                           const uint32_t *d_landed, uint32_t *d_applied, int *n_arrivals);
 int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, const float *d_buckets,
                                   int64_t bucket_stride, const float *d_keeps, int64_t keep_stride,
-                                  const uint32_t *d_applied);
-/* on `hip_stream` of `device`: wait until *d_counter >= target (after timeout_ms: *d_error = 1 and the stream moves on);
- * set *d_flag = value */
+                                  const uint32_t *d_applied, const uint32_t *d_landed);
+/* on `hip_stream` of `device`: wait until *d_counter >= target (after timeout_ms: *d_error = 1 and the stream moves on;
+ * every later wait on the same d_error returns at once); set *d_flag = value unless d_unless != NULL and *d_unless != 0.
+ * The resident exchange passes its d_error as d_unless: a bucket that was all-reduced incomplete never gets its landed
+ * flag, so neither the launch nor cornac_hip_bpr_resident_flush (d_landed) applies it; the caller reports d_error. */
 int cornac_hip_stream_wait_counter(int device, void *hip_stream, const uint32_t *d_counter, uint32_t target,
                                    uint32_t *d_error, int timeout_ms);
-int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value);
+int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value, const uint32_t *d_unless);
 
 /* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.

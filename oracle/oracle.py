@@ -469,9 +469,10 @@ def _ldsbin_mix(h):
     return h.astype(np.uint32)
 
 
-def ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000):
+def ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000, share=None):
     """The static tables of the LDS-bin form (csrc/bpr.hip ldsbin_build): CSC, popularity ranks, hot items and their
-    interaction list in the shuffled order (stable order of a hash of the item-major list index)."""
+    interaction list in the shuffled order (stable order of a hash of the item-major list index).  share: the interaction
+    count the hot threshold is a fraction of — nnz / n_bins (resident bins, the default) or nnz / (4 x CUs) (passing bins)."""
     import scipy.sparse as sp
 
     indptr = np.ascontiguousarray(indptr, np.int32)
@@ -482,7 +483,7 @@ def ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000):
     cptr, cusers = X.indptr.astype(np.int32), X.indices.astype(np.int32)
     deg = np.diff(cptr)
     rank_item = np.argsort(-deg.astype(np.int64), kind="stable").astype(np.int32)
-    share = nnz / n_bins
+    share = nnz / n_bins if share is None else float(share)
     n_hot = 0
     while n_hot < n_items and deg[rank_item[n_hot]] * 1000.0 > share * hot_x1000:
         n_hot += 1
@@ -523,10 +524,10 @@ def ldsbin_deal(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, strata
 
 
 def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False, neg_pop=False,
-                 strata_groups=16, hot_cost_x16=32, tables=None):
+                 strata_groups=16, hot_cost_x16=32, tables=None, share=None):
     """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
     positive touches per item, negative touches per item])."""
-    t = tables if tables is not None else ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000)
+    t = tables if tables is not None else ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000, share)
     key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)))
     draws = C.c_int64()
     pos = np.zeros(n_items, np.int64) if count_touches else None

@@ -601,6 +601,76 @@ def test_ldsbin_popularity_negatives_wbpr(oracle):
         assert abs(float(B3.astype(np.float64).sum())) <= 1e-4 * np.abs(B3).sum() + 1e-3
 
 
+def _passing_case(n_users=100_000, n_items=300_000, degree=9, seed=21):
+    """a user slice of a large item table (the configs[4] pattern): `degree` distinct items per user over n_items items, two
+    thirds of the mass Zipf-free and a popular head on top so that a few items are hot"""
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, n_items, size=n_users, dtype=np.int64)
+    step = rs.randint(1, n_items // (2 * degree), size=n_users, dtype=np.int64)
+    items = (base[:, None] + step[:, None] * np.arange(degree, dtype=np.int64)[None, :]) % n_items
+    head = rs.randint(0, 40, size=n_users)                 # every user also names one of 40 popular items
+    items[:, 0] = head
+    items.sort(axis=1)
+    keep = np.ones_like(items, bool)
+    keep[:, 1:] = items[:, 1:] != items[:, :-1]            # (drop the rare duplicate)
+    indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+    return n_users, n_items, indptr, items[keep].astype(np.int32)
+
+
+def test_ldsbin_passing_bins_sampler_exactness_and_learning(oracle):
+    """The LDS-bin form with PASSING bins (csrc/bpr.hip ldsbin_plan: an item table beyond 4 rounds of CU-owning bins — the
+    configs[4] regime — passes through the LDS once per epoch in 8-wave workgroups, two per CU): the same deal and sampler
+    as the resident bins, so (1) with lr = 0 the skip counter of two epochs equals the CPU restatement exactly (CSR
+    membership test: no bitmap at this size) and nothing moves; (2) updates are exact — with reg = 0 the column sums of V
+    and the bias sum are conserved, the lock counter stays 0; (3) it learns like the fused atomic kernel."""
+    n_users, n_items, indptr, indices = _passing_case()
+    nnz, k, seed = len(indices), 128, 0xC0FFEE
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    st = tr.ldsbin_stats()
+    assert st["bins"] > 4 * 256 and st["bins"] % 256 == 0 and st["block_threads"] == 512 and st["bitmap_words"] == 0, st
+    assert 48 <= st["rows_per_bin"] and st["lds_bytes"] <= 64 * 1024 and st["n_hot"] > 0, st
+    rs = np.random.RandomState(0)
+    U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
+    B = rs.normal(0, 0.1, n_items).astype(np.float32)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(seed)
+    c, s = tr.fit_epochs(2, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    U2, V2, B2 = tr.get_factors()
+    tr.close()
+    want = 0
+    for epoch in range(2):
+        sk, draws, n_hot = oracle.ldsbin_epoch(seed, epoch, st["bins"], 75, indptr, indices, n_items, share=nnz / 1024.0)
+        assert draws == nnz and n_hot == st["n_hot"]
+        want += sk
+    assert s == want and want > 0
+    assert np.array_equal(V2, V) and np.array_equal(B2, B) and np.array_equal(U2, U)
+    out = {}
+    for name, flags in (("passing", 0), ("fused", _lib.FORM_FUSED)):
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.set_factors(U, V, np.zeros(n_items, np.float32))
+        tr.seed_hogwild(9)
+        tr.fit_epochs(5, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        out[name] = (c / (nnz - s), tr.get_factors())
+        if name == "passing":
+            assert tr.ldsbin_stats()["lock_timeouts"] == 0
+        tr.close()
+    assert abs(out["passing"][0] - out["fused"][0]) < 0.02, (out["passing"][0], out["fused"][0])
+    for name in out:
+        V3, B3 = out[name][1][1], out[name][1][2]
+        assert np.isfinite(V3).all() and np.abs(V3 - V).max() > 1e-3
+        moved = np.abs(V3.astype(np.float64) - V).sum(0)
+        assert np.abs(V3.astype(np.float64).sum(0) - V.astype(np.float64).sum(0)).max() <= 1e-4 * moved.max() + 1e-3
+        assert abs(float(B3.astype(np.float64).sum())) <= 1e-4 * np.abs(B3).sum() + 1e-3
+    # a quarter of an epoch still takes the regime, a smaller chunk falls back (a launch of passing bins moves the whole
+    # item table through the LDS); switching the regime off hands the shape to the other forms
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    tr.ldsbin_pass_config(False)
+    assert tr.ldsbin_stats()["bins"] == 0
+    tr.close()
+
+
 @pytest.mark.parametrize("k,use_bias,form", [(40, True, "ldsbin"), (100, True, "ldsbin"), (128, False, "ldsbin"), (200, True, "ldsbin"),
                                              (128, True, "strata"), (200, False, "strata")])
 def test_ldsbin_and_strata_forms_at_other_k(k, use_bias, form):
