@@ -655,28 +655,74 @@ def leg_dist_tax(args, _lib):
             tr.seed_hogwild(11)
             sh = ShardedBprTrainer(tr, ni, k, dev, sync_every=(nnz + spe - 1) // spe, sparse_threshold=None, rule=rule)
             sh.load_items(V, B)
+            timed = {}
             # the resident exchange (ONE launch per epoch, the exchange points inside it) where the handle takes the LDS-bin
             # form, chunk launches with the overlapped exchange between them otherwise: ShardedBprTrainer.run_epoch decides
             resident = os.environ.get("CORNAC_BENCH_DIST_CHUNKS") is None and 1 <= spe <= 32 and sh.resident_bins() > 0
-            for _ in range(2 * interval):   # warm-up with the timed region's own pattern (begin, step, finish: both buffer sets exist)
-                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
-            sh.finish()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(epochs):
-                sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
-            sh.finish()
-            torch.cuda.synchronize()
-            driven = (time.perf_counter() - t0) / epochs
+            # twice: as RCCL runs it on one rank (a process group of one launches NO kernel for an all-reduce), and with
+            # a stand-in where each all-reduce sits that streams what a ring all-reduce over 8 ranks moves through a rank
+            # (2 x 7/8 x the bucket) with 16 workgroups — the collective's memory traffic and CU share, not its link time
+            for world in (0, 8):
+                sh.table.emulate_world = world
+                for _ in range(2 * interval):   # warm-up with the timed region's own pattern (begin, step, finish: both buffer sets exist)
+                    sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
+                sh.finish()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(epochs):
+                    sh.run_epoch(nnz, spe, args.lr, args.reg, True, _lib.NEG_UNIFORM, 0, resident=resident, epochs_per_exchange=interval)
+                sh.finish()
+                torch.cuda.synchronize()
+                timed[world] = (time.perf_counter() - t0) / epochs
+            driven = timed[0]
             tr.close()
             del sh
             torch.cuda.empty_cache()
             out[shape] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven,
                           "exchanges_per_epoch": spe if interval == 1 else 1.0 / interval, "rule": rule, "epochs_timed": epochs,
                           "tax": 1.0 - plain / driven,
+                          "driver_ms_per_epoch_with_8_rank_standin": 1e3 * timed[8], "tax_with_8_rank_standin": 1.0 - plain / timed[8],
                           "protocol": "resident exchange (one launch per epoch)" if resident else "chunk launches",
                           "triplets_per_s_plain": nnz / plain, "triplets_per_s_driver": nnz / driven,
                           "workload": "%d users x %d items, %d interactions, k = %d" % (nu, ni, nnz, k)}
+        # regime 2 at the configs[4] slice: the item table as 2 N blocks on a ring (cornac_amd.dist.RingShardedBprTrainer) — on
+        # one rank 2 blocks, a handle per block, and the trained block copied to the free buffer on the communication
+        # stream beside the next step's launch (what a neighbour's receive writes on a node: table / 2 N per step)
+        if "scale" in out and os.environ.get("CORNAC_BENCH_RING", "1") != "0":
+            from cornac_amd.dist import RingShardedBprTrainer
+
+            nu, ni, indptr, indices = scale_slice(0)
+            k, epochs = SCALE["k"], 4
+            U, V, B = scale_factors(nu, ni, k, 0)
+            t0 = time.time()
+            ring = RingShardedBprTrainer(indptr, indices, nu, ni, k, dev, seed=11, emulate_traffic=True)
+            ring.set_user_factors(U)
+            ring.load_items(V, B)
+            del U, V, B
+            ring.run_epoch(args.lr, args.reg)
+            ring.finish()
+            t_setup = time.time() - t0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                ring.run_epoch(args.lr, args.reg)
+            c, s = ring.finish()
+            torch.cuda.synchronize()
+            driven = (time.perf_counter() - t0) / epochs
+            forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
+            plain = out["scale"]["plain_ms_per_epoch"] / 1e3
+            out["scale_ring"] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
+                                 "tax": 1.0 - plain / driven, "protocol": "ring conveyor of item blocks (regime 2): %d steps per "
+                                 "epoch, one launch each, %.0f MB copied per step on the communication stream"
+                                 % (ring.nb, ring.bufs[0].numel() * 4 / 1e6),
+                                 "blocks": ring.nb, "block_forms": [{"bins": f["bins"], "rows_per_bin": f["rows_per_bin"],
+                                                                     "block_threads": f["block_threads"]} for f in forms],
+                                 "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
+                                 "correct_frac": c / max(ring.nnz * epochs - s, 1), "setup_s": t_setup,
+                                 "workload": out["scale"]["workload"]}
+            ring.close()
+            del ring
+            torch.cuda.empty_cache()
         out["value"] = max(v["tax"] for v in out.values() if isinstance(v, dict))
     finally:
         close()

@@ -29,7 +29,7 @@ SYMBOLS = [
     "cornac_hip_last_error", "cornac_hip_version", "cornac_hip_device_count", "cornac_hip_device_info",
     "cornac_hip_device_probe",
     "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
-    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
+    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_rebind_items", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_set_factors_f64", "cornac_hip_bpr_get_factors_f64", "cornac_hip_bpr_fit_epochs_f64",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
@@ -46,7 +46,7 @@ SYMBOLS = [
     "cornac_hip_bpr_scatter_add_rows", "cornac_hip_bpr_table_delta_begin", "cornac_hip_bpr_table_delta_finish",
     "cornac_hip_bpr_table_delta_step", "cornac_hip_table_delta", "cornac_hip_bpr_table_delta",
     "cornac_hip_bpr_resident_exchange_bins", "cornac_hip_bpr_epoch_resident_enqueue", "cornac_hip_bpr_resident_flush",
-    "cornac_hip_stream_wait_counter", "cornac_hip_stream_set_flag",
+    "cornac_hip_stream_wait_counter", "cornac_hip_stream_set_flag", "cornac_hip_stream_ring_standin",
     "cornac_hip_vbpr_create", "cornac_hip_vbpr_destroy", "cornac_hip_vbpr_set_params", "cornac_hip_vbpr_get_params",
     "cornac_hip_vbpr_fit_batches", "cornac_hip_vbpr_item_tables",
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
@@ -137,6 +137,7 @@ def lib():
         L.cornac_hip_bpr_set_factors.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_get_factors.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_bind_device.argtypes = [_vp, _vp, _vp, _vp]
+        L.cornac_hip_bpr_rebind_items.argtypes = [_vp, _vp, _vp]
         L.cornac_hip_bpr_device_ptrs.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
         L.cornac_hip_bpr_set_stream.argtypes = [_vp, _vp]
         L.cornac_hip_bpr_switch_stream.argtypes = [_vp, _vp]
@@ -184,6 +185,7 @@ def lib():
         L.cornac_hip_bpr_resident_flush.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp]
         L.cornac_hip_stream_wait_counter.argtypes = [C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_int]
         L.cornac_hip_stream_set_flag.argtypes = [C.c_int, _vp, _vp, C.c_uint32, _vp]
+        L.cornac_hip_stream_ring_standin.argtypes = [C.c_int, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int]
         L.cornac_hip_bpr_debug_ownership.argtypes = [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp]
         L.cornac_hip_bpr_strata_config.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_chunk_records.argtypes = [_vp, C.c_int]
@@ -261,6 +263,12 @@ def check(rc):
 def stream_wait_counter(device, stream, d_counter, target, d_error, timeout_ms=5000):
     """enqueue on `stream` (a hipStream_t as int): wait until *d_counter >= target; after timeout_ms *d_error = 1"""
     check(lib().cornac_hip_stream_wait_counter(int(device), stream, d_counter, int(target), d_error, int(timeout_ms)))
+
+
+def stream_ring_standin(device, stream, d_src, src_floats, d_dst, dst_floats, n_floats, n_workgroups=16):
+    """what a ring all-reduce would move through this rank, as n_workgroups workgroups on `stream` (measurement aid)"""
+    check(lib().cornac_hip_stream_ring_standin(int(device), stream, d_src, int(src_floats), d_dst, int(dst_floats),
+                                               int(n_floats), int(n_workgroups)))
 
 
 def stream_set_flag(device, stream, d_flag, value=1, d_unless=None):
@@ -388,6 +396,10 @@ class BprTrainer:
 
     def bind_device(self, dU=None, dV=None, dB=None):
         check(lib().cornac_hip_bpr_bind_device(self.h, dU, dV, dB))
+
+    def rebind_items(self, dV, dB):
+        """swap the bound (caller-owned) item tables without synchronising the handle's stream"""
+        check(lib().cornac_hip_bpr_rebind_items(self.h, dV, dB))
 
     def device_ptrs(self):
         u, v, b = _vp(), _vp(), _vp()

@@ -896,6 +896,19 @@ int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *
     });
 }
 
+int cornac_hip_bpr_rebind_items(cornac_hip_bpr_t h, float *dV, float *dB) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(dV && dB, "NULL device pointer");
+        REQUIRE(!h->V.owned && !h->B.owned, "the item tables are the handle's own: bind caller-owned ones first "
+                "(cornac_hip_bpr_bind_device); rebind_items only swaps them");
+        // no stream synchronisation: launches already enqueued keep the pointers they were given, later ones on the
+        // handle's stream see the new ones (the ring conveyor of cornac_amd/dist.py rebinds once per step)
+        h->V.bind(dV, (size_t)h->total_items * h->k);
+        h->B.bind(dB, (size_t)h->total_items);
+    });
+}
+
 int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB) {
     return guarded([&] {
         bpr_check(h);
@@ -2211,6 +2224,19 @@ int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, u
         REQUIRE(d_flag != nullptr, "NULL device pointer");
         use_device(device);
         hipLaunchKernelGGL(stream_set_flag_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)hip_stream, d_flag, value, d_unless);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int cornac_hip_stream_ring_standin(int device, void *hip_stream, const float *d_src, int64_t src_floats, float *d_dst,
+                                   int64_t dst_floats, int64_t n_floats, int n_workgroups) {
+    return guarded([&] {
+        REQUIRE(d_src && d_dst && src_floats > 0 && dst_floats > 0, "NULL / empty buffer");
+        REQUIRE(n_floats >= 0 && n_workgroups >= 1 && n_workgroups <= 1024, "n_workgroups must be in [1, 1024]");
+        use_device(device);
+        if (n_floats == 0) return;
+        hipLaunchKernelGGL(stream_ring_standin_kernel, dim3((unsigned)n_workgroups), dim3(512), 0, (hipStream_t)hip_stream, d_src,
+                           (long long)src_floats, d_dst, (long long)dst_floats, (long long)n_floats);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -106,6 +106,12 @@ class ItemTableReplica:
         # configs[4] size a bucket is 5.3 GB — allocated once, not per exchange
         self._sets = [None, None]
         self._turn = 0
+        # measurement aid: with a process group of ONE rank RCCL launches nothing; emulate_world = N > 1 puts a stand-in
+        # where the all-reduce sits that streams the bytes a ring all-reduce over N ranks moves through a rank
+        # (2 (N - 1) / N x the bucket) with a collective's workgroup count (cornac_hip_stream_ring_standin)
+        self.emulate_world, self.standin_workgroups = 0, 16
+        self._standin = None   # (stream, scratch)
+        self._standin_event = None
 
     def _next_buffers(self):
         """(bucket [n k + 3 n], local [n k + n]) of the next exchange"""
@@ -115,6 +121,33 @@ class ItemTableReplica:
             self._sets[self._turn] = (torch.empty(n * k + 3 * n, dtype=torch.float32, device=self.flat.device),
                                       torch.empty(n * k + n, dtype=torch.float32, device=self.flat.device))
         return self._sets[self._turn]
+
+    def _emulate_collective(self, bucket, stream=None):
+        """the stand-in of one all-reduce of `bucket` (see emulate_world); on `stream` (a raw handle: the caller orders it) or
+        on a side stream ordered after the current one, whose completion finish_sync() / step_sync() wait for"""
+        if self.emulate_world <= 1 or not bucket.is_cuda:
+            return
+        from . import _lib
+
+        n = bucket.numel()
+        if self._standin is None:
+            self._standin = (torch.cuda.Stream(bucket.device), torch.empty(min(n, 1 << 26), dtype=torch.float32, device=bucket.device))
+        side, scratch = self._standin
+        moved = int(2 * (self.emulate_world - 1) * n // self.emulate_world)
+        dev = bucket.device.index or 0
+        if stream is not None:
+            _lib.stream_ring_standin(dev, stream, bucket.data_ptr(), n, scratch.data_ptr(), scratch.numel(), moved, self.standin_workgroups)
+            return
+        side.wait_stream(torch.cuda.current_stream(bucket.device))
+        _lib.stream_ring_standin(dev, side.cuda_stream, bucket.data_ptr(), n, scratch.data_ptr(), scratch.numel(), moved,
+                                 self.standin_workgroups)
+        self._standin_event = torch.cuda.Event()
+        self._standin_event.record(side)
+
+    def _await_emulated(self):
+        if self._standin_event is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(self._standin_event)
+            self._standin_event = None
 
     def _factors(self, S, w):
         """per-row factor the summed delta S [m, width] is multiplied with; w = the all-reduced per-row weights"""
@@ -174,6 +207,7 @@ class ItemTableReplica:
             return
         self.exchanges["dense"] += 1
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._emulate_collective(bucket)
         self._pending = (work, bucket, local)
 
     # ---- sparse form: records (row id, [delta V row | delta bias]) of the touched rows, all_gather'ed ----------------
@@ -295,12 +329,14 @@ class ItemTableReplica:
         work, bucket_prev, local_prev = self._pending
         self._pending = None
         work.wait()
+        self._await_emulated()
         n, k = self.total_items, self.k
         bucket, local = self._next_buffers()
         self.trainer.table_delta_step(self.flat.data_ptr(), self.base.data_ptr(), bucket_prev.data_ptr(),
                                       local_prev.data_ptr(), n, k, bucket.data_ptr(), local.data_ptr(), rule=RULES[self.rule])
         self.exchanges["dense"] += 1
         work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._emulate_collective(bucket)
         self._pending = (work, bucket, local)
 
     def finish_sync(self):
@@ -315,6 +351,7 @@ class ItemTableReplica:
             self._finish_sparse(bucket, local)
             return
         work.wait()  # stream-level wait on CUDA, blocking on gloo
+        self._await_emulated()
         n, k = self.total_items, self.k
         if self.trainer is not None and self.flat.is_cuda:
             self.trainer.table_delta_finish(self.flat.data_ptr(), self.base.data_ptr(), bucket.data_ptr(),
@@ -448,6 +485,7 @@ class ShardedBprTrainer:
                 _lib.stream_wait_counter(dev_index, comm.cuda_stream, p_arrive + 4 * e, arrivals, p_err, self.resident_timeout_ms)
                 if collective:
                     dist.all_reduce(st["buckets"][e], op=dist.ReduceOp.SUM, group=t.group, async_op=True).wait()
+                t._emulate_collective(st["buckets"][e], stream=comm.cuda_stream)
                 if self.resident_bucket_hook is not None:
                     self.resident_bucket_hook(e, st["buckets"][e])
                 # a wait that gave up (p_err set) leaves this and every later flag of the epoch down: a bucket that was
@@ -1008,6 +1046,285 @@ class RowShardedBprTrainer:
         return out
 
 
+# ---- regime 2 as a ring conveyor of item blocks --------------------------------------------------------------------------
+def split_csr_by_item_block(indptr, indices, n_blocks):
+    """the CSR of a user slice cut by item block (item i -> block i % n_blocks, block-local id i // n_blocks): a list of
+    (indptr_b [n_users + 1] int32, indices_b int32) with the rows still sorted"""
+    indptr = np.asarray(indptr, np.int64)
+    indices = np.asarray(indices, np.int64)
+    n_users = len(indptr) - 1
+    blk = (indices % n_blocks).astype(np.int32)
+    order = np.argsort(blk, kind="stable")                     # block-major, CSR order kept inside a block
+    users = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(indptr))[order]
+    local = (indices[order] // n_blocks).astype(np.int32)
+    cuts = np.searchsorted(blk[order], np.arange(n_blocks + 1))
+    out = []
+    for b in range(n_blocks):
+        a, e = int(cuts[b]), int(cuts[b + 1])
+        ip = np.zeros(n_users + 1, np.int64)
+        np.cumsum(np.bincount(users[a:e], minlength=n_users), out=ip[1:])
+        out.append((ip.astype(np.int32), np.ascontiguousarray(local[a:e])))
+    return out
+
+
+class _DeviceBlockTrainer:
+    """one item block's cornac_hip BPR handle: the rank's interactions with the block's items in block-local ids, the user
+    table shared with the other blocks' handles, the item tables rebound to wherever the block's buffer is"""
+
+    def __init__(self, indptr, indices, n_users, n_rows, k, U, stream, device_index):
+        from . import _lib
+
+        self.nnz = len(indices)
+        self.tr = _lib.BprTrainer(indptr, indices, n_users, n_rows, n_users, n_rows, k, device=device_index)
+        self._bound = False
+        self.U, self.stream = U, stream
+
+    def seed_hogwild(self, seed):
+        self.tr.seed_hogwild(seed)
+
+    def bind_items(self, V, B):
+        if not self._bound:   # first time: also hands the handle the shared user table and the driver's stream (synchronises)
+            self.tr.bind_device(self.U.data_ptr(), V.data_ptr(), B.data_ptr())
+            self.tr.set_stream(self.stream.cuda_stream)
+            self._bound = True
+        else:
+            self.tr.rebind_items(V.data_ptr(), B.data_ptr())
+
+    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
+        self.tr.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
+
+    def sync(self):
+        return self.tr.sync()
+
+    def close(self):
+        self.tr.close()
+
+
+class _OnceWork:
+    """a point-to-point work handle that is waited for at most once (gloo's send / receive works block for ever on a second
+    wait: they wait for the NEXT completion of their buffer)"""
+
+    def __init__(self, work):
+        self.work, self.done = work, False
+
+    def wait(self):
+        if not self.done:
+            self.work.wait()
+            self.done = True
+
+
+class RingShardedBprTrainer:
+    """Multi-GPU BPR with the item table SHARDED BY ROW and never replicated (SURVEY.md 8e regime 2; BASELINE configs[4]:
+    "item table row-sharded across 8 x MI355X via RCCL / xGMI"), as DSGD's block rotation (Gemulla et al. 2011) laid on
+    the xGMI ring instead of round 2's all-to-all of the touched rows:
+
+      * users are partitioned over the N ranks (their rows of U never move); the items are cut into 2 N blocks
+        (item i -> block i % 2N); every rank holds 2-3 blocks at any time;
+      * an epoch is 2 N steps.  In step t rank r trains block (2 r + t) % 2N: the draws of ITS users' interactions with the
+        block's items (sum over the steps = its nnz draws per epoch; the negative comes from the same block — and, inside
+        the handle, from the positive's LDS bin: the block is an ordinary single-GPU problem, so it runs in whatever form
+        cornac_hip picks for its shape, passing bins at the configs[4] size);
+      * a block trained in step t travels to rank r - 1 during step t + 1 and is trained there in step t + 2: every block
+        is in exactly ONE place — in training or in flight — so there is no staleness, no reconciliation rule and no lost
+        update (the replicas of regime 1 trade those for fewer bytes), and each step's transfer (table / 2N per rank:
+        322 MB at configs[4], one xGMI hop) hides behind the next step's launch;
+      * after an epoch's last step every rank holds blocks 2 r and 2 r + 1 again; gather() assembles the table.
+
+    The draws of a step on different ranks touch disjoint user rows AND disjoint item rows, so the parallel run equals
+    the serial execution of the same steps in any order (tests/test_dist_cpu.py runs both).  The reference has no
+    counterpart (one process; the update it distributes is recom_bpr.pyx:252-265).
+
+    trainer_factory(block, indptr_b, indices_b, n_users, n_rows, k, U): host stand-ins (gloo tests) with
+    bind_items(V, B) / seed_hogwild / hogwild_enqueue / sync / close.  emulate_traffic (one rank only): the block that
+    would travel is copied to the free buffer on the communication stream, so a one-GPU run carries the conveyor's
+    memory traffic and dependency chain."""
+
+    def __init__(self, indptr, indices, n_users, n_items, k, device, group=None, trainer_factory=None, seed=0,
+                 emulate_traffic=False):
+        self.device, self.group, self.k = device, group, int(k)
+        self.world, self.rank = _world(group)
+        self.nb = 2 * self.world
+        self.n_items, self.n_users = int(n_items), int(n_users)
+        if self.n_items < self.nb:
+            raise ValueError("%d items cannot be cut into %d blocks" % (self.n_items, self.nb))
+        self.rows_max = (self.n_items + self.nb - 1) // self.nb
+        self.rows = [(self.n_items - b + self.nb - 1) // self.nb for b in range(self.nb)]
+        cuda = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device) if cuda else None
+        self.comm = torch.cuda.Stream(device) if cuda else None
+        self.emulate_traffic = bool(emulate_traffic) and self.world == 1
+        width = self.rows_max * (self.k + 1)
+        self.bufs = [torch.zeros(width, dtype=torch.float32, device=device) for _ in range(3)]
+        self.U = torch.zeros((self.n_users, self.k), dtype=torch.float32, device=device)
+        self.where = {2 * self.rank: 0, 2 * self.rank + 1: 1}      # block -> buffer
+        self.arrived = [None, None, None]                            # per buffer: event / works of the receive that fills it
+        self.t = 0
+        self.steps_trained = []                                      # (epoch step, block): inspection / tests
+        self.trainers = []
+        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, self.nb)):
+            if len(ix) == 0:
+                self.trainers.append(None)
+                continue
+            if trainer_factory is not None:
+                tr = trainer_factory(b, ip, ix, self.n_users, self.rows[b], self.k, self.U)
+            else:
+                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[b], self.k, self.U, self.stream, device.index or 0)
+            tr.nnz = len(ix)
+            tr.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
+            self.trainers.append(tr)
+        self.nnz = int(sum(tr.nnz for tr in self.trainers if tr is not None))
+
+    def _views(self, buf, b):
+        """(V [rows_b, k], B [rows_b]) of block b in buffer `buf`"""
+        flat = self.bufs[buf]
+        return flat[: self.rows[b] * self.k].view(self.rows[b], self.k), flat[self.rows_max * self.k: self.rows_max * self.k + self.rows[b]]
+
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def load_items(self, V, B):
+        """this rank's two starting blocks of the full host tables"""
+        V, B = np.asarray(V, np.float32), np.asarray(B, np.float32)
+        with self._on(self.stream):
+            for slot, b in enumerate((2 * self.rank, 2 * self.rank + 1)):
+                v, bias = self._views(slot, b)
+                v.copy_(torch.as_tensor(np.ascontiguousarray(V[b:: self.nb])))
+                bias.copy_(torch.as_tensor(np.ascontiguousarray(B[b:: self.nb])))
+        self.where = {2 * self.rank: 0, 2 * self.rank + 1: 1}
+        self.arrived = [None, None, None]
+        self.t = 0
+        if self.stream is not None:
+            self.stream.synchronize()
+
+    def set_user_factors(self, U):
+        self.U.copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(U, np.float32))))
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def get_user_factors(self):
+        if self.stream is not None:
+            self.stream.synchronize()
+        return self.U.cpu().numpy()
+
+    def step(self, lr, reg, use_bias=True, neg_population=0, flags=0):
+        """one step of the conveyor: train the block whose turn it is, then hand the trained block to rank - 1 and take
+        the one rank + 1 has just trained (both beside the NEXT step's launch)"""
+        b = (2 * self.rank + self.t) % self.nb
+        buf = self.where[b]
+        with self._on(self.stream):
+            got = self.arrived[buf]
+            if got is not None:                       # the receive that brought the block here
+                if self.stream is not None:
+                    self.stream.wait_event(got)
+                else:
+                    for w in got:
+                        w.wait()
+                self.arrived[buf] = None
+            tr = self.trainers[b]
+            if tr is not None:
+                tr.bind_items(*self._views(buf, b))
+                tr.hogwild_enqueue(tr.nnz, lr, reg, use_bias, neg_population, flags)
+            self.steps_trained.append((self.t % self.nb, b))
+            trained = None
+            if self.stream is not None:
+                trained = torch.cuda.Event()
+                trained.record(self.stream)
+        free = ({0, 1, 2} - set(self.where.values())).pop()
+        nxt = (b + 2) % self.nb                       # what rank + 1 trained in this step
+        if self.world > 1:
+            with self._on(self.comm):
+                if self.comm is not None:
+                    self.comm.wait_event(trained)
+                ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.world))
+                dst, src = ranks[(self.rank - 1) % self.world], ranks[(self.rank + 1) % self.world]
+                if self.comm is None:                 # gloo: the previous phase's send still owns the buffer this receive fills
+                    for w in getattr(self, "_sent", []):
+                        w.wait()
+                ops = [dist.P2POp(dist.isend, self.bufs[buf], dst, self.group), dist.P2POp(dist.irecv, self.bufs[free], src, self.group)]
+                works = [_OnceWork(w) for w in dist.batch_isend_irecv(ops)]
+                if self.comm is not None:
+                    for w in works:
+                        w.wait()                      # (stream-level on RCCL: the communication stream waits, the host does not)
+                    ev = torch.cuda.Event()
+                    ev.record(self.comm)
+                    self.arrived[free] = ev
+                else:
+                    self.arrived[free] = works        # gloo: waited for before the block is trained (or gathered)
+                    self._sent = list(works)
+            del self.where[b]
+            self.where[nxt] = free
+        elif self.emulate_traffic:
+            with self._on(self.comm):
+                if self.comm is not None:
+                    self.comm.wait_event(trained)
+                self.bufs[free].copy_(self.bufs[buf])
+                if self.comm is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(self.comm)
+                    self.arrived[free] = ev
+            del self.where[b]
+            self.where[nxt] = free                    # (2 blocks on one rank: block b itself, two steps later)
+        self.t += 1
+
+    def run_epoch(self, lr, reg, use_bias=True, neg_population=0, flags=0):
+        for _ in range(self.nb):
+            self.step(lr, reg, use_bias, neg_population, flags)
+
+    def _drain(self):
+        for buf in range(3):
+            got = self.arrived[buf]
+            if got is None:
+                continue
+            if self.stream is not None:
+                self.stream.wait_event(got)
+            else:
+                for w in got:
+                    w.wait()
+            self.arrived[buf] = None
+        for w in getattr(self, "_sent", []):
+            w.wait()
+        self._sent = []
+        if self.stream is not None:
+            self.stream.synchronize()
+            self.comm.synchronize()
+
+    def finish(self):
+        """(correct, skipped) of this rank since the last finish(); every transfer has landed"""
+        self._drain()
+        c = s = 0
+        for tr in self.trainers:
+            if tr is not None:
+                dc, ds = tr.sync()
+                c, s = c + dc, s + ds
+        return c, s
+
+    def gather(self):
+        """the full (V, B) host tables on every rank; at an epoch boundary (every rank holds its blocks 2 r, 2 r + 1)"""
+        if self.t % self.nb:
+            raise RuntimeError("gather() in the middle of an epoch (step %d of %d)" % (self.t % self.nb, self.nb))
+        self._drain()
+        mine = torch.stack([self.bufs[self.where[2 * self.rank]], self.bufs[self.where[2 * self.rank + 1]]])
+        if self.world > 1:
+            comm_dev = _comm_device(self.device, self.group)
+            full = torch.empty((self.nb,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm_dev)
+            dist.all_gather_into_tensor(full, mine.to(comm_dev).contiguous(), group=self.group)
+        else:
+            full = mine
+        full = full.cpu().numpy()
+        V = np.empty((self.n_items, self.k), np.float32)
+        B = np.empty(self.n_items, np.float32)
+        for b in range(self.nb):
+            V[b:: self.nb] = full[b, : self.rows[b] * self.k].reshape(self.rows[b], self.k)
+            B[b:: self.nb] = full[b, self.rows_max * self.k: self.rows_max * self.k + self.rows[b]]
+        return V, B
+
+    def close(self):
+        for tr in self.trainers:
+            if tr is not None:
+                tr.close()
+        self.trainers = []
+
+
 # ---- model-level entry points: model.fit(train_set) over all ranks of a process group ----------------------------------
 def _world(group):
     if dist.is_available() and dist.is_initialized():
@@ -1127,6 +1444,59 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
         V, B = sh.table.V.cpu().numpy(), sh.table.B.cpu().numpy()
     finally:
         trainer.close()
+    model.u_factors[: bounds[-1]] = _gather_user_rows(U_local, bounds, device, group)
+    model.i_factors[...] = V
+    model.i_biases[...] = B
+    c, s = _sum_over_ranks([correct, skipped], device, group)
+    model.fit_stats = [(int(c), int(s))]
+    model._drop_scorer()
+    return model
+
+
+def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None, local_popularity=False):
+    """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group with the item table sharded
+    by row and rotating around the ring (regime 2, RingShardedBprTrainer): the same calling convention and restrictions as
+    fit_bpr_sharded, no replica and no reconciliation rule — every item row is in one place at any time, so the result
+    is the serial execution of the ranks' steps.  The memory an item table needs per rank is 3 / (2 N) of it.
+    WBPR's negatives follow the popularity of the rank's OWN users inside the block being trained (local_popularity=True to
+    accept that over more than one rank)."""
+    from . import _lib
+    from .recommender import Recommender
+
+    if model.effective_mode != "hogwild":
+        raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
+    world, rank = _world(group)
+    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+        raise ValueError("WBPR's popularity-weighted negatives would follow each rank's own users, not the global item "
+                         "popularity of recom_wbpr.pyx:135: pass local_popularity=True to accept that")
+    device = device if device is not None else torch.device("cpu")
+    Recommender.fit(model, train_set)
+    model._init()
+    if model.trains_float64:
+        raise ValueError("float64 tables train on the sequential engine only")
+    _broadcast_from_rank0([model.u_factors, model.i_factors, model.i_biases], device, group)
+    X = train_set.matrix
+    if not X.has_sorted_indices:
+        X.sort_indices()
+    bounds = partition_users_by_nnz(X.indptr, world)
+    counts = [int(X.indptr[bounds[r + 1]] - X.indptr[bounds[r]]) for r in range(world)]
+    if min(counts) == 0:
+        raise ValueError("a rank would receive no interactions (%r): use fewer ranks" % (counts,))
+    u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
+    indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
+    lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
+    ring = RingShardedBprTrainer(indptr, indices, u1 - u0, model.total_items, model.k, device, group=group,
+                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo)
+    try:
+        ring.set_user_factors(model.u_factors[u0:u1])
+        ring.load_items(model.i_factors, model.i_biases)
+        for _ in range(model.max_iter):
+            ring.run_epoch(model.learning_rate, model.lambda_reg, model.use_bias, model._neg_population)
+        correct, skipped = ring.finish()
+        U_local = ring.get_user_factors()
+        V, B = ring.gather()
+    finally:
+        ring.close()
     model.u_factors[: bounds[-1]] = _gather_user_rows(U_local, bounds, device, group)
     model.i_factors[...] = V
     model.i_biases[...] = B

@@ -94,6 +94,10 @@ int cornac_hip_bpr_fit_epochs_f64(cornac_hip_bpr_t h, int n_epochs, double lr, d
 /* Use caller-owned device buffers (same shapes) instead of the library's. */
 int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *dB);
 int cornac_hip_bpr_device_ptrs(cornac_hip_bpr_t h, float **dU, float **dV, float **dB);
+/* Swap caller-owned item tables for other caller-owned ones WITHOUT synchronising the handle's stream (bind_device waits
+ * for it): work already enqueued keeps its pointers, later work sees the new ones.  For drivers that move the item
+ * table between launches — the ring conveyor of cornac_amd/dist.py binds the block that has just arrived. */
+int cornac_hip_bpr_rebind_items(cornac_hip_bpr_t h, float *dV, float *dB);
 /* run the handle's work on a caller-provided hipStream_t (NULL = the handle's own); waits for the previous stream */
 int cornac_hip_bpr_set_stream(cornac_hip_bpr_t h, void *hip_stream);
 /* the same without waiting for the work already queued on the previous stream: for callers that alternate between two
@@ -307,6 +311,13 @@ int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule,
 int cornac_hip_stream_wait_counter(int device, void *hip_stream, const uint32_t *d_counter, uint32_t target,
                                    uint32_t *d_error, int timeout_ms);
 int cornac_hip_stream_set_flag(int device, void *hip_stream, uint32_t *d_flag, uint32_t value, const uint32_t *d_unless);
+/* Measurement aid (no reference counterpart): what a ring all-reduce costs THIS rank's memory system and CUs when the
+ * process group has a single member and RCCL therefore launches nothing — n_workgroups workgroups of 512 threads stream
+ * n_floats floats from d_src (read cyclically over src_floats) to d_dst (written cyclically over dst_floats) on
+ * hip_stream.  cornac_amd/dist.py puts it where the collective sits when asked to emulate a world of N ranks
+ * (n_floats = 2 (N - 1) / N x the bucket). */
+int cornac_hip_stream_ring_standin(int device, void *hip_stream, const float *d_src, int64_t src_floats, float *d_dst,
+                                   int64_t dst_floats, int64_t n_floats, int n_workgroups);
 
 /* ------------------------------------------------------------------------- *
  * VEBPR (view-enhanced BPR) on the same handle.

@@ -377,18 +377,38 @@ def test_strata_packed_item_records_round_trip_and_stay_coherent(k):
     assert acc[2] > acc[0] > 0.45, acc
 
 
+def _planted_interactions(n_users, n_items, n_clusters, per_user, own_share, zipf, seed):
+    """users in n_clusters taste clusters, item i in cluster i % n_clusters; a user's items come from the own cluster with
+    probability own_share and from everywhere otherwise, Zipf(zipf) popularity (by item id) in both cases — personal
+    structure on top of popularity, so a most-popular list is a poor recommender.  Unique pairs sorted by (user, item)."""
+    rs = np.random.RandomState(seed)
+    m = n_users * per_user
+    u = np.repeat(np.arange(n_users, dtype=np.int64), per_user)
+    per_c = n_items // n_clusters
+    p_in = 1.0 / np.arange(1, per_c + 1) ** zipf
+    p_all = 1.0 / np.arange(1, n_items + 1) ** zipf
+    inside = rs.random_sample(m) < own_share
+    r_in = np.searchsorted(np.cumsum(p_in / p_in.sum()), rs.random_sample(m)).clip(0, per_c - 1)
+    r_all = np.searchsorted(np.cumsum(p_all / p_all.sum()), rs.random_sample(m)).clip(0, n_items - 1)
+    items = np.where(inside, r_in * n_clusters + (u % n_clusters), r_all)
+    keys = np.unique(u * n_items + items)
+    return keys // n_items, keys % n_items
+
+
 def test_ldsbin_ranking_metrics_match_the_global_negative_draw(capsys):
-    """Advisor r3: judge the binned negatives by a RANKING metric, not only by the pairwise loss.  One held-out positive
-    per user; BPR trained from the same start tables for the same epochs by (a) the LDS-bin form — negatives from the
-    positive's bin, bins re-dealt every epoch from permuted popularity strata — and (b) the fused kernel, whose negatives
-    are uniform over ALL items like the reference's (recom_bpr.pyx:235-238); Recall@20 / NDCG@20 of the held-out item with
-    the training positives excluded (the evaluation protocol, on the device top-k kernel).  The data is popularity-driven
-    (Zipf items), so the metric is decided by the order among the popular items — exactly the comparisons the round-3
-    deal could not make."""
+    """Judge the binned negatives by a RANKING metric on data where ranking is more than popularity (verdict r4: on pure
+    Zipf data both arms sat AT the most-popular baseline and the A/B could not fail).  Users in 40 taste clusters, each
+    preferring its own items on top of a Zipf popularity; one held-out positive per user; BPR trained from the same start
+    tables for the same epochs by (a) the LDS-bin form — negatives from the positive's bin, bins re-dealt every epoch —,
+    (b) the fused kernel, whose negatives are uniform over ALL items like the reference's (recom_bpr.pyx:235-238), and
+    (c) the REAL reference's compiled `BPR._fit_sgd` with threads (oracle/_ref; skipped where that is not built).
+    Recall@20 / NDCG@20 of the held-out item with the training positives excluded, on the device top-k kernel.
+    Every arm must beat the most-popular baseline by >= 30 %, and the LDS-bin arm must be within 3 % (+ sampling error)
+    of the global-draw arm and of the reference's."""
     from cornac_amd import synth
 
-    n_users, n_items, k = 8000, 12800, 64
-    users, items = synth.zipf_interactions(n_users, n_items, 800_000, 0.9, 17)
+    n_users, n_items, k, epochs = 8000, 12800, 64, 25
+    users, items = _planted_interactions(n_users, n_items, 40, 110, 0.75, 0.9, 17)
     rs = np.random.RandomState(3)
     # hold out one interaction of every user with at least 5
     order = np.lexsort((rs.random_sample(len(users)), users))
@@ -401,10 +421,20 @@ def test_ldsbin_ranking_metrics_match_the_global_negative_draw(capsys):
     o2 = np.lexsort((items[keep], users[keep]))
     tr_u, tr_i = users[keep][o2], items[keep][o2]
     indptr, indices = synth.csr_from_sorted(tr_u, tr_i, n_users)
+    nnz = len(indices)
     U0 = ((rs.random_sample((n_users, k)) - 0.5) / k).astype(np.float32)
     V0 = ((rs.random_sample((n_items, k)) - 0.5) / k).astype(np.float32)
     excl = (np.concatenate([[0], np.cumsum(np.diff(indptr)[tu])]).astype(np.int64),          # the listed users' training
             np.concatenate([indices[indptr[u]:indptr[u + 1]] for u in tu]).astype(np.int32))  # positives, CSR per listed user
+
+    def metrics(U, V, B):
+        sc = _lib.Scorer(U, V, B, None)
+        top, _ = sc.rank_topk(tu.astype(np.int32), 20, exclude=excl)
+        sc.close()
+        hit = top == ti[:, None].astype(np.int32)
+        rank = np.where(hit.any(1), hit.argmax(1), -1)
+        return float((rank >= 0).mean()), float(np.where(rank >= 0, 1.0 / np.log2(np.maximum(rank, 0) + 2.0), 0.0).mean())
+
     out = {}
     for name, flags in (("ldsbin", _lib.FORM_AUTO), ("fused", _lib.FORM_FUSED)):
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
@@ -412,28 +442,41 @@ def test_ldsbin_ranking_metrics_match_the_global_negative_draw(capsys):
             assert tr.ldsbin_stats()["bins"] == 256
         tr.set_factors(U0, V0, np.zeros(n_items, np.float32))
         tr.seed_hogwild(99)
-        tr.fit_epochs(25, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
-        U, V, B = tr.get_factors()
+        tr.fit_epochs(epochs, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD, flags=flags)
+        out[name] = metrics(*tr.get_factors())
         tr.close()
-        sc = _lib.Scorer(U, V, B, None)
-        top, _ = sc.rank_topk(tu.astype(np.int32), 20, exclude=excl)
-        sc.close()
-        hit = top == ti[:, None].astype(np.int32)
-        rank = np.where(hit.any(1), hit.argmax(1), -1)
-        recall = float((rank >= 0).mean())
-        ndcg = float(np.where(rank >= 0, 1.0 / np.log2(rank + 2.0), 0.0).mean())
-        out[name] = (recall, ndcg)
-    pop = np.argsort(-np.bincount(indices, minlength=n_items), kind="stable")[:40]
+    try:   # the reference's own threads on the same data and start tables
+        from oracle import ref_loader
+
+        RNGVector, RefBPR = ref_loader.load_kernel_only()
+        Ur, Vr, Br = U0.copy(), V0.copy(), np.zeros(n_items, np.float32)
+        user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+        model = RefBPR(k=k, learning_rate=0.05, lambda_reg=0.01)
+        for e in range(epochs):
+            model._fit_sgd(RNGVector(16, nnz - 1, 1000 + e), RNGVector(16, n_items - 1, 2000 + e), 16, user_ids,
+                           np.ascontiguousarray(indices, np.int32), np.arange(n_items, dtype=np.int32),
+                           np.ascontiguousarray(indptr, np.int32), Ur, Vr, Br)
+        out["reference"] = metrics(Ur, Vr, Br)
+    except Exception as e:  # oracle/_ref not built on this box
+        out["reference"] = None
+        why = repr(e)
+    pop = np.argsort(-np.bincount(indices, minlength=n_items), kind="stable")[:400]
     pop_recall = float(np.mean([ti[t] in set(pop[~np.isin(pop, indices[indptr[u]:indptr[u + 1]])][:20].tolist())
                                 for t, u in enumerate(tu)]))
     with capsys.disabled():
-        print("\nheld-out Recall@20 / NDCG@20 over %d users: LDS-bin negatives %.4f / %.4f, global negatives (fused kernel) "
-              "%.4f / %.4f; most-popular baseline Recall@20 %.4f" % ((len(tu),) + out["ldsbin"] + out["fused"] + (pop_recall,)))
+        print("\nplanted-cluster data, held-out Recall@20 / NDCG@20 over %d users: LDS-bin negatives %.4f / %.4f, global negatives "
+              "(fused kernel) %.4f / %.4f, the reference's 16 threads %s; most-popular baseline Recall@20 %.4f"
+              % ((len(tu),) + out["ldsbin"] + out["fused"] + (("%.4f / %.4f" % out["reference"]) if out["reference"] else "n/a (%s)" % why,
+                 pop_recall)))
     (ra, na), (rb, nb) = out["ldsbin"], out["fused"]
     se = np.sqrt(max(rb, 1e-3) * (1 - rb) / len(tu))
-    assert rb > 0.5 * pop_recall and ra > 0.5 * pop_recall, (out, pop_recall)   # both really rank
-    assert abs(ra - rb) <= 4 * se + 0.05 * rb, (out, se)
-    assert abs(na - nb) <= 4 * se + 0.05 * nb, (out, se)
+    assert rb >= 1.3 * pop_recall and ra >= 1.3 * pop_recall, (out, pop_recall)   # personalisation is there to be learnt
+    assert abs(ra - rb) <= 3 * se + 0.03 * rb, (out, se)
+    assert abs(na - nb) <= 3 * se + 0.03 * nb, (out, se)
+    if out["reference"]:
+        rr, nr = out["reference"]
+        assert rr >= 1.3 * pop_recall, (out, pop_recall)
+        assert abs(ra - rr) <= 3 * se + 0.03 * rr and abs(na - nr) <= 3 * se + 0.03 * nr, (out, se)
 
 
 def _ldsbin_case(n_users=6000, n_items=3003, nnz=700_000, zipf=0.8, seed=3):

@@ -945,3 +945,221 @@ def test_multi_epoch_exchange_interval_world2():
     assert ex0["dense"] == 3, ex0
     assert np.array_equal(base0, base1) and np.allclose(V0, V1, rtol=0, atol=1e-6)
     assert acc0 > 0.75 and acc1 > 0.75, (acc0, acc1)
+
+
+# ---- regime 2 as a ring conveyor of item blocks (RingShardedBprTrainer) ---------------------------------------------------
+class _RingMarkTrainer:
+    """adds a rank-dependent constant to the block it is bound to: the conveyor's bookkeeping made visible"""
+
+    def __init__(self, rank, block, log):
+        self.rank, self.block, self.log, self.n = rank, block, log, 0
+
+    def seed_hogwild(self, seed):
+        pass
+
+    def bind_items(self, V, B):
+        self.V, self.B = V, B
+
+    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
+        self.V += float(self.rank + 1)
+        self.B += 10.0 * (self.rank + 1)
+        self.n += n
+        self.log.append(self.block)
+
+    def sync(self):
+        return (self.n, 0)
+
+    def close(self):
+        pass
+
+
+class _RingOracleTrainer:
+    """real BPR arithmetic on one item block: the oracle's sequential epoch over the rank's interactions with the block's
+    items (block-local ids), in place on the shared user table and on wherever the block's buffer currently is"""
+
+    def __init__(self, indptr, indices, n_rows, k, U):
+        import ctypes as C
+
+        from oracle import oracle as orc
+
+        self.C, self.orc = C, orc
+        self.indptr, self.indices = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
+        self.user_ids = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr)).astype(np.int32)
+        self.neg_ids = np.arange(n_rows, dtype=np.int32)
+        self.U, self.k, self.n_rows, self.correct, self.skipped = U.numpy(), k, n_rows, 0, 0
+
+    def seed_hogwild(self, seed):
+        self.gp, self.gn = self.orc.MT19937(seed % (2 ** 31)), self.orc.MT19937((seed >> 32) % (2 ** 31) + 1)
+
+    def bind_items(self, V, B):
+        self.V, self.B = V.numpy(), B.numpy()
+        assert self.V.flags.c_contiguous and self.V.shape == (self.n_rows, self.k)
+
+    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
+        c, s = self.C.c_int64(), self.C.c_int64()
+        rc = self.orc.lib().oracle_bpr_epoch_seq(self.gp.ptr, self.gn.ptr, len(self.user_ids) - 1, self.n_rows - 1, int(n),
+                                                 self.user_ids, self.indices, self.neg_ids, self.indptr, self.U, self.V, self.B,
+                                                 self.k, lr, reg, int(use_bias), self.C.byref(c), self.C.byref(s), None, None, None)
+        assert rc == 0
+        self.correct, self.skipped = self.correct + c.value, self.skipped + s.value
+
+    def sync(self):
+        out, self.correct, self.skipped = (self.correct, self.skipped), 0, 0
+        return out
+
+    def close(self):
+        pass
+
+
+def _ring_data(rank, n_users=120, n_items=50, per_user=14):
+    rs = np.random.RandomState(300 + rank)
+    p = 1.0 / np.arange(1, n_items + 1) ** 0.8
+    rows = [np.sort(rs.choice(n_items, per_user, replace=False, p=p / p.sum())) for _ in range(n_users)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return indptr, np.concatenate(rows).astype(np.int32)
+
+
+def _ring_tables(n_users, n_items, k, rank):
+    rs = np.random.RandomState(7)
+    V0 = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
+    B0 = rs.normal(0, 0.01, n_items).astype(np.float32)
+    U0 = ((np.random.RandomState(70 + rank).uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    return U0, V0, B0
+
+
+def _ring_worker(rank, world, port, out, kind, epochs):
+    from cornac_amd.dist import RingShardedBprTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_items, k = 50, 6
+        indptr, indices = _ring_data(rank)
+        log = []
+        if kind == "mark":
+            factory = lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log)
+        else:
+            factory = lambda b, ip, ix, nu, rows, k_, U: _RingOracleTrainer(ip, ix, rows, k_, U)
+        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), trainer_factory=factory, seed=5)
+        U0, V0, B0 = _ring_tables(len(indptr) - 1, n_items, k, rank)
+        ring.load_items(V0, B0)
+        ring.set_user_factors(U0)
+        for _ in range(epochs):
+            ring.run_epoch(0.05, 0.01)
+        c, s = ring.finish()
+        V, B = ring.gather()
+        out[rank] = (V, B, ring.get_user_factors(), list(ring.steps_trained), log, c, s, ring.nnz)
+        ring.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ring_conveyor_world2_every_rank_trains_every_block_once_per_epoch():
+    """the bookkeeping of RingShardedBprTrainer over two gloo ranks: 4 blocks, an epoch = 4 steps, rank r trains block
+    (2 r + t) % 4 in step t — every (rank, block) pair exactly once per epoch, a block never in two places — and after the
+    epochs every rank gathers the same table: every row moved by (1 + 2) per epoch"""
+    out = mp.Manager().dict()
+    mp.spawn(_ring_worker, args=(2, _free_port(), out, "mark", 3), nprocs=2, join=True)
+    _, V0, B0 = _ring_tables(120, 50, 6, 0)
+    for rank in (0, 1):
+        V, B, U, steps, log, c, s, nnz = out[rank]
+        assert steps == [(t % 4, (2 * rank + t) % 4) for t in range(12)]
+        assert log == [(2 * rank + t) % 4 for t in range(12)] and c == 3 * nnz
+        assert np.allclose(V, V0 + 3 * 3.0) and np.allclose(B, B0 + 3 * 30.0)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_ring_conveyor_world2_equals_its_serial_execution():
+    """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
+    disjoint item blocks, so two gloo ranks must produce bit for bit what ONE process gets by running the same (step,
+    rank) pairs one after the other — item table, biases and both ranks' user rows; and the model learns"""
+    from cornac_amd.dist import split_csr_by_item_block
+
+    epochs, n_items, k, world = 3, 50, 6, 2
+    out = mp.Manager().dict()
+    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs), nprocs=world, join=True)
+    # the serial execution
+    nb = 2 * world
+    _, V, B = _ring_tables(120, n_items, k, 0)
+    V, B = V.copy(), B.copy()
+    blocks = [(np.ascontiguousarray(V[b::nb]), np.ascontiguousarray(B[b::nb])) for b in range(nb)]
+    Us, trainers, nnz = [], [], []
+    for rank in range(world):
+        indptr, indices = _ring_data(rank)
+        U = torch.as_tensor(_ring_tables(len(indptr) - 1, n_items, k, rank)[0].copy())
+        Us.append(U)
+        row = []
+        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, nb)):
+            tr = _RingOracleTrainer(ip, ix, len(blocks[b][1]), k, U)
+            tr.nnz = len(ix)
+            tr.seed_hogwild((5 * 0x9E3779B97F4A7C15 + 7919 * rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
+            row.append(tr)
+        trainers.append(row)
+        nnz.append(len(indices))
+    for t in range(epochs * nb):
+        for rank in range(world):
+            b = (2 * rank + t) % nb
+            tr = trainers[rank][b]
+            tr.bind_items(torch.as_tensor(blocks[b][0]), torch.as_tensor(blocks[b][1]))
+            tr.hogwild_enqueue(tr.nnz, 0.05, 0.01, True, 0, 0)
+    for b in range(nb):
+        V[b::nb], B[b::nb] = blocks[b]
+    for rank in range(world):
+        Vr, Br, Ur, steps, _, c, s, n = out[rank]
+        assert n == nnz[rank] and 0 < c and c + s <= epochs * n
+        assert np.array_equal(Vr, V) and np.array_equal(Br, B), "rank %d: the conveyor's table differs from the serial execution" % rank
+        assert np.array_equal(Ur, Us[rank].numpy())
+        indptr, indices = _ring_data(rank)
+        assert _pairwise_accuracy(Ur, Vr, Br, indptr, indices, n_items) > 0.62
+
+
+def test_split_csr_by_item_block_is_a_partition():
+    from cornac_amd.dist import split_csr_by_item_block
+
+    indptr, indices = _ring_data(3, n_users=40, n_items=37, per_user=9)
+    parts = split_csr_by_item_block(indptr, indices, 4)
+    seen = []
+    for b, (ip, ix) in enumerate(parts):
+        assert ip[0] == 0 and ip[-1] == len(ix) and (np.diff(ip) >= 0).all()
+        for u in range(40):
+            row = ix[ip[u]:ip[u + 1]]
+            assert (np.diff(row) > 0).all()
+            seen += [(u, int(j) * 4 + b) for j in row]
+    want = [(u, int(i)) for u in range(40) for i in indices[indptr[u]:indptr[u + 1]]]
+    assert sorted(seen) == sorted(want)
+
+
+def _fit_ring_worker(rank, world, port, out):
+    import cornac_amd as ca
+    from cornac_amd.dist import fit_bpr_ring
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = ca.Dataset.from_uir(_model_data(), seed=3)
+        bpr = ca.BPR(k=6, max_iter=8, learning_rate=0.05, lambda_reg=0.01, seed=rank, mode="hogwild")
+        fit_bpr_ring(bpr, ds, trainer_factory=lambda b, ip, ix, nu, rows, k, U: _RingOracleTrainer(ip, ix, rows, k, U))
+        out[rank] = dict(U=bpr.u_factors.copy(), V=bpr.i_factors.copy(), B=bpr.i_biases.copy(), stats=bpr.fit_stats)
+        with pytest.raises(ValueError):
+            fit_bpr_ring(ca.BPR(k=4, seed=1), ds)   # seeded => sequential semantics do not shard
+        with pytest.raises(ValueError):
+            fit_bpr_ring(ca.WBPR(k=4, mode="hogwild"), ds)   # global popularity over > 1 rank has to be waived explicitly
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_level_ring_fit_returns_one_complete_model_on_every_rank():
+    """fit_bpr_ring on two gloo ranks (item blocks rotating, real arithmetic behind the block trainers): both ranks return
+    the SAME complete model, bit for bit — there is no replica to reconcile —, started from rank 0's tables, and it ranks
+    the training positives above random negatives"""
+    import cornac_amd as ca
+
+    out = mp.Manager().dict()
+    mp.spawn(_fit_ring_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    for name in ("U", "V", "B"):
+        assert np.array_equal(a[name], b[name]), name
+    assert a["stats"] == b["stats"] and a["stats"][0][0] > 0
+    ds = ca.Dataset.from_uir(_model_data(), seed=3)
+    X = ds.matrix
+    assert _pairwise_accuracy(a["U"], a["V"], a["B"], X.indptr, X.indices, ds.num_items) > 0.7

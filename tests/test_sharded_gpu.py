@@ -762,3 +762,55 @@ def test_resident_exchange_trains_like_the_plain_launch_through_rccl():
             assert cos > 0.97 and abs(np.linalg.norm(dg) / np.linalg.norm(dr) - 1.0) < 0.02, cos
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("emulate", [False, True])
+def test_ring_conveyor_single_rank_on_the_device(emulate):
+    """RingShardedBprTrainer (multi-GPU regime 2 as a ring of item blocks) on ONE rank with the real handles: 2 blocks, a
+    handle per block sharing the user table, the item tables rebound per step (cornac_hip_bpr_rebind_items); with
+    emulate_traffic the trained block is copied to the free buffer on the communication stream, as a neighbour's
+    receive would.  (1) lr = 0 returns every table bit for bit and draws nnz samples per epoch; (2) training moves both
+    blocks, stays finite, and learns like the plain single-handle fit of the same data (the negatives come from the
+    positive's half of the items instead of all of them)."""
+    import torch
+
+    from cornac_amd import synth
+    from cornac_amd.dist import RingShardedBprTrainer
+
+    n_users, n_items, k = 30000, 4001, 64
+    users, items = synth.zipf_interactions(n_users, n_items, 1_200_000, 0.7, 4)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    nnz = len(indices)
+    rs = np.random.RandomState(0)
+    U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
+    B = rs.normal(0, 0.01, n_items).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=3, emulate_traffic=emulate)
+    assert ring.nb == 2 and ring.nnz == nnz and ring.rows == [2001, 2000]
+    ring.set_user_factors(U)
+    ring.load_items(V, B)
+    ring.run_epoch(0.0, 0.0)
+    c, s = ring.finish()
+    V1, B1 = ring.gather()
+    assert 0 < s < 0.2 * nnz and c + s <= nnz
+    assert np.array_equal(V1, V) and np.array_equal(B1, B) and np.array_equal(ring.get_user_factors(), U)
+    for _ in range(5):
+        ring.run_epoch(0.05, 0.01)
+    ring.finish()
+    ring.run_epoch(0.05, 0.01)
+    c, s = ring.finish()
+    acc_ring = c / (nnz - s)
+    V2, B2 = ring.gather()
+    U2 = ring.get_user_factors()
+    assert ring.steps_trained[:4] == [(0, 0), (1, 1), (0, 0), (1, 1)]
+    ring.close()
+    assert np.isfinite(V2).all() and np.isfinite(U2).all()
+    assert np.abs(V2[0::2] - V[0::2]).max() > 1e-3 and np.abs(V2[1::2] - V[1::2]).max() > 1e-3 and np.abs(U2 - U).max() > 1e-3
+    tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+    tr.set_factors(U, V, B)
+    tr.seed_hogwild(3)
+    tr.fit_epochs(5, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    c, s = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    tr.close()
+    assert abs(acc_ring - c / (nnz - s)) < 0.02, (acc_ring, c / (nnz - s))
