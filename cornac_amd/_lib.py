@@ -29,7 +29,7 @@ SYMBOLS = [
     "cornac_hip_last_error", "cornac_hip_version", "cornac_hip_device_count", "cornac_hip_device_info",
     "cornac_hip_device_probe",
     "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
-    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_rebind_items", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
+    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_rebind_items", "cornac_hip_bpr_set_negative_population", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_set_factors_f64", "cornac_hip_bpr_get_factors_f64", "cornac_hip_bpr_fit_epochs_f64",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
@@ -138,6 +138,7 @@ def lib():
         L.cornac_hip_bpr_get_factors.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_bind_device.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_rebind_items.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_bpr_set_negative_population.argtypes = [_vp, _vp, C.c_int64]
         L.cornac_hip_bpr_device_ptrs.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
         L.cornac_hip_bpr_set_stream.argtypes = [_vp, _vp]
         L.cornac_hip_bpr_switch_stream.argtypes = [_vp, _vp]
@@ -396,6 +397,12 @@ class BprTrainer:
 
     def bind_device(self, dU=None, dV=None, dB=None):
         check(lib().cornac_hip_bpr_bind_device(self.h, dU, dV, dB))
+
+    def set_negative_population(self, items):
+        """population of the popularity-weighted negative draw (WBPR): a multiset of train item ids, e.g. the GLOBAL item
+        popularity when this handle holds a user slice; None / empty = the handle's own interactions (recom_wbpr.pyx:135)"""
+        items = np.ascontiguousarray(items if items is not None else [], np.int32)
+        check(lib().cornac_hip_bpr_set_negative_population(self.h, items.ctypes.data if len(items) else None, len(items)))
 
     def rebind_items(self, dV, dB):
         """swap the bound (caller-owned) item tables without synchronising the handle's stream"""

@@ -152,6 +152,8 @@ __global__ __launch_bounds__(kBlock) void bpr_det_bucket_kernel(const int32_t *_
 // ------------------------------------------------------------------------------------------------
 struct HogArgs {
     const int32_t *user_ids, *indices, *indptr;
+    const int32_t *neg_items;  // population of the popularity-weighted negative draw: `indices` (recom_wbpr.pyx:135), or the
+                               // caller's (cornac_hip_bpr_set_negative_population: the GLOBAL popularity over a rank's slice)
     float *U, *V, *B;
     unsigned long long *counters;
     int64_t n;        // samples in this launch
@@ -194,7 +196,7 @@ __device__ __forceinline__ bool hog_sample(const HogArgs &a, int64_t local, int3
     const uint32_t jj = lemire_bounded2(w[2], w[3], a.n_neg, a.th_neg);
     u = a.user_ids[ii];
     i = a.indices[ii];
-    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
+    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.neg_items[jj] : (int32_t)jj;
     const bool skip = HOG_ABLATE(a, 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
 }
@@ -212,7 +214,7 @@ __device__ __forceinline__ bool hog_sample_owned(const HogArgs &a, uint32_t wave
     u_enc = a.own_u[base + r];
     i = a.own_i[base + r];
     const int32_t u = u_enc < 0 ? ~u_enc : u_enc;
-    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.indices[jj] : (int32_t)jj;
+    j = a.neg_population == CORNAC_HIP_NEG_POPULARITY ? a.neg_items[jj] : (int32_t)jj;
     if (share_neg) j = __shfl(j, lane_id() & ~3, kWave);  // every lane draws; groups of 4 keep their leader's
     const bool skip = HOG_ABLATE(a, 1) ? false : csr_row_contains(a.indices, a.indptr[u], a.indptr[u + 1], j);
     return in_range && !skip;
@@ -670,6 +672,8 @@ struct cornac_hip_bpr {
     int k = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<int32_t> indptr, indices, user_ids;
+    DevBuf<int32_t> neg_pop;   // caller's negative population (cornac_hip_bpr_set_negative_population), empty: `indices`
+    int64_t neg_pop_n = 0;
     DevBuf<float> U, V, B;
     bool vebpr_owned = false;  // the last VEBPR hogwild epoch ran with user-row ownership
     bool f64 = false;  // float64 tables (set_factors_f64): deterministic mode only, like the reference's fused-type loop
@@ -893,6 +897,23 @@ int cornac_hip_bpr_bind_device(cornac_hip_bpr_t h, float *dU, float *dV, float *
         if (dU) h->U.bind(dU, (size_t)h->total_users * h->k);
         if (dV) h->V.bind(dV, (size_t)h->total_items * h->k);
         if (dB) h->B.bind(dB, (size_t)h->total_items);
+    });
+}
+
+int cornac_hip_bpr_set_negative_population(cornac_hip_bpr_t h, const int32_t *items, int64_t n) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(n >= 0 && n < (int64_t(1) << 32), "population size out of range");
+        REQUIRE(n == 0 || items != nullptr, "items is NULL");
+        for (int64_t t = 0; t < n; ++t)
+            REQUIRE(items[t] >= 0 && items[t] < h->n_items, "population entry %lld = %d is not a train item", (long long)t, items[t]);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->neg_pop_n = n;
+        if (n) {
+            h->neg_pop.ensure((size_t)n);
+            h->neg_pop.upload(items, (size_t)n, h->stream);
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
     });
 }
 
@@ -1398,7 +1419,8 @@ static void fill_hog_args(cornac_hip_bpr_t h, HogArgs &a, int64_t n, float lr, f
     a.seed = h->hog_seed;
     a.epoch = h->hog_epoch;
     a.n_pos = (uint32_t)h->nnz;
-    a.n_neg = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint32_t)h->nnz : (uint32_t)h->n_items;
+    a.neg_items = h->neg_pop_n ? h->neg_pop.p : h->indices.p;
+    a.n_neg = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint32_t)(h->neg_pop_n ? h->neg_pop_n : h->nnz) : (uint32_t)h->n_items;
     a.th_pos = lemire_thresh(a.n_pos);
     a.th_neg = lemire_thresh(a.n_neg);
     a.k = h->k; a.neg_population = neg_population; a.use_bias = use_bias;
@@ -1798,7 +1820,9 @@ static bool hogwild_uses_ldsbin(cornac_hip_bpr_t h, int64_t n_samples, int neg_p
     flags &= ~0xff00;
 #endif
     if (!(form == 0 || form == 3) || (flags & 0xffff) != 0) return false;
-    (void)neg_population;  // uniform (BPR) and popularity-weighted (WBPR) negatives both have a binned form
+    // uniform (BPR) and popularity-weighted (WBPR) negatives both have a binned form — the latter weights by the handle's
+    // OWN interactions; a caller-supplied population (the global popularity of a multi-GPU fit) takes the fused kernel
+    if (neg_population == CORNAC_HIP_NEG_POPULARITY && h->neg_pop_n) return false;
     // any chunk of an epoch: a launch takes its share of every bin's draws — but a launch of passing bins moves the whole
     // item table through the LDS, so only launches of at least a quarter of an epoch take that regime
     const LbPlan pl = ldsbin_plan(h);

@@ -1369,6 +1369,21 @@ def _sum_over_ranks(values, device, group):
     return [float(x) for x in t.cpu()]
 
 
+def global_negative_population(indices_local, n_items, device=None, group=None, at_most=1 << 26):
+    """WBPR's negative population over all ranks (recom_wbpr.pyx:135: neg_item_ids = X.indices of the WHOLE matrix): the
+    ranks all-reduce their item degrees — n_items counts, 107 KB at the ML-20M shape — and every rank builds the same
+    multiset, item i repeated degree(i) times (scaled to at most `at_most` entries, every interacted item at least once)"""
+    deg = torch.as_tensor(np.bincount(np.asarray(indices_local, np.int64), minlength=int(n_items)).astype(np.int64))
+    if _world(group)[0] > 1:
+        deg = deg.to(_comm_device(device, group))
+        dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
+    deg = deg.cpu().numpy()
+    total = int(deg.sum())
+    if total > at_most:
+        deg = np.where(deg > 0, np.maximum(1, np.rint(deg * (float(at_most) / total)).astype(np.int64)), 0)
+    return np.repeat(np.arange(int(n_items), dtype=np.int32), deg)
+
+
 def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
                     trainer_factory=None, local_popularity=False, rule=None):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
@@ -1379,9 +1394,11 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     hogwild mode (`mode="hogwild"`, or no seed) — a seed then fixes the initial tables and the sample streams.
     sync_per_epoch = None: exchange_schedule() of the largest rank's interaction count (the same on every rank): how many
     exchanges per epoch — or, for sparse item sides, every how many epochs — and the reconciliation rule (rule = None).
-    WBPR draws its negatives from the rank's OWN interactions (recom_wbpr.pyx:135 reads X.indices: popularity-weighted) —
-    the popularity of the rank's users, not of all users; that approximation has to be asked for (local_popularity=True),
-    otherwise a WBPR model over more than one rank is refused.
+    WBPR draws its negative as the item of a uniformly chosen interaction (recom_wbpr.pyx:135 reads X.indices: popularity-
+    weighted).  Over several ranks the population is the GLOBAL one: the ranks all-reduce their item degrees (n_items
+    counts) and every handle is given a population with those multiplicities (global_negative_population,
+    cornac_hip_bpr_set_negative_population; the draw then runs in the fused kernel).  local_popularity=True keeps each
+    rank's own interactions as its population (the LDS-bin form's binned draw; the popularity of the rank's users only).
     trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo)."""
     from . import _lib
     from .recommender import Recommender
@@ -1389,9 +1406,6 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     if model.effective_mode != "hogwild":
         raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
     world, rank = _world(group)
-    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
-        raise ValueError("WBPR's popularity-weighted negatives would follow each rank's own users, not the global item "
-                         "popularity of recom_wbpr.pyx:135: pass local_popularity=True to accept that")
     device = device if device is not None else torch.device("cpu")
     Recommender.fit(model, train_set)
     model._init()
@@ -1408,6 +1422,9 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
     n_local, nnz = u1 - u0, counts[rank]
+    population = None
+    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+        population = global_negative_population(indices, train_set.num_items, device, group)
     interval = 1
     if sync_per_epoch is None:
         sync_per_epoch, interval, scheduled_rule = exchange_schedule(max(counts), model.total_items)
@@ -1429,6 +1446,8 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
                                                model.k)
     try:
         trainer.set_factors(model.u_factors[u0:u1], None, None)
+        if population is not None:
+            trainer.set_negative_population(population)
         lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
         trainer.seed_hogwild((((hi << 32) | lo) + 7919 * rank) & 0xFFFFFFFFFFFFFFFF)
         sh.load_items(model.i_factors, model.i_biases)

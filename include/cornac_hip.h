@@ -115,6 +115,13 @@ int cornac_hip_bpr_seed_mt19937(cornac_hip_bpr_t h, uint32_t mt_seed_pos, uint32
  * the epoch counter persists across calls. */
 int cornac_hip_bpr_seed_hogwild(cornac_hip_bpr_t h, uint64_t seed);
 
+/* Popularity-weighted negatives (CORNAC_HIP_NEG_POPULARITY) draw the item of a uniformly chosen entry of `neg_item_ids`
+ * (recom_wbpr.pyx:135-139: neg_item_ids = X.indices, the handle's own interactions by default).  A handle that holds only
+ * a SLICE of the users (multi-GPU) can be given the population of the whole matrix instead: items[n], any multiset of
+ * train item ids whose multiplicities are (proportional to) the global item degrees; n = 0 restores the default.  With a
+ * caller's population the popularity draw runs in the fused kernel (the LDS-bin form weights by the handle's own CSC). */
+int cornac_hip_bpr_set_negative_population(cornac_hip_bpr_t h, const int32_t *items, int64_t n);
+
 /* Run n_epochs epochs of nnz samples each.  correct/skipped accumulate the
  * reference's per-epoch counters over the epochs run (either may be NULL).
  * hogwild_flags (0 = default).  Bits 16..19 select the form of a hogwild call:

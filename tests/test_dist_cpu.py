@@ -1163,3 +1163,31 @@ def test_model_level_ring_fit_returns_one_complete_model_on_every_rank():
     ds = ca.Dataset.from_uir(_model_data(), seed=3)
     X = ds.matrix
     assert _pairwise_accuracy(a["U"], a["V"], a["B"], X.indptr, X.indices, ds.num_items) > 0.7
+
+
+def _pop_worker(rank, world, port, out):
+    from cornac_amd.dist import global_negative_population
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, indices, n_items = _popularity_data(rank)
+        out[rank] = (global_negative_population(indices, n_items), global_negative_population(indices, n_items, at_most=500))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_negative_population_world2():
+    """WBPR over ranks (recom_wbpr.pyx:135): every rank builds the population of the WHOLE matrix from the all-reduced item
+    degrees — the same multiset on both ranks, item i exactly degree(i) times; scaled down it keeps the proportions and
+    every interacted item"""
+    out = mp.Manager().dict()
+    mp.spawn(_pop_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    deg = sum(np.bincount(_popularity_data(r)[1], minlength=90) for r in (0, 1))
+    for r in (0, 1):
+        full, small = out[r]
+        assert np.array_equal(np.bincount(full, minlength=90), deg)
+        hs = np.bincount(small, minlength=90)
+        assert len(small) <= 600 and ((hs > 0) == (deg > 0)).all()
+        assert np.abs(hs / hs.sum() - deg / deg.sum()).max() < 0.01
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

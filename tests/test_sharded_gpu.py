@@ -814,3 +814,147 @@ def test_ring_conveyor_single_rank_on_the_device(emulate):
     c, s = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
     tr.close()
     assert abs(acc_ring - c / (nnz - s)) < 0.02, (acc_ring, c / (nnz - s))
+
+
+def _planted_slice(rank, n_users, n_items, degree, n_clusters):
+    """a rank's user slice at the configs[4] density pattern (a handful of items per user, Zipf-free) with structure to
+    learn: user u prefers the items of its taste cluster (item i in cluster i % n_clusters) for 4 of its 5 items"""
+    rs = np.random.RandomState(500 + rank)
+    c = rs.randint(0, n_clusters, size=n_users)
+    own = rs.randint(0, n_items // n_clusters, size=(n_users, degree)) * n_clusters + c[:, None]
+    anyi = rs.randint(0, n_items, size=(n_users, degree))
+    items = np.where(np.arange(degree)[None, :] < degree - 1, own, anyi)
+    items.sort(axis=1)
+    keep = np.ones_like(items, bool)
+    keep[:, 1:] = items[:, 1:] != items[:, :-1]
+    indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+    return indptr, items[keep].astype(np.int32)
+
+
+def test_exchange_schedule_holds_on_eight_virtual_ranks_at_the_slice_density(capsys):
+    """cornac_amd.dist.exchange_schedule trades exchanges for staleness on sparse item sides ("align", one exchange every few
+    epochs at the configs[4] density).  Round 4 backed that with a CPU toy; here R = 8 virtual ranks run ON THE DEVICE —
+    each its own user slice (6.25 draws per item row and epoch, the slice's density) and its own handle, trained one after
+    the other from the shared base table, reconciled with ItemTableReplica's algebra at the interval the schedule returns —
+    next to ONE process that trains all eight slices' users together for the same epochs.  Gate: the consolidated table's
+    pairwise accuracy on rank 0's probe triplets is at most 1.5 points below the single process's."""
+    from cornac_amd.dist import exchange_schedule
+
+    R, n_items, k, epochs, lr, reg = 8, 48_000, 32, 8, 0.05, 0.01
+    n_users, degree = 60_000, 5
+    slices = [_planted_slice(r, n_users, n_items, degree, 60) for r in range(R)]
+    nnz_r = max(len(ix) for _, ix in slices)
+    per_epoch, interval, rule = exchange_schedule(nnz_r, n_items)
+    assert per_epoch == 1 and interval >= 2 and rule == "align", (per_epoch, interval, rule)
+    rs = np.random.RandomState(0)
+    V0 = ((rs.uniform(0, 1, (n_items, k)) - .5) / k).astype(np.float32)
+    U0 = [((np.random.RandomState(10 + r).uniform(0, 1, (n_users, k)) - .5) / k).astype(np.float32) for r in range(R)]
+    prs = np.random.RandomState(99)
+    ip0, ix0 = slices[0]
+    pp = prs.randint(0, len(ix0), 100_000)
+    probe_u = np.repeat(np.arange(n_users), np.diff(ip0))[pp]
+    probe_i, probe_j = ix0[pp], prs.randint(0, n_items, len(pp))
+
+    def accuracy(U, V, B):
+        sc = np.einsum("nk,nk->n", U[probe_u], V[probe_i] - V[probe_j]) + B[probe_i] - B[probe_j]
+        return float((sc > 0).mean())
+
+    # one process on all the data
+    ip_all = np.concatenate([[0]] + [ip[1:].astype(np.int64) + sum(len(s[1]) for s in slices[:r]) for r, (ip, _) in enumerate(slices)]).astype(np.int32)
+    ix_all = np.concatenate([ix for _, ix in slices])
+    tr = _lib.BprTrainer(ip_all, ix_all, R * n_users, n_items, R * n_users, n_items, k)
+    tr.set_factors(np.concatenate(U0), V0, np.zeros(n_items, np.float32))
+    tr.seed_hogwild(5)
+    tr.fit_epochs(epochs, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    U1, V1, B1 = tr.get_factors()
+    tr.close()
+    acc_one = accuracy(U1[:n_users], V1, B1)
+
+    def virtual(every):
+        trainers = []
+        for r, (ip, ix) in enumerate(slices):
+            t = _lib.BprTrainer(ip, ix, n_users, n_items, n_users, n_items, k)
+            t.set_factors(U0[r], V0, np.zeros(n_items, np.float32))
+            t.seed_hogwild(1000 + r)
+            trainers.append(t)
+        V, B = V0.copy(), np.zeros(n_items, np.float32)
+        for e0 in range(0, epochs, every):
+            dV, dB = np.zeros_like(V), np.zeros_like(B)
+            qV, qB = np.zeros(n_items, np.float64), np.zeros(n_items, np.float64)
+            for t in trainers:
+                t.set_factors(None, V, B)
+                t.fit_epochs(min(every, epochs - e0), lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+                Vr, Br = t.get_item_factors()
+                dV += Vr - V; dB += Br - B
+                qV += ((Vr - V).astype(np.float64) ** 2).sum(1); qB += (Br - B).astype(np.float64) ** 2
+            nV, nB = (dV.astype(np.float64) ** 2).sum(1), dB.astype(np.float64) ** 2   # rule "align" (ItemTableReplica._factors)
+            dV *= np.where(nV > 0, np.minimum(1.0, qV / np.maximum(nV, 1e-300)), 1.0).astype(np.float32)[:, None]
+            dB *= np.where(nB > 0, np.minimum(1.0, qB / np.maximum(nB, 1e-300)), 1.0).astype(np.float32)
+            V, B = V + dV, B + dB
+        Ur = trainers[0].get_user_factors()
+        for t in trainers:
+            t.close()
+        return accuracy(Ur, V, B)
+
+    acc = {every: virtual(every) for every in sorted({1, 2, interval})}
+    with capsys.disabled():
+        print("\n8 virtual ranks at the configs[4] density (%d items, %d draws per rank and epoch, %d epochs), consolidated pairwise "
+              "accuracy on rank 0's probe: one process on all data %.4f; 'align' with one exchange every %s epochs: %s; "
+              "exchange_schedule -> every %d epochs" % (n_items, nnz_r, epochs, acc_one, sorted(acc), ["%.4f" % acc[e] for e in sorted(acc)], interval))
+    assert acc_one > 0.70, acc_one
+    assert acc[interval] >= acc_one - 0.015, (acc, acc_one)
+
+
+def test_negative_population_of_the_whole_matrix_on_a_user_slice():
+    """WBPR over several ranks (recom_wbpr.pyx:135: the negative is the item of a uniformly drawn interaction of the WHOLE
+    matrix): a handle that holds a user slice is given the global population (cornac_hip_bpr_set_negative_population);
+    the sampled negatives then follow the GLOBAL item degrees, not the slice's — and a WBPR epoch still trains (fused
+    kernel: the LDS-bin form's binned popularity draw weights by the handle's own interactions)."""
+    import torch
+
+    from cornac_amd import synth
+    from cornac_amd.dist import global_negative_population
+
+    n_users, n_items, k = 6000, 3003, 32
+    users, items = synth.zipf_interactions(n_users, n_items, 600_000, 0.9, 5)
+    indptr, indices = synth.csr_from_sorted(users, items, n_users)
+    # the slice: the first 1500 users, whose own interactions are made UNLIKE the global ones: only even items
+    m = (users < 1500) & (items % 2 == 0)
+    ip, ix = synth.csr_from_sorted(users[m], items[m], 1500)
+    pop = global_negative_population(indices, n_items)             # (one process: the whole matrix's degrees)
+    assert len(pop) == len(indices) and np.array_equal(np.bincount(pop, minlength=n_items), np.bincount(indices, minlength=n_items))
+    tr = _lib.BprTrainer(ip, ix, 1500, n_items, 1500, n_items, k)
+    tr.seed_hogwild(21)
+    dev = torch.device("cuda", 0)
+    n = 400_000
+    u, i, j = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+
+    def neg_hist():
+        torch.cuda.synchronize()
+        tr.sample_triplets(n, u.data_ptr(), i.data_ptr(), j.data_ptr(), _lib.NEG_POPULARITY)
+        tr.sync()
+        jj = j.cpu().numpy()
+        return np.bincount(jj[jj >= 0], minlength=n_items).astype(np.float64)
+
+    own = neg_hist()
+    assert own[1::2].sum() == 0, "by default the population is the handle's own interactions (even items only here)"
+    tr.set_negative_population(pop)
+    glob = neg_hist()
+    assert glob[1::2].sum() > 0.3 * glob.sum()
+    want = np.bincount(indices, minlength=n_items).astype(np.float64)
+    top = np.argsort(-want)[:200]
+    # accepted negatives ~ global degree x P(not a positive of the drawn user): compare the popular head up to that factor
+    ratio = (glob[top] / glob.sum()) / (want[top] / want.sum())
+    assert 0.5 < np.median(ratio) < 1.2 and np.corrcoef(glob[top], want[top])[0, 1] > 0.95, (np.median(ratio),)
+    rs = np.random.RandomState(0)
+    U = ((rs.uniform(0, 1, (1500, k)) - .5) / k).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items, k)) - .5) / k).astype(np.float32)
+    tr.set_factors(U, V, np.zeros(n_items, np.float32))
+    c1, s1 = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD)
+    c2, s2 = tr.fit_epochs(3, 0.05, 0.01, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD)
+    U2, V2, _ = tr.get_factors()
+    assert np.isfinite(V2).all() and np.abs(V2[1::2] - V[1::2]).max() > 1e-4, "odd items are negatives only through the global population"
+    assert c2 / (3 * len(ix) - s2) > c1 / (len(ix) - s1) - 0.01
+    tr.set_negative_population(None)
+    assert neg_hist()[1::2].sum() == 0
+    tr.close()
