@@ -336,8 +336,10 @@ def leg_mf_netflix(args, _lib):
                                "hottest_item_row_share": z["top"], "form": "block rotation" if z["rotation"] else "fused atomic kernel",
                                "frac": z["achieved"] / HBM_PEAK_GBS, "frac_of_step": nnz * b / (z["dt"] / z["epochs"]) / 1e9 / HBM_PEAK_GBS,
                                "mse_per_epoch": [float(x) / nnz for x in z["loss"]],
-                               "note": "the same shape with SURVEY 8d's Zipf exponent: one item row holds 2.8 % of the ratings "
-                                       "and lives in an LDS bin under a lock (csrc/mf_blocks.inc)"}
+                               "note": "the same shape with SURVEY 8d's Zipf exponent: one item row holds 3.2 % of the ratings; rows "
+                                       "above 0.1 % are split into virtual rows (one per 0.1 %), trained like any hot row and merged "
+                                       "after every phase with the align rule (csrc/mf_blocks.inc; round 4 kept such a row in one LDS "
+                                       "bin under its lock: 679 ms per epoch)"}
         except Exception as e:
             out["zipf_0.8"] = {"error": repr(e)}
     return out
@@ -513,6 +515,15 @@ def leg_bpr_k128_scale(args, _lib):
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
            "train_stats": {"correct_frac": c / max(nnz * epochs - sk, 1), "skipped_frac": skip},
            "host_s": {"generate": t_gen, "create_and_first_epoch": t_setup}}
+    if passing:
+        # what bounds the passing-bin kernel: the item rows cross the memory system once per epoch (LDS), every processed
+        # triplet still issues the k / 16 fp32 atomic requests (64 B granules) of its user row
+        req = nnz * (1 - skip) * (k / 16.0) / (dt / epochs) / 1e9
+        out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules) of the user rows",
+                                      "requests_per_triplet": k / 16.0, "achieved_G_per_s": req, "probe_ceiling_G_per_s": 20.0,
+                                      "frac_of_probe_ceiling": req / 20.0,
+                                      "evidence": "profiles/r05_scale_pmc.csv, profiles/r05_exp_scale_passing.log (ablations: no "
+                                                  "updates 19.8 ms, user rows by racy read-modify-write instead of atomics 32.0 vs 33.8)"}
     # this leg's rate differs by up to 25 % between GPU boxes (11.5 GB of randomly accessed tables); the line carries a
     # calibration of the box it ran on — copy, streaming read and random 512-byte gather rates over 6 GiB buffers — and
     # the partition modes rocm-smi reports, so that a slow run can be told from a slow box
@@ -742,6 +753,62 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
+    """`--config scale` over a process group: configs[4] as the ring conveyor of item blocks (cornac_amd.dist.
+    RingShardedBprTrainer — every rank its own 12.5 M users, the 10 M x k item table cut into 2 N blocks that rotate; a step
+    = one epoch = 2 N launches per rank, each beside the previous block's transfer).  Same JSON contract; the roofline block
+    is the whole step's algorithmic bytes over its wall time (there is one handle per block: no single kernel's events)."""
+    from cornac_amd.dist import RingShardedBprTrainer
+
+    n_users, n_items, indptr, indices = scale_slice(rank)
+    nnz = len(indices)
+    U, V, B = scale_factors(n_users, n_items, k, rank)
+    t0 = time.time()
+    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=0xC0FFEE, emulate_traffic=(world == 1))
+    ring.set_user_factors(U)
+    ring.load_items(V, B)
+    del U, V, B
+    t_setup = time.time() - t0
+    for _ in range(args.warmup):
+        ring.run_epoch(args.lr, args.reg)
+    ring.finish()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ring.run_epoch(args.lr, args.reg)
+    correct, skipped = ring.finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
+    if rank == 0:
+        b_full, b_skip = algorithmic_bytes_per_triplet(k, nnz / n_users)
+        skip = skipped / float(nnz * args.steps)
+        gbs = nnz * ((1 - skip) * b_full + skip * b_skip) * args.steps / elapsed / 1e9   # rank 0's share of the job
+        out = {"metric": "bpr_triplets_per_sec", "value": float(nnz) * args.steps * world / elapsed, "unit": "triplets/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BPR k=%d on one GPU's user slice per rank of the 100 M x 10 M synthetic (%d users x %d items, "
+                                      "%d interactions per GPU), hogwild mode, fp32 tables resident in HBM"
+                                      % (k, n_users, n_items, nnz), "k": k, "lr": args.lr, "reg": args.reg,
+                          "form": "ldsbin (passing bins) per item block" if forms and forms[0]["bins"] else "per item block: automatic",
+                          "parallelism": "user-partitioned dp%d, item table sharded by row into %d blocks on a ring (regime 2, "
+                                         "RingShardedBprTrainer): a step = %d launches per rank, each beside the transfer of the "
+                                         "previously trained block (%.0f MB) to the next rank%s"
+                                         % (world, ring.nb, ring.nb, ring.bufs[0].numel() * 4 / 1e6,
+                                            " — one rank: the block is copied on the communication stream instead" if world == 1 else "")},
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": "bpr_ldsbin_kernel<2,4> per item block (whole step: bytes / wall time)",
+                            "algorithmic_bytes_per_triplet": b_full},
+               "train_stats": {"correct_frac": correct / max(nnz * args.steps - skipped, 1.0), "skipped_frac": skip},
+               "host_s": {"setup": t_setup}, "cpu_baseline": None}
+        print(json.dumps(out))
+    ring.close()
+    dist.destroy_process_group()
+
+
 def dry_run(args):
     """The launcher / rendezvous / timing / JSON scaffolding with a stand-in step and the gloo backend: what the CPU
     test of `--gpus N` exercises (tests/test_bench_launcher_cpu.py).  No HIP code runs."""
@@ -822,6 +889,9 @@ def main():
                          "even where the resident exchange (one launch per epoch) is available")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
+    ap.add_argument("--replicated-items", action="store_true",
+                    help="--config scale over N > 1 ranks: regime 1 (replicated item table, delta all-reduce at exchange_schedule's "
+                         "interval) instead of the default for that shape, regime 2 as a ring conveyor of item blocks")
     ap.add_argument("--legs", default="mf_netflix,wmf_netflix,vbpr_tradesy,bpr_k128_scale,dist_tax",
                     help="extra single-GPU legs reported under `legs` at N = 1 (comma list; empty = none)")
     ap.add_argument("--no-legs", action="store_true")
@@ -863,6 +933,8 @@ def main():
 
     scale = args.config == "scale"
     k = args.k or (SCALE["k"] if scale else 64)
+    if scale and distributed and not args.replicated_items and not args.sharded_items:
+        return main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier)
     if scale:
         n_users, n_items, indptr, indices = scale_slice(rank)
         args.no_rank = args.no_legs = True  # the scoring leg and the other legs belong to the headline configuration
@@ -988,6 +1060,7 @@ def main():
         avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else None
         kernel_name = ("sample/apply kernels of the row-sharded path (no fused SGD kernel)" if args.sharded_items else
+                       "bpr_ldsbin_kernel<2,4> (passing bins)" if form == "ldsbin" and trainer_stats["ldsbin"]["block_threads"] == 512 and 64 < k <= 128 else
                        "bpr_ldsbin_kernel<%d,%d>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]) if form == "ldsbin" else
                        "bpr_strata_kernel<%d,%d>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]) if form == "strata" else
                        "bpr_hogwild_rowwise_kernel<64,%d,%d,atomic,owned>" % ((k + 63) // 64, {1: 4, 2: 2, 3: 2, 4: 1}[(k + 63) // 64]))
@@ -1027,7 +1100,7 @@ def main():
             out["roofline"]["limiter"] = {"what": "memory-side fp32 atomic requests (64 B granules) of the user rows and the hot item rows",
                                           "requests_per_triplet": req_per, "achieved_G_per_s": req, "probe_ceiling_G_per_s": 20.0,
                                           "frac_of_probe_ceiling": req / 20.0, "bins": lb["bins"], "rows_per_bin": lb["rows_per_bin"],
-                                          "hot_items": lb["n_hot"], "evidence": "profiles/r03_sgd_pmc.csv, profiles/r01_pmc_calibration.txt"}
+                                          "hot_items": lb["n_hot"], "evidence": "profiles/r05_sgd_pmc.csv (TCC_ATOMIC / TCC_EA0_ATOMIC per launch), profiles/r01_pmc_calibration.txt (the probe ceiling)"}
         elif achieved and form == "fused" and k == 64:
             # every processed triplet issues 10.04 64-byte fp32 atomic requests (TCC_ATOMIC counters, profiles/r02_sgd_pmc.csv:
             # all forwarded to the memory side); the chip retires ~20 G such requests/s in tools/atomic_probe.hip

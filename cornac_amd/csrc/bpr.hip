@@ -1781,14 +1781,18 @@ static LbPlan ldsbin_plan(cornac_hip_bpr_t h) {
     LbPlan pl;
     const int cus = device_info(h->device).cus;
     if (h->k > 256 || h->nnz < (int64_t)cus * kLbWaves * kWave) return pl;
-    for (int rounds = 1; rounds <= h->lb_max_rounds; ++rounds) {
+    // (profile builds: CORNAC_HIP_LDSBIN_MIN_ROUNDS / _RES_WAVES / _EXCL_KB vary the resident regime's bin count, the waves of a
+    // bin's workgroup and the LDS floor that keeps a CU to one workgroup — the experiments of DESIGN.md 7)
+    const int res_waves = prof_env_int("CORNAC_HIP_LDSBIN_RES_WAVES", kLbWaves);
+    for (int rounds = prof_env_int("CORNAC_HIP_LDSBIN_MIN_ROUNDS", 1); rounds <= h->lb_max_rounds; ++rounds) {
         const int64_t bins = (int64_t)cus * rounds;
         const int64_t cap = (h->n_items + bins - 1) / bins;
         if (cap < h->lb_min_candidates) return pl;  // negatives would be drawn from too few items
-        if (ldsbin_lds_bytes((int)cap, h->k) <= (size_t)prof_env_int("CORNAC_HIP_LDSBIN_BUDGET_KB", (int)(kLbLdsBudget >> 10)) << 10) {
+        if (ldsbin_lds_bytes((int)cap, h->k, res_waves) <= (size_t)prof_env_int("CORNAC_HIP_LDSBIN_BUDGET_KB", (int)(kLbLdsBudget >> 10)) << 10) {
             pl.bins = (int)bins;
             pl.cap = (int)cap;
-            pl.lds = std::max(ldsbin_lds_bytes((int)cap, h->k), kLbLdsExclusive);
+            pl.block = res_waves * kWave;
+            pl.lds = std::max(ldsbin_lds_bytes((int)cap, h->k, res_waves), (size_t)prof_env_int("CORNAC_HIP_LDSBIN_EXCL_KB", (int)(kLbLdsExclusive >> 10)) << 10);
             return pl;
         }
     }
@@ -2257,6 +2261,8 @@ int cornac_hip_stream_ring_standin(int device, void *hip_stream, const float *d_
     return guarded([&] {
         REQUIRE(d_src && d_dst && src_floats > 0 && dst_floats > 0, "NULL / empty buffer");
         REQUIRE(n_floats >= 0 && n_workgroups >= 1 && n_workgroups <= 1024, "n_workgroups must be in [1, 1024]");
+        REQUIRE(src_floats >= 4 && dst_floats >= 4 && ((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_dst & 15) == 0,
+                "buffers must be 16-byte aligned and hold at least 4 floats");
         use_device(device);
         if (n_floats == 0) return;
         hipLaunchKernelGGL(stream_ring_standin_kernel, dim3((unsigned)n_workgroups), dim3(512), 0, (hipStream_t)hip_stream, d_src,

@@ -227,6 +227,11 @@ struct MfHogArgs {
     const float *own_r;
     const int64_t *wave_ptr;
     float *U, *V, *Bu, *Bi;
+    // split items (mf_blocks.inc, "virtual rows"): an item id >= n_items names copy id - n_items of a hot row, which lives in
+    // the side table; Vx_shifted = that table - n_items * k, so the row of id i is (i < n_items ? V : Vx_shifted) + i * k.
+    // The padded bias table simply has the copies' lines after the items'.  No split: n_items = INT32_MAX.
+    float *Vx_shifted;
+    int32_t n_items;
     double *loss_acc;
     int64_t n;
     int k, use_bias, bstride;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void mf_hogwild_rowwise_kernel(const MfHogA
                 ti[q] = __shfl(mi_, sl, kWave);
                 rt[q] = __shfl(mr, sl, kWave);
                 pu[q] = a.U + (size_t)tu[q] * a.k + lg;
-                pi[q] = a.V + (size_t)ti[q] * a.k + lg;
+                pi[q] = (ti[q] < a.n_items ? a.V : a.Vx_shifted) + (size_t)ti[q] * a.k + lg;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     u[q][r] = inb[r] ? __builtin_nontemporal_load(pu[q] + G * r) : 0.f;
@@ -456,6 +461,9 @@ struct cornac_hip_mf {
     DevBuf<float> mb_vx, mb_bix;
     DevBuf<int32_t> mb_split_item, mb_split_ptr;
     int mb_n_split = 0, mb_n_virtual = 0;
+    bool split_built = false;
+    std::vector<int32_t> split_of, split_ptr_h;   // item -> split index (-1: not split); copies of split j: [ptr[j], ptr[j + 1])
+    DevBuf<int64_t> cid_split;                    // the COO item ids with the split items' ratings renamed to their copies (fused kernel)
     double timing[4] = {0, 0, 0, 0};
     EventTimer ktimer;  // hogwild SGD kernel launches
     DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
@@ -685,10 +693,11 @@ static bool mf_epoch_chain(cornac_hip_mf_t h, float lr, float reg, float mu, int
         void *kargs[] = {(void *)&a};
         const hipError_t st = hipLaunchCooperativeKernel((const void *)pick_chain_kernel(h->k, h->chain_own_user),
                                                          dim3(h->chain_grid), dim3(kBlock), kargs, 0, h->stream);
-        if (st != hipSuccess) {
+        if (st == hipErrorCooperativeLaunchTooLarge) {  // the grid cannot be co-resident here: the level schedule takes over
             (void)hipGetLastError();
             return false;
         }
+        HIP_CHECK(st);  // any other status is a real launch error, not a refusal (advisor r4)
     }
     unsigned int ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(ab, h->chain_abort.p, sizeof ab, hipMemcpyDeviceToHost, h->stream));
@@ -723,10 +732,54 @@ static MfHogKernel pick_mf_kernel(int k, bool owned) {
     return mf_hogwild_generic_kernel<64>;
 }
 
+// ---- split items ("virtual rows", mf_blocks.inc header): which items, how many copies each, the side tables ----
+// An item holding more than 0.1 % of the ratings of a LARGE problem (>= 2^20 ratings: below that the launch does not hold
+// enough ratings in flight for the staleness to matter) is split into W = ceil(share / 0.1 %) copies.
+static void mf_build_split(cornac_hip_mf_t h) {
+    if (h->split_built) return;
+    const int64_t n = h->nnz, ni = h->n_items;
+    h->split_of.assign((size_t)ni, -1);
+    h->split_ptr_h.assign(1, 0);
+    std::vector<int32_t> items;
+    if (n >= (int64_t(1) << 20)) {
+        std::vector<int64_t> cnt((size_t)ni, 0);
+        for (int64_t s = 0; s < n; ++s) ++cnt[(size_t)h->host_cid[(size_t)s]];
+        for (int64_t i = 0; i < ni; ++i)
+            if (cnt[(size_t)i] * 1000 > n) {
+                const int64_t W = std::min<int64_t>(256, (cnt[(size_t)i] * 1000 + n - 1) / n);
+                h->split_of[(size_t)i] = (int32_t)items.size();
+                items.push_back((int32_t)i);
+                h->split_ptr_h.push_back(h->split_ptr_h.back() + (int32_t)W);
+            }
+    }
+    h->mb_n_split = (int)items.size();
+    h->mb_n_virtual = h->split_ptr_h.back();
+    if (h->mb_n_split) {
+        h->mb_split_item.alloc(items.size());
+        h->mb_split_ptr.alloc(h->split_ptr_h.size());
+        h->mb_split_item.upload(items.data(), items.size(), h->stream);
+        h->mb_split_ptr.upload(h->split_ptr_h.data(), h->split_ptr_h.size(), h->stream);
+        h->mb_vx.alloc((size_t)h->mb_n_virtual * (size_t)h->k);
+        h->mb_bix.alloc((size_t)h->mb_n_virtual * kBiasStride);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    h->split_built = true;
+}
+// the row a rating of item `it` at COO position s updates: the item, or the copy a hash of the position names
+static inline int32_t mf_split_id(cornac_hip_mf_t h, int64_t s, int64_t it) {
+    const int32_t j = h->split_of[(size_t)it];
+    if (j < 0) return (int32_t)it;
+    uint32_t x = (uint32_t)s * 0x85EBCA6Bu + 0x165667B1u;
+    x ^= x >> 16; x *= 0x9E3779B1u; x ^= x >> 13;
+    const uint32_t W = (uint32_t)(h->split_ptr_h[(size_t)j + 1] - h->split_ptr_h[(size_t)j]);
+    return (int32_t)(h->n_items + h->split_ptr_h[(size_t)j] + (int32_t)(x % W));
+}
+
 // Users -> waves of the persistent grid, balanced by rating count (LPT); users heavier than half a
 // wave's share are shared (their ratings are dealt evenly to all waves, atomics).  Inside a wave the
 // ratings of its users are interleaved round-robin.
 static void mf_build_ownership(cornac_hip_mf_t h, int64_t W) {
+    mf_build_split(h);
     if (h->own_waves == W) return;
     const int64_t nnz = h->nnz, nu = h->n_users;
     std::vector<int64_t> uptr((size_t)nu + 1, 0);
@@ -772,7 +825,7 @@ static void mf_build_ownership(cornac_hip_mf_t h, int64_t W) {
     auto emit = [&](int64_t dst, int32_t s, bool shared) {
         const int32_t u = (int32_t)h->host_rid[(size_t)s];
         ou[(size_t)dst] = shared ? ~u : u;
-        oi[(size_t)dst] = (int32_t)h->host_cid[(size_t)s];
+        oi[(size_t)dst] = mf_split_id(h, s, h->host_cid[(size_t)s]);
         orr[(size_t)dst] = h->host_val[(size_t)s];
     };
     // Shared ratings are dealt round-robin (rating p of the shared sequence -> wave p % W) so that a
@@ -897,27 +950,13 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     // overshoot and the factorisation diverges (measured at SURVEY 8d's Zipf(0.8): one row with 3.2 % of the ratings, loss
     // = nan in this form AND in the fused kernel).  The copies are hot rows of their own (ids n_items + v, a side table),
     // merged after every phase (mf_virtual_merge_kernel); a rating takes the copy a hash of its position names.
-    std::vector<int32_t> split_item, split_ptr(1, 0), split_of((size_t)ni, -1);
+    mf_build_split(h);
     for (int64_t i = 0; i < ni; ++i)
         if (cnt_i[(size_t)i] * 10 * 256 > n) {
             hot[(size_t)i] = 1;
             cnt_cold[(size_t)i] = 0;
-            if (cnt_i[(size_t)i] * 1000 > n) {
-                const int64_t W = std::min<int64_t>(256, (cnt_i[(size_t)i] * 1000 + n - 1) / n);
-                split_of[(size_t)i] = (int32_t)split_item.size();
-                split_item.push_back((int32_t)i);
-                split_ptr.push_back(split_ptr.back() + (int32_t)W);
-            }
         }
-    auto hot_id = [&](int64_t s) -> int32_t {  // the row a hot rating updates: the item, or one of its copies
-        const int64_t it = h->host_cid[(size_t)s];
-        const int32_t j = split_of[(size_t)it];
-        if (j < 0) return (int32_t)it;
-        uint32_t x = (uint32_t)s * 0x85EBCA6Bu + 0x165667B1u;
-        x ^= x >> 16; x *= 0x9E3779B1u; x ^= x >> 13;
-        const uint32_t W = (uint32_t)(split_ptr[(size_t)j + 1] - split_ptr[(size_t)j]);
-        return (int32_t)(ni + split_ptr[(size_t)j] + (int32_t)(x % W));
-    };
+    auto hot_id = [&](int64_t s) -> int32_t { return mf_split_id(h, s, h->host_cid[(size_t)s]); };
     int cap = 0;
     const std::vector<int32_t> ibin = mf_lpt_256(cnt_cold, &cap), ublk = mf_lpt_256(cnt_u, nullptr);
     cap = std::max(cap, 1);
@@ -1024,16 +1063,6 @@ static bool mf_build_blocks(cornac_hip_mf_t h) {
     h->mb_r.upload(b_r.data(), (size_t)n, h->stream);
     h->mb_bin_ptr.upload(bin_ptr.data(), 257, h->stream);
     h->mb_bin_items.upload(bin_items.data(), bin_items.size(), h->stream);
-    h->mb_n_split = (int)split_item.size();
-    h->mb_n_virtual = split_ptr.back();
-    if (h->mb_n_split) {
-        h->mb_split_item.alloc(split_item.size());
-        h->mb_split_ptr.alloc(split_ptr.size());
-        h->mb_split_item.upload(split_item.data(), split_item.size(), h->stream);
-        h->mb_split_ptr.upload(split_ptr.data(), split_ptr.size(), h->stream);
-        h->mb_vx.alloc((size_t)h->mb_n_virtual * (size_t)h->k);
-        h->mb_bix.alloc((size_t)h->mb_n_virtual * kBiasStride);
-    }
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->mb_cap = cap;
     h->mb_lds = std::max(mf_blocks_lds(cap, h->k), (size_t)82 * 1024);  // >= 82 KB: one workgroup per CU
@@ -1075,7 +1104,7 @@ static bool mf_epoch_blocks(cornac_hip_mf_t h, float lr, float reg, float mu, in
     a.cap = h->mb_cap; a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
     a.Vx = h->mb_vx.p; a.Bix = h->mb_bix.p; a.n_items = (int32_t)h->n_items;
     MfVirtArgs va;
-    va.V = h->V.p; va.Bi = h->Bi.p; va.Vx = h->mb_vx.p; va.Bix = h->mb_bix.p;
+    va.V = h->V.p; va.Bi = h->Bi.p; va.bi_stride = 1; va.Vx = h->mb_vx.p; va.Bix = h->mb_bix.p;
     va.item = h->mb_split_item.p; va.ptr = h->mb_split_ptr.p; va.n_split = h->mb_n_split; va.k = h->k;
     HIP_CHECK(hipMemsetAsync(h->mb_sync.p, 0, 24 * sizeof(unsigned int), h->stream));
     for (int ph = 0; ph < 8; ++ph) {
@@ -1120,11 +1149,24 @@ static void mf_launch_fused(cornac_hip_mf_t h, int64_t s0, int64_t n, float lr, 
         h->hog_kernel = kern;
         h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
     }
+    // hot items of a large problem train through copies of their rows (mf_blocks.inc, "virtual rows"): thousands of atomic
+    // updates of one row computed from one stale copy overshoot and diverge (round 4 raised "diverged" here instead)
+    mf_build_split(h);
+    const int nv = h->mb_n_virtual;
+    if (nv && !h->cid_split.p) {
+        std::vector<int64_t> c((size_t)h->nnz);
+        for (int64_t s = 0; s < h->nnz; ++s) c[(size_t)s] = mf_split_id(h, s, h->host_cid[(size_t)s]);
+        h->cid_split.alloc((size_t)h->nnz);
+        h->cid_split.upload(c.data(), (size_t)h->nnz, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
     MfHogArgs a;
-    a.rid = h->rid.p + s0; a.cid = h->cid.p + s0; a.val = h->val.p + s0;
+    a.rid = h->rid.p + s0; a.cid = (nv ? h->cid_split.p : h->cid.p) + s0; a.val = h->val.p + s0;
     a.own_u = nullptr; a.own_i = nullptr; a.own_r = nullptr; a.wave_ptr = nullptr;
     a.U = h->U.p; a.V = h->V.p; a.Bu = h->Bu.p;
-    h->Bipad.ensure((size_t)h->n_items * kBiasStride);
+    a.n_items = nv ? (int32_t)h->n_items : INT32_MAX;
+    a.Vx_shifted = nv ? h->mb_vx.p - (size_t)h->n_items * (size_t)k : h->V.p;
+    h->Bipad.ensure((size_t)(h->n_items + nv) * kBiasStride);
     a.Bi = h->Bipad.p;
     a.bstride = kBiasStride;
     a.loss_acc = loss_slot;
@@ -1141,9 +1183,21 @@ static void mf_launch_fused(cornac_hip_mf_t h, int64_t s0, int64_t n, float lr, 
     }
     const unsigned bgrid = (unsigned)((h->n_items + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bi.p, h->Bipad.p, h->n_items);
+    MfVirtArgs va;
+    va.V = h->V.p; va.Bi = h->Bipad.p; va.bi_stride = kBiasStride; va.Vx = h->mb_vx.p;
+    va.Bix = h->Bipad.p + (size_t)h->n_items * kBiasStride;   // the copies' bias lines follow the items' in the padded table
+    va.item = h->mb_split_item.p; va.ptr = h->mb_split_ptr.p; va.n_split = h->mb_n_split; va.k = k;
+    if (nv) {  // the copies start the launch equal to their rows
+        va.merge = 0;
+        hipLaunchKernelGGL(mf_virtual_merge_kernel, dim3(h->mb_n_split), dim3(kWave), 0, h->stream, va);
+    }
     h->ktimer.before(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, h->stream, a);
     h->ktimer.after(h->stream);
+    if (nv) {  // ... and are folded back into them after it ("align": sum of the copies' deltas x min(1, sum |d|^2 / |sum d|^2))
+        va.merge = 1;
+        hipLaunchKernelGGL(mf_virtual_merge_kernel, dim3(h->mb_n_split), dim3(kWave), 0, h->stream, va);
+    }
     hipLaunchKernelGGL(bias_unpad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bipad.p, h->Bi.p, h->n_items);
     HIP_CHECK(hipGetLastError());
 }

@@ -57,7 +57,15 @@ def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=6
     0.825 / 0.819 / 0.814 / 0.813 against 0.836 for one process on all ranks' data.  So: fewer than 16 exchanges per
     epoch -> "align"; and a rank whose rows collect less than the 93.5 updates per exchange in a whole epoch exchanges
     every floor(93.5 / updates per row and epoch) epochs, at most every `max_epochs` (0.011 below exchanging every
-    epoch in the emulation, for a quarter of the table passes)."""
+    epoch in the emulation, for a quarter of the table passes).
+
+    Round 5 re-measured the sparse case ON THE DEVICE (tests/test_sharded_gpu.py::test_eight_virtual_ranks_..., 8 virtual
+    ranks at the slice's density, profiles/r05_virtual_ranks.log): the replicas reach the single process's quality only at
+    convergence (0.9948 vs 0.9964 after 32 epochs); in the MIDDLE of training the averaged, stale item side lags badly
+    (16 epochs: 0.869 / 0.708 / 0.618 at one exchange every 1 / 2 / 4 epochs against 0.990 for one process) — every rank
+    moves every row the same way and "align" keeps the mean.  The ring conveyor (RingShardedBprTrainer, fit_bpr_ring) has
+    no such trade: 0.990 in the same measurement, 3.8 % one-rank tax.  Sparse item sides should take the ring; this
+    schedule remains what regime 1 does when asked."""
     x = 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row))
     if x >= 0.75:
         per_epoch, epochs = int(min(max(1, int(x + 0.5)), at_most)), 1
@@ -129,9 +137,12 @@ class ItemTableReplica:
             return
         from . import _lib
 
-        n = bucket.numel()
+        bucket = bucket[(-(bucket.data_ptr() // 4)) % 4:]     # (16-byte accesses: start at an aligned float)
+        n = bucket.numel() & ~3
+        if n < 4:
+            return
         if self._standin is None:
-            self._standin = (torch.cuda.Stream(bucket.device), torch.empty(min(n, 1 << 26), dtype=torch.float32, device=bucket.device))
+            self._standin = (torch.cuda.Stream(bucket.device), torch.empty(max(4, min(n, 1 << 26)), dtype=torch.float32, device=bucket.device))
         side, scratch = self._standin
         moved = int(2 * (self.emulate_world - 1) * n // self.emulate_world)
         dev = bucket.device.index or 0
