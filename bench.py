@@ -725,7 +725,7 @@ def leg_dist_tax(args, _lib):
             out["scale_ring"] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
                                  "tax": 1.0 - plain / driven, "protocol": "ring conveyor of item blocks (regime 2): %d steps per "
                                  "epoch, one launch each, %.0f MB copied per step on the communication stream"
-                                 % (ring.nb, ring.bufs[0].numel() * 4 / 1e6),
+                                 % (ring.nb, ring.bufs[0][0].numel() * 4 / 1e6),
                                  "blocks": ring.nb, "block_forms": [{"bins": f["bins"], "rows_per_bin": f["rows_per_bin"],
                                                                      "block_threads": f["block_threads"]} for f in forms],
                                  "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
@@ -764,7 +764,7 @@ def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
     nnz = len(indices)
     U, V, B = scale_factors(n_users, n_items, k, rank)
     t0 = time.time()
-    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=0xC0FFEE, emulate_traffic=(world == 1))
+    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=0xC0FFEE, emulate_traffic=(world == 1), rings=args.rings)
     ring.set_user_factors(U)
     ring.load_items(V, B)
     del U, V, B
@@ -794,10 +794,10 @@ def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
                                       "%d interactions per GPU), hogwild mode, fp32 tables resident in HBM"
                                       % (k, n_users, n_items, nnz), "k": k, "lr": args.lr, "reg": args.reg,
                           "form": "ldsbin (passing bins) per item block" if forms and forms[0]["bins"] else "per item block: automatic",
-                          "parallelism": "user-partitioned dp%d, item table sharded by row into %d blocks on a ring (regime 2, "
+                          "parallelism": "user-partitioned dp%d, item table sharded by row into %d blocks on %d ring(s) (regime 2, "
                                          "RingShardedBprTrainer): a step = %d launches per rank, each beside the transfer of the "
-                                         "previously trained block (%.0f MB) to the next rank%s"
-                                         % (world, ring.nb, ring.nb, ring.bufs[0].numel() * 4 / 1e6,
+                                         "previously trained block(s) (%.0f MB each) to the next rank%s"
+                                         % (world, ring.nb_total, ring.K, ring.nb * ring.K, ring.bufs[0][0].numel() * 4 / 1e6,
                                             " — one rank: the block is copied on the communication stream instead" if world == 1 else "")},
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "traffic": None, "kernel": "bpr_ldsbin_kernel<2,4> per item block (whole step: bytes / wall time)",
@@ -889,6 +889,9 @@ def main():
                          "even where the resident exchange (one launch per epoch) is available")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
+    ap.add_argument("--rings", type=int, default=1,
+                    help="--config scale over ranks: the conveyor's item blocks ride this many strided rings at once (different "
+                         "xGMI links; 4 at N = 8), each moving a K-th of a step's bytes")
     ap.add_argument("--replicated-items", action="store_true",
                     help="--config scale over N > 1 ranks: regime 1 (replicated item table, delta all-reduce at exchange_schedule's "
                          "interval) instead of the default for that shape, regime 2 as a ring conveyor of item blocks")

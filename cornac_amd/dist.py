@@ -1124,6 +1124,23 @@ class _OnceWork:
             self.done = True
 
 
+def ring_strides(world, rings):
+    """the strides of up to `rings` conveyor rings over `world` ranks: rank r hands its block to rank r - s.  A stride must be
+    coprime to the world size (the block has to visit every rank); s and world - s use the two directions of the same
+    links, two different strides different links — N = 8: 1, 7, 3, 5 (four directed link sets)"""
+    import math
+
+    if world <= 1:
+        return [1] * max(1, int(rings))  # (one rank: K groups of two blocks each — the launch granularity of K rings)
+    good = [s for s in range(1, max(world, 2)) if math.gcd(s, world) == 1] or [1]
+    order = []
+    for s in good:                      # 1, N - 1, 3, N - 3, ...: fill both directions of a link before taking the next one
+        for c in (s, world - s):
+            if c in good and c not in order:
+                order.append(c)
+    return order[: max(1, int(rings))]
+
+
 class RingShardedBprTrainer:
     """Multi-GPU BPR with the item table SHARDED BY ROW and never replicated (SURVEY.md 8e regime 2; BASELINE configs[4]:
     "item table row-sharded across 8 x MI355X via RCCL / xGMI"), as DSGD's block rotation (Gemulla et al. 2011) laid on
@@ -1141,6 +1158,11 @@ class RingShardedBprTrainer:
         322 MB at configs[4], one xGMI hop) hides behind the next step's launch;
       * after an epoch's last step every rank holds blocks 2 r and 2 r + 1 again; gather() assembles the table.
 
+    rings = K > 1: xGMI is a mesh of point-to-point links and ONE ring uses one of a GPU's seven.  The items are then cut
+    into K groups of 2 N blocks, group g rotating on its own ring with stride s_g (ring_strides: rank r hands to r - s_g;
+    1, N - 1, 3, N - 3, ... — different directed links); a step trains one block of every group and moves K blocks at once,
+    each a K-th of the size, over K links.  Same invariants per ring; an epoch is still 2 N steps and nnz draws.
+
     The draws of a step on different ranks touch disjoint user rows AND disjoint item rows, so the parallel run equals
     the serial execution of the same steps in any order (tests/test_dist_cpu.py runs both).  The reference has no
     counterpart (one process; the update it distributes is recom_bpr.pyx:252-265).
@@ -1151,58 +1173,70 @@ class RingShardedBprTrainer:
     memory traffic and dependency chain."""
 
     def __init__(self, indptr, indices, n_users, n_items, k, device, group=None, trainer_factory=None, seed=0,
-                 emulate_traffic=False):
+                 emulate_traffic=False, rings=1):
         self.device, self.group, self.k = device, group, int(k)
         self.world, self.rank = _world(group)
-        self.nb = 2 * self.world
+        self.strides = ring_strides(self.world, rings)
+        self.K = len(self.strides)
+        self.nb = 2 * self.world                  # blocks per ring = steps per epoch
+        self.nb_total = self.nb * self.K          # item i -> global block B = i % nb_total = (ring B % K, ring block B // K)
         self.n_items, self.n_users = int(n_items), int(n_users)
-        if self.n_items < self.nb:
-            raise ValueError("%d items cannot be cut into %d blocks" % (self.n_items, self.nb))
-        self.rows_max = (self.n_items + self.nb - 1) // self.nb
-        self.rows = [(self.n_items - b + self.nb - 1) // self.nb for b in range(self.nb)]
+        if self.n_items < self.nb_total:
+            raise ValueError("%d items cannot be cut into %d blocks" % (self.n_items, self.nb_total))
+        self.rows_max = (self.n_items + self.nb_total - 1) // self.nb_total
+        self.rows = [(self.n_items - B + self.nb_total - 1) // self.nb_total for B in range(self.nb_total)]
+        # position of this rank on ring g: the rank it hands to (rank - s_g) has position - 1
+        self.pos = [(self.rank * pow(s, -1, self.world)) % self.world if self.world > 1 else 0 for s in self.strides]
         cuda = device.type == "cuda"
         self.stream = torch.cuda.Stream(device) if cuda else None
         self.comm = torch.cuda.Stream(device) if cuda else None
         self.emulate_traffic = bool(emulate_traffic) and self.world == 1
         width = self.rows_max * (self.k + 1)
-        self.bufs = [torch.zeros(width, dtype=torch.float32, device=device) for _ in range(3)]
+        self.bufs = [[torch.zeros(width, dtype=torch.float32, device=device) for _ in range(3)] for _ in range(self.K)]
         self.U = torch.zeros((self.n_users, self.k), dtype=torch.float32, device=device)
-        self.where = {2 * self.rank: 0, 2 * self.rank + 1: 1}      # block -> buffer
-        self.arrived = [None, None, None]                            # per buffer: event / works of the receive that fills it
+        self.where = [{2 * p: 0, 2 * p + 1: 1} for p in self.pos]  # per ring: ring block -> buffer
+        self.arrived = [[None, None, None] for _ in range(self.K)]  # per ring and buffer: event / works of the receive that fills it
+        self._sent = []
         self.t = 0
-        self.steps_trained = []                                      # (epoch step, block): inspection / tests
+        self.steps_trained = []                                      # (epoch step, global block): inspection / tests
         self.trainers = []
-        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, self.nb)):
+        for B, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, self.nb_total)):
             if len(ix) == 0:
                 self.trainers.append(None)
                 continue
             if trainer_factory is not None:
-                tr = trainer_factory(b, ip, ix, self.n_users, self.rows[b], self.k, self.U)
+                tr = trainer_factory(B, ip, ix, self.n_users, self.rows[B], self.k, self.U)
             else:
-                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[b], self.k, self.U, self.stream, device.index or 0)
+                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[B], self.k, self.U, self.stream, device.index or 0)
             tr.nnz = len(ix)
-            tr.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
+            tr.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 104729 * B + 1) & 0xFFFFFFFFFFFFFFFF)
             self.trainers.append(tr)
         self.nnz = int(sum(tr.nnz for tr in self.trainers if tr is not None))
 
-    def _views(self, buf, b):
-        """(V [rows_b, k], B [rows_b]) of block b in buffer `buf`"""
-        flat = self.bufs[buf]
-        return flat[: self.rows[b] * self.k].view(self.rows[b], self.k), flat[self.rows_max * self.k: self.rows_max * self.k + self.rows[b]]
+    def block_id(self, g, b):
+        """global block (= item residue class mod nb_total) of ring g's block b"""
+        return b * self.K + g
+
+    def _views(self, g, buf, b):
+        """(V [rows, k], B [rows]) of ring g's block b in that ring's buffer `buf`"""
+        flat, rows = self.bufs[g][buf], self.rows[self.block_id(g, b)]
+        return flat[: rows * self.k].view(rows, self.k), flat[self.rows_max * self.k: self.rows_max * self.k + rows]
 
     def _on(self, stream):
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
     def load_items(self, V, B):
-        """this rank's two starting blocks of the full host tables"""
+        """this rank's two starting blocks of every ring, from the full host tables"""
         V, B = np.asarray(V, np.float32), np.asarray(B, np.float32)
         with self._on(self.stream):
-            for slot, b in enumerate((2 * self.rank, 2 * self.rank + 1)):
-                v, bias = self._views(slot, b)
-                v.copy_(torch.as_tensor(np.ascontiguousarray(V[b:: self.nb])))
-                bias.copy_(torch.as_tensor(np.ascontiguousarray(B[b:: self.nb])))
-        self.where = {2 * self.rank: 0, 2 * self.rank + 1: 1}
-        self.arrived = [None, None, None]
+            for g, p in enumerate(self.pos):
+                for slot, b in enumerate((2 * p, 2 * p + 1)):
+                    v, bias = self._views(g, slot, b)
+                    blk = self.block_id(g, b)
+                    v.copy_(torch.as_tensor(np.ascontiguousarray(V[blk:: self.nb_total])))
+                    bias.copy_(torch.as_tensor(np.ascontiguousarray(B[blk:: self.nb_total])))
+        self.where = [{2 * p: 0, 2 * p + 1: 1} for p in self.pos]
+        self.arrived = [[None, None, None] for _ in range(self.K)]
         self.t = 0
         if self.stream is not None:
             self.stream.synchronize()
@@ -1217,64 +1251,79 @@ class RingShardedBprTrainer:
             self.stream.synchronize()
         return self.U.cpu().numpy()
 
+    def _await(self, got):
+        if got is None:
+            return
+        if self.stream is not None:
+            self.stream.wait_event(got)
+        else:
+            for w in got:
+                w.wait()
+
     def step(self, lr, reg, use_bias=True, neg_population=0, flags=0):
-        """one step of the conveyor: train the block whose turn it is, then hand the trained block to rank - 1 and take
-        the one rank + 1 has just trained (both beside the NEXT step's launch)"""
-        b = (2 * self.rank + self.t) % self.nb
-        buf = self.where[b]
+        """one step of the conveyor: on every ring, train the block whose turn it is; then hand the trained blocks to the
+        rings' next ranks and take the ones their previous ranks have just trained (beside the NEXT step's launches)"""
+        ranks = dist.get_process_group_ranks(self.group) if (self.group is not None and self.world > 1) else list(range(self.world))
+        moves = []                                    # (ring, trained block, its buffer, free buffer, block arriving)
         with self._on(self.stream):
-            got = self.arrived[buf]
-            if got is not None:                       # the receive that brought the block here
-                if self.stream is not None:
-                    self.stream.wait_event(got)
-                else:
-                    for w in got:
-                        w.wait()
-                self.arrived[buf] = None
-            tr = self.trainers[b]
-            if tr is not None:
-                tr.bind_items(*self._views(buf, b))
-                tr.hogwild_enqueue(tr.nnz, lr, reg, use_bias, neg_population, flags)
-            self.steps_trained.append((self.t % self.nb, b))
+            for g, p in enumerate(self.pos):
+                b = (2 * p + self.t) % self.nb
+                buf = self.where[g][b]
+                self._await(self.arrived[g][buf])     # the receive that brought the block here
+                self.arrived[g][buf] = None
+                tr = self.trainers[self.block_id(g, b)]
+                if tr is not None:
+                    tr.bind_items(*self._views(g, buf, b))
+                    tr.hogwild_enqueue(tr.nnz, lr, reg, use_bias, neg_population, flags)
+                self.steps_trained.append((self.t % self.nb, self.block_id(g, b)))
+                free = ({0, 1, 2} - set(self.where[g].values())).pop()
+                moves.append((g, b, buf, free, (b + 2) % self.nb))
             trained = None
             if self.stream is not None:
                 trained = torch.cuda.Event()
                 trained.record(self.stream)
-        free = ({0, 1, 2} - set(self.where.values())).pop()
-        nxt = (b + 2) % self.nb                       # what rank + 1 trained in this step
         if self.world > 1:
             with self._on(self.comm):
                 if self.comm is not None:
                     self.comm.wait_event(trained)
-                ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.world))
-                dst, src = ranks[(self.rank - 1) % self.world], ranks[(self.rank + 1) % self.world]
-                if self.comm is None:                 # gloo: the previous phase's send still owns the buffer this receive fills
-                    for w in getattr(self, "_sent", []):
+                else:                                 # gloo: the previous phase's sends still own the buffers these receives fill
+                    for w in self._sent:
                         w.wait()
-                ops = [dist.P2POp(dist.isend, self.bufs[buf], dst, self.group), dist.P2POp(dist.irecv, self.bufs[free], src, self.group)]
+                ops = []
+                for g, b, buf, free, nxt in moves:
+                    s = self.strides[g]
+                    dst, src = ranks[(self.rank - s) % self.world], ranks[(self.rank + s) % self.world]
+                    ops.append(dist.P2POp(dist.isend, self.bufs[g][buf], dst, self.group))
+                    ops.append(dist.P2POp(dist.irecv, self.bufs[g][free], src, self.group))
                 works = [_OnceWork(w) for w in dist.batch_isend_irecv(ops)]
                 if self.comm is not None:
                     for w in works:
                         w.wait()                      # (stream-level on RCCL: the communication stream waits, the host does not)
                     ev = torch.cuda.Event()
                     ev.record(self.comm)
-                    self.arrived[free] = ev
+                    for g, b, buf, free, nxt in moves:
+                        self.arrived[g][free] = ev
                 else:
-                    self.arrived[free] = works        # gloo: waited for before the block is trained (or gathered)
+                    for g, b, buf, free, nxt in moves:
+                        self.arrived[g][free] = works # gloo: waited for before the block is trained (or gathered)
                     self._sent = list(works)
-            del self.where[b]
-            self.where[nxt] = free
+            for g, b, buf, free, nxt in moves:
+                del self.where[g][b]
+                self.where[g][nxt] = free
         elif self.emulate_traffic:
             with self._on(self.comm):
                 if self.comm is not None:
                     self.comm.wait_event(trained)
-                self.bufs[free].copy_(self.bufs[buf])
+                for g, b, buf, free, nxt in moves:
+                    self.bufs[g][free].copy_(self.bufs[g][buf])
+                ev = None
                 if self.comm is not None:
                     ev = torch.cuda.Event()
                     ev.record(self.comm)
-                    self.arrived[free] = ev
-            del self.where[b]
-            self.where[nxt] = free                    # (2 blocks on one rank: block b itself, two steps later)
+                for g, b, buf, free, nxt in moves:
+                    self.arrived[g][free] = ev
+                    del self.where[g][b]
+                    self.where[g][nxt] = free         # (2 blocks per ring on one rank: block b itself, two steps later)
         self.t += 1
 
     def run_epoch(self, lr, reg, use_bias=True, neg_population=0, flags=0):
@@ -1282,17 +1331,11 @@ class RingShardedBprTrainer:
             self.step(lr, reg, use_bias, neg_population, flags)
 
     def _drain(self):
-        for buf in range(3):
-            got = self.arrived[buf]
-            if got is None:
-                continue
-            if self.stream is not None:
-                self.stream.wait_event(got)
-            else:
-                for w in got:
-                    w.wait()
-            self.arrived[buf] = None
-        for w in getattr(self, "_sent", []):
+        for g in range(self.K):
+            for buf in range(3):
+                self._await(self.arrived[g][buf])
+                self.arrived[g][buf] = None
+        for w in self._sent:
             w.wait()
         self._sent = []
         if self.stream is not None:
@@ -1310,23 +1353,28 @@ class RingShardedBprTrainer:
         return c, s
 
     def gather(self):
-        """the full (V, B) host tables on every rank; at an epoch boundary (every rank holds its blocks 2 r, 2 r + 1)"""
+        """the full (V, B) host tables on every rank; at an epoch boundary (every rank holds its two blocks of every ring)"""
         if self.t % self.nb:
             raise RuntimeError("gather() in the middle of an epoch (step %d of %d)" % (self.t % self.nb, self.nb))
         self._drain()
-        mine = torch.stack([self.bufs[self.where[2 * self.rank]], self.bufs[self.where[2 * self.rank + 1]]])
+        mine = torch.stack([self.bufs[g][self.where[g][2 * p + h]] for g, p in enumerate(self.pos) for h in (0, 1)])
         if self.world > 1:
             comm_dev = _comm_device(self.device, self.group)
-            full = torch.empty((self.nb,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm_dev)
+            full = torch.empty((self.world * 2 * self.K,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm_dev)
             dist.all_gather_into_tensor(full, mine.to(comm_dev).contiguous(), group=self.group)
         else:
             full = mine
-        full = full.cpu().numpy()
+        full = full.cpu().numpy().reshape(self.world, self.K, 2, -1)
         V = np.empty((self.n_items, self.k), np.float32)
         B = np.empty(self.n_items, np.float32)
-        for b in range(self.nb):
-            V[b:: self.nb] = full[b, : self.rows[b] * self.k].reshape(self.rows[b], self.k)
-            B[b:: self.nb] = full[b, self.rows_max * self.k: self.rows_max * self.k + self.rows[b]]
+        for r in range(self.world):
+            for g, s in enumerate(self.strides):
+                p = (r * pow(s, -1, self.world)) % self.world if self.world > 1 else 0
+                for h in (0, 1):
+                    blk = self.block_id(g, 2 * p + h)
+                    rows = self.rows[blk]
+                    V[blk:: self.nb_total] = full[r, g, h, : rows * self.k].reshape(rows, self.k)
+                    B[blk:: self.nb_total] = full[r, g, h, self.rows_max * self.k: self.rows_max * self.k + rows]
         return V, B
 
     def close(self):
@@ -1483,7 +1531,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     return model
 
 
-def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None, local_popularity=False):
+def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None, local_popularity=False, rings=1):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group with the item table sharded
     by row and rotating around the ring (regime 2, RingShardedBprTrainer): the same calling convention and restrictions as
     fit_bpr_sharded, no replica and no reconciliation rule — every item row is in one place at any time, so the result
@@ -1516,7 +1564,7 @@ def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
     lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
     ring = RingShardedBprTrainer(indptr, indices, u1 - u0, model.total_items, model.k, device, group=group,
-                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo)
+                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo, rings=rings)
     try:
         ring.set_user_factors(model.u_factors[u0:u1])
         ring.load_items(model.i_factors, model.i_biases)

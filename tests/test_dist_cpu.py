@@ -1027,7 +1027,7 @@ def _ring_tables(n_users, n_items, k, rank):
     return U0, V0, B0
 
 
-def _ring_worker(rank, world, port, out, kind, epochs):
+def _ring_worker(rank, world, port, out, kind, epochs, rings=1):
     from cornac_amd.dist import RingShardedBprTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -1040,7 +1040,8 @@ def _ring_worker(rank, world, port, out, kind, epochs):
             factory = lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log)
         else:
             factory = lambda b, ip, ix, nu, rows, k_, U: _RingOracleTrainer(ip, ix, rows, k_, U)
-        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), trainer_factory=factory, seed=5)
+        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), trainer_factory=factory, seed=5,
+                                     rings=rings)
         U0, V0, B0 = _ring_tables(len(indptr) - 1, n_items, k, rank)
         ring.load_items(V0, B0)
         ring.set_user_factors(U0)
@@ -1069,48 +1070,68 @@ def test_ring_conveyor_world2_every_rank_trains_every_block_once_per_epoch():
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_ring_conveyor_world2_equals_its_serial_execution():
+@pytest.mark.parametrize("world,rings", [(2, 1), (3, 2)])
+def test_ring_conveyor_equals_its_serial_execution(world, rings):
     """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
-    disjoint item blocks, so two gloo ranks must produce bit for bit what ONE process gets by running the same (step,
-    rank) pairs one after the other — item table, biases and both ranks' user rows; and the model learns"""
-    from cornac_amd.dist import split_csr_by_item_block
+    disjoint item blocks, so the gloo ranks must produce bit for bit what ONE process gets by running the same (step,
+    rank, ring) triples one after the other — item table, biases and every rank's user rows; and the model learns.
+    world 3 with two rings: the blocks of ring 1 travel r -> r - 2 (the other direction of the links), both rings
+    advance in the same steps."""
+    from cornac_amd.dist import ring_strides, split_csr_by_item_block
 
-    epochs, n_items, k, world = 3, 50, 6, 2
+    epochs, n_items, k = 3, 50, 6
     out = mp.Manager().dict()
-    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs), nprocs=world, join=True)
+    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs, rings), nprocs=world, join=True)
     # the serial execution
-    nb = 2 * world
+    strides = ring_strides(world, rings)
+    K, nb = len(strides), 2 * world
+    assert K == rings
+    nbt = nb * K
     _, V, B = _ring_tables(120, n_items, k, 0)
     V, B = V.copy(), B.copy()
-    blocks = [(np.ascontiguousarray(V[b::nb]), np.ascontiguousarray(B[b::nb])) for b in range(nb)]
+    blocks = [(np.ascontiguousarray(V[b::nbt]), np.ascontiguousarray(B[b::nbt])) for b in range(nbt)]
     Us, trainers, nnz = [], [], []
     for rank in range(world):
         indptr, indices = _ring_data(rank)
         U = torch.as_tensor(_ring_tables(len(indptr) - 1, n_items, k, rank)[0].copy())
         Us.append(U)
         row = []
-        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, nb)):
-            tr = _RingOracleTrainer(ip, ix, len(blocks[b][1]), k, U)
-            tr.nnz = len(ix)
-            tr.seed_hogwild((5 * 0x9E3779B97F4A7C15 + 7919 * rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
+        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, nbt)):
+            tr = None
+            if len(ix):
+                tr = _RingOracleTrainer(ip, ix, len(blocks[b][1]), k, U)
+                tr.nnz = len(ix)
+                tr.seed_hogwild((5 * 0x9E3779B97F4A7C15 + 7919 * rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
             row.append(tr)
         trainers.append(row)
         nnz.append(len(indices))
     for t in range(epochs * nb):
         for rank in range(world):
-            b = (2 * rank + t) % nb
-            tr = trainers[rank][b]
-            tr.bind_items(torch.as_tensor(blocks[b][0]), torch.as_tensor(blocks[b][1]))
-            tr.hogwild_enqueue(tr.nnz, 0.05, 0.01, True, 0, 0)
-    for b in range(nb):
-        V[b::nb], B[b::nb] = blocks[b]
+            for g, stride in enumerate(strides):
+                p = (rank * pow(stride, -1, world)) % world
+                b = ((2 * p + t) % nb) * K + g
+                tr = trainers[rank][b]
+                if tr is None:
+                    continue
+                tr.bind_items(torch.as_tensor(blocks[b][0]), torch.as_tensor(blocks[b][1]))
+                tr.hogwild_enqueue(tr.nnz, 0.05, 0.01, True, 0, 0)
+    for b in range(nbt):
+        V[b::nbt], B[b::nbt] = blocks[b]
     for rank in range(world):
         Vr, Br, Ur, steps, _, c, s, n = out[rank]
         assert n == nnz[rank] and 0 < c and c + s <= epochs * n
+        assert len(steps) == epochs * nb * K and len(set(steps[: nb * K])) == nb * K, "every block of every ring once per epoch"
         assert np.array_equal(Vr, V) and np.array_equal(Br, B), "rank %d: the conveyor's table differs from the serial execution" % rank
         assert np.array_equal(Ur, Us[rank].numpy())
         indptr, indices = _ring_data(rank)
         assert _pairwise_accuracy(Ur, Vr, Br, indptr, indices, n_items) > 0.62
+
+
+def test_ring_strides():
+    from cornac_amd.dist import ring_strides
+
+    assert ring_strides(8, 4) == [1, 7, 3, 5] and ring_strides(8, 1) == [1] and ring_strides(8, 9) == [1, 7, 3, 5]
+    assert ring_strides(2, 4) == [1] and ring_strides(1, 3) == [1, 1, 1] and ring_strides(3, 2) == [1, 2] and ring_strides(6, 4) == [1, 5]
 
 
 def test_split_csr_by_item_block_is_a_partition():

@@ -764,14 +764,15 @@ def test_resident_exchange_trains_like_the_plain_launch_through_rccl():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("emulate", [False, True])
-def test_ring_conveyor_single_rank_on_the_device(emulate):
+@pytest.mark.parametrize("emulate,rings", [(False, 1), (True, 1), (True, 2)])
+def test_ring_conveyor_single_rank_on_the_device(emulate, rings):
     """RingShardedBprTrainer (multi-GPU regime 2 as a ring of item blocks) on ONE rank with the real handles: 2 blocks, a
     handle per block sharing the user table, the item tables rebound per step (cornac_hip_bpr_rebind_items); with
     emulate_traffic the trained block is copied to the free buffer on the communication stream, as a neighbour's
     receive would.  (1) lr = 0 returns every table bit for bit and draws nnz samples per epoch; (2) training moves both
     blocks, stays finite, and learns like the plain single-handle fit of the same data (the negatives come from the
-    positive's half of the items instead of all of them)."""
+    positive's block of the items instead of all of them).  rings = 2 on one rank: two groups of two blocks, two launches and two
+    copies per step (the launch granularity of two rings)."""
     import torch
 
     from cornac_amd import synth
@@ -786,8 +787,8 @@ def test_ring_conveyor_single_rank_on_the_device(emulate):
     V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
     B = rs.normal(0, 0.01, n_items).astype(np.float32)
     dev = torch.device("cuda", 0)
-    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=3, emulate_traffic=emulate)
-    assert ring.nb == 2 and ring.nnz == nnz and ring.rows == [2001, 2000]
+    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=3, emulate_traffic=emulate, rings=rings)
+    assert ring.nb == 2 and ring.K == rings and ring.nnz == nnz and sum(ring.rows) == n_items and len(ring.rows) == 2 * rings
     ring.set_user_factors(U)
     ring.load_items(V, B)
     ring.run_epoch(0.0, 0.0)
@@ -803,10 +804,10 @@ def test_ring_conveyor_single_rank_on_the_device(emulate):
     acc_ring = c / (nnz - s)
     V2, B2 = ring.gather()
     U2 = ring.get_user_factors()
-    assert ring.steps_trained[:4] == [(0, 0), (1, 1), (0, 0), (1, 1)]
+    assert ring.steps_trained[: 4 * rings] == [(t % 2, (t % 2) * rings + g) for t in range(4) for g in range(rings)]
     ring.close()
     assert np.isfinite(V2).all() and np.isfinite(U2).all()
-    assert np.abs(V2[0::2] - V[0::2]).max() > 1e-3 and np.abs(V2[1::2] - V[1::2]).max() > 1e-3 and np.abs(U2 - U).max() > 1e-3
+    assert all(np.abs(V2[b:: 2 * rings] - V[b:: 2 * rings]).max() > 1e-3 for b in range(2 * rings)) and np.abs(U2 - U).max() > 1e-3
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
     tr.set_factors(U, V, B)
     tr.seed_hogwild(3)
