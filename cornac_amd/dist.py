@@ -392,6 +392,7 @@ class ShardedBprTrainer:
         self.stream = None
         self._resident = None            # buffers of the resident exchange (device path), allocated at first use
         self._resident_open = False      # resident launches since the last closing exchange (finish())
+        self._carry = (0, 0)             # counters fetched by a sync() outside finish() (load_items)
         self.resident_timeout_ms = 20000
         self.resident_lag = 1            # host path: an exchange is applied this many boundaries after its publication
         # emulation / test hook: called as hook(e, bucket) on the communication stream where the all-reduce of exchange e
@@ -414,6 +415,11 @@ class ShardedBprTrainer:
 
     def load_items(self, V, B):
         with self._on_stream():
+            if self.device.type == "cuda" and self.trainer is not None and hasattr(self.trainer, "sync"):
+                # (chunk_records mode: the handle may be training on packed item records; a load into the dense replica would be
+                # overwritten by the stale records at the next write-back — make the dense table current first; advisor r4)
+                c, s = self.trainer.sync()
+                self._carry = (self._carry[0] + c, self._carry[1] + s)
             self.table.load(V, B)
         if self.stream is not None:
             self.stream.synchronize()
@@ -574,6 +580,8 @@ class ShardedBprTrainer:
                 self.table.finish_sync()
                 self._resident_open = False
         out = self.trainer.sync()
+        if self._carry != (0, 0) and isinstance(out, tuple) and len(out) == 2:
+            out, self._carry = (out[0] + self._carry[0], out[1] + self._carry[1]), (0, 0)
         if self.stream is not None:
             self.stream.synchronize()
         if self._resident is not None:

@@ -56,7 +56,13 @@ class _DropoutMasks:
 class MF(Recommender):
     """Parameters are those of the reference (recom_mf.py:32-131); `backend` accepts "hip" and
     "hip-minibatch" (the reference raises ValueError for an unknown backend, recom_mf.py:183 — so does this).
-    `mode` as in BPR: None -> deterministic when seeded, hogwild otherwise."""
+    `mode` as in BPR: None -> deterministic when seeded, hogwild otherwise.
+
+    One behaviour differs from the reference on purpose: a hogwild fit whose loss becomes non-finite RAISES (`HipError`,
+    "diverged") after the tables have been overwritten, where `fit_sgd` (backend_cpu.pyx:62-97) returns the NaN model
+    silently; the sequential (seeded) mode reproduces the reference, NaNs included.  Very popular items no longer get there
+    by themselves: rows above 0.1 % of the ratings of a large problem train through copies merged every phase / launch
+    (csrc/mf_blocks.inc "virtual rows")."""
 
     def __init__(self, name="MF", k=10, backend="hip", optimizer="sgd", max_iter=20, learning_rate=0.01,
                  batch_size=256, lambda_reg=0.02, dropout=0.0, use_bias=True, early_stop=False, num_threads=0,

@@ -660,14 +660,15 @@ def _passing_case(n_users=100_000, n_items=300_000, degree=9, seed=21):
     return n_users, n_items, indptr, items[keep].astype(np.int32)
 
 
-def test_ldsbin_passing_bins_sampler_exactness_and_learning(oracle):
+@pytest.mark.parametrize("k,n_items", [(128, 300_000), (64, 400_000), (200, 300_000)])
+def test_ldsbin_passing_bins_sampler_exactness_and_learning(oracle, k, n_items):
     """The LDS-bin form with PASSING bins (csrc/bpr.hip ldsbin_plan: an item table beyond 4 rounds of CU-owning bins — the
     configs[4] regime — passes through the LDS once per epoch in 8-wave workgroups, two per CU): the same deal and sampler
     as the resident bins, so (1) with lr = 0 the skip counter of two epochs equals the CPU restatement exactly (CSR
     membership test: no bitmap at this size) and nothing moves; (2) updates are exact — with reg = 0 the column sums of V
     and the bias sum are conserved, the lock counter stays 0; (3) it learns like the fused atomic kernel."""
-    n_users, n_items, indptr, indices = _passing_case()
-    nnz, k, seed = len(indices), 128, 0xC0FFEE
+    n_users, n_items, indptr, indices = _passing_case(n_items=n_items)
+    nnz, seed = len(indices), 0xC0FFEE
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
     st = tr.ldsbin_stats()
     assert st["bins"] > 4 * 256 and st["bins"] % 256 == 0 and st["block_threads"] == 512 and st["bitmap_words"] == 0, st
