@@ -509,7 +509,9 @@ def leg_bpr_k128_scale(args, _lib):
            # algorithmic bytes / ms_per_step; the 8 partition launches alone: frac_kernel_only
            "roofline": {"bound": "hbm", "achieved": bytes_launch * launches / dt / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_launch * launches / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": bytes_launch * launches / dt / 1e9 / HBM_PEAK_GBS,
+                        "traffic": leg_traffic("bpr_k128_scale", kernel="bpr_ldsbin_kernel<2,4> (passing bins)", k=int(k),
+                                               draws_per_launch=int(nnz)) if passing else None,
                         "frac_kernel_only": bytes_launch / (kms / max(launches, 1) / 1e3) / 1e9 / HBM_PEAK_GBS,
                         "kernel": kernel, "launches": launches,
                         "avg_launch_ms": kms / max(launches, 1), "algorithmic_bytes_per_triplet": b_full},
