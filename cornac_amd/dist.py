@@ -1452,7 +1452,7 @@ def global_negative_population(indices_local, n_items, device=None, group=None, 
 
 
 def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
-                    trainer_factory=None, local_popularity=False, rule=None):
+                    trainer_factory=None, local_popularity=False, rule=None, regime="auto"):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
     calls it with a model built from the same arguments and the SAME train_set; the users are cut into contiguous ranges
     of equal interaction counts, rank r trains its range in hogwild mode against its replica of the item table
@@ -1466,14 +1466,32 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     counts) and every handle is given a population with those multiplicities (global_negative_population,
     cornac_hip_bpr_set_negative_population; the draw then runs in the fused kernel).  local_popularity=True keeps each
     rank's own interactions as its population (the LDS-bin form's binned draw; the popularity of the rank's users only).
-    trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo)."""
+    trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo).
+    regime: "replicated" = this regime; "ring" = fit_bpr_ring; "auto" (default) = the ring where exchange_schedule would
+    space the replicas' exchanges over several epochs (sparse item sides — where the replicas lag in mid-training,
+    DESIGN.md 5), the replicas otherwise and whenever the caller fixes the replica protocol (sync_per_epoch, rule,
+    sparse_threshold, trainer_factory)."""
     from . import _lib
     from .recommender import Recommender
 
+    if regime not in ("auto", "replicated", "ring"):
+        raise ValueError("regime must be 'auto', 'replicated' or 'ring'")
     if model.effective_mode != "hogwild":
         raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
     world, rank = _world(group)
     device = device if device is not None else torch.device("cpu")
+    if regime == "auto" and (sync_per_epoch is not None or rule is not None or sparse_threshold is not None
+                             or trainer_factory is not None):
+        regime = "replicated"
+    if regime != "replicated":
+        X0 = train_set.matrix
+        per_rank = int(X0.nnz // max(world, 1)) + 1
+        if regime == "ring" or exchange_schedule(per_rank, train_set.num_items)[1] > 1:
+            if model._neg_population != _lib.NEG_POPULARITY or local_popularity or world == 1:
+                return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity)
+            if regime == "ring":
+                raise ValueError("the ring regime draws WBPR's negatives from the popularity of the rank's own users inside "
+                                 "a block: pass local_popularity=True to accept that")
     Recommender.fit(model, train_set)
     model._init()
     if model.trains_float64:

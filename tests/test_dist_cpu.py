@@ -1070,13 +1070,13 @@ def test_ring_conveyor_world2_every_rank_trains_every_block_once_per_epoch():
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("world,rings", [(2, 1), (3, 2)])
+@pytest.mark.parametrize("world,rings", [(2, 1), (3, 2), (4, 2)])
 def test_ring_conveyor_equals_its_serial_execution(world, rings):
     """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
     disjoint item blocks, so the gloo ranks must produce bit for bit what ONE process gets by running the same (step,
     rank, ring) triples one after the other — item table, biases and every rank's user rows; and the model learns.
     world 3 with two rings: the blocks of ring 1 travel r -> r - 2 (the other direction of the links), both rings
-    advance in the same steps."""
+    advance in the same steps; world 4: strides 1 and 3."""
     from cornac_amd.dist import ring_strides, split_csr_by_item_block
 
     epochs, n_items, k = 3, 50, 6

@@ -620,6 +620,11 @@ def test_model_level_sharded_fits_single_rank_through_rccl():
         assert np.abs(a.score(3) - (a.i_biases + a.i_factors @ a.u_factors[3])).max() < 1e-5
         with pytest.raises(ValueError):
             fit_bpr_sharded(ca.BPR(k=8, seed=1), ds, device=dev)   # seeded => sequential semantics: refused
+        # the same fit as the ring conveyor of item blocks (regime 2; one rank: two blocks, a handle per block)
+        c = fit_bpr_sharded(ca.BPR(**kw), ds, device=dev, regime="ring")
+        fc = c.fit_stats[0][0] / max(6 * nnz - c.fit_stats[0][1], 1)
+        assert np.isfinite(c.u_factors).all() and np.isfinite(c.i_factors).all() and abs(fc - fb) < 0.03, (fc, fb)
+        assert np.abs(c.score(3) - (c.i_biases + c.i_factors @ c.u_factors[3])).max() < 1e-5
         kw = dict(k=64, max_iter=8, learning_rate=0.01, lambda_reg=0.02, seed=5, mode="hogwild")
         m = fit_mf_sharded(ca.MF(**kw), ds, device=dev, parts_per_epoch=8)
         p = ca.MF(**kw).fit(ds)
