@@ -689,6 +689,14 @@ def test_ldsbin_passing_bins_sampler_exactness_and_learning(oracle, k, n_items):
         want += sk
     assert s == want and want > 0
     assert np.array_equal(V2, V) and np.array_equal(B2, B) and np.array_equal(U2, U)
+    if k == 128:   # WBPR's popularity-weighted negatives in the same regime (the <2,4,POP> instantiation): draw for draw
+        tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
+        tr.set_factors(U, V, B)
+        tr.seed_hogwild(seed)
+        c, s = tr.fit_epochs(1, 0.0, 0.0, True, _lib.NEG_POPULARITY, _lib.MODE_HOGWILD)
+        tr.close()
+        sk, draws, _ = oracle.ldsbin_epoch(seed, 0, st["bins"], 75, indptr, indices, n_items, share=nnz / 1024.0, neg_pop=True)
+        assert draws == nnz and s == sk, (s, sk)
     out = {}
     for name, flags in (("passing", 0), ("fused", _lib.FORM_FUSED)):
         tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
