@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""prints the key numbers of bench.py JSON lines read from stdin (one per line)"""
+"""prints the key numbers of bench.py JSON lines (one per line) read from the files named on the command line, or from stdin"""
 import json
 import sys
 
-for line in sys.stdin:
+import fileinput
+
+for line in fileinput.input():
     if not line.startswith("{"):
         continue
     j = json.loads(line)
