@@ -1930,7 +1930,9 @@ static void ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t epoch, uint3
     d.key = key;
     d.n_items = (int32_t)h->n_items; d.n_bins = h->lb_bins; d.n_hot = h->lb_n_hot; d.n_hot_inter = h->lb_n_hot_inter;
     d.n_strata = h->lb_n_strata; d.hot_cost_x16 = h->lb_hot_cost_x16;
-    const unsigned grid = (unsigned)std::min<int64_t>(64, (h->n_items + kLbBlock - 1) / kLbBlock);
+    // (64 workgroups cover the resident regime's tables in one pass; the 10 M items of a passing-bin table took 0.5 ms of the
+    // 0.7 ms of per-epoch bookkeeping that way: up to 1024 workgroups)
+    const unsigned grid = (unsigned)std::min<int64_t>(h->lb_passing ? 1024 : 64, (h->n_items + kLbBlock - 1) / kLbBlock);
     hipLaunchKernelGGL(ldsbin_mass_kernel, dim3(grid), dim3(kLbBlock), 0, h->stream, d);
     hipLaunchKernelGGL(ldsbin_level_kernel, dim3(1), dim3(kLbBlock), 0, h->stream, d);
     HIP_CHECK(hipGetLastError());
