@@ -86,6 +86,21 @@ def test_every_pair_class_shares_a_bin_at_the_uniform_rate(deals):
         assert 0.75 <= together.var() / together.mean() <= 1.35, name
 
 
+def test_passing_bins_keep_the_uniform_pair_rate():
+    """the same deal with MANY bins (the passing-bin regime of large item tables, csrc/bpr.hip ldsbin_plan: thousands of bins
+    of ~100 rows, no hot items in a flat popularity): every pair class still shares a bin at the uniform rate 1 / bins"""
+    n_items, bins, n_keys = 50_000, 1024, 1500
+    rank_item, cptr, deg = _zipf_tables(n_items, 400_000, 0.2, seed=2)
+    where = _bins_over_keys(n_keys, 16, rank_item, cptr, 0, 0, n_items=n_items, bins=bins)
+    rs = np.random.RandomState(6)
+    for name, (x, y) in _pair_classes(rs, 6000, n_items=n_items, bins=bins).items():
+        assert len(x) >= 2000, name
+        together = (where[:, x] == where[:, y]).sum(axis=0)
+        rate = together.mean() / n_keys
+        assert abs(rate * bins - 1.0) <= 0.10, "%s: co-bin rate %.6f vs 1/bins = %.6f" % (name, rate, 1.0 / bins)
+        assert 0.75 <= together.var() / together.mean() <= 1.35, name
+
+
 def test_static_groups_would_exclude_their_own_pairs(deals):
     """strata_groups = 1 permutes inside single groups only, i.e. the round-3 deal: the pair-coverage test above must
     be able to see that defect."""
@@ -96,7 +111,7 @@ def test_static_groups_would_exclude_their_own_pairs(deals):
 
 
 @pytest.mark.parametrize("n_items,bins,groups", [(N_ITEMS, B, 16), (3003, 256, 16), (3003, 256, 4), (1000, 512, 16),
-                                                 (70_000, 1024, 8), (257, 256, 16), (256, 256, 2)])
+                                                 (70_000, 1024, 8), (257, 256, 16), (256, 256, 2), (300_000, 2816, 16)])
 def test_deal_is_a_partition_with_one_item_per_group_and_levelled_bins(n_items, bins, groups):
     rank_item, cptr, deg = _zipf_tables(n_items, 40 * n_items * 8, 0.7, seed=3)
     share = cptr[-1] / bins
