@@ -1027,14 +1027,14 @@ def _ring_tables(n_users, n_items, k, rank):
     return U0, V0, B0
 
 
-def _ring_worker(rank, world, port, out, kind, epochs, rings=1):
+def _ring_worker(rank, world, port, out, kind, epochs, rings=1, n_items=50):
     from cornac_amd.dist import RingShardedBprTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n_items, k = 50, 6
-        indptr, indices = _ring_data(rank)
+        k = 6
+        indptr, indices = _ring_data(rank, n_items=n_items)
         log = []
         if kind == "mark":
             factory = lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log)
@@ -1070,18 +1070,19 @@ def test_ring_conveyor_world2_every_rank_trains_every_block_once_per_epoch():
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("world,rings", [(2, 1), (3, 2), (4, 2)])
-def test_ring_conveyor_equals_its_serial_execution(world, rings):
+@pytest.mark.parametrize("world,rings,n_items", [(2, 1, 50), (3, 2, 50), (4, 2, 50), (8, 4, 200)])
+def test_ring_conveyor_equals_its_serial_execution(world, rings, n_items):
     """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
     disjoint item blocks, so the gloo ranks must produce bit for bit what ONE process gets by running the same (step,
     rank, ring) triples one after the other — item table, biases and every rank's user rows; and the model learns.
     world 3 with two rings: the blocks of ring 1 travel r -> r - 2 (the other direction of the links), both rings
-    advance in the same steps; world 4: strides 1 and 3."""
+    advance in the same steps; world 4: strides 1 and 3; world 8 with four rings (strides 1, 7, 3, 5: the configuration meant
+    for configs[4] on a node: 64 blocks, 16 steps per epoch, four blocks trained and four in flight per rank and step)."""
     from cornac_amd.dist import ring_strides, split_csr_by_item_block
 
-    epochs, n_items, k = 3, 50, 6
+    epochs, k = 3, 6
     out = mp.Manager().dict()
-    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs, rings), nprocs=world, join=True)
+    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs, rings, n_items), nprocs=world, join=True)
     # the serial execution
     strides = ring_strides(world, rings)
     K, nb = len(strides), 2 * world
@@ -1092,7 +1093,7 @@ def test_ring_conveyor_equals_its_serial_execution(world, rings):
     blocks = [(np.ascontiguousarray(V[b::nbt]), np.ascontiguousarray(B[b::nbt])) for b in range(nbt)]
     Us, trainers, nnz = [], [], []
     for rank in range(world):
-        indptr, indices = _ring_data(rank)
+        indptr, indices = _ring_data(rank, n_items=n_items)
         U = torch.as_tensor(_ring_tables(len(indptr) - 1, n_items, k, rank)[0].copy())
         Us.append(U)
         row = []
@@ -1123,8 +1124,8 @@ def test_ring_conveyor_equals_its_serial_execution(world, rings):
         assert len(steps) == epochs * nb * K and len(set(steps[: nb * K])) == nb * K, "every block of every ring once per epoch"
         assert np.array_equal(Vr, V) and np.array_equal(Br, B), "rank %d: the conveyor's table differs from the serial execution" % rank
         assert np.array_equal(Ur, Us[rank].numpy())
-        indptr, indices = _ring_data(rank)
-        assert _pairwise_accuracy(Ur, Vr, Br, indptr, indices, n_items) > 0.62
+        indptr, indices = _ring_data(rank, n_items=n_items)
+        assert _pairwise_accuracy(Ur, Vr, Br, indptr, indices, n_items) > (0.62 if n_items <= 50 else 0.55)
 
 
 def test_ring_strides():
