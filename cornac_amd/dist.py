@@ -1452,7 +1452,7 @@ def global_negative_population(indices_local, n_items, device=None, group=None, 
 
 
 def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
-                    trainer_factory=None, local_popularity=False, rule=None, regime="auto"):
+                    trainer_factory=None, local_popularity=False, rule=None, regime="auto", rings=1):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group (regime 1).  Every rank
     calls it with a model built from the same arguments and the SAME train_set; the users are cut into contiguous ranges
     of equal interaction counts, rank r trains its range in hogwild mode against its replica of the item table
@@ -1470,7 +1470,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     regime: "replicated" = this regime; "ring" = fit_bpr_ring; "auto" (default) = the ring where exchange_schedule would
     space the replicas' exchanges over several epochs (sparse item sides — where the replicas lag in mid-training,
     DESIGN.md 5), the replicas otherwise and whenever the caller fixes the replica protocol (sync_per_epoch, rule,
-    sparse_threshold, trainer_factory)."""
+    sparse_threshold, trainer_factory).  rings: strided rings of the conveyor (fit_bpr_ring)."""
     from . import _lib
     from .recommender import Recommender
 
@@ -1488,7 +1488,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
         per_rank = int(X0.nnz // max(world, 1)) + 1
         if regime == "ring" or exchange_schedule(per_rank, train_set.num_items)[1] > 1:
             if model._neg_population != _lib.NEG_POPULARITY or local_popularity or world == 1:
-                return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity)
+                return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity, rings=rings)
             if regime == "ring":
                 raise ValueError("the ring regime draws WBPR's negatives from the popularity of the rank's own users inside "
                                  "a block: pass local_popularity=True to accept that")
