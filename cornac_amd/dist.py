@@ -1097,6 +1097,9 @@ class _DeviceBlockTrainer:
         self.tr = _lib.BprTrainer(indptr, indices, n_users, n_rows, n_users, n_rows, k, device=device_index)
         self._bound = False
         self.U, self.stream = U, stream
+        # the handle's own user table goes at once (a rank has 2 N K such handles: 64 x 6.4 GB at configs[4] with four rings
+        # would not fit beside the shared one); its block-sized item tables follow at the first bind_items
+        self.tr.bind_device(self.U.data_ptr(), None, None)
 
     def seed_hogwild(self, seed):
         self.tr.seed_hogwild(seed)
