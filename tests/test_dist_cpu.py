@@ -1213,3 +1213,40 @@ def test_global_negative_population_world2():
         assert len(small) <= 600 and ((hs > 0) == (deg > 0)).all()
         assert np.abs(hs / hs.sum() - deg / deg.sum()).max() < 0.01
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def _ring_sparse_worker(rank, world, port, out):
+    from cornac_amd.dist import RingShardedBprTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_items, k = 40, 3
+        indptr, indices = _ring_data(rank, n_users=30, n_items=n_items, per_user=6)
+        if rank == 1:   # rank 1's users only ever touched items of blocks 0 and 2 (item % 4 in {0, 2})
+            keep = indices % 2 == 0
+            counts = np.add.reduceat(keep.astype(np.int64), indptr[:-1])
+            indptr, indices = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), indices[keep]
+        log = []
+        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), seed=1,
+                                     trainer_factory=lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log))
+        assert [tr is None for tr in ring.trainers] == ([False] * 4 if rank == 0 else [False, True, False, True])
+        ring.load_items(np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32))
+        for _ in range(2):
+            ring.run_epoch(0.05, 0.01)
+        ring.finish()
+        out[rank] = ring.gather() + (log,)
+        ring.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ring_conveyor_with_blocks_a_rank_has_no_interactions_in():
+    """a rank whose users never touched a block still receives it, holds it for its step and passes it on untouched"""
+    out = mp.Manager().dict()
+    mp.spawn(_ring_sparse_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (V0, B0, log0), (V1, B1, log1) = out[0], out[1]
+    assert np.array_equal(V0, V1) and np.array_equal(B0, B1)
+    assert sorted(set(log1)) == [0, 2] and sorted(set(log0)) == [0, 1, 2, 3]
+    want = np.where(np.arange(40) % 2 == 0, 2 * (1.0 + 2.0), 2 * 1.0)   # even blocks: both ranks, odd blocks: rank 0 only
+    assert np.allclose(V0, want[:, None]) and np.allclose(B0, 10.0 * want)
