@@ -1090,11 +1090,14 @@ class _DeviceBlockTrainer:
     """one item block's cornac_hip BPR handle: the rank's interactions with the block's items in block-local ids, the user
     table shared with the other blocks' handles, the item tables rebound to wherever the block's buffer is"""
 
-    def __init__(self, indptr, indices, n_users, n_rows, k, U, stream, device_index):
+    def __init__(self, indptr, indices, n_users, n_rows, k, U, stream, device_index, n_train=None):
         from . import _lib
 
         self.nnz = len(indices)
-        self.tr = _lib.BprTrainer(indptr, indices, n_users, n_rows, n_users, n_rows, k, device=device_index)
+        # n_train: the block's TRAIN items (a prefix of its rows: item i of the block is row i // blocks) — negatives are drawn
+        # among them only, like neg_item_ids = arange(train_set.num_items) in the reference (recom_bpr.pyx:156)
+        self.tr = _lib.BprTrainer(indptr, indices, n_users, n_rows if n_train is None else n_train, n_users, n_rows, k,
+                                  device=device_index)
         self._bound = False
         self.U, self.stream = U, stream
         # the handle's own user table goes at once (a rank has 2 N K such handles: 64 x 6.4 GB at configs[4] with four rings
@@ -1103,6 +1106,9 @@ class _DeviceBlockTrainer:
 
     def seed_hogwild(self, seed):
         self.tr.seed_hogwild(seed)
+
+    def set_negative_population(self, items):
+        self.tr.set_negative_population(items)
 
     def bind_items(self, V, B):
         if not self._bound:   # first time: also hands the handle the shared user table and the driver's stream (synchronises)
@@ -1184,7 +1190,9 @@ class RingShardedBprTrainer:
     memory traffic and dependency chain."""
 
     def __init__(self, indptr, indices, n_users, n_items, k, device, group=None, trainer_factory=None, seed=0,
-                 emulate_traffic=False, rings=1):
+                 emulate_traffic=False, rings=1, n_train_items=None):
+        """n_items: rows of the item table (the model's total_items); n_train_items (default: all of them): the items a
+        negative may be — ids below it, as the reference draws negatives among the train items only"""
         self.device, self.group, self.k = device, group, int(k)
         self.world, self.rank = _world(group)
         self.strides = ring_strides(self.world, rings)
@@ -1196,6 +1204,8 @@ class RingShardedBprTrainer:
             raise ValueError("%d items cannot be cut into %d blocks" % (self.n_items, self.nb_total))
         self.rows_max = (self.n_items + self.nb_total - 1) // self.nb_total
         self.rows = [(self.n_items - B + self.nb_total - 1) // self.nb_total for B in range(self.nb_total)]
+        n_train = self.n_items if n_train_items is None else int(n_train_items)
+        self.rows_train = [max(0, (n_train - B + self.nb_total - 1) // self.nb_total) for B in range(self.nb_total)]
         # position of this rank on ring g: the rank it hands to (rank - s_g) has position - 1
         self.pos = [(self.rank * pow(s, -1, self.world)) % self.world if self.world > 1 else 0 for s in self.strides]
         cuda = device.type == "cuda"
@@ -1218,11 +1228,23 @@ class RingShardedBprTrainer:
             if trainer_factory is not None:
                 tr = trainer_factory(B, ip, ix, self.n_users, self.rows[B], self.k, self.U)
             else:
-                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[B], self.k, self.U, self.stream, device.index or 0)
+                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[B], self.k, self.U, self.stream, device.index or 0,
+                                         n_train=self.rows_train[B])
             tr.nnz = len(ix)
+            tr.n_train = self.rows_train[B]
             tr.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 104729 * B + 1) & 0xFFFFFFFFFFFFFFFF)
             self.trainers.append(tr)
         self.nnz = int(sum(tr.nnz for tr in self.trainers if tr is not None))
+
+    def set_negative_population(self, global_degrees):
+        """WBPR over ranks: the popularity-weighted negative of a draw comes from the block being trained, weighted by the
+        GLOBAL item degrees (recom_wbpr.pyx:135 weights by the degrees of the whole matrix) — every block handle gets the
+        population of its own items, item i of the block (row i // blocks) repeated degree(i) times"""
+        deg = np.asarray(global_degrees, np.int64)
+        for B, tr in enumerate(self.trainers):
+            if tr is None:
+                continue
+            tr.set_negative_population(population_from_degrees(deg[B:: self.nb_total][: self.rows_train[B]], at_most=1 << 24))
 
     def block_id(self, g, b):
         """global block (= item residue class mod nb_total) of ring g's block b"""
@@ -1439,19 +1461,31 @@ def _sum_over_ranks(values, device, group):
     return [float(x) for x in t.cpu()]
 
 
-def global_negative_population(indices_local, n_items, device=None, group=None, at_most=1 << 26):
-    """WBPR's negative population over all ranks (recom_wbpr.pyx:135: neg_item_ids = X.indices of the WHOLE matrix): the
-    ranks all-reduce their item degrees — n_items counts, 107 KB at the ML-20M shape — and every rank builds the same
-    multiset, item i repeated degree(i) times (scaled to at most `at_most` entries, every interacted item at least once)"""
+def global_item_degrees(indices_local, n_items, device=None, group=None):
+    """item degrees of the WHOLE matrix: the ranks all-reduce the degrees among their own users (n_items counts — 107 KB at
+    the ML-20M shape)"""
     deg = torch.as_tensor(np.bincount(np.asarray(indices_local, np.int64), minlength=int(n_items)).astype(np.int64))
     if _world(group)[0] > 1:
         deg = deg.to(_comm_device(device, group))
         dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
-    deg = deg.cpu().numpy()
+    return deg.cpu().numpy()
+
+
+def population_from_degrees(deg, at_most=1 << 26):
+    """the multiset a popularity-weighted draw picks from: id i repeated deg[i] times, scaled down to at most `at_most`
+    entries (every id with a positive degree at least once)"""
+    deg = np.asarray(deg, np.int64)
     total = int(deg.sum())
     if total > at_most:
         deg = np.where(deg > 0, np.maximum(1, np.rint(deg * (float(at_most) / total)).astype(np.int64)), 0)
-    return np.repeat(np.arange(int(n_items), dtype=np.int32), deg)
+    return np.repeat(np.arange(len(deg), dtype=np.int32), deg)
+
+
+def global_negative_population(indices_local, n_items, device=None, group=None, at_most=1 << 26):
+    """WBPR's negative population over all ranks (recom_wbpr.pyx:135: neg_item_ids = X.indices of the WHOLE matrix): every
+    rank builds the same multiset from the all-reduced item degrees, item i repeated degree(i) times (scaled to at most
+    `at_most` entries, every interacted item at least once)"""
+    return population_from_degrees(global_item_degrees(indices_local, n_items, device, group), at_most)
 
 
 def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=None, sparse_threshold=None,
@@ -1490,11 +1524,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
         X0 = train_set.matrix
         per_rank = int(X0.nnz // max(world, 1)) + 1
         if regime == "ring" or exchange_schedule(per_rank, train_set.num_items)[1] > 1:
-            if model._neg_population != _lib.NEG_POPULARITY or local_popularity or world == 1:
-                return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity, rings=rings)
-            if regime == "ring":
-                raise ValueError("the ring regime draws WBPR's negatives from the popularity of the rank's own users inside "
-                                 "a block: pass local_popularity=True to accept that")
+            return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity, rings=rings)
     Recommender.fit(model, train_set)
     model._init()
     if model.trains_float64:
@@ -1565,17 +1595,14 @@ def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None
     by row and rotating around the ring (regime 2, RingShardedBprTrainer): the same calling convention and restrictions as
     fit_bpr_sharded, no replica and no reconciliation rule — every item row is in one place at any time, so the result
     is the serial execution of the ranks' steps.  The memory an item table needs per rank is 3 / (2 N) of it.
-    WBPR's negatives follow the popularity of the rank's OWN users inside the block being trained (local_popularity=True to
-    accept that over more than one rank)."""
+    WBPR: a draw's popularity-weighted negative comes from the block being trained, weighted by the GLOBAL item degrees (the
+    ranks all-reduce them; local_popularity=True: by the degrees among the rank's own users)."""
     from . import _lib
     from .recommender import Recommender
 
     if model.effective_mode != "hogwild":
         raise ValueError("sequential (seeded, mode=None) semantics do not shard: build the model with mode='hogwild'")
     world, rank = _world(group)
-    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
-        raise ValueError("WBPR's popularity-weighted negatives would follow each rank's own users, not the global item "
-                         "popularity of recom_wbpr.pyx:135: pass local_popularity=True to accept that")
     device = device if device is not None else torch.device("cpu")
     Recommender.fit(model, train_set)
     model._init()
@@ -1593,8 +1620,14 @@ def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
     lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
     ring = RingShardedBprTrainer(indptr, indices, u1 - u0, model.total_items, model.k, device, group=group,
-                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo, rings=rings)
+                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo, rings=rings,
+                                 n_train_items=train_set.num_items)
     try:
+        if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+            # the popularity of the WHOLE matrix (the ranks all-reduce their item degrees), block by block
+            deg = np.zeros(model.total_items, np.int64)
+            deg[: train_set.num_items] = global_item_degrees(indices, train_set.num_items, device, group)
+            ring.set_negative_population(deg)
         ring.set_user_factors(model.u_factors[u0:u1])
         ring.load_items(model.i_factors, model.i_biases)
         for _ in range(model.max_iter):

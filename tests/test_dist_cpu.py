@@ -1164,8 +1164,21 @@ def _fit_ring_worker(rank, world, port, out):
         out[rank] = dict(U=bpr.u_factors.copy(), V=bpr.i_factors.copy(), B=bpr.i_biases.copy(), stats=bpr.fit_stats)
         with pytest.raises(ValueError):
             fit_bpr_ring(ca.BPR(k=4, seed=1), ds)   # seeded => sequential semantics do not shard
-        with pytest.raises(ValueError):
-            fit_bpr_ring(ca.WBPR(k=4, mode="hogwild"), ds)   # global popularity over > 1 rank has to be waived explicitly
+        # WBPR: every block trainer is handed the GLOBAL degrees of its own items as the negative population
+        pops = {}
+
+        class _Pop(_RingOracleTrainer):
+            def __init__(self, b, *a):
+                super().__init__(*a)
+                self.b = b
+
+            def set_negative_population(self, items):
+                pops[self.b] = np.bincount(items, minlength=self.n_rows)
+
+        fit_bpr_ring(ca.WBPR(k=4, max_iter=1, mode="hogwild", seed=rank),
+                     ds, trainer_factory=lambda b, ip, ix, nu, rows, k, U: _Pop(b, ip, ix, rows, k, U))
+        deg = np.bincount(ds.matrix.indices, minlength=ds.num_items)
+        assert sorted(pops) == [0, 1, 2, 3] and all(np.array_equal(pops[b][: len(deg[b::4])], deg[b::4]) for b in pops)
     finally:
         dist.destroy_process_group()
 
