@@ -702,41 +702,45 @@ def leg_dist_tax(args, _lib):
         # one rank 2 blocks, a handle per block, and the trained block copied to the free buffer on the communication
         # stream beside the next step's launch (what a neighbour's receive writes on a node: table / 2 N per step)
         if "scale" in out and os.environ.get("CORNAC_BENCH_RING", "1") != "0":
-            from cornac_amd.dist import RingShardedBprTrainer
+            try:
+                from cornac_amd.dist import RingShardedBprTrainer
 
-            nu, ni, indptr, indices = scale_slice(0)
-            k, epochs = SCALE["k"], 4
-            U, V, B = scale_factors(nu, ni, k, 0)
-            t0 = time.time()
-            ring = RingShardedBprTrainer(indptr, indices, nu, ni, k, dev, seed=11, emulate_traffic=True)
-            ring.set_user_factors(U)
-            ring.load_items(V, B)
-            del U, V, B
-            ring.run_epoch(args.lr, args.reg)
-            ring.finish()
-            t_setup = time.time() - t0
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(epochs):
+                nu, ni, indptr, indices = scale_slice(0)
+                k, epochs = SCALE["k"], 4
+                U, V, B = scale_factors(nu, ni, k, 0)
+                t0 = time.time()
+                ring = RingShardedBprTrainer(indptr, indices, nu, ni, k, dev, seed=11, emulate_traffic=True)
+                ring.set_user_factors(U)
+                ring.load_items(V, B)
+                del U, V, B
                 ring.run_epoch(args.lr, args.reg)
-            c, s = ring.finish()
-            torch.cuda.synchronize()
-            driven = (time.perf_counter() - t0) / epochs
-            forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
-            plain = out["scale"]["plain_ms_per_epoch"] / 1e3
-            out["scale_ring"] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
-                                 "tax": 1.0 - plain / driven, "protocol": "ring conveyor of item blocks (regime 2): %d steps per "
-                                 "epoch, one launch each, %.0f MB copied per step on the communication stream"
-                                 % (ring.nb, ring.bufs[0][0].numel() * 4 / 1e6),
-                                 "blocks": ring.nb, "block_forms": [{"bins": f["bins"], "rows_per_bin": f["rows_per_bin"],
-                                                                     "block_threads": f["block_threads"]} for f in forms],
-                                 "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
-                                 "correct_frac": c / max(ring.nnz * epochs - s, 1), "setup_s": t_setup,
-                                 "workload": out["scale"]["workload"]}
-            ring.close()
-            del ring
-            torch.cuda.empty_cache()
-        out["value"] = max(v["tax"] for v in out.values() if isinstance(v, dict))
+                ring.finish()
+                t_setup = time.time() - t0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(epochs):
+                    ring.run_epoch(args.lr, args.reg)
+                c, s = ring.finish()
+                torch.cuda.synchronize()
+                driven = (time.perf_counter() - t0) / epochs
+                forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
+                plain = out["scale"]["plain_ms_per_epoch"] / 1e3
+                out["scale_ring"] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
+                                     "tax": 1.0 - plain / driven, "protocol": "ring conveyor of item blocks (regime 2): %d steps per "
+                                     "epoch, one launch each, %.0f MB copied per step on the communication stream"
+                                     % (ring.nb, ring.bufs[0][0].numel() * 4 / 1e6),
+                                     "blocks": ring.nb, "block_forms": [{"bins": f["bins"], "rows_per_bin": f["rows_per_bin"],
+                                                                         "block_threads": f["block_threads"]} for f in forms],
+                                     "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
+                                     "correct_frac": c / max(ring.nnz * epochs - s, 1), "setup_s": t_setup,
+                                     "workload": out["scale"]["workload"]}
+                ring.close()
+                del ring
+                torch.cuda.empty_cache()
+            except Exception as e:  # (the other shapes of the leg stay in the line)
+                print("[bench] dist_tax scale_ring failed: %r" % (e,), file=sys.stderr)
+                out["scale_ring"] = {"error": repr(e)}
+        out["value"] = max(v["tax"] for v in out.values() if isinstance(v, dict) and "tax" in v)
     finally:
         close()
     return out
