@@ -629,6 +629,59 @@ def _one_rank_group():
     return dist.destroy_process_group
 
 
+CONVEYOR_SAMPLING = ("every draw picks an interaction with probability 1 / nnz (nnz draws per rank and epoch, each by the rank that "
+                     "owns its user); the negative is uniform over the ~%d items sharing the positive's LDS bin in that epoch; the "
+                     "bins — and the conveyor's blocks, which are ranges of %d bins — are re-dealt from ALL items every epoch with a "
+                     "key the ranks share (rows move to their new slots in one all_to_all at the epoch boundary), so every item "
+                     "pair can meet (csrc/bpr_ldsbin.inc, tests/test_dist_cpu.py::test_conveyor_blocks_are_redealt...); item-row "
+                     "updates exact (LDS read-modify-write under a row lock), user rows by fp32 atomics; no hot-item path")
+
+
+def conveyor_one_rank(args, torch, dev, rings, epochs, plain_s=None, virtual_world=8):
+    """the configs[4] slice through BinConveyorBprTrainer on ONE rank laid out like a node of `virtual_world` ranks: per-step launch,
+    per-step block copy (communication stream), per-epoch re-deal — each timed with events on its own stream"""
+    from cornac_amd.dist import BinConveyorBprTrainer
+
+    nu, ni, indptr, indices = scale_slice(0)
+    k = SCALE["k"]
+    U, V, B = scale_factors(nu, ni, k, 0)
+    t0 = time.time()
+    ring = BinConveyorBprTrainer(indptr, indices, nu, ni, k, dev, seed=11, emulate_traffic=True, rings=rings, virtual_world=virtual_world)
+    ring.set_user_factors(U)
+    ring.load_items(V, B)
+    del U, V, B
+    ring.run_epoch(args.lr, args.reg)
+    ring.finish()
+    t_setup = time.time() - t0
+    mem = torch.cuda.memory_allocated(dev)
+    ring.timing = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        ring.run_epoch(args.lr, args.reg)
+    c, s = ring.finish()
+    torch.cuda.synchronize()
+    driven = (time.perf_counter() - t0) / epochs
+    ev = ring.timing_summary()
+    st = ring.trainer.tr.ldsbin_stats()
+    out = {"driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
+           "protocol": "conveyor laid out for %d ranks on one: %d blocks of %d bins on %d ring(s), %d steps per epoch, ONE launch per "
+                       "step over %d bin range(s), %.0f MB copied per step on the communication stream, rows re-dealt every epoch"
+                       % (virtual_world, ring.nb_total, ring.bpb, ring.K, ring.nb, ring.K, ring.K * ring.bufs[0][0].numel() * 4 / 1e6),
+           "blocks": ring.nb_total, "bins": ring.n_bins, "rows_per_bin": ring.cap, "block_threads": st["block_threads"],
+           "launch_ms": ev["launch"][1], "launches": ev["launch"][0], "move_ms": ev["move"][1], "redeal_ms": ev["redeal"][1],
+           "redeals": ev["redeal"][0], "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
+           "correct_frac": c / max(ring.nnz * epochs - s, 1), "lock_timeouts": st["lock_timeouts"], "setup_s": t_setup,
+           "torch_bytes_allocated": int(mem), "sampling": CONVEYOR_SAMPLING % (ring.cap, ring.bpb)}
+    if plain_s is not None:
+        out["plain_ms_per_epoch"] = 1e3 * plain_s
+        out["tax"] = 1.0 - plain_s / driven
+    ring.close()
+    del ring
+    torch.cuda.empty_cache()
+    return out
+
+
 def leg_dist_tax(args, _lib):
     """What the multi-GPU driver costs BEFORE a second GPU is involved: one rank through RCCL (process group of one, the
     replicated item table bound to the handle, delta passes, all-reduce, overlapped schedule) next to the plain
@@ -698,45 +751,15 @@ def leg_dist_tax(args, _lib):
                           "protocol": "resident exchange (one launch per epoch)" if resident else "chunk launches",
                           "triplets_per_s_plain": nnz / plain, "triplets_per_s_driver": nnz / driven,
                           "workload": "%d users x %d items, %d interactions, k = %d" % (nu, ni, nnz, k)}
-        # regime 2 at the configs[4] slice: the item table as 2 N blocks on a ring (cornac_amd.dist.RingShardedBprTrainer) — on
-        # one rank 2 blocks, a handle per block, and the trained block copied to the free buffer on the communication
-        # stream beside the next step's launch (what a neighbour's receive writes on a node: table / 2 N per step)
+        # regime 2 at the configs[4] slice: the conveyor (cornac_amd.dist.BinConveyorBprTrainer) laid out for EIGHT ranks on this
+        # one — 16 blocks (bin ranges of the epoch's deal), a step = one launch over a sixteenth of the bins, exactly a node
+        # rank's launch size; the trained block is copied to the free buffer on the communication stream beside the next
+        # step's launch (what a neighbour's receive writes on a node: table / 16 per step), and the rows are re-dealt to the
+        # next epoch's slots at every epoch boundary (on a node: one all_to_all of table / 8 per rank)
         if "scale" in out and os.environ.get("CORNAC_BENCH_RING", "1") != "0":
             try:
-                from cornac_amd.dist import RingShardedBprTrainer
-
-                nu, ni, indptr, indices = scale_slice(0)
-                k, epochs = SCALE["k"], 4
-                U, V, B = scale_factors(nu, ni, k, 0)
-                t0 = time.time()
-                ring = RingShardedBprTrainer(indptr, indices, nu, ni, k, dev, seed=11, emulate_traffic=True)
-                ring.set_user_factors(U)
-                ring.load_items(V, B)
-                del U, V, B
-                ring.run_epoch(args.lr, args.reg)
-                ring.finish()
-                t_setup = time.time() - t0
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(epochs):
-                    ring.run_epoch(args.lr, args.reg)
-                c, s = ring.finish()
-                torch.cuda.synchronize()
-                driven = (time.perf_counter() - t0) / epochs
-                forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
-                plain = out["scale"]["plain_ms_per_epoch"] / 1e3
-                out["scale_ring"] = {"plain_ms_per_epoch": 1e3 * plain, "driver_ms_per_epoch": 1e3 * driven, "epochs_timed": epochs,
-                                     "tax": 1.0 - plain / driven, "protocol": "ring conveyor of item blocks (regime 2): %d steps per "
-                                     "epoch, one launch each, %.0f MB copied per step on the communication stream"
-                                     % (ring.nb, ring.bufs[0][0].numel() * 4 / 1e6),
-                                     "blocks": ring.nb, "block_forms": [{"bins": f["bins"], "rows_per_bin": f["rows_per_bin"],
-                                                                         "block_threads": f["block_threads"]} for f in forms],
-                                     "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
-                                     "correct_frac": c / max(ring.nnz * epochs - s, 1), "setup_s": t_setup,
-                                     "workload": out["scale"]["workload"]}
-                ring.close()
-                del ring
-                torch.cuda.empty_cache()
+                out["scale_ring"] = conveyor_one_rank(args, torch, dev, rings=1, epochs=4, plain_s=out["scale"]["plain_ms_per_epoch"] / 1e3)
+                out["scale_ring"]["workload"] = out["scale"]["workload"]
             except Exception as e:  # (the other shapes of the leg stay in the line)
                 print("[bench] dist_tax scale_ring failed: %r" % (e,), file=sys.stderr)
                 out["scale_ring"] = {"error": repr(e)}
@@ -760,17 +783,22 @@ def self_launch(args):
 
 
 def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
-    """`--config scale` over a process group: configs[4] as the ring conveyor of item blocks (cornac_amd.dist.
-    RingShardedBprTrainer — every rank its own 12.5 M users, the 10 M x k item table cut into 2 N blocks that rotate; a step
-    = one epoch = 2 N launches per rank, each beside the previous block's transfer).  Same JSON contract; the roofline block
-    is the whole step's algorithmic bytes over its wall time (there is one handle per block: no single kernel's events)."""
-    from cornac_amd.dist import RingShardedBprTrainer
+    """`--config scale` over a process group: configs[4] as the ring conveyor (cornac_amd.dist.BinConveyorBprTrainer — every rank
+    its own 12.5 M users, the 10 M x k item table as 2 N K blocks = bin ranges of the epoch's deal that rotate over K strided
+    rings; a bench step = one epoch = 2 N launches per rank, each beside the previous blocks' transfer, plus the re-deal of the
+    rows at the boundary).  Same JSON contract; the roofline block prices the launches (HIP events on the compute stream)."""
+    from cornac_amd.dist import BinConveyorBprTrainer
 
     n_users, n_items, indptr, indices = scale_slice(rank)
     nnz = len(indices)
     U, V, B = scale_factors(n_users, n_items, k, rank)
     t0 = time.time()
-    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=0xC0FFEE, emulate_traffic=(world == 1), rings=args.rings)
+    # the popularity order of the WHOLE matrix: every rank must deal the same items to the same bins
+    from cornac_amd.dist import global_item_degrees
+
+    order = np.argsort(-global_item_degrees(indices, n_items, dev, None), kind="stable").astype(np.int32)
+    ring = BinConveyorBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=0xC0FFEE, emulate_traffic=(world == 1), rings=args.rings,
+                                 item_order=order, virtual_world=(args.virtual_world or None) if world == 1 else None)
     ring.set_user_factors(U)
     ring.load_items(V, B)
     del U, V, B
@@ -778,6 +806,7 @@ def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
     for _ in range(args.warmup):
         ring.run_epoch(args.lr, args.reg)
     ring.finish()
+    ring.timing = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -788,27 +817,38 @@ def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    forms = [tr.tr.ldsbin_stats() for tr in ring.trainers if tr is not None]
+    ev = ring.timing_summary()
+    st = ring.trainer.tr.ldsbin_stats()
     if rank == 0:
         b_full, b_skip = algorithmic_bytes_per_triplet(k, nnz / n_users)
         skip = skipped / float(nnz * args.steps)
-        gbs = nnz * ((1 - skip) * b_full + skip * b_skip) * args.steps / elapsed / 1e9   # rank 0's share of the job
+        step_bytes = nnz * ((1 - skip) * b_full + skip * b_skip)                        # rank 0's share of one epoch
+        gbs = step_bytes * args.steps / elapsed / 1e9
+        launch_s = ev["launch"][1] / 1e3
         out = {"metric": "bpr_triplets_per_sec", "value": float(nnz) * args.steps * world / elapsed, "unit": "triplets/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BPR k=%d on one GPU's user slice per rank of the 100 M x 10 M synthetic (%d users x %d items, "
                                       "%d interactions per GPU), hogwild mode, fp32 tables resident in HBM"
                                       % (k, n_users, n_items, nnz), "k": k, "lr": args.lr, "reg": args.reg,
-                          "form": "ldsbin (passing bins) per item block" if forms and forms[0]["bins"] else "per item block: automatic",
-                          "parallelism": "user-partitioned dp%d, item table sharded by row into %d blocks on %d ring(s) (regime 2, "
-                                         "RingShardedBprTrainer): a step = %d launches per rank, each beside the transfer of the "
-                                         "previously trained block(s) (%.0f MB each) to the next rank%s"
-                                         % (world, ring.nb_total, ring.K, ring.nb * ring.K, ring.bufs[0][0].numel() * 4 / 1e6,
+                          "form": "ldsbin (passing bins), conveyor layout: %d bins of <= %d rows" % (ring.n_bins, ring.cap),
+                          "sampling": CONVEYOR_SAMPLING % (ring.cap, ring.bpb),
+                          "parallelism": "user-partitioned dp%d, item table sharded by row into %d blocks (bin ranges of the epoch's "
+                                         "deal) on %d ring(s) (regime 2, BinConveyorBprTrainer): an epoch = %d steps per rank, a step = "
+                                         "ONE launch over %d bin range(s) beside the transfer of the previously trained block(s) "
+                                         "(%.0f MB each) to the next rank%s; rows re-dealt at every epoch boundary"
+                                         % (world, ring.nb_total, ring.K, ring.nb, ring.K, ring.bufs[0][0].numel() * 4 / 1e6,
                                             " — one rank: the block is copied on the communication stream instead" if world == 1 else "")},
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None, "kernel": "bpr_ldsbin_kernel<2,4> per item block (whole step: bytes / wall time)",
+                            "traffic": None, "kernel": "bpr_ldsbin_kernel<2,4> over a block's bins (frac: the whole epoch's bytes / "
+                                                       "wall time, transfers and the re-deal included)",
+                            "frac_kernel_only": (step_bytes / ring.nb / launch_s / 1e9 / HBM_PEAK_GBS) if launch_s else None,
+                            "avg_launch_ms": ev["launch"][1], "launches": ev["launch"][0],
                             "algorithmic_bytes_per_triplet": b_full},
-               "train_stats": {"correct_frac": correct / max(nnz * args.steps - skipped, 1.0), "skipped_frac": skip},
+               "per_step": {"launch_ms": ev["launch"][1], "transfer_ms": ev["move"][1], "redeal_ms_per_epoch": ev["redeal"][1],
+                            "steps_per_epoch": ring.nb, "transfer_MB": ring.K * ring.bufs[0][0].numel() * 4 / 1e6},
+               "train_stats": {"correct_frac": correct / max(nnz * args.steps - skipped, 1.0), "skipped_frac": skip,
+                               "lock_timeouts": st["lock_timeouts"]},
                "host_s": {"setup": t_setup}, "cpu_baseline": None}
         print(json.dumps(out))
     ring.close()
@@ -895,6 +935,8 @@ def main():
                          "even where the resident exchange (one launch per epoch) is available")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the multi-GPU code path (process group, bound item table, all-reduce) with 1 rank")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="--config scale on ONE rank: lay the conveyor out for this many ranks (a node rank's launch size)")
     ap.add_argument("--rings", type=int, default=1,
                     help="--config scale over ranks: the conveyor's item blocks ride this many strided rings at once (different "
                          "xGMI links; 4 at N = 8), each moving a K-th of a step's bytes")

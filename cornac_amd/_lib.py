@@ -29,7 +29,7 @@ SYMBOLS = [
     "cornac_hip_last_error", "cornac_hip_version", "cornac_hip_device_count", "cornac_hip_device_info",
     "cornac_hip_device_probe",
     "cornac_hip_bpr_create", "cornac_hip_bpr_destroy", "cornac_hip_bpr_set_factors", "cornac_hip_bpr_get_factors",
-    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_rebind_items", "cornac_hip_bpr_set_negative_population", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
+    "cornac_hip_bpr_bind_device", "cornac_hip_bpr_rebind_items", "cornac_hip_bpr_conveyor_setup", "cornac_hip_bpr_conveyor_layout", "cornac_hip_bpr_conveyor_enqueue", "cornac_hip_bpr_set_negative_population", "cornac_hip_bpr_device_ptrs", "cornac_hip_bpr_set_stream",
     "cornac_hip_bpr_seed_mt19937", "cornac_hip_bpr_seed_hogwild", "cornac_hip_bpr_fit_epochs",
     "cornac_hip_bpr_set_factors_f64", "cornac_hip_bpr_get_factors_f64", "cornac_hip_bpr_fit_epochs_f64",
     "cornac_hip_bpr_hogwild_enqueue", "cornac_hip_bpr_sync", "cornac_hip_bpr_debug_draw",
@@ -138,6 +138,11 @@ def lib():
         L.cornac_hip_bpr_get_factors.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_bind_device.argtypes = [_vp, _vp, _vp, _vp]
         L.cornac_hip_bpr_rebind_items.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_bpr_conveyor_setup.argtypes = [_vp, C.c_int, _vp, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                    C.POINTER(C.c_int)]
+        L.cornac_hip_bpr_conveyor_layout.argtypes = [_vp, C.c_uint32, _vp, _vp]
+        L.cornac_hip_bpr_conveyor_enqueue.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int32), C.POINTER(_vp),
+                                                      C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         L.cornac_hip_bpr_set_negative_population.argtypes = [_vp, _vp, C.c_int64]
         L.cornac_hip_bpr_device_ptrs.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
         L.cornac_hip_bpr_set_stream.argtypes = [_vp, _vp]
@@ -407,6 +412,27 @@ class BprTrainer:
     def rebind_items(self, dV, dB):
         """swap the bound (caller-owned) item tables without synchronising the handle's stream"""
         check(lib().cornac_hip_bpr_rebind_items(self.h, dV, dB))
+
+    # ---- conveyor layout (multi-GPU regime 2; cornac_amd/dist.py BinConveyorBprTrainer) ----------------------
+    def conveyor_setup(self, n_blocks, rank_item=None, deal_seed=0, release_item_tables=True):
+        """-> (n_bins, bins_per_block, cap): see include/cornac_hip.h"""
+        order = None if rank_item is None else np.ascontiguousarray(rank_item, np.int32)
+        nb, bpb, cap = C.c_int(), C.c_int(), C.c_int()
+        check(lib().cornac_hip_bpr_conveyor_setup(self.h, int(n_blocks), None if order is None else order.ctypes.data,
+                                                  int(deal_seed) & 0xFFFFFFFFFFFFFFFF, int(bool(release_item_tables)),
+                                                  C.byref(nb), C.byref(bpb), C.byref(cap)))
+        return nb.value, bpb.value, cap.value
+
+    def conveyor_layout(self, layout_epoch, d_slot_item, d_item_slot):
+        check(lib().cornac_hip_bpr_conveyor_layout(self.h, int(layout_epoch), d_slot_item, d_item_slot))
+
+    def conveyor_enqueue(self, epoch, layout_epoch, first_blocks, d_rows, lr, reg, use_bias=True, neg_population=NEG_UNIFORM,
+                         flags=0):
+        n = len(first_blocks)
+        fb = (C.c_int32 * n)(*[int(b) for b in first_blocks])
+        rows = (_vp * n)(*[int(p) for p in d_rows])
+        check(lib().cornac_hip_bpr_conveyor_enqueue(self.h, int(epoch), int(layout_epoch), n, fb, rows, lr, reg, int(use_bias),
+                                                    neg_population, int(flags)))
 
     def device_ptrs(self):
         u, v, b = _vp(), _vp(), _vp()

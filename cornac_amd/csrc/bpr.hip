@@ -750,6 +750,13 @@ struct cornac_hip_bpr {
     size_t lb_lds_bytes = 0;
     bool lb_attr_set = false;
     int64_t lb_lock_timeouts = 0;
+    // conveyor layout of the LDS-bin form (multi-GPU regime 2; cornac_hip_bpr_conveyor_setup): cv_blocks != 0 — the bins are
+    // planned as cv_blocks equal ranges (the conveyor's item blocks), no hot items, the deal keyed by cv_deal_seed (shared
+    // by the ranks of a fit, unlike hog_seed) over cv_rank_item (the popularity order all ranks agree on)
+    int cv_blocks = 0;
+    uint64_t cv_deal_seed = 0;
+    bool cv_own_order = false;
+    DevBuf<int32_t> cv_rank_item;
     // binned item updates (bpr_binned.inc): item -> (bucket, local row), bucket -> items, message segments
     int bin_buckets = 0, bin_neg_population = -1, bin_max_rows = 0, bin_wg_per_cu = 0, bin_n_hot = 0;
     int bin_hot_threshold = 0;
@@ -1780,6 +1787,32 @@ struct LbPlan {
 static LbPlan ldsbin_plan(cornac_hip_bpr_t h) {
     LbPlan pl;
     const int cus = device_info(h->device).cus;
+    if (h->cv_blocks) {
+        // conveyor layout: passing bins (8-wave workgroups, <= lb_pass_kb of LDS), their number a multiple of the block count.
+        // As few rows per bin as lb_min_candidates allows while a block still has few bins (a step launches one block per
+        // ring: small tables get more, smaller bins so that the step fills more CUs), never more rows than the LDS holds.
+        if (h->k > 256) return pl;
+        const int waves = h->lb_pass_waves;
+        const size_t budget = (size_t)h->lb_pass_kb << 10;
+        const int kp = ((h->k + kWave - 1) / kWave) * kWave;
+        const size_t fixed = sizeof(float) + (size_t)waves * 3 * kWave * sizeof(int32_t);
+        if (budget <= fixed) return pl;
+        const int64_t cap_lds = (int64_t)((budget - fixed) / ((size_t)(kp + 5) * sizeof(float)));
+        const int64_t cap_min = std::max<int64_t>(h->lb_min_candidates, 16);
+        if (cap_lds < cap_min) return pl;
+        int64_t bins = (h->n_items + cap_lds - 1) / cap_lds;
+        const int64_t more = std::min<int64_t>(h->n_items / (cap_min + cap_min / 3), (int64_t)2 * cus * h->cv_blocks);
+        bins = std::max(bins, more);
+        bins = std::max<int64_t>(1, (bins + h->cv_blocks - 1) / h->cv_blocks) * h->cv_blocks;
+        const int64_t cap = (h->n_items + bins - 1) / bins;
+        if (cap > cap_lds || bins > (int64_t(1) << 22) || bins * cap >= (int64_t(1) << 31)) return pl;
+        pl.bins = (int)bins;
+        pl.cap = (int)cap;
+        pl.block = waves * kWave;
+        pl.lds = ldsbin_lds_bytes((int)cap, h->k, waves);
+        pl.passing = true;
+        return pl;
+    }
     if (h->k > 256 || h->nnz < (int64_t)cus * kLbWaves * kWave) return pl;
     // (profile builds: CORNAC_HIP_LDSBIN_MIN_ROUNDS / _RES_WAVES / _EXCL_KB vary the resident regime's bin count, the waves of a
     // bin's workgroup and the LDS floor that keeps a CU to one workgroup — the experiments of DESIGN.md 7)
@@ -1854,8 +1887,9 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
     // epoch: the share that counts is a slot's, priced at a quarter (hot_x1000 = 75: degree > nnz / 13 653 at 256 CUs)
     const double share = plan.passing ? (double)nnz / (4.0 * device_info(h->device).cus) : (double)nnz / bins;
     int n_hot = 0;
-    while (n_hot < ni && (double)(cptr[(size_t)h->h_rank_item[(size_t)n_hot] + 1] - cptr[(size_t)h->h_rank_item[(size_t)n_hot]]) * 1000.0 >
-                             share * h->lb_hot_x1000)
+    while (!h->cv_blocks && n_hot < ni &&
+           (double)(cptr[(size_t)h->h_rank_item[(size_t)n_hot] + 1] - cptr[(size_t)h->h_rank_item[(size_t)n_hot]]) * 1000.0 >
+               share * h->lb_hot_x1000)
         ++n_hot;
     std::vector<int32_t> hot_u, hot_i;
     {
@@ -1920,12 +1954,14 @@ static void ldsbin_build(cornac_hip_bpr_t h) {
     h->lb_built = true;
 }
 
+static const int32_t *ldsbin_rank_item(cornac_hip_bpr_t h) { return (h->cv_blocks && h->cv_own_order) ? h->cv_rank_item.p : h->rank_item.p; }
+
 // the deal bookkeeping of (seed, epoch): cold masses per bin and the hot runs that level them (two small launches,
 // once per epoch: the chunks of an epoch share them)
 static void ldsbin_deal(cornac_hip_bpr_t h, uint64_t seed, uint32_t epoch, uint32_t key) {
     if (h->lb_deal_valid && h->lb_deal_seed == seed && h->lb_deal_epoch == epoch) return;
     LdsDealArgs d;
-    d.cptr = h->lb_cptr.p; d.rank_item = h->rank_item.p;
+    d.cptr = h->lb_cptr.p; d.rank_item = ldsbin_rank_item(h);
     d.mass = h->lb_mass.p; d.cold_out = h->lb_cold.p; d.hot_off = h->lb_hot_off.p;
     d.key = key;
     d.n_items = (int32_t)h->n_items; d.n_bins = h->lb_bins; d.n_hot = h->lb_n_hot; d.n_hot_inter = h->lb_n_hot_inter;
@@ -1950,7 +1986,7 @@ static uint32_t ldsbin_key(uint64_t seed, uint32_t epoch) {
 static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float reg, int use_bias, int neg_population,
                              int flags) {
     a.neg_pop = neg_population == CORNAC_HIP_NEG_POPULARITY ? 1 : 0;
-    a.cptr = h->lb_cptr.p; a.cusers = h->lb_cusers.p; a.rank_item = h->rank_item.p;
+    a.cptr = h->lb_cptr.p; a.cusers = h->lb_cusers.p; a.rank_item = ldsbin_rank_item(h);
     a.hot_u = h->lb_hot_u.p; a.hot_i = h->lb_hot_i.p; a.hot_off = h->lb_hot_off.p;
     a.indptr = h->indptr.p; a.indices = h->indices.p;
     a.bitmap = h->lb_bm_words ? h->lb_bitmap.p : nullptr;
@@ -1963,6 +1999,11 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
     a.ablate = (flags >> 8) & 0xff;
     a.wg_clock = nullptr;
     a.ex = LdsBinExchange{};
+    a.conv_bpb = 0;
+    for (int r = 0; r < kLbMaxRanges; ++r) {
+        a.conv_first[r] = 0;
+        a.conv_rows[r] = nullptr;
+    }
 }
 
 // one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
@@ -2215,6 +2256,100 @@ int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float re
                                                          keep_stride, d_arrive, d_landed, d_applied);
         ldsbin_resident_enqueue(h, lr, reg, use_bias, neg_population, hogwild_flags, ex);
         if (n_arrivals) *n_arrivals = h->lb_bins;
+    });
+}
+
+// ---- conveyor layout (multi-GPU regime 2: the item table sharded by row, its blocks rotating over the ranks; cornac_amd/dist.py
+// BinConveyorBprTrainer).  The reference has no counterpart (one process); what a step computes is
+// recom_bpr.pyx:231-267 for the draws of the block's bins.
+int cornac_hip_bpr_conveyor_setup(cornac_hip_bpr_t h, int n_blocks, const int32_t *rank_item, uint64_t deal_seed,
+                                  int release_item_tables, int *n_bins, int *bins_per_block, int *cap) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(n_blocks >= 1 && n_blocks <= (1 << 16), "n_blocks out of range");
+        REQUIRE(!h->f64, "the handle holds float64 tables");
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (rank_item) {
+            std::vector<uint8_t> seen((size_t)h->n_items, 0);
+            for (int64_t r = 0; r < h->n_items; ++r) {
+                REQUIRE(rank_item[r] >= 0 && rank_item[r] < h->n_items && !seen[(size_t)rank_item[r]],
+                        "rank_item is not a permutation of the train items (entry %lld)", (long long)r);
+                seen[(size_t)rank_item[r]] = 1;
+            }
+            h->cv_rank_item.ensure((size_t)h->n_items);
+            h->cv_rank_item.upload(rank_item, (size_t)h->n_items, h->stream);
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+        h->cv_own_order = rank_item != nullptr;
+        h->cv_blocks = n_blocks;
+        h->cv_deal_seed = deal_seed;
+        const LbPlan pl = ldsbin_plan(h);
+        if (pl.bins == 0) {
+            h->cv_blocks = 0;
+            fail(CORNAC_HIP_ERR_INVALID, "no conveyor layout for %lld items in %d blocks at k = %d (a bin needs >= %d rows and its "
+                 "rows must fit %d KB of LDS)", (long long)h->n_items, n_blocks, h->k, h->lb_min_candidates, h->lb_pass_kb);
+        }
+        h->lb_built = false;
+        ldsbin_build(h);
+        HIP_CHECK(hipMemsetAsync(h->lb_hot_off.p, 0, ((size_t)pl.bins + 1) * sizeof(uint32_t), h->stream));
+        if (release_item_tables) {  // the rows live in the caller's block buffers: the handle's own item tables are not needed
+            h->V.bind(nullptr, 0);
+            h->B.bind(nullptr, 0);
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (n_bins) *n_bins = pl.bins;
+        if (bins_per_block) *bins_per_block = pl.bins / n_blocks;
+        if (cap) *cap = pl.cap;
+    });
+}
+
+int cornac_hip_bpr_conveyor_layout(cornac_hip_bpr_t h, uint32_t layout_epoch, int32_t *d_slot_item, int32_t *d_item_slot) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->cv_blocks && h->lb_built, "cornac_hip_bpr_conveyor_setup first");
+        REQUIRE(d_slot_item || d_item_slot, "NULL device pointers");
+        const int64_t total = (int64_t)h->lb_bins * h->lb_cap;
+        const unsigned grid = (unsigned)std::min<int64_t>(2048, (total + kLbBlock - 1) / kLbBlock);
+        hipLaunchKernelGGL(ldsbin_layout_kernel, dim3(grid), dim3(kLbBlock), 0, h->stream, ldsbin_rank_item(h),
+                           ldsbin_key(h->cv_deal_seed, layout_epoch), (int32_t)h->n_items, h->lb_bins, h->lb_cap, h->lb_n_strata,
+                           d_slot_item, d_item_slot);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int cornac_hip_bpr_conveyor_enqueue(cornac_hip_bpr_t h, uint32_t epoch, uint32_t layout_epoch, int n_ranges,
+                                    const int32_t *first_block, float *const *d_rows, float lr, float reg, int use_bias,
+                                    int neg_population, int hogwild_flags) {
+    return guarded([&] {
+        bpr_check(h);
+        REQUIRE(h->cv_blocks && h->lb_built, "cornac_hip_bpr_conveyor_setup first");
+        REQUIRE(h->hog_seeded, "hogwild mode needs cornac_hip_bpr_seed_hogwild first");
+        REQUIRE(n_ranges >= 1 && n_ranges <= kLbMaxRanges, "n_ranges must be in [1, %d]", kLbMaxRanges);
+        REQUIRE(first_block && d_rows, "NULL argument");
+        REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
+                "unknown neg_population %d", neg_population);
+        const int bpb = h->lb_bins / h->cv_blocks;
+        LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, false, true);
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
+        LdsBinArgs a;
+        ldsbin_fill_args(h, a, lr, reg, use_bias, neg_population, hogwild_flags);
+        a.V = nullptr; a.B = nullptr;   // every row of these bins is in a block buffer
+        a.epoch = epoch;
+        a.key = ldsbin_key(h->cv_deal_seed, layout_epoch);
+        a.s_begin = 0;
+        a.n = (uint64_t)h->nnz;
+        a.nnz = (uint64_t)h->nnz;
+        a.conv_bpb = bpb;
+        for (int r = 0; r < n_ranges; ++r) {
+            REQUIRE(first_block[r] >= 0 && first_block[r] < h->cv_blocks && d_rows[r], "range %d: block %d / NULL buffer", r, first_block[r]);
+            for (int q = 0; q < r; ++q) REQUIRE(first_block[q] != first_block[r], "block %d twice in one launch", first_block[r]);
+            a.conv_first[r] = first_block[r] * bpb;
+            a.conv_rows[r] = d_rows[r];
+        }
+        h->ktimer.before(h->stream);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(bpb * n_ranges)), dim3(h->lb_block), h->lb_lds_bytes, h->stream, a);
+        h->ktimer.after(h->stream);
+        HIP_CHECK(hipGetLastError());
     });
 }
 

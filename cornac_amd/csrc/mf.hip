@@ -388,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void mf_hogwild_generic_kernel(const MfHogA
             const int sl = act ? slot : b;
             const int32_t tu = __shfl(mu_, sl, kWave), ti = __shfl(mi_, sl, kWave);
             const float tr = __shfl(mr, sl, kWave);
-            float *pu = a.U + (size_t)tu * a.k, *pi = a.V + (size_t)ti * a.k;
+            // (an id >= n_items names a copy of a split hot item's row: MfHogArgs::Vx_shifted)
+            float *pu = a.U + (size_t)tu * a.k, *pi = (ti < a.n_items ? a.V : a.Vx_shifted) + (size_t)ti * a.k;
             const float bu = load_f32_fresh(a.Bu + tu), bi = load_f32_fresh(a.Bi + (size_t)ti * a.bstride);
             float part = 0.f;
             for (int f = lg; f < a.k; f += G) part += load_f32_fresh(pu + f) * load_f32_fresh(pi + f);

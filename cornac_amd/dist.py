@@ -1,6 +1,8 @@
 """Multi-GPU BPR (and MF, `ShardedMfTrainer`): one process per GPU, users partitioned across ranks.  Two regimes for the item table
 (SURVEY.md §8e): (1) replicated and reconciled with RCCL all-reduce of its deltas — `ShardedBprTrainer`,
-described first; (2) sharded by row with all-to-all exchanges of the touched rows — `RowShardedBprTrainer`.
+described first; (2) sharded by row — `BinConveyorBprTrainer`: the table's blocks (bin ranges of the epoch's LDS-bin deal) rotate
+over the ranks on point-to-point xGMI hops and are re-dealt at the epoch boundaries; round 2's all-to-all exchange of the touched
+rows is kept as `RowShardedBprTrainer`.
 
   * every rank owns a disjoint user population (its CSR slice and its U rows) -> user rows never
     leave the GPU and never conflict across GPUs: no data-path collective for them;
@@ -63,7 +65,7 @@ def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=6
     ranks at the slice's density, profiles/r05_virtual_ranks.log): the replicas reach the single process's quality only at
     convergence (0.9948 vs 0.9964 after 32 epochs); in the MIDDLE of training the averaged, stale item side lags badly
     (16 epochs: 0.869 / 0.708 / 0.618 at one exchange every 1 / 2 / 4 epochs against 0.990 for one process) — every rank
-    moves every row the same way and "align" keeps the mean.  The ring conveyor (RingShardedBprTrainer, fit_bpr_ring) has
+    moves every row the same way and "align" keeps the mean.  The ring conveyor (BinConveyorBprTrainer, fit_bpr_ring; round 5's form with static item blocks) has
     no such trade: 0.990 in the same measurement, 3.8 % one-rank tax.  Sparse item sides should take the ring; this
     schedule remains what regime 1 does when asked."""
     x = 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row))
@@ -1065,69 +1067,7 @@ class RowShardedBprTrainer:
         return out
 
 
-# ---- regime 2 as a ring conveyor of item blocks --------------------------------------------------------------------------
-def split_csr_by_item_block(indptr, indices, n_blocks):
-    """the CSR of a user slice cut by item block (item i -> block i % n_blocks, block-local id i // n_blocks): a list of
-    (indptr_b [n_users + 1] int32, indices_b int32) with the rows still sorted"""
-    indptr = np.asarray(indptr, np.int64)
-    indices = np.asarray(indices, np.int64)
-    n_users = len(indptr) - 1
-    blk = (indices % n_blocks).astype(np.int32)
-    order = np.argsort(blk, kind="stable")                     # block-major, CSR order kept inside a block
-    users = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(indptr))[order]
-    local = (indices[order] // n_blocks).astype(np.int32)
-    cuts = np.searchsorted(blk[order], np.arange(n_blocks + 1))
-    out = []
-    for b in range(n_blocks):
-        a, e = int(cuts[b]), int(cuts[b + 1])
-        ip = np.zeros(n_users + 1, np.int64)
-        np.cumsum(np.bincount(users[a:e], minlength=n_users), out=ip[1:])
-        out.append((ip.astype(np.int32), np.ascontiguousarray(local[a:e])))
-    return out
-
-
-class _DeviceBlockTrainer:
-    """one item block's cornac_hip BPR handle: the rank's interactions with the block's items in block-local ids, the user
-    table shared with the other blocks' handles, the item tables rebound to wherever the block's buffer is"""
-
-    def __init__(self, indptr, indices, n_users, n_rows, k, U, stream, device_index, n_train=None):
-        from . import _lib
-
-        self.nnz = len(indices)
-        # n_train: the block's TRAIN items (a prefix of its rows: item i of the block is row i // blocks) — negatives are drawn
-        # among them only, like neg_item_ids = arange(train_set.num_items) in the reference (recom_bpr.pyx:156)
-        self.tr = _lib.BprTrainer(indptr, indices, n_users, n_rows if n_train is None else n_train, n_users, n_rows, k,
-                                  device=device_index)
-        self._bound = False
-        self.U, self.stream = U, stream
-        # the handle's own user table goes at once (a rank has 2 N K such handles: 64 x 6.4 GB at configs[4] with four rings
-        # would not fit beside the shared one); its block-sized item tables follow at the first bind_items
-        self.tr.bind_device(self.U.data_ptr(), None, None)
-
-    def seed_hogwild(self, seed):
-        self.tr.seed_hogwild(seed)
-
-    def set_negative_population(self, items):
-        self.tr.set_negative_population(items)
-
-    def bind_items(self, V, B):
-        if not self._bound:   # first time: also hands the handle the shared user table and the driver's stream (synchronises)
-            self.tr.bind_device(self.U.data_ptr(), V.data_ptr(), B.data_ptr())
-            self.tr.set_stream(self.stream.cuda_stream)
-            self._bound = True
-        else:
-            self.tr.rebind_items(V.data_ptr(), B.data_ptr())
-
-    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
-        self.tr.hogwild_enqueue(n, lr, reg, use_bias, neg_population, flags)
-
-    def sync(self):
-        return self.tr.sync()
-
-    def close(self):
-        self.tr.close()
-
-
+# ---- regime 2: a ring conveyor of item blocks ------------------------------------------------------------------------------
 class _OnceWork:
     """a point-to-point work handle that is waited for at most once (gloo's send / receive works block for ever on a second
     wait: they wait for the NEXT completion of their buffer)"""
@@ -1158,119 +1098,225 @@ def ring_strides(world, rings):
     return order[: max(1, int(rings))]
 
 
-class RingShardedBprTrainer:
+# ---- regime 2, current form: the conveyor's blocks are bin ranges of the epoch's deal ---------------------------------------
+class _DeviceConveyorTrainer:
+    """the rank's ONE cornac_hip BPR handle in conveyor layout (cornac_hip_bpr_conveyor_*): its CSR / CSC over the global item
+    ids stay put; what changes per step is which block buffers the launch reads its bins' rows from"""
+
+    def __init__(self, indptr, indices, n_users, n_items, k, U, stream, device_index):
+        from . import _lib
+
+        self.tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k, device=device_index)
+        self.U, self.stream, self.device = U, stream, U.device
+        self.tr.bind_device(self.U.data_ptr(), None, None)
+        self.tr.set_stream(stream.cuda_stream)
+
+    def seed_hogwild(self, seed):
+        self.tr.seed_hogwild(seed)
+
+    def conveyor_setup(self, n_blocks, rank_item, deal_seed):
+        self.n_bins, self.bpb, self.cap = self.tr.conveyor_setup(n_blocks, rank_item, deal_seed, release_item_tables=True)
+        return self.n_bins, self.bpb, self.cap
+
+    def conveyor_layout(self, layout_epoch):
+        """(slot_item [n_bins cap], item_slot [n_items]) int32 device tensors, written on the trainer's stream"""
+        n_items = self.tr.n_items
+        slot_item = torch.empty(self.n_bins * self.cap, dtype=torch.int32, device=self.device)
+        item_slot = torch.empty(n_items, dtype=torch.int32, device=self.device)
+        self.tr.conveyor_layout(layout_epoch, slot_item.data_ptr(), item_slot.data_ptr())
+        return slot_item, item_slot
+
+    def conveyor_enqueue(self, epoch, layout_epoch, blocks, bufs, lr, reg, use_bias, neg_population, flags):
+        self.tr.conveyor_enqueue(epoch, layout_epoch, blocks, [b.data_ptr() for b in bufs], lr, reg, use_bias, neg_population, flags)
+
+    def sync(self):
+        return self.tr.sync()
+
+    def close(self):
+        self.tr.close()
+
+
+class BinConveyorBprTrainer:
     """Multi-GPU BPR with the item table SHARDED BY ROW and never replicated (SURVEY.md 8e regime 2; BASELINE configs[4]:
-    "item table row-sharded across 8 x MI355X via RCCL / xGMI"), as DSGD's block rotation (Gemulla et al. 2011) laid on
-    the xGMI ring instead of round 2's all-to-all of the touched rows:
+    "item table row-sharded across 8 x MI355X via RCCL / xGMI"): DSGD's block rotation (Gemulla et al. 2011) laid on the
+    xGMI ring, with the blocks cut from the LDS-bin deal of the epoch instead of from the item ids.
 
-      * users are partitioned over the N ranks (their rows of U never move); the items are cut into 2 N blocks
-        (item i -> block i % 2N); every rank holds 2-3 blocks at any time;
-      * an epoch is 2 N steps.  In step t rank r trains block (2 r + t) % 2N: the draws of ITS users' interactions with the
-        block's items (sum over the steps = its nnz draws per epoch; the negative comes from the same block — and, inside
-        the handle, from the positive's LDS bin: the block is an ordinary single-GPU problem, so it runs in whatever form
-        cornac_hip picks for its shape, passing bins at the configs[4] size);
-      * a block trained in step t travels to rank r - 1 during step t + 1 and is trained there in step t + 2: every block
-        is in exactly ONE place — in training or in flight — so there is no staleness, no reconciliation rule and no lost
-        update (the replicas of regime 1 trade those for fewer bytes), and each step's transfer (table / 2N per rank:
-        322 MB at configs[4], one xGMI hop) hides behind the next step's launch;
-      * after an epoch's last step every rank holds blocks 2 r and 2 r + 1 again; gather() assembles the table.
+      * users are partitioned over the N ranks (their rows of U never move).  Every rank holds ONE handle over its users'
+        interactions in global item ids, in the conveyor layout of the LDS-bin form (csrc/bpr.hip
+        cornac_hip_bpr_conveyor_setup): the epoch's deal (csrc/bpr_ldsbin.inc: popularity strata, a keyed bijection inside
+        each, one item of every group per bin; the key shared by all ranks) puts every item into one of n_bins bins, and
+        conveyor block B is the bins [B bpb, (B + 1) bpb).  A block's buffer holds the rows of its bins in (bin, slot) order;
+      * an epoch is 2 N steps.  In step t rank r trains ring block (2 p + t) % 2N (p its position on the ring): one
+        launch over the block's bins — the draws of ITS users' interactions with the bins' items, the negative among the
+        items sharing the positive's bin (the single-GPU LDS-bin sampler, bench.py config.sampling) — reading and writing
+        the rows in the buffer.  Sum over the steps = its nnz draws per epoch;
+      * a block trained in step t travels to rank r - s during step t + 1 and is trained there in step t + 2: every row is
+        in exactly ONE place — in training or in flight — so there is no replica, no staleness, no reconciliation rule;
+      * THE DEAL CHANGES WITH THE EPOCH (every `redeal_every` epochs): at the boundary every rank holds its home blocks and the
+        rows move from their slot under the old key to their slot under the new one — one all_to_all_single over the ranks
+        (table / N per rank, ~two steps' worth of link traffic).  So the blocks — like the bins — are re-dealt: any two items
+        share a bin with probability ~1 / n_bins per epoch whatever their ids (tests/test_ldsbin_deal_cpu.py), where round 5's
+        static residue classes i % 2NK excluded 1 - 1 / 2NK of all (positive, negative) pairs for the whole fit.  The
+        reference draws the negative over ALL items (recom_bpr.pyx:235-238);
+      * rings = K > 1: xGMI is a mesh of point-to-point links and one ring uses one of a GPU's seven.  The blocks are then
+        K groups of 2 N (block b K + g is ring block b of ring g, stride s_g: ring_strides); a step trains one block of
+        every ring in ONE launch over K bin ranges and moves K blocks over K links.
 
-    rings = K > 1: xGMI is a mesh of point-to-point links and ONE ring uses one of a GPU's seven.  The items are then cut
-    into K groups of 2 N blocks, group g rotating on its own ring with stride s_g (ring_strides: rank r hands to r - s_g;
-    1, N - 1, 3, N - 3, ... — different directed links); a step trains one block of every group and moves K blocks at once,
-    each a K-th of the size, over K links.  Same invariants per ring; an epoch is still 2 N steps and nnz draws.
-
-    The draws of a step on different ranks touch disjoint user rows AND disjoint item rows, so the parallel run equals
-    the serial execution of the same steps in any order (tests/test_dist_cpu.py runs both).  The reference has no
+    The draws of a step on different ranks touch disjoint user rows AND disjoint item rows, so the parallel run equals the
+    serial execution of the same steps and re-deals in any order (tests/test_dist_cpu.py runs both).  The reference has no
     counterpart (one process; the update it distributes is recom_bpr.pyx:252-265).
 
-    trainer_factory(block, indptr_b, indices_b, n_users, n_rows, k, U): host stand-ins (gloo tests) with
-    bind_items(V, B) / seed_hogwild / hogwild_enqueue / sync / close.  emulate_traffic (one rank only): the block that
-    would travel is copied to the free buffer on the communication stream, so a one-GPU run carries the conveyor's
-    memory traffic and dependency chain."""
+    No hot-item path in this layout: a very popular item makes its bin heavy (the bins of a launch are scheduled dynamically;
+    the heaviest one bounds the step).  WBPR's popularity-weighted negative is drawn among the interactions of the RANK'S OWN
+    users with the bin's items (local popularity).
 
-    def __init__(self, indptr, indices, n_users, n_items, k, device, group=None, trainer_factory=None, seed=0,
-                 emulate_traffic=False, rings=1, n_train_items=None):
-        """n_items: rows of the item table (the model's total_items); n_train_items (default: all of them): the items a
-        negative may be — ids below it, as the reference draws negatives among the train items only"""
+    trainer_factory(indptr, indices, n_users, n_items, k, U): host stand-ins (gloo tests) with seed_hogwild / conveyor_setup /
+    conveyor_layout / conveyor_enqueue / sync / close.  emulate_traffic (one rank only): the block that would travel is copied
+    to the free buffer on the communication stream, so a one-GPU run carries the conveyor's memory traffic and dependencies."""
+
+    def __init__(self, indptr, indices, n_users, n_items, k, device, group=None, trainer_factory=None, seed=0, deal_seed=None,
+                 emulate_traffic=False, rings=1, n_train_items=None, item_order=None, redeal_every=1, virtual_world=None):
+        """n_items: rows of the item table (the model's total_items); n_train_items (default: all): the items training may
+        touch — ids below it (the reference draws positives and negatives among the train items only).  item_order: the
+        popularity order of the train items all ranks share (None: this rank's own).  deal_seed: the SAME on every rank
+        (default: derived from `seed`, which the ranks of fit_bpr_ring share); the draws are keyed by (seed, rank).
+        virtual_world (one rank only): lay the conveyor out for that many ranks — 2 virtual_world blocks per ring, all of them
+        this rank's — for one-GPU measurements of an N-rank step's launch size."""
         self.device, self.group, self.k = device, group, int(k)
         self.world, self.rank = _world(group)
-        self.strides = ring_strides(self.world, rings)
+        self.lay_world = int(virtual_world) if (virtual_world and self.world == 1) else self.world
+        self.strides = ring_strides(self.lay_world, rings)
         self.K = len(self.strides)
-        self.nb = 2 * self.world                  # blocks per ring = steps per epoch
-        self.nb_total = self.nb * self.K          # item i -> global block B = i % nb_total = (ring B % K, ring block B // K)
+        self.nb = 2 * self.lay_world               # blocks per ring = steps per epoch
+        self.nb_total = self.nb * self.K
         self.n_items, self.n_users = int(n_items), int(n_users)
-        if self.n_items < self.nb_total:
-            raise ValueError("%d items cannot be cut into %d blocks" % (self.n_items, self.nb_total))
-        self.rows_max = (self.n_items + self.nb_total - 1) // self.nb_total
-        self.rows = [(self.n_items - B + self.nb_total - 1) // self.nb_total for B in range(self.nb_total)]
-        n_train = self.n_items if n_train_items is None else int(n_train_items)
-        self.rows_train = [max(0, (n_train - B + self.nb_total - 1) // self.nb_total) for B in range(self.nb_total)]
-        # position of this rank on ring g: the rank it hands to (rank - s_g) has position - 1
-        self.pos = [(self.rank * pow(s, -1, self.world)) % self.world if self.world > 1 else 0 for s in self.strides]
+        self.n_train = self.n_items if n_train_items is None else int(n_train_items)
+        self.redeal_every = max(1, int(redeal_every))
         cuda = device.type == "cuda"
         self.stream = torch.cuda.Stream(device) if cuda else None
         self.comm = torch.cuda.Stream(device) if cuda else None
         self.emulate_traffic = bool(emulate_traffic) and self.world == 1
-        width = self.rows_max * (self.k + 1)
-        self.bufs = [[torch.zeros(width, dtype=torch.float32, device=device) for _ in range(3)] for _ in range(self.K)]
         self.U = torch.zeros((self.n_users, self.k), dtype=torch.float32, device=device)
-        self.where = [{2 * p: 0, 2 * p + 1: 1} for p in self.pos]  # per ring: ring block -> buffer
-        self.arrived = [[None, None, None] for _ in range(self.K)]  # per ring and buffer: event / works of the receive that fills it
+        indices = np.ascontiguousarray(indices, np.int32)
+        self.nnz = len(indices)
+        if trainer_factory is not None:
+            self.trainer = trainer_factory(indptr, indices, self.n_users, self.n_train, self.k, self.U)
+        else:
+            self.trainer = _DeviceConveyorTrainer(indptr, indices, self.n_users, self.n_train, self.k, self.U, self.stream,
+                                                  device.index or 0)
+        self.trainer.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 1) & 0xFFFFFFFFFFFFFFFF)
+        self.deal_seed = (int(seed) ^ 0xD1B54A32D192ED03 if deal_seed is None else int(deal_seed)) & 0xFFFFFFFFFFFFFFFF
+        self.n_bins, self.bpb, self.cap = self.trainer.conveyor_setup(self.nb_total, item_order, self.deal_seed)
+        if self.n_bins != self.bpb * self.nb_total:
+            raise RuntimeError("conveyor layout: %d bins are not %d blocks of %d" % (self.n_bins, self.nb_total, self.bpb))
+        self.W = self.bpb * self.cap              # slots (rows) per block
+        # position of this rank on ring g: the rank it hands to (rank - s_g) has position - 1
+        self.pos = [(self.rank * pow(s, -1, self.world)) % self.world if self.world > 1 else 0 for s in self.strides]
+        width = self.W * (self.k + 1)
+        n_home = self.nb if self.world == 1 else 2   # (one rank: every block of the ring is its own)
+        self.bufs = [[torch.zeros(width, dtype=torch.float32, device=device) for _ in range(n_home + 1)] for _ in range(self.K)]
+        self.where = [self._home_where(p) for p in self.pos]        # per ring: ring block -> buffer
+        self.arrived = [[None] * (n_home + 1) for _ in range(self.K)]  # per ring and buffer: event / works of the receive that fills it
         self._sent = []
         self.t = 0
-        self.steps_trained = []                                      # (epoch step, global block): inspection / tests
-        self.trainers = []
-        for B, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, self.nb_total)):
-            if len(ix) == 0:
-                self.trainers.append(None)
-                continue
-            if trainer_factory is not None:
-                tr = trainer_factory(B, ip, ix, self.n_users, self.rows[B], self.k, self.U)
-            else:
-                tr = _DeviceBlockTrainer(ip, ix, self.n_users, self.rows[B], self.k, self.U, self.stream, device.index or 0,
-                                         n_train=self.rows_train[B])
-            tr.nnz = len(ix)
-            tr.n_train = self.rows_train[B]
-            tr.seed_hogwild((int(seed) * 0x9E3779B97F4A7C15 + 7919 * self.rank + 104729 * B + 1) & 0xFFFFFFFFFFFFFFFF)
-            self.trainers.append(tr)
-        self.nnz = int(sum(tr.nnz for tr in self.trainers if tr is not None))
+        self.layout_epoch = 0
+        self.steps_trained = []                    # (epoch step, global block): inspection / tests
+        self.redeals = 0
+        self._tail = None                          # rows [n_train, n_items) of the table: never trained, kept on the host
+        self.timing = False                        # True (device only): events around every launch, transfer and re-deal
+        self._events = {"launch": [], "move": [], "redeal": []}
 
-    def set_negative_population(self, global_degrees):
-        """WBPR over ranks: the popularity-weighted negative of a draw comes from the block being trained, weighted by the
-        GLOBAL item degrees (recom_wbpr.pyx:135 weights by the degrees of the whole matrix) — every block handle gets the
-        population of its own items, item i of the block (row i // blocks) repeated degree(i) times"""
-        deg = np.asarray(global_degrees, np.int64)
-        for B, tr in enumerate(self.trainers):
-            if tr is None:
-                continue
-            tr.set_negative_population(population_from_degrees(deg[B:: self.nb_total][: self.rows_train[B]], at_most=1 << 24))
+    # ---- layout ----
+    def _home_where(self, p):
+        if self.world == 1:
+            return {b: b for b in range(self.nb)}
+        return {2 * p: 0, 2 * p + 1: 1}
 
     def block_id(self, g, b):
-        """global block (= item residue class mod nb_total) of ring g's block b"""
+        """global block (= bin range) of ring g's block b"""
         return b * self.K + g
 
-    def _views(self, g, buf, b):
-        """(V [rows, k], B [rows]) of ring g's block b in that ring's buffer `buf`"""
-        flat, rows = self.bufs[g][buf], self.rows[self.block_id(g, b)]
-        return flat[: rows * self.k].view(rows, self.k), flat[self.rows_max * self.k: self.rows_max * self.k + rows]
+    def home_blocks(self, rank=None):
+        """[(ring, ring block, global block)] a rank holds at an epoch boundary, in ascending global block order"""
+        if self.world == 1:
+            out = [(g, b, self.block_id(g, b)) for g in range(self.K) for b in range(self.nb)]
+        else:
+            r = self.rank if rank is None else rank
+            out = []
+            for g, s in enumerate(self.strides):
+                p = (r * pow(s, -1, self.world)) % self.world
+                out += [(g, 2 * p + h, self.block_id(g, 2 * p + h)) for h in (0, 1)]
+        return sorted(out, key=lambda x: x[2])
+
+    def _block_owner(self):
+        """[nb_total] -> the rank a block is at home on"""
+        own = np.zeros(self.nb_total, np.int64)
+        for r in range(self.world):
+            for _, _, B in self.home_blocks(r):
+                own[B] = r
+        return own
+
+    def _views(self, g, buf):
+        """(V [W, k], B [W]) of ring g's buffer `buf`"""
+        flat = self.bufs[g][buf]
+        return flat[: self.W * self.k].view(self.W, self.k), flat[self.W * self.k:]
 
     def _on(self, stream):
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
+    def _timed(self, what, stream):
+        """context: HIP events on `stream` around the block when self.timing (timing_summary() reads them)"""
+        ring = self
+
+        class _T:
+            def __enter__(self_):
+                self_.on = ring.timing and stream is not None
+                if self_.on:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.a.record(stream)
+
+            def __exit__(self_, *exc):
+                if self_.on:
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record(stream)
+                    ring._events[what].append((self_.a, b))
+
+        return _T()
+
+    def timing_summary(self):
+        """{what: (count, mean ms)} of the launches (compute stream), the block transfers (communication stream) and the re-deals
+        recorded since the last call; synchronises"""
+        self._drain()
+        out = {}
+        for what, evs in self._events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[what] = (len(ms), float(np.mean(ms)) if ms else 0.0)
+            evs.clear()
+        return out
+
+    def _layout(self, layout_epoch):
+        slot_item, item_slot = self.trainer.conveyor_layout(layout_epoch)
+        return torch.as_tensor(slot_item).to(self.device), torch.as_tensor(item_slot).to(self.device)
+
     def load_items(self, V, B):
-        """this rank's two starting blocks of every ring, from the full host tables"""
+        """this rank's home blocks of every ring, from the full host tables, in the layout of epoch 0"""
         V, B = np.asarray(V, np.float32), np.asarray(B, np.float32)
+        self._tail = (V[self.n_train:].copy(), B[self.n_train:].copy())
+        self.where = [self._home_where(p) for p in self.pos]
+        self.arrived = [[None] * len(self.bufs[0]) for _ in range(self.K)]
+        self.t, self.layout_epoch = 0, 0
         with self._on(self.stream):
-            for g, p in enumerate(self.pos):
-                for slot, b in enumerate((2 * p, 2 * p + 1)):
-                    v, bias = self._views(g, slot, b)
-                    blk = self.block_id(g, b)
-                    v.copy_(torch.as_tensor(np.ascontiguousarray(V[blk:: self.nb_total])))
-                    bias.copy_(torch.as_tensor(np.ascontiguousarray(B[blk:: self.nb_total])))
-        self.where = [{2 * p: 0, 2 * p + 1: 1} for p in self.pos]
-        self.arrived = [[None, None, None] for _ in range(self.K)]
-        self.t = 0
+            slot_item, _ = self._layout(0)
+            slot_item = slot_item.cpu().numpy()
+            for g, b, blk in self.home_blocks():
+                items = slot_item[blk * self.W: (blk + 1) * self.W]
+                ok = items >= 0
+                rows = np.zeros((self.W, self.k), np.float32)
+                bias = np.zeros(self.W, np.float32)
+                rows[ok], bias[ok] = V[items[ok]], B[items[ok]]
+                v, bb = self._views(g, self.where[g][b])
+                v.copy_(torch.as_tensor(rows))
+                bb.copy_(torch.as_tensor(bias))
         if self.stream is not None:
             self.stream.synchronize()
 
@@ -1293,24 +1339,90 @@ class RingShardedBprTrainer:
             for w in got:
                 w.wait()
 
+    # ---- the epoch-boundary re-deal ----
+    def _redeal(self, new_layout_epoch):
+        """every row from its slot under the deal of self.layout_epoch to its slot under the deal of new_layout_epoch; at an
+        epoch boundary (every rank holds its home blocks).  One all_to_all_single of [row | bias] records."""
+        W, k, S = self.W, self.k, self.n_bins * self.cap
+        home = self.home_blocks()
+        for g in range(self.K):                       # the last step's receives fill home buffers
+            for buf in range(len(self.bufs[g])):
+                self._await(self.arrived[g][buf])
+                self.arrived[g][buf] = None
+        for w in self._sent:
+            w.wait()
+        self._sent = []
+        with self._on(self.stream), self._timed("redeal", self.stream):
+            old_slot_item, old_item_slot = self._layout(self.layout_epoch)
+            new_slot_item, new_item_slot = self._layout(new_layout_epoch)
+            owner = torch.as_tensor(self._block_owner(), device=self.device)
+            base = torch.cat([torch.arange(blk * W, (blk + 1) * W, device=self.device) for _, _, blk in home])  # my slots, ascending
+            # sender side: my rows, ordered by (destination rank, destination slot)
+            items = old_slot_item[base].long()
+            have = items >= 0
+            dst_slot = new_item_slot[items[have]].long()
+            dst_rank = owner[dst_slot // W]
+            order = torch.argsort(dst_rank * S + dst_slot)
+            send_counts = torch.bincount(dst_rank, minlength=self.world)
+            rec = torch.empty((len(base), k + 1), dtype=torch.float32, device=self.device)
+            for h, (g, b, blk) in enumerate(home):
+                v, bb = self._views(g, self.where[g][b])
+                rec[h * W: (h + 1) * W, :k] = v
+                rec[h * W: (h + 1) * W, k] = bb
+            send = rec[have][order].contiguous()
+            # receiver side: my new slots, ordered by (source rank, slot) — the order the senders packed them in
+            items_n = new_slot_item[base].long()
+            want = items_n >= 0
+            my_slot = base[want]
+            src_rank = owner[old_item_slot[items_n[want]].long() // W]
+            order_r = torch.argsort(src_rank * S + my_slot)
+            recv_counts = torch.bincount(src_rank, minlength=self.world)
+            recv = torch.empty((int(want.sum()), k + 1), dtype=torch.float32, device=self.device)
+            if self.world > 1:
+                dist.all_to_all_single(recv, send, [int(c) for c in recv_counts.cpu()], [int(c) for c in send_counts.cpu()],
+                                       group=self.group)
+            else:
+                recv.copy_(send)
+            rec.zero_()
+            # position of a global slot in `rec`: the home block's index x W + the slot's offset inside the block
+            hpos = torch.full((self.nb_total,), -1, dtype=torch.long, device=self.device)
+            for h, (_, _, blk) in enumerate(home):
+                hpos[blk] = h
+            tgt = my_slot[order_r]
+            rec[hpos[tgt // W] * W + tgt % W] = recv
+            for h, (g, b, blk) in enumerate(home):
+                v, bb = self._views(g, self.where[g][b])
+                v.copy_(rec[h * W: (h + 1) * W, :k])
+                bb.copy_(rec[h * W: (h + 1) * W, k])
+        self.layout_epoch = new_layout_epoch
+        self.redeals += 1
+
+    # ---- a step ----
     def step(self, lr, reg, use_bias=True, neg_population=0, flags=0):
-        """one step of the conveyor: on every ring, train the block whose turn it is; then hand the trained blocks to the
-        rings' next ranks and take the ones their previous ranks have just trained (beside the NEXT step's launches)"""
+        """one step of the conveyor: ONE launch trains, on every ring, the block whose turn it is; then the trained blocks go to
+        the rings' next ranks and the ones their previous ranks have just trained arrive (beside the NEXT step's launch)"""
+        epoch, ts = divmod(self.t, self.nb)
+        if ts == 0:
+            want = epoch - epoch % self.redeal_every
+            if want != self.layout_epoch:
+                self._redeal(want)
         ranks = dist.get_process_group_ranks(self.group) if (self.group is not None and self.world > 1) else list(range(self.world))
         moves = []                                    # (ring, trained block, its buffer, free buffer, block arriving)
         with self._on(self.stream):
+            blocks, bufs = [], []
             for g, p in enumerate(self.pos):
-                b = (2 * p + self.t) % self.nb
+                b = (2 * p + ts) % self.nb
                 buf = self.where[g][b]
                 self._await(self.arrived[g][buf])     # the receive that brought the block here
                 self.arrived[g][buf] = None
-                tr = self.trainers[self.block_id(g, b)]
-                if tr is not None:
-                    tr.bind_items(*self._views(g, buf, b))
-                    tr.hogwild_enqueue(tr.nnz, lr, reg, use_bias, neg_population, flags)
-                self.steps_trained.append((self.t % self.nb, self.block_id(g, b)))
-                free = ({0, 1, 2} - set(self.where[g].values())).pop()
-                moves.append((g, b, buf, free, (b + 2) % self.nb))
+                blocks.append(self.block_id(g, b))
+                bufs.append(self.bufs[g][buf])
+                self.steps_trained.append((ts, self.block_id(g, b)))
+                if self.world > 1 or self.emulate_traffic:
+                    free = (set(range(len(self.bufs[g]))) - set(self.where[g].values())).pop()
+                    moves.append((g, b, buf, free, (b + 2) % self.nb))
+            with self._timed("launch", self.stream):
+                self.trainer.conveyor_enqueue(epoch, self.layout_epoch, blocks, bufs, lr, reg, use_bias, neg_population, flags)
             trained = None
             if self.stream is not None:
                 trained = torch.cuda.Event()
@@ -1328,10 +1440,12 @@ class RingShardedBprTrainer:
                     dst, src = ranks[(self.rank - s) % self.world], ranks[(self.rank + s) % self.world]
                     ops.append(dist.P2POp(dist.isend, self.bufs[g][buf], dst, self.group))
                     ops.append(dist.P2POp(dist.irecv, self.bufs[g][free], src, self.group))
-                works = [_OnceWork(w) for w in dist.batch_isend_irecv(ops)]
+                with self._timed("move", self.comm):
+                    works = [_OnceWork(w) for w in dist.batch_isend_irecv(ops)]
+                    if self.comm is not None:
+                        for w in works:
+                            w.wait()                  # (stream-level on RCCL: the communication stream waits, the host does not)
                 if self.comm is not None:
-                    for w in works:
-                        w.wait()                      # (stream-level on RCCL: the communication stream waits, the host does not)
                     ev = torch.cuda.Event()
                     ev.record(self.comm)
                     for g, b, buf, free, nxt in moves:
@@ -1344,19 +1458,20 @@ class RingShardedBprTrainer:
                 del self.where[g][b]
                 self.where[g][nxt] = free
         elif self.emulate_traffic:
+            # one rank: the block goes to the free buffer as if it travelled (and is trained from there next epoch)
             with self._on(self.comm):
                 if self.comm is not None:
                     self.comm.wait_event(trained)
-                for g, b, buf, free, nxt in moves:
-                    self.bufs[g][free].copy_(self.bufs[g][buf])
+                with self._timed("move", self.comm):
+                    for g, b, buf, free, nxt in moves:
+                        self.bufs[g][free].copy_(self.bufs[g][buf])
                 ev = None
                 if self.comm is not None:
                     ev = torch.cuda.Event()
                     ev.record(self.comm)
                 for g, b, buf, free, nxt in moves:
                     self.arrived[g][free] = ev
-                    del self.where[g][b]
-                    self.where[g][nxt] = free         # (2 blocks per ring on one rank: block b itself, two steps later)
+                    self.where[g][b] = free
         self.t += 1
 
     def run_epoch(self, lr, reg, use_bias=True, neg_population=0, flags=0):
@@ -1365,7 +1480,7 @@ class RingShardedBprTrainer:
 
     def _drain(self):
         for g in range(self.K):
-            for buf in range(3):
+            for buf in range(len(self.bufs[g])):
                 self._await(self.arrived[g][buf])
                 self.arrived[g][buf] = None
         for w in self._sent:
@@ -1378,43 +1493,42 @@ class RingShardedBprTrainer:
     def finish(self):
         """(correct, skipped) of this rank since the last finish(); every transfer has landed"""
         self._drain()
-        c = s = 0
-        for tr in self.trainers:
-            if tr is not None:
-                dc, ds = tr.sync()
-                c, s = c + dc, s + ds
-        return c, s
+        return self.trainer.sync()
 
     def gather(self):
-        """the full (V, B) host tables on every rank; at an epoch boundary (every rank holds its two blocks of every ring)"""
+        """the full (V, B) host tables on every rank; at an epoch boundary (every rank holds its home blocks)"""
         if self.t % self.nb:
             raise RuntimeError("gather() in the middle of an epoch (step %d of %d)" % (self.t % self.nb, self.nb))
         self._drain()
-        mine = torch.stack([self.bufs[g][self.where[g][2 * p + h]] for g, p in enumerate(self.pos) for h in (0, 1)])
+        home = self.home_blocks()
+        mine = torch.stack([self.bufs[g][self.where[g][b]] for g, b, _ in home])
         if self.world > 1:
             comm_dev = _comm_device(self.device, self.group)
-            full = torch.empty((self.world * 2 * self.K,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm_dev)
+            full = torch.empty((self.world * len(home),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm_dev)
             dist.all_gather_into_tensor(full, mine.to(comm_dev).contiguous(), group=self.group)
         else:
             full = mine
-        full = full.cpu().numpy().reshape(self.world, self.K, 2, -1)
-        V = np.empty((self.n_items, self.k), np.float32)
-        B = np.empty(self.n_items, np.float32)
+        full = full.cpu().numpy().reshape(self.world, len(home), -1)
+        with self._on(self.stream):
+            slot_item, _ = self._layout(self.layout_epoch)
+            slot_item = slot_item.cpu().numpy()
+        V = np.zeros((self.n_items, self.k), np.float32)
+        B = np.zeros(self.n_items, np.float32)
+        if self._tail is not None:
+            V[self.n_train:], B[self.n_train:] = self._tail
+        W, k = self.W, self.k
         for r in range(self.world):
-            for g, s in enumerate(self.strides):
-                p = (r * pow(s, -1, self.world)) % self.world if self.world > 1 else 0
-                for h in (0, 1):
-                    blk = self.block_id(g, 2 * p + h)
-                    rows = self.rows[blk]
-                    V[blk:: self.nb_total] = full[r, g, h, : rows * self.k].reshape(rows, self.k)
-                    B[blk:: self.nb_total] = full[r, g, h, self.rows_max * self.k: self.rows_max * self.k + rows]
+            for h, (_, _, blk) in enumerate(self.home_blocks(r)):
+                items = slot_item[blk * W: (blk + 1) * W]
+                ok = items >= 0
+                V[items[ok]] = full[r, h, : W * k].reshape(W, k)[ok]
+                B[items[ok]] = full[r, h, W * k:][ok]
         return V, B
 
     def close(self):
-        for tr in self.trainers:
-            if tr is not None:
-                tr.close()
-        self.trainers = []
+        if self.trainer is not None:
+            self.trainer.close()
+        self.trainer = None
 
 
 # ---- model-level entry points: model.fit(train_set) over all ranks of a process group ----------------------------------
@@ -1520,11 +1634,14 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     if regime == "auto" and (sync_per_epoch is not None or rule is not None or sparse_threshold is not None
                              or trainer_factory is not None):
         regime = "replicated"
+    if regime == "auto" and world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+        regime = "replicated"   # WBPR with the GLOBAL popularity: the conveyor only has the rank-local one (fit_bpr_ring)
     if regime != "replicated":
         X0 = train_set.matrix
         per_rank = int(X0.nnz // max(world, 1)) + 1
         if regime == "ring" or exchange_schedule(per_rank, train_set.num_items)[1] > 1:
-            return fit_bpr_ring(model, train_set, device=device, group=group, local_popularity=local_popularity, rings=rings)
+            return fit_bpr_ring(model, train_set, device=device, group=group,
+                                local_popularity=local_popularity or model._neg_population != _lib.NEG_POPULARITY, rings=rings)
     Recommender.fit(model, train_set)
     model._init()
     if model.trains_float64:
@@ -1590,13 +1707,21 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     return model
 
 
-def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None, local_popularity=False, rings=1):
+def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None, local_popularity=True, rings=1,
+                 redeal_every=1):
     """`model.fit(train_set)` for a cornac_amd BPR / WBPR over all ranks of the process group with the item table sharded
-    by row and rotating around the ring (regime 2, RingShardedBprTrainer): the same calling convention and restrictions as
+    by row and rotating around the ring (regime 2, BinConveyorBprTrainer): the same calling convention and restrictions as
     fit_bpr_sharded, no replica and no reconciliation rule — every item row is in one place at any time, so the result
     is the serial execution of the ranks' steps.  The memory an item table needs per rank is 3 / (2 N) of it.
-    WBPR: a draw's popularity-weighted negative comes from the block being trained, weighted by the GLOBAL item degrees (the
-    ranks all-reduce them; local_popularity=True: by the degrees among the rank's own users)."""
+
+    Sampling contract: every interaction is drawn with the reference's probability 1 / nnz per draw, nnz draws per epoch
+    (each by the rank that owns its user); the negative of a draw is uniform over the ~cap items that share the positive's
+    LDS bin in that epoch; bins — and with them the conveyor's blocks, which are ranges of bins — are re-dealt from ALL train
+    items every `redeal_every` epochs with a key the ranks share, over the popularity order of the WHOLE matrix (the ranks
+    all-reduce their item degrees), so every (positive, negative) pair of items can meet (recom_bpr.pyx:235-238 draws j over
+    all items; csrc/bpr_ldsbin.inc, tests/test_ldsbin_deal_cpu.py).
+    WBPR: the popularity-weighted negative is the item of a second interaction drawn among the RANK'S OWN users' interactions
+    with the bin's items (local popularity — the only form the conveyor has: local_popularity=False raises)."""
     from . import _lib
     from .recommender import Recommender
 
@@ -1608,7 +1733,11 @@ def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None
     model._init()
     if model.trains_float64:
         raise ValueError("float64 tables train on the sequential engine only")
-    _broadcast_from_rank0([model.u_factors, model.i_factors, model.i_biases], device, group)
+    if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
+        raise ValueError("the conveyor draws WBPR's negative by the popularity among the rank's own users (local_popularity=True); "
+                         "the global popularity is served by regime='replicated'")
+    seeds = np.array([int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))], np.int64)
+    _broadcast_from_rank0([model.u_factors, model.i_factors, model.i_biases, seeds], device, group)
     X = train_set.matrix
     if not X.has_sorted_indices:
         X.sort_indices()
@@ -1618,16 +1747,13 @@ def fit_bpr_ring(model, train_set, device=None, group=None, trainer_factory=None
         raise ValueError("a rank would receive no interactions (%r): use fewer ranks" % (counts,))
     u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
     indptr, indices = slice_csr(X.indptr, X.indices, u0, u1)
-    lo, hi = int(model.rng.randint(2 ** 31)), int(model.rng.randint(2 ** 31))
-    ring = RingShardedBprTrainer(indptr, indices, u1 - u0, model.total_items, model.k, device, group=group,
-                                 trainer_factory=trainer_factory, seed=(hi << 32) | lo, rings=rings,
-                                 n_train_items=train_set.num_items)
+    # the popularity order of the WHOLE matrix (every rank must deal the same items to the same bins)
+    deg = global_item_degrees(indices, train_set.num_items, device, group)
+    order = np.argsort(-deg, kind="stable").astype(np.int32)
+    ring = BinConveyorBprTrainer(indptr, indices, u1 - u0, model.total_items, model.k, device, group=group,
+                                 trainer_factory=trainer_factory, seed=(int(seeds[1]) << 32) | int(seeds[0]), rings=rings,
+                                 n_train_items=train_set.num_items, item_order=order, redeal_every=redeal_every)
     try:
-        if world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
-            # the popularity of the WHOLE matrix (the ranks all-reduce their item degrees), block by block
-            deg = np.zeros(model.total_items, np.int64)
-            deg[: train_set.num_items] = global_item_degrees(indices, train_set.num_items, device, group)
-            ring.set_negative_population(deg)
         ring.set_user_factors(model.u_factors[u0:u1])
         ring.load_items(model.i_factors, model.i_biases)
         for _ in range(model.max_iter):

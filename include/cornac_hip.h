@@ -311,6 +311,27 @@ int cornac_hip_bpr_epoch_resident_enqueue(cornac_hip_bpr_t h, float lr, float re
 int cornac_hip_bpr_resident_flush(cornac_hip_bpr_t h, int n_exchanges, int rule, float *d_base, const float *d_buckets,
                                   int64_t bucket_stride, const float *d_keeps, int64_t keep_stride,
                                   const uint32_t *d_applied, const uint32_t *d_landed);
+/* Conveyor layout of the LDS-bin form — multi-GPU regime 2 ("V rows owned by ..." — here the item table is
+ * sharded by row into n_blocks blocks that rotate over the ranks, cornac_amd/dist.py BinConveyorBprTrainer).  No reference
+ * counterpart (cornac is one process); a launch computes recom_bpr.pyx:231-267 for the draws of its bins.
+ *   conveyor_setup   plans the bins as n_blocks equal ranges (block B = the bins [B bpb, (B + 1) bpb) of the epoch's deal: a
+ *                    block's ITEMS change with the deal key like any bin's, so every (positive, negative) pair of items can
+ *                    meet), no hot items; rank_item [n_items]: the popularity order every rank of the fit agrees on (NULL: the
+ *                    handle's own interactions'); deal_seed: shared by the ranks (the draws keep the handle's hogwild seed);
+ *                    release_item_tables != 0 frees the handle's own V / B (the rows live in the caller's block buffers).
+ *                    Out: *n_bins, *bins_per_block, *cap (slots per bin).  A block buffer is [bpb cap k rows | bpb cap biases]
+ *                    floats, row (bin - first bin of the block) cap + slot.
+ *   conveyor_layout  on the handle's stream: d_slot_item [n_bins cap] = the item at (bin, slot) under the deal of layout_epoch
+ *                    (-1: none), d_item_slot [n_items] = its inverse (either may be NULL)
+ *   conveyor_enqueue one launch on the handle's stream: all of this handle's draws of `epoch` whose positive lies in the blocks
+ *                    first_block[0 .. n_ranges) (distinct; n_ranges <= 8), rows read from / written to d_rows[r]; the deal is
+ *                    that of layout_epoch (the caller re-deals the buffers when it changes).  Counters: cornac_hip_bpr_sync. */
+int cornac_hip_bpr_conveyor_setup(cornac_hip_bpr_t h, int n_blocks, const int32_t *rank_item, uint64_t deal_seed,
+                                  int release_item_tables, int *n_bins, int *bins_per_block, int *cap);
+int cornac_hip_bpr_conveyor_layout(cornac_hip_bpr_t h, uint32_t layout_epoch, int32_t *d_slot_item, int32_t *d_item_slot);
+int cornac_hip_bpr_conveyor_enqueue(cornac_hip_bpr_t h, uint32_t epoch, uint32_t layout_epoch, int n_ranges,
+                                    const int32_t *first_block, float *const *d_rows, float lr, float reg, int use_bias,
+                                    int neg_population, int hogwild_flags);
 /* on `hip_stream` of `device`: wait until *d_counter >= target (after timeout_ms: *d_error = 1 and the stream moves on;
  * every later wait on the same d_error returns at once); set *d_flag = value unless d_unless != NULL and *d_unless != 0.
  * The resident exchange passes its d_error as d_unless: a bucket that was all-reduced incomplete never gets its landed

@@ -719,6 +719,26 @@ void oracle_ldsbin_deal(uint32_t key, uint32_t n_bins, uint32_t n_items, uint32_
     }
 }
 
+/* The (bin, slot) layout of a deal (csrc/bpr_ldsbin.inc ldsbin_layout_kernel; the conveyor's block buffers hold their rows in
+ * this order): slot_item[b cap + g] = the item dealt to slot g of bin b, -1 where the last group has none; item_slot = its
+ * inverse.  cap = ceil(n_items / n_bins). */
+void oracle_ldsbin_layout(uint32_t key, uint32_t n_bins, uint32_t n_items, uint32_t n_strata, const int32_t *rank_item,
+                          int32_t *slot_item, int32_t *item_slot) {
+    const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
+    for (uint64_t p = 0; p < (uint64_t)n_groups * n_bins; ++p) {
+        const uint32_t g = (uint32_t)(p / n_bins), o = (uint32_t)(p % n_bins);
+        const uint32_t b = (o + ldsbin_rot(g, key, n_bins)) % n_bins;
+        const uint64_t slot = (uint64_t)b * n_groups + g;
+        if (p < n_items) {
+            const int32_t it = rank_item[ldsbin_deal_rank((uint32_t)p, key, n_bins, n_items, n_groups, n_strata)];
+            slot_item[slot] = it;
+            item_slot[it] = (int32_t)slot;
+        } else {
+            slot_item[slot] = -1;
+        }
+    }
+}
+
 uint32_t oracle_ldsbin_key(uint64_t seed, uint32_t epoch) {
     uint32_t w[4];
     oracle_philox4x32(epoch, 0x1D5B1Au, 0u, 4u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
@@ -734,12 +754,32 @@ static int csr_has(const int32_t *indices, int32_t lo, int32_t hi, int32_t col) 
     return lo < end && indices[lo] == col;
 }
 
+int64_t oracle_ldsbin_epoch_skips_range(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
+                                        uint32_t n_hot, uint32_t n_strata, uint32_t hot_cost_x16, const int32_t *rank_item,
+                                        const int32_t *cptr, const int32_t *cusers,
+                                        const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
+                                        const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count,
+                                        int neg_pop, uint32_t b_lo, uint32_t b_hi);
+
 int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
                                   uint32_t n_hot, uint32_t n_strata, uint32_t hot_cost_x16, const int32_t *rank_item,
                                   const int32_t *cptr, const int32_t *cusers,
                                   const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
                                   const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count,
                                   int neg_pop) {
+    return oracle_ldsbin_epoch_skips_range(seed, epoch, key, n_bins, n_items, n_hot, n_strata, hot_cost_x16, rank_item, cptr, cusers,
+                                           hot_u, hot_i, n_hot_inter, indptr, indices, n_draws_out, pos_count, neg_count, neg_pop,
+                                           0u, n_bins);
+}
+
+/* the same for the bins [b_lo, b_hi) only (a conveyor block's launch; a sample of the bins at sizes where the whole epoch
+ * would take minutes on one core) */
+int64_t oracle_ldsbin_epoch_skips_range(uint64_t seed, uint32_t epoch, uint32_t key, uint32_t n_bins, uint32_t n_items,
+                                        uint32_t n_hot, uint32_t n_strata, uint32_t hot_cost_x16, const int32_t *rank_item,
+                                        const int32_t *cptr, const int32_t *cusers,
+                                        const int32_t *hot_u, const int32_t *hot_i, uint32_t n_hot_inter, const int32_t *indptr,
+                                        const int32_t *indices, int64_t *n_draws_out, int64_t *pos_count, int64_t *neg_count,
+                                        int neg_pop, uint32_t b_lo, uint32_t b_hi) {
     const uint32_t n_groups = (n_items + n_bins - 1) / n_bins;
     uint32_t *cold_all = (uint32_t *)malloc(sizeof(uint32_t) * n_bins);
     uint32_t *hot_off = (uint32_t *)malloc(sizeof(uint32_t) * (n_bins + 1));
@@ -750,7 +790,7 @@ int64_t oracle_ldsbin_epoch_skips(uint64_t seed, uint32_t epoch, uint32_t key, u
     uint32_t *cum = (uint32_t *)malloc(sizeof(uint32_t) * (n_groups + 1));
     uint8_t *hot = (uint8_t *)malloc(n_groups);
     int64_t skipped = 0, total = 0;
-    for (uint32_t b = 0; b < n_bins; ++b) {
+    for (uint32_t b = b_lo; b < b_hi && b < n_bins; ++b) {
         uint32_t n_slots = n_groups;
         cum[0] = 0;
         for (uint32_t g = 0; g < n_groups; ++g) {

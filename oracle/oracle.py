@@ -108,11 +108,15 @@ def _bind(L):
         L.oracle_ldsbin_hot_shuffle_key.restype = C.c_uint32
         L.oracle_ldsbin_deal.argtypes = [C.c_uint32] * 6 + [i32p, i32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_ldsbin_deal.restype = None
+        L.oracle_ldsbin_layout.argtypes = [C.c_uint32] * 4 + [i32p, C.c_void_p, C.c_void_p]
+        L.oracle_ldsbin_layout.restype = None
         L.oracle_ldsbin_epoch_skips.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.c_uint32, i32p,
                                                 i32p, i32p, i32p, i32p, C.c_uint32, i32p, i32p, C.POINTER(C.c_int64),
                                                 C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_ldsbin_epoch_skips.restype = C.c_int64
+        L.oracle_ldsbin_epoch_skips_range.argtypes = list(L.oracle_ldsbin_epoch_skips.argtypes) + [C.c_uint32, C.c_uint32]
+        L.oracle_ldsbin_epoch_skips_range.restype = C.c_int64
         L.oracle_num_threads.restype = C.c_int
         L.oracle_sizeof_mt.restype = C.c_int
     return L
@@ -523,21 +527,35 @@ def ldsbin_deal(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, strata
     return bin_of, cold, off, t["hot_u"][:t["n_hot_inter"]], t["hot_i"][:t["n_hot_inter"]], t["n_hot"]
 
 
+def ldsbin_layout(deal_seed, layout_epoch, n_bins, n_items, rank_item, strata_groups=16):
+    """(slot_item [n_bins cap], item_slot [n_items]) of the deal keyed by (deal_seed, layout_epoch): the order in which the
+    conveyor's block buffers hold their rows (csrc/bpr_ldsbin.inc ldsbin_layout_kernel)."""
+    cap = (n_items + n_bins - 1) // n_bins
+    slot_item, item_slot = np.empty(n_bins * cap, np.int32), np.empty(n_items, np.int32)
+    lib().oracle_ldsbin_layout(int(lib().oracle_ldsbin_key(int(deal_seed), int(layout_epoch))), int(n_bins), int(n_items),
+                               int(ldsbin_n_strata(n_items, n_bins, strata_groups)), np.ascontiguousarray(rank_item, np.int32),
+                               slot_item.ctypes.data, item_slot.ctypes.data)
+    return slot_item, item_slot
+
+
 def ldsbin_epoch(seed, epoch, n_bins, hot_x1000, indptr, indices, n_items, count_touches=False, neg_pop=False,
-                 strata_groups=16, hot_cost_x16=32, tables=None, share=None):
+                 strata_groups=16, hot_cost_x16=32, tables=None, share=None, deal=None, bins=None):
     """CPU restatement of one epoch of the LDS-bin sampler (csrc/bpr_ldsbin.inc): returns (skipped, draws, n_hot[,
-    positive touches per item, negative touches per item])."""
+    positive touches per item, negative touches per item]).  deal = (deal_seed, layout_epoch): the deal's key comes from
+    there instead of (seed, epoch) — the conveyor layout, whose ranks share the deal but not the draws' seed.  bins = (lo, hi): the
+    draws of the bins [lo, hi) only."""
     t = tables if tables is not None else ldsbin_tables(indptr, indices, n_items, n_bins, hot_x1000, share)
-    key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)))
+    key = int(lib().oracle_ldsbin_key(int(seed), int(epoch)) if deal is None else lib().oracle_ldsbin_key(int(deal[0]), int(deal[1])))
     draws = C.c_int64()
     pos = np.zeros(n_items, np.int64) if count_touches else None
     neg = np.zeros(n_items, np.int64) if count_touches else None
-    s = lib().oracle_ldsbin_epoch_skips(int(seed), int(epoch), key, int(n_bins), int(n_items), int(t["n_hot"]),
-                                        int(ldsbin_n_strata(n_items, n_bins, strata_groups)), int(hot_cost_x16),
-                                        t["rank_item"], t["cptr"], t["cusers"], t["hot_u"], t["hot_i"],
-                                        int(t["n_hot_inter"]), t["indptr"], t["indices"], C.byref(draws),
-                                        pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None,
-                                        int(bool(neg_pop)))
+    lo, hi = (0, int(n_bins)) if bins is None else (int(bins[0]), int(bins[1]))
+    s = lib().oracle_ldsbin_epoch_skips_range(int(seed), int(epoch), key, int(n_bins), int(n_items), int(t["n_hot"]),
+                                              int(ldsbin_n_strata(n_items, n_bins, strata_groups)), int(hot_cost_x16),
+                                              t["rank_item"], t["cptr"], t["cusers"], t["hot_u"], t["hot_i"],
+                                              int(t["n_hot_inter"]), t["indptr"], t["indices"], C.byref(draws),
+                                              pos.ctypes.data if count_touches else None, neg.ctypes.data if count_touches else None,
+                                              int(bool(neg_pop)), lo, hi)
     return (int(s), int(draws.value), t["n_hot"]) + ((pos, neg) if count_touches else ())
 
 

@@ -947,61 +947,49 @@ def test_multi_epoch_exchange_interval_world2():
     assert acc0 > 0.75 and acc1 > 0.75, (acc0, acc1)
 
 
-# ---- regime 2 as a ring conveyor of item blocks (RingShardedBprTrainer) ---------------------------------------------------
-class _RingMarkTrainer:
-    """adds a rank-dependent constant to the block it is bound to: the conveyor's bookkeeping made visible"""
+# ---- regime 2: the ring conveyor, its blocks bin ranges of the epoch's deal (BinConveyorBprTrainer) ------------------------
+class _ConveyorHostTrainer:
+    """host stand-in of a rank's conveyor handle (cornac_hip_bpr_conveyor_*): the layout is the oracle's restatement of the
+    device's deal; what a launch does to the rows is left to the subclasses"""
 
-    def __init__(self, rank, block, log):
-        self.rank, self.block, self.log, self.n = rank, block, log, 0
-
-    def seed_hogwild(self, seed):
-        pass
-
-    def bind_items(self, V, B):
-        self.V, self.B = V, B
-
-    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
-        self.V += float(self.rank + 1)
-        self.B += 10.0 * (self.rank + 1)
-        self.n += n
-        self.log.append(self.block)
-
-    def sync(self):
-        return (self.n, 0)
-
-    def close(self):
-        pass
-
-
-class _RingOracleTrainer:
-    """real BPR arithmetic on one item block: the oracle's sequential epoch over the rank's interactions with the block's
-    items (block-local ids), in place on the shared user table and on wherever the block's buffer currently is"""
-
-    def __init__(self, indptr, indices, n_rows, k, U):
-        import ctypes as C
-
+    def __init__(self, indptr, indices, n_users, n_items, k, U, cap_target=7):
         from oracle import oracle as orc
 
-        self.C, self.orc = C, orc
+        self.orc = orc
         self.indptr, self.indices = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
         self.user_ids = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr)).astype(np.int32)
-        self.neg_ids = np.arange(n_rows, dtype=np.int32)
-        self.U, self.k, self.n_rows, self.correct, self.skipped = U.numpy(), k, n_rows, 0, 0
+        self.n_items, self.k, self.U, self.cap_target = int(n_items), int(k), U.numpy(), cap_target
+        self.correct = self.skipped = 0
+        self._layouts = {}
 
     def seed_hogwild(self, seed):
         self.gp, self.gn = self.orc.MT19937(seed % (2 ** 31)), self.orc.MT19937((seed >> 32) % (2 ** 31) + 1)
 
-    def bind_items(self, V, B):
-        self.V, self.B = V.numpy(), B.numpy()
-        assert self.V.flags.c_contiguous and self.V.shape == (self.n_rows, self.k)
+    def conveyor_setup(self, n_blocks, rank_item, deal_seed):
+        per_block = max(1, -(-self.n_items // (self.cap_target * n_blocks)))
+        self.n_bins = n_blocks * per_block
+        self.bpb, self.cap = per_block, -(-self.n_items // self.n_bins)
+        self.deal_seed = deal_seed
+        self.rank_item = (np.argsort(-np.bincount(self.indices, minlength=self.n_items), kind="stable") if rank_item is None
+                          else np.asarray(rank_item)).astype(np.int32)
+        return self.n_bins, self.bpb, self.cap
 
-    def hogwild_enqueue(self, n, lr, reg, use_bias, neg_population, flags):
-        c, s = self.C.c_int64(), self.C.c_int64()
-        rc = self.orc.lib().oracle_bpr_epoch_seq(self.gp.ptr, self.gn.ptr, len(self.user_ids) - 1, self.n_rows - 1, int(n),
-                                                 self.user_ids, self.indices, self.neg_ids, self.indptr, self.U, self.V, self.B,
-                                                 self.k, lr, reg, int(use_bias), self.C.byref(c), self.C.byref(s), None, None, None)
-        assert rc == 0
-        self.correct, self.skipped = self.correct + c.value, self.skipped + s.value
+    def _layout(self, layout_epoch):
+        if layout_epoch not in self._layouts:
+            self._layouts[layout_epoch] = self.orc.ldsbin_layout(self.deal_seed, layout_epoch, self.n_bins, self.n_items, self.rank_item)
+        return self._layouts[layout_epoch]
+
+    def conveyor_layout(self, layout_epoch):
+        si, isl = self._layout(layout_epoch)
+        return torch.as_tensor(si.copy()), torch.as_tensor(isl.copy())
+
+    def conveyor_enqueue(self, epoch, layout_epoch, blocks, bufs, lr, reg, use_bias, neg_population, flags):
+        W = self.bpb * self.cap
+        slot_item, item_slot = self._layout(layout_epoch)
+        for blk, buf in zip(blocks, bufs):
+            flat = buf.numpy()
+            self.train_block(blk, slot_item[blk * W: (blk + 1) * W], item_slot, flat[: W * self.k].reshape(W, self.k), flat[W * self.k:],
+                             lr, reg, use_bias)
 
     def sync(self):
         out, self.correct, self.skipped = (self.correct, self.skipped), 0, 0
@@ -1009,6 +997,47 @@ class _RingOracleTrainer:
 
     def close(self):
         pass
+
+
+class _ConveyorMarkTrainer(_ConveyorHostTrainer):
+    """adds a rank-dependent constant to every row of the blocks it is handed: the conveyor's bookkeeping made visible"""
+
+    def __init__(self, rank, log, *a):
+        super().__init__(*a)
+        self.rank, self.log = rank, log
+
+    def train_block(self, blk, items, item_slot, V, B, lr, reg, use_bias):
+        ok = items >= 0
+        V[ok] += float(self.rank + 1)
+        B[ok] += 10.0 * (self.rank + 1)
+        self.correct += int(ok.sum())
+        self.log.append(blk)
+
+
+class _ConveyorOracleTrainer(_ConveyorHostTrainer):
+    """real BPR arithmetic on one block: the oracle's sequential epoch over the rank's interactions with the block's items
+    (ids = the rows' slots in the block's buffer, negatives among the block's items), in place on the shared user table and
+    on the block's buffer"""
+
+    def train_block(self, blk, items, item_slot, V, B, lr, reg, use_bias):
+        import ctypes as C
+
+        W = len(items)
+        slots = item_slot[self.indices].astype(np.int64)
+        mine = (slots // W) == blk
+        if not mine.any():
+            return
+        users, local = self.user_ids[mine], (slots[mine] - blk * W).astype(np.int32)
+        order = np.lexsort((local, users))
+        users, local = np.ascontiguousarray(users[order]), np.ascontiguousarray(local[order])
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(users, minlength=len(self.indptr) - 1))]).astype(np.int32)
+        neg_ids = np.flatnonzero(items >= 0).astype(np.int32)
+        c, s = C.c_int64(), C.c_int64()
+        rc = self.orc.lib().oracle_bpr_epoch_seq(self.gp.ptr, self.gn.ptr, len(users) - 1, len(neg_ids) - 1, len(users), users, local,
+                                                 neg_ids, indptr, self.U, V, B, self.k, lr, reg, int(use_bias), C.byref(c),
+                                                 C.byref(s), None, None, None)
+        assert rc == 0
+        self.correct, self.skipped = self.correct + c.value, self.skipped + s.value
 
 
 def _ring_data(rank, n_users=120, n_items=50, per_user=14):
@@ -1027,21 +1056,29 @@ def _ring_tables(n_users, n_items, k, rank):
     return U0, V0, B0
 
 
-def _ring_worker(rank, world, port, out, kind, epochs, rings=1, n_items=50):
-    from cornac_amd.dist import RingShardedBprTrainer
+def _ring_order(world, n_items):
+    """the popularity order of the whole matrix (every rank computes the same one)"""
+    deg = sum(np.bincount(_ring_data(r, n_items=n_items)[1], minlength=n_items) for r in range(world))
+    return np.argsort(-deg, kind="stable").astype(np.int32)
+
+
+def _ring_worker(rank, world, port, out, kind, epochs, rings=1, n_items=50, redeal_every=1, n_train=None):
+    from cornac_amd.dist import BinConveyorBprTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         k = 6
-        indptr, indices = _ring_data(rank, n_items=n_items)
+        n_train = n_items if n_train is None else n_train
+        indptr, indices = _ring_data(rank, n_items=n_train)
         log = []
         if kind == "mark":
-            factory = lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log)
+            factory = lambda *a: _ConveyorMarkTrainer(rank, log, *a)
         else:
-            factory = lambda b, ip, ix, nu, rows, k_, U: _RingOracleTrainer(ip, ix, rows, k_, U)
-        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), trainer_factory=factory, seed=5,
-                                     rings=rings)
+            factory = lambda *a: _ConveyorOracleTrainer(*a)
+        ring = BinConveyorBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), trainer_factory=factory, seed=5,
+                                     rings=rings, item_order=_ring_order(world, n_train), redeal_every=redeal_every,
+                                     n_train_items=n_train)
         U0, V0, B0 = _ring_tables(len(indptr) - 1, n_items, k, rank)
         ring.load_items(V0, B0)
         ring.set_user_factors(U0)
@@ -1049,83 +1086,121 @@ def _ring_worker(rank, world, port, out, kind, epochs, rings=1, n_items=50):
             ring.run_epoch(0.05, 0.01)
         c, s = ring.finish()
         V, B = ring.gather()
-        out[rank] = (V, B, ring.get_user_factors(), list(ring.steps_trained), log, c, s, ring.nnz)
+        out[rank] = (V, B, ring.get_user_factors(), list(ring.steps_trained), log, c, s, ring.nnz, ring.redeals,
+                     (ring.n_bins, ring.bpb, ring.cap))
         ring.close()
     finally:
         dist.destroy_process_group()
 
 
 def test_ring_conveyor_world2_every_rank_trains_every_block_once_per_epoch():
-    """the bookkeeping of RingShardedBprTrainer over two gloo ranks: 4 blocks, an epoch = 4 steps, rank r trains block
-    (2 r + t) % 4 in step t — every (rank, block) pair exactly once per epoch, a block never in two places — and after the
-    epochs every rank gathers the same table: every row moved by (1 + 2) per epoch"""
+    """the bookkeeping of BinConveyorBprTrainer over two gloo ranks: 4 blocks, an epoch = 4 steps, rank r trains block
+    (2 r + t) % 4 in step t — every (rank, block) pair exactly once per epoch, a block never in two places; between the epochs
+    the rows are re-dealt to new slots (one all_to_all) without losing or duplicating one; after the epochs every rank gathers
+    the same table: every train row moved by (1 + 2) per epoch, the rows beyond the train items untouched"""
     out = mp.Manager().dict()
-    mp.spawn(_ring_worker, args=(2, _free_port(), out, "mark", 3), nprocs=2, join=True)
-    _, V0, B0 = _ring_tables(120, 50, 6, 0)
+    mp.spawn(_ring_worker, args=(2, _free_port(), out, "mark", 3, 1, 53, 1, 50), nprocs=2, join=True)
+    _, V0, B0 = _ring_tables(120, 53, 6, 0)
     for rank in (0, 1):
-        V, B, U, steps, log, c, s, nnz = out[rank]
+        V, B, U, steps, log, c, s, nnz, redeals, _ = out[rank]
         assert steps == [(t % 4, (2 * rank + t) % 4) for t in range(12)]
-        assert log == [(2 * rank + t) % 4 for t in range(12)] and c == 3 * nnz
-        assert np.allclose(V, V0 + 3 * 3.0) and np.allclose(B, B0 + 3 * 30.0)
+        assert log == [(2 * rank + t) % 4 for t in range(12)] and c == 3 * 50 and redeals == 2
+        assert np.allclose(V[:50], V0[:50] + 3 * 3.0) and np.allclose(B[:50], B0[:50] + 3 * 30.0)
+        assert np.array_equal(V[50:], V0[50:]) and np.array_equal(B[50:], B0[50:])
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("world,rings,n_items", [(2, 1, 50), (3, 2, 50), (4, 2, 50), (8, 4, 200)])
-def test_ring_conveyor_equals_its_serial_execution(world, rings, n_items):
-    """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
-    disjoint item blocks, so the gloo ranks must produce bit for bit what ONE process gets by running the same (step,
-    rank, ring) triples one after the other — item table, biases and every rank's user rows; and the model learns.
-    world 3 with two rings: the blocks of ring 1 travel r -> r - 2 (the other direction of the links), both rings
-    advance in the same steps; world 4: strides 1 and 3; world 8 with four rings (strides 1, 7, 3, 5: the configuration meant
-    for configs[4] on a node: 64 blocks, 16 steps per epoch, four blocks trained and four in flight per rank and step)."""
-    from cornac_amd.dist import ring_strides, split_csr_by_item_block
+def _serial_conveyor(world, rings, n_items, epochs, k, redeal_every, dims):
+    """ONE process running the same (step, rank, ring) triples one after the other on ONE item table in item order: a block's
+    buffer is cut out of the table by the layout of the step's epoch, trained, and written back — so the re-deal is implicit"""
+    from cornac_amd.dist import ring_strides
+    from oracle import oracle as orc
 
-    epochs, k = 3, 6
-    out = mp.Manager().dict()
-    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs, rings, n_items), nprocs=world, join=True)
-    # the serial execution
     strides = ring_strides(world, rings)
     K, nb = len(strides), 2 * world
-    assert K == rings
-    nbt = nb * K
+    n_bins, bpb, cap = dims
+    W = bpb * cap
     _, V, B = _ring_tables(120, n_items, k, 0)
     V, B = V.copy(), B.copy()
-    blocks = [(np.ascontiguousarray(V[b::nbt]), np.ascontiguousarray(B[b::nbt])) for b in range(nbt)]
-    Us, trainers, nnz = [], [], []
+    order = _ring_order(world, n_items)
+    Us, trainers = [], []
     for rank in range(world):
         indptr, indices = _ring_data(rank, n_items=n_items)
         U = torch.as_tensor(_ring_tables(len(indptr) - 1, n_items, k, rank)[0].copy())
+        tr = _ConveyorOracleTrainer(indptr, indices, len(indptr) - 1, n_items, k, U)
+        tr.seed_hogwild((5 * 0x9E3779B97F4A7C15 + 7919 * rank + 1) & 0xFFFFFFFFFFFFFFFF)
+        assert tr.conveyor_setup(nb * K, order, (5 ^ 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF) == dims
         Us.append(U)
-        row = []
-        for b, (ip, ix) in enumerate(split_csr_by_item_block(indptr, indices, nbt)):
-            tr = None
-            if len(ix):
-                tr = _RingOracleTrainer(ip, ix, len(blocks[b][1]), k, U)
-                tr.nnz = len(ix)
-                tr.seed_hogwild((5 * 0x9E3779B97F4A7C15 + 7919 * rank + 104729 * b + 1) & 0xFFFFFFFFFFFFFFFF)
-            row.append(tr)
-        trainers.append(row)
-        nnz.append(len(indices))
+        trainers.append(tr)
     for t in range(epochs * nb):
+        epoch, ts = divmod(t, nb)
+        lay = epoch - epoch % redeal_every
         for rank in range(world):
+            tr = trainers[rank]
+            slot_item, item_slot = tr._layout(lay)
             for g, stride in enumerate(strides):
                 p = (rank * pow(stride, -1, world)) % world
-                b = ((2 * p + t) % nb) * K + g
-                tr = trainers[rank][b]
-                if tr is None:
-                    continue
-                tr.bind_items(torch.as_tensor(blocks[b][0]), torch.as_tensor(blocks[b][1]))
-                tr.hogwild_enqueue(tr.nnz, 0.05, 0.01, True, 0, 0)
-    for b in range(nbt):
-        V[b::nbt], B[b::nbt] = blocks[b]
+                blk = ((2 * p + ts) % nb) * K + g
+                items = slot_item[blk * W: (blk + 1) * W]
+                ok = items >= 0
+                Vb, Bb = np.zeros((W, k), np.float32), np.zeros(W, np.float32)
+                Vb[ok], Bb[ok] = V[items[ok]], B[items[ok]]
+                tr.train_block(blk, items, item_slot, Vb, Bb, 0.05, 0.01, True)
+                V[items[ok]], B[items[ok]] = Vb[ok], Bb[ok]
+    return V, B, Us
+
+
+@pytest.mark.parametrize("world,rings,n_items,redeal_every", [(2, 1, 50, 1), (3, 2, 50, 1), (4, 2, 50, 2), (8, 4, 200, 1)])
+def test_ring_conveyor_equals_its_serial_execution(world, rings, n_items, redeal_every):
+    """real arithmetic (the oracle's BPR loop per block): the steps of one conveyor step touch disjoint user rows and
+    disjoint item blocks, so the gloo ranks — blocks travelling between them, rows re-dealt between the epochs by the
+    all_to_all — must produce bit for bit what ONE process gets by running the same (step, rank, ring) triples one after the
+    other on one table; and the model learns.  world 3 with two rings: the blocks of ring 1 travel r -> r - 2 (the other
+    direction of the links); world 4: strides 1 and 3, a re-deal every second epoch; world 8 with four rings (strides 1, 7,
+    3, 5: the configuration meant for configs[4] on a node: 64 blocks, 16 steps per epoch, four blocks trained in one launch
+    and four in flight per rank and step)."""
+    epochs, k = 4, 6
+    out = mp.Manager().dict()
+    mp.spawn(_ring_worker, args=(world, _free_port(), out, "oracle", epochs, rings, n_items, redeal_every), nprocs=world, join=True)
+    dims = out[0][9]
+    assert dims[0] == dims[1] * 2 * world * rings
+    V, B, Us = _serial_conveyor(world, rings, n_items, epochs, k, redeal_every, dims)
     for rank in range(world):
-        Vr, Br, Ur, steps, _, c, s, n = out[rank]
-        assert n == nnz[rank] and 0 < c and c + s <= epochs * n
-        assert len(steps) == epochs * nb * K and len(set(steps[: nb * K])) == nb * K, "every block of every ring once per epoch"
+        Vr, Br, Ur, steps, _, c, s, n, redeals, _ = out[rank]
+        assert 0 < c and c + s <= epochs * n and redeals == (epochs - 1) // redeal_every
+        assert len(steps) == epochs * 2 * world * rings and len(set(steps[: 2 * world * rings])) == 2 * world * rings, "every block once per epoch"
         assert np.array_equal(Vr, V) and np.array_equal(Br, B), "rank %d: the conveyor's table differs from the serial execution" % rank
         assert np.array_equal(Ur, Us[rank].numpy())
         indptr, indices = _ring_data(rank, n_items=n_items)
         assert _pairwise_accuracy(Ur, Vr, Br, indptr, indices, n_items) > (0.62 if n_items <= 50 else 0.55)
+
+
+def test_conveyor_blocks_are_redealt_so_every_item_pair_can_meet():
+    """round 5's conveyor fixed item i to block i % 2NK for the whole fit: 1 - 1 / 2NK of all (positive, negative) item pairs
+    could never be drawn (recom_bpr.pyx:235-238 draws j over ALL items).  Here a block is a range of bins of the epoch's deal:
+    over the epochs' layouts every pair of items shares a BIN at the rate 1 / n_bins (and a block at 1 / n_blocks), whatever
+    their ids or popularity ranks; with the layout frozen (the static conveyor's behaviour) most pairs never meet."""
+    from oracle import oracle as orc
+
+    n_items, n_blocks, n_bins = 26744, 64, 448      # ML-20M's items in 64 blocks (N = 8, four rings) of 7 bins
+    order = np.random.RandomState(1).permutation(n_items).astype(np.int32)
+    cap = -(-n_items // n_bins)
+    rs = np.random.RandomState(2)
+    x, y = rs.randint(0, n_items, 4000), rs.randint(0, n_items, 4000)
+    x, y = x[x != y], y[x != y]
+    epochs = 1500
+    same_bin, same_block = np.zeros(len(x), np.int64), np.zeros(len(x), np.int64)
+    for e in range(epochs):
+        _, item_slot = orc.ldsbin_layout(77, e, n_bins, n_items, order)
+        bx, by = item_slot[x] // cap, item_slot[y] // cap
+        same_bin += bx == by
+        same_block += (bx // (n_bins // n_blocks)) == (by // (n_bins // n_blocks))
+    assert abs(same_bin.mean() / epochs * n_bins - 1.0) < 0.1 and abs(same_block.mean() / epochs * n_blocks - 1.0) < 0.05
+    assert (same_block == 0).mean() < 1e-3 and (same_bin == 0).mean() < 0.08    # P(never in 1500 epochs) = e^-3.3 = 0.035 per pair
+    assert 0.7 <= same_bin.var() / same_bin.mean() <= 1.4
+    _, frozen = orc.ldsbin_layout(77, 0, n_bins, n_items, order)                   # negative control: one layout for ever
+    never = (frozen[x] // cap // (n_bins // n_blocks)) != (frozen[y] // cap // (n_bins // n_blocks))
+    assert abs(never.mean() - (1 - 1 / n_blocks)) < 0.01
 
 
 def test_ring_strides():
@@ -1135,68 +1210,48 @@ def test_ring_strides():
     assert ring_strides(2, 4) == [1] and ring_strides(1, 3) == [1, 1, 1] and ring_strides(3, 2) == [1, 2] and ring_strides(6, 4) == [1, 5]
 
 
-def test_split_csr_by_item_block_is_a_partition():
-    from cornac_amd.dist import split_csr_by_item_block
-
-    indptr, indices = _ring_data(3, n_users=40, n_items=37, per_user=9)
-    parts = split_csr_by_item_block(indptr, indices, 4)
-    seen = []
-    for b, (ip, ix) in enumerate(parts):
-        assert ip[0] == 0 and ip[-1] == len(ix) and (np.diff(ip) >= 0).all()
-        for u in range(40):
-            row = ix[ip[u]:ip[u + 1]]
-            assert (np.diff(row) > 0).all()
-            seen += [(u, int(j) * 4 + b) for j in row]
-    want = [(u, int(i)) for u in range(40) for i in indices[indptr[u]:indptr[u + 1]]]
-    assert sorted(seen) == sorted(want)
-
-
 def _fit_ring_worker(rank, world, port, out):
     import cornac_amd as ca
-    from cornac_amd.dist import fit_bpr_ring
+    from cornac_amd.dist import fit_bpr_ring, fit_bpr_sharded
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ds = ca.Dataset.from_uir(_model_data(), seed=3)
         bpr = ca.BPR(k=6, max_iter=8, learning_rate=0.05, lambda_reg=0.01, seed=rank, mode="hogwild")
-        fit_bpr_ring(bpr, ds, trainer_factory=lambda b, ip, ix, nu, rows, k, U: _RingOracleTrainer(ip, ix, rows, k, U))
-        out[rank] = dict(U=bpr.u_factors.copy(), V=bpr.i_factors.copy(), B=bpr.i_biases.copy(), stats=bpr.fit_stats)
+        seen = []
+
+        def factory(*a):
+            seen.append(_ConveyorOracleTrainer(*a))
+            return seen[-1]
+
+        fit_bpr_ring(bpr, ds, trainer_factory=factory)
+        out[rank] = dict(U=bpr.u_factors.copy(), V=bpr.i_factors.copy(), B=bpr.i_biases.copy(), stats=bpr.fit_stats,
+                         order=seen[0].rank_item.copy(), deal_seed=seen[0].deal_seed)
         with pytest.raises(ValueError):
             fit_bpr_ring(ca.BPR(k=4, seed=1), ds)   # seeded => sequential semantics do not shard
-        # WBPR: every block trainer is handed the GLOBAL degrees of its own items as the negative population
-        pops = {}
-
-        class _Pop(_RingOracleTrainer):
-            def __init__(self, b, *a):
-                super().__init__(*a)
-                self.b = b
-
-            def set_negative_population(self, items):
-                pops[self.b] = np.bincount(items, minlength=self.n_rows)
-
-        fit_bpr_ring(ca.WBPR(k=4, max_iter=1, mode="hogwild", seed=rank),
-                     ds, trainer_factory=lambda b, ip, ix, nu, rows, k, U: _Pop(b, ip, ix, rows, k, U))
-        deg = np.bincount(ds.matrix.indices, minlength=ds.num_items)
-        assert sorted(pops) == [0, 1, 2, 3] and all(np.array_equal(pops[b][: len(deg[b::4])], deg[b::4]) for b in pops)
+        with pytest.raises(ValueError):               # WBPR with the global popularity is regime 1's
+            fit_bpr_ring(ca.WBPR(k=4, max_iter=1, mode="hogwild", seed=rank), ds, trainer_factory=factory, local_popularity=False)
     finally:
         dist.destroy_process_group()
 
 
 def test_model_level_ring_fit_returns_one_complete_model_on_every_rank():
-    """fit_bpr_ring on two gloo ranks (item blocks rotating, real arithmetic behind the block trainers): both ranks return
-    the SAME complete model, bit for bit — there is no replica to reconcile —, started from rank 0's tables, and it ranks
-    the training positives above random negatives"""
+    """fit_bpr_ring on two gloo ranks (blocks rotating and re-dealt, real arithmetic behind the trainers): both ranks return
+    the SAME complete model, bit for bit — there is no replica to reconcile —, started from rank 0's tables, dealt with ONE
+    key over the popularity order of the whole matrix (the models' own seeds differ), and it ranks the training positives
+    above random negatives"""
     import cornac_amd as ca
 
     out = mp.Manager().dict()
     mp.spawn(_fit_ring_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     a, b = out[0], out[1]
-    for name in ("U", "V", "B"):
+    for name in ("U", "V", "B", "order"):
         assert np.array_equal(a[name], b[name]), name
-    assert a["stats"] == b["stats"] and a["stats"][0][0] > 0
+    assert a["stats"] == b["stats"] and a["stats"][0][0] > 0 and a["deal_seed"] == b["deal_seed"]
     ds = ca.Dataset.from_uir(_model_data(), seed=3)
     X = ds.matrix
+    assert np.array_equal(a["order"], np.argsort(-np.bincount(X.indices, minlength=ds.num_items), kind="stable"))
     assert _pairwise_accuracy(a["U"], a["V"], a["B"], X.indptr, X.indices, ds.num_items) > 0.7
 
 
@@ -1227,39 +1282,3 @@ def test_global_negative_population_world2():
         assert np.abs(hs / hs.sum() - deg / deg.sum()).max() < 0.01
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
-
-def _ring_sparse_worker(rank, world, port, out):
-    from cornac_amd.dist import RingShardedBprTrainer
-
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        n_items, k = 40, 3
-        indptr, indices = _ring_data(rank, n_users=30, n_items=n_items, per_user=6)
-        if rank == 1:   # rank 1's users only ever touched items of blocks 0 and 2 (item % 4 in {0, 2})
-            keep = indices % 2 == 0
-            counts = np.add.reduceat(keep.astype(np.int64), indptr[:-1])
-            indptr, indices = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), indices[keep]
-        log = []
-        ring = RingShardedBprTrainer(indptr, indices, len(indptr) - 1, n_items, k, torch.device("cpu"), seed=1,
-                                     trainer_factory=lambda b, ip, ix, nu, rows, k_, U: _RingMarkTrainer(rank, b, log))
-        assert [tr is None for tr in ring.trainers] == ([False] * 4 if rank == 0 else [False, True, False, True])
-        ring.load_items(np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32))
-        for _ in range(2):
-            ring.run_epoch(0.05, 0.01)
-        ring.finish()
-        out[rank] = ring.gather() + (log,)
-        ring.close()
-    finally:
-        dist.destroy_process_group()
-
-
-def test_ring_conveyor_with_blocks_a_rank_has_no_interactions_in():
-    """a rank whose users never touched a block still receives it, holds it for its step and passes it on untouched"""
-    out = mp.Manager().dict()
-    mp.spawn(_ring_sparse_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    (V0, B0, log0), (V1, B1, log1) = out[0], out[1]
-    assert np.array_equal(V0, V1) and np.array_equal(B0, B1)
-    assert sorted(set(log1)) == [0, 2] and sorted(set(log0)) == [0, 1, 2, 3]
-    want = np.where(np.arange(40) % 2 == 0, 2 * (1.0 + 2.0), 2 * 1.0)   # even blocks: both ranks, odd blocks: rank 0 only
-    assert np.allclose(V0, want[:, None]) and np.allclose(B0, 10.0 * want)

@@ -204,14 +204,7 @@ def test_hogwild_full_size_gate_against_the_reference_threads(ml20m):
     c_gpu, s_gpu = tr.fit_epochs(1, lr, reg, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
     g = probes(*tr.get_factors())
     tr.close()
-    Ur, Vr, Br = init_factors(n_users, n_items, k, 3)
-    model = RefBPR(k=k, learning_rate=lr, lambda_reg=reg)
-    threads = min(32, os.cpu_count() or 1)
-    neg_item_ids = np.arange(n_items, dtype=np.int32)
-    ip, ix = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
-    for e in range(epochs):
-        c_ref, s_ref = model._fit_sgd(RNGVector(threads, nnz - 1, 100 + e), RNGVector(threads, n_items - 1, 200 + e), threads,
-                                      user_ids, ix, neg_item_ids, ip, Ur, Vr, Br)
+    (Ur, Vr, Br), (c_ref, s_ref), threads = _reference_threads_fit(ml20m, k, lr, reg, epochs)
     r = probes(Ur, Vr, Br)
     print("full-size gate vs the reference's %d threads after %d epochs: all-items probe loss %.4f -> gpu %.4f ref %.4f, acc "
           "gpu %.4f ref %.4f | rank-neighbour probe loss %.4f -> gpu %.4f ref %.4f, acc gpu %.4f ref %.4f | correct gpu %.4f "
@@ -222,6 +215,163 @@ def test_hogwild_full_size_gate_against_the_reference_threads(ml20m):
     assert abs(g[2] - r[2]) < 0.03 * l0[2] and abs(g[3] - r[3]) < 0.015
     assert abs(c_gpu / (nnz - s_gpu) - c_ref / (nnz - s_ref)) < 0.015
     assert abs(s_gpu - s_ref) < 0.02 * s_ref
+
+
+_REF_FITS = {}
+
+
+def _reference_threads_fit(ml20m, k, lr, reg, epochs):
+    """the REAL reference's `BPR._fit_sgd` (oracle/_ref, OpenMP threads) for `epochs` epochs from init_factors(seed 3), driven with
+    raw arrays as `BPR.fit` drives it (recom_bpr.pyx:186-201); cached per module (two gates compare against the same fit)"""
+    from oracle import ref_loader
+
+    key = (k, lr, reg, epochs)
+    if key not in _REF_FITS:
+        RNGVector, RefBPR = ref_loader.load_kernel_only()
+        n_users, n_items, indptr, indices, init_factors = ml20m
+        nnz = len(indices)
+        user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+        Ur, Vr, Br = init_factors(n_users, n_items, k, 3)
+        model = RefBPR(k=k, learning_rate=lr, lambda_reg=reg)
+        threads = min(32, os.cpu_count() or 1)
+        neg_item_ids = np.arange(n_items, dtype=np.int32)
+        ip, ix = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32)
+        for e in range(epochs):
+            c_ref, s_ref = model._fit_sgd(RNGVector(threads, nnz - 1, 100 + e), RNGVector(threads, n_items - 1, 200 + e), threads,
+                                          user_ids, ix, neg_item_ids, ip, Ur, Vr, Br)
+        _REF_FITS[key] = ((Ur, Vr, Br), (c_ref, s_ref), threads)
+    return _REF_FITS[key]
+
+
+def _gate_probes(ml20m, n=300000):
+    """(probes(U, V, B) -> [loss_all, acc_all, loss_near, acc_near]): j uniform over all items (the reference's own negative
+    population), and j among the 2 x 128 popularity-rank neighbours of i"""
+    n_users, n_items, indptr, indices, _ = ml20m
+    nnz = len(indices)
+    user_ids = np.repeat(np.arange(n_users), np.diff(indptr)).astype(np.int32)
+    deg = np.bincount(indices, minlength=n_items)
+    rank_item = np.argsort(-deg, kind="stable")
+    item_rank = np.empty(n_items, np.int64)
+    item_rank[rank_item] = np.arange(n_items)
+    rs = np.random.RandomState(1)
+    pick = rs.randint(nnz, size=n)
+    pu, pi = user_ids[pick], indices[pick]
+    pj_all = rs.randint(n_items, size=n)
+    delta = rs.randint(1, 129, size=n) * rs.choice([-1, 1], size=n)
+    pj_near = rank_item[np.clip(item_rank[pi] + delta, 0, n_items - 1)]
+    allk = np.sort(user_ids.astype(np.int64) * n_items + indices)
+    near_ok = (pj_near != pi) & ~np.isin(pu.astype(np.int64) * n_items + pj_near, allk)
+
+    def probes(U, V, B):
+        out = []
+        for j, ok in ((pj_all, None), (pj_near, near_ok)):
+            x = B[pi] - B[j] + np.einsum("nk,nk->n", U[pu], V[pi] - V[j])
+            x = x if ok is None else x[ok]
+            out += [float(np.mean(np.log1p(np.exp(-x)))), float(np.mean(x > 0))]
+        return out
+
+    return probes
+
+
+@pytest.mark.parametrize("rings", [1, 4])
+def test_conveyor_of_eight_virtual_ranks_at_the_ml20m_shape_against_the_reference_threads(ml20m, rings):
+    """Multi-GPU regime 2 (cornac_amd/dist.py BinConveyorBprTrainer) at the ML-20M shape and skew, EIGHT virtual ranks on one
+    device — users cut into eight ranges of equal interaction counts, one handle per rank in conveyor layout, 16 blocks (one
+    ring) or 64 (four rings: a step of a rank = one launch over four bin ranges), the blocks' rows re-dealt to the next epoch's
+    slots between the epochs; the schedule executed step by step, which the gloo tests show the ranks' parallel run to equal
+    bit for bit — against the REAL reference's threads on the same data, init, hyper-parameters and epochs.  Same probes and
+    tolerances as the single-GPU gate above: j over ALL items (recom_bpr.pyx:235-238 — round 5's conveyor fixed item i to
+    block i % 2NK and could never draw 15 / 16 resp. 63 / 64 of these pairs) and j among i's popularity-rank neighbours."""
+    import torch
+
+    from cornac_amd.dist import partition_users_by_nnz, ring_strides, slice_csr
+    from oracle import ref_loader
+
+    if not (ref_loader.available() or ref_loader.kernel_available()):
+        pytest.skip("oracle/_ref (the compiled reference kernel) is not built")
+    n_users, n_items, indptr, indices, init_factors = ml20m
+    k, lr, reg, epochs, R = 64, 0.05, 0.01, 12, 8
+    nnz = len(indices)
+    probes = _gate_probes(ml20m)
+    U, V, B = init_factors(n_users, n_items, k, 3)
+    l0 = probes(U, V, B)
+    dev = torch.device("cuda", 0)
+    bounds = partition_users_by_nnz(indptr, R)
+    strides = ring_strides(R, rings)
+    K, nb = len(strides), 2 * R
+    order = np.argsort(-np.bincount(indices, minlength=n_items), kind="stable").astype(np.int32)
+    Ut = torch.as_tensor(U).to(dev)
+    handles, dims = [], None
+    for r in range(R):
+        u0, u1 = int(bounds[r]), int(bounds[r + 1])
+        ip, ix = slice_csr(indptr, indices, u0, u1)
+        t = _lib.BprTrainer(ip, ix, u1 - u0, n_items, u1 - u0, n_items, k)
+        t.bind_device(Ut[u0:u1].data_ptr(), None, None)
+        t.seed_hogwild(9000 + r)
+        d = t.conveyor_setup(nb * K, order, 777)
+        assert dims is None or d == dims
+        dims = d
+        handles.append(t)
+    n_bins, bpb, cap = dims
+    W = bpb * cap
+    table = torch.zeros((nb * K, W * (k + 1)), dtype=torch.float32, device=dev)
+
+    def layout(e):
+        si = torch.empty(n_bins * cap, dtype=torch.int32, device=dev)
+        handles[0].conveyor_layout(e, si.data_ptr(), None)
+        handles[0].sync()
+        return si.long()
+
+    def scatter(Vd, Bd, si):
+        ok = si >= 0
+        rows, bias = torch.zeros((nb * K * W, k), device=dev), torch.zeros(nb * K * W, device=dev)
+        rows[ok], bias[ok] = Vd[si[ok]], Bd[si[ok]]
+        table[:, : W * k] = rows.view(nb * K, W * k)
+        table[:, W * k:] = bias.view(nb * K, W)
+
+    def collect(si):
+        ok = si >= 0
+        Vd, Bd = torch.zeros((n_items, k), device=dev), torch.zeros(n_items, device=dev)
+        Vd[si[ok]] = table[:, : W * k].reshape(nb * K * W, k)[ok]
+        Bd[si[ok]] = table[:, W * k:].reshape(nb * K * W)[ok]
+        return Vd, Bd
+
+    si = layout(0)
+    scatter(torch.as_tensor(V).to(dev), torch.as_tensor(B).to(dev), si)
+    torch.cuda.synchronize()
+    c_gpu = s_gpu = 0
+    for e in range(epochs):
+        if e:
+            Vd, Bd = collect(si)
+            si = layout(e)
+            scatter(Vd, Bd, si)
+            torch.cuda.synchronize()
+        for t_ in handles:
+            t_.sync()
+        for step in range(nb):
+            for r in range(R):
+                blocks = [((2 * ((r * pow(s_, -1, R)) % R) + step) % nb) * K + g for g, s_ in enumerate(strides)]
+                handles[r].conveyor_enqueue(e, e, blocks, [table[b].data_ptr() for b in blocks], lr, reg, True, _lib.NEG_UNIFORM, 0)
+            for r in range(R):      # the ranks of a step touch disjoint user rows and disjoint blocks: they may overlap
+                c, s_k = handles[r].sync()
+                if e == epochs - 1:
+                    c_gpu, s_gpu = c_gpu + c, s_gpu + s_k
+    Vd, Bd = collect(si)
+    assert sum(t.ldsbin_stats()["lock_timeouts"] for t in handles) == 0
+    for t in handles:
+        t.close()
+    g = probes(Ut.cpu().numpy(), Vd.cpu().numpy(), Bd.cpu().numpy())
+    (Ur, Vr, Br), (c_ref, s_ref), threads = _reference_threads_fit(ml20m, k, lr, reg, epochs)
+    r = probes(Ur, Vr, Br)
+    print("conveyor of 8 virtual ranks, %d blocks of %d bins (%d rows per bin), vs the reference's %d threads after %d epochs: "
+          "all-items probe loss %.4f -> conveyor %.4f ref %.4f, acc %.4f ref %.4f | rank-neighbour probe loss %.4f -> %.4f ref "
+          "%.4f, acc %.4f ref %.4f | correct %.4f ref %.4f | skipped %d ref %d"
+          % (nb * K, bpb, cap, threads, epochs, l0[0], g[0], r[0], g[1], r[1], l0[2], g[2], r[2], g[3], r[3],
+             c_gpu / (nnz - s_gpu), c_ref / (nnz - s_ref), s_gpu, s_ref))
+    assert r[0] < 0.97 * l0[0] and r[2] < 0.98 * l0[2], "the task must be learnable on both probes for the gate to mean anything"
+    assert abs(g[0] - r[0]) < 0.03 * l0[0] and abs(g[1] - r[1]) < 0.015
+    assert abs(g[2] - r[2]) < 0.03 * l0[2] and abs(g[3] - r[3]) < 0.015
+    assert abs(c_gpu / (nnz - s_gpu) - c_ref / (nnz - s_ref)) < 0.015
 
 
 def test_mf_full_size_deterministic_and_hogwild(oracle, ml20m):
@@ -490,3 +640,115 @@ def test_wmf_netflix_user_count_matches_the_oracle():
     assert np.abs(Vg - o.V).max() <= 1e-4, np.abs(Vg - o.V).max()
     assert np.allclose(lg, lo, rtol=1e-4), np.abs(lg / lo - 1).max()
     assert np.abs(o.U - U).max() > 1e-3 and np.abs(o.V - V).max() > 1e-3
+
+
+# ---- BASELINE configs[4], one GPU's slice: 12.5 M users x 10 M items, k = 128 (bench.py legs.bpr_k128_scale) -----------------
+@pytest.fixture(scope="module")
+def scale_slice0():
+    from bench import SCALE, scale_slice
+
+    nu, ni, indptr, indices = scale_slice(0)
+    return nu, ni, indptr, indices, SCALE["k"]
+
+
+def _device_tables(torch, nu, ni, k, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    U = (torch.rand((nu, k), device="cuda", generator=g) - 0.5) / k
+    V = (torch.rand((ni, k), device="cuda", generator=g) - 0.5) / k
+    B = torch.randn(ni, device="cuda", generator=g) * 0.01
+    return U, V, B
+
+
+def test_configs4_slice_passing_bins_invariants(oracle, scale_slice0):
+    """The passing-bin regime of the LDS-bin form at the size it exists for (90 112 bins of <= 111 rows, CSR membership
+    without a bitmap, U 6.4 GB + V 5.1 GB) — until round 6 only bench.py ran this shape, asserting nothing.
+      * the deal is a partition: every bin holds <= cap items, the bins' draw counts sum to nnz (recom_bpr.pyx:218,234: nnz
+        draws per epoch);
+      * lr = 0 leaves U / V / B bit-identical (every row passes through the LDS and is written back);
+      * the sampler equals the oracle's restatement draw for draw on a sample of the bins: a 1 / 128 block of the conveyor
+        layout of the same handle data (cornac_hip_bpr_conveyor_enqueue launches exactly those bins), skip counter == oracle;
+      * reg = 0 conserves the column sums of V and the sum of B (a step adds +d to the positive's row and -d to the
+        negative's, exactly, in LDS), while U, V, B all move; no row lock timed out."""
+    import torch
+
+    nu, ni, indptr, indices, k = scale_slice0
+    nnz = len(indices)
+    tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+    st = tr.ldsbin_stats()
+    assert st["bins"] >= 80_000 and st["rows_per_bin"] <= 128 and st["bitmap_words"] == 0 and st["block_threads"] == 512, st
+    bin_of, cold, off, _, _ = tr.debug_ldsbin_deal(7, 0)
+    per_bin = np.bincount(bin_of, minlength=st["bins"])
+    assert per_bin.max() <= st["rows_per_bin"] and per_bin.min() >= st["rows_per_bin"] - 1
+    assert int(cold.astype(np.int64).sum()) + int(off[-1]) == nnz
+    U, V, B = _device_tables(torch, nu, ni, k, 0)
+    U0, V0, B0 = U.clone(), V.clone(), B.clone()
+    torch.cuda.synchronize()
+    tr.bind_device(U.data_ptr(), V.data_ptr(), B.data_ptr())
+    tr.seed_hogwild(7)
+    c, s = tr.fit_epochs(1, 0.0, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    assert 0 <= s < 1e-4 * nnz and 0 < c <= nnz - s          # 5 of 10 M items per user: a negative is almost never a positive
+    assert torch.equal(U, U0) and torch.equal(V, V0) and torch.equal(B, B0)
+    c, s = tr.fit_epochs(1, 0.05, 0.0, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
+    assert tr.ldsbin_stats()["lock_timeouts"] == 0
+    dv = (V.double().sum(0) - V0.double().sum(0)).abs().max().item()
+    db = abs((B.double().sum() - B0.double().sum()).item())
+    moved = [(x - y).abs().max().item() for x, y in ((U, U0), (V, V0), (B, B0))]
+    print("configs[4] slice, one epoch at reg = 0: column sums of V drift by %.3g, sum of B by %.3g; max moves %s" % (dv, db, moved))
+    assert dv < 0.02 and db < 0.02 and min(moved) > 1e-4
+    assert torch.isfinite(U).all() and torch.isfinite(V).all()
+    tr.close()
+    # the sampler on a sample of the bins, through the conveyor layout
+    U.copy_(U0)
+    tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
+    tr.bind_device(U.data_ptr(), None, None)
+    tr.seed_hogwild(99)
+    n_bins, bpb, cap = tr.conveyor_setup(128, None, 4242)
+    W = bpb * cap
+    buf = torch.zeros(W * (k + 1), device="cuda")
+    blk, epoch = 37, 3
+    tr.conveyor_enqueue(epoch, epoch, [blk], [buf.data_ptr()], 0.0, 0.0, True, _lib.NEG_UNIFORM, 0)
+    c, s = tr.sync()
+    tables = oracle.ldsbin_tables(indptr, indices, ni, n_bins, 10 ** 9)
+    want, draws, _ = oracle.ldsbin_epoch(99, epoch, n_bins, 10 ** 9, indptr, indices, ni, tables=tables, deal=(4242, epoch),
+                                         bins=(blk * bpb, (blk + 1) * bpb))
+    assert 0.5 * nnz / 128 < draws < 2 * nnz / 128 and s == want, (s, want, draws)
+    assert torch.equal(U, U0) and float(buf.abs().max()) == 0.0
+    tr.close()
+
+
+@pytest.mark.parametrize("rings", [1, 4])
+def test_configs4_slice_conveyor_as_a_node_rank(scale_slice0, rings):
+    """regime 2 at the configs[4] size on one rank laid out like a node of eight (16 or 64 blocks, 16 steps per epoch, a launch =
+    one or four bin ranges): lr = 0 through three epochs and two re-deals returns the item table bit for bit; one trained epoch
+    at reg = 0 conserves its column sums, moves every table, no lock timeout"""
+    import torch
+
+    from cornac_amd.dist import BinConveyorBprTrainer
+
+    nu, ni, indptr, indices, k = scale_slice0
+    nnz = len(indices)
+    rs = np.random.RandomState(3)
+    V = ((rs.random_sample((ni, k)).astype(np.float32) - 0.5) / k)
+    B = (rs.standard_normal(ni) * 0.01).astype(np.float32)
+    ring = BinConveyorBprTrainer(indptr, indices, nu, ni, k, torch.device("cuda", 0), seed=5, emulate_traffic=True, rings=rings,
+                                 virtual_world=8)
+    assert ring.nb == 16 and ring.nb_total == 16 * rings and ring.n_bins >= 80_000 and ring.cap <= 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ring.U.copy_((torch.rand((nu, k), device="cuda", generator=g) - 0.5) / k)
+    U0 = ring.U.clone()
+    ring.load_items(V, B)
+    for _ in range(3):
+        ring.run_epoch(0.0, 0.0)
+    c, s = ring.finish()
+    V1, B1 = ring.gather()
+    assert ring.redeals == 2 and 0 <= s < 1e-4 * 3 * nnz and 0 < c <= 3 * nnz
+    assert np.array_equal(V1, V) and np.array_equal(B1, B) and torch.equal(ring.U, U0)
+    del V1, B1
+    ring.run_epoch(0.05, 0.0)
+    ring.finish()
+    V2, B2 = ring.gather()
+    assert ring.trainer.tr.ldsbin_stats()["lock_timeouts"] == 0
+    dv = np.abs(V2.sum(0, dtype=np.float64) - V.sum(0, dtype=np.float64)).max()
+    assert dv < 0.02 and abs(B2.sum(dtype=np.float64) - B.sum(dtype=np.float64)) < 0.02, dv
+    assert np.abs(V2 - V).max() > 1e-4 and (ring.U - U0).abs().max().item() > 1e-4 and np.isfinite(V2).all()
+    ring.close()

@@ -126,14 +126,15 @@ def test_hogwild_divergence_is_reported_not_returned():
     tr.close()
 
 
-@pytest.mark.parametrize("k,form", [(16, 1), (64, 1), (64, 2)])
+@pytest.mark.parametrize("k,form", [(16, 1), (64, 1), (64, 2), (300, 1)])
 def test_hogwild_trains_through_a_very_popular_item_instead_of_diverging(k, form):
     """One item holding a fifth of 2 M ratings: thousands of atomic updates of its row, all computed from one stale copy, are
     in flight at once — round 4's fused kernel diverged on such data (and raised), the block rotation serialised the row in
     one workgroup.  Hot rows (> 0.1 % of the ratings) now train through copies merged after every launch / phase
     (csrc/mf_blocks.inc "virtual rows"), in BOTH hogwild forms: the run stays finite, lr = 0 leaves the tables untouched,
     and the training error follows the sequential engine's (backend_cpu.pyx:62-88 on one thread) within a few per cent,
-    the hot item's row and bias included."""
+    the hot item's row and bias included.  k = 300: the generic kernel (k > 256) resolves the copies' ids too (round 5's
+    did not: it read and wrote past the end of V)."""
     n_users, n_items, nnz = 60_000, 3_000, 1 << 21
     rs = np.random.RandomState(5)
     act = rs.lognormal(0, 1.0, n_users)

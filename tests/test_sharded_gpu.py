@@ -620,7 +620,7 @@ def test_model_level_sharded_fits_single_rank_through_rccl():
         assert np.abs(a.score(3) - (a.i_biases + a.i_factors @ a.u_factors[3])).max() < 1e-5
         with pytest.raises(ValueError):
             fit_bpr_sharded(ca.BPR(k=8, seed=1), ds, device=dev)   # seeded => sequential semantics: refused
-        # the same fit as the ring conveyor of item blocks (regime 2; one rank: two blocks, a handle per block)
+        # the same fit as the ring conveyor (regime 2; one rank: two blocks = two halves of the epoch's bins, one handle)
         c = fit_bpr_sharded(ca.BPR(**kw), ds, device=dev, regime="ring")
         fc = c.fit_stats[0][0] / max(6 * nnz - c.fit_stats[0][1], 1)
         assert np.isfinite(c.u_factors).all() and np.isfinite(c.i_factors).all() and abs(fc - fb) < 0.03, (fc, fb)
@@ -769,19 +769,23 @@ def test_resident_exchange_trains_like_the_plain_launch_through_rccl():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("emulate,rings", [(False, 1), (True, 1), (True, 2)])
-def test_ring_conveyor_single_rank_on_the_device(emulate, rings):
-    """RingShardedBprTrainer (multi-GPU regime 2 as a ring of item blocks) on ONE rank with the real handles: 2 blocks, a
-    handle per block sharing the user table, the item tables rebound per step (cornac_hip_bpr_rebind_items); with
-    emulate_traffic the trained block is copied to the free buffer on the communication stream, as a neighbour's
-    receive would.  (1) lr = 0 returns every table bit for bit and draws nnz samples per epoch; (2) training moves both
-    blocks, stays finite, and learns like the plain single-handle fit of the same data (the negatives come from the
-    positive's block of the items instead of all of them).  rings = 2 on one rank: two groups of two blocks, two launches and two
-    copies per step (the launch granularity of two rings)."""
+@pytest.mark.parametrize("emulate,rings,virtual", [(False, 1, None), (True, 1, None), (True, 2, None), (False, 4, 8)])
+def test_ring_conveyor_single_rank_on_the_device(emulate, rings, virtual):
+    """BinConveyorBprTrainer (multi-GPU regime 2) on ONE rank with the real handle in conveyor layout: the blocks are bin ranges
+    of the epoch's deal, a step is ONE launch over `rings` bin ranges reading / writing its rows in the block buffers
+    (cornac_hip_bpr_conveyor_enqueue), the rows are re-dealt to new slots between the epochs; with emulate_traffic the trained
+    block is copied to the free buffer on the communication stream, as a neighbour's receive would.
+    (1) lr = 0 returns every table bit for bit — through the epochs' re-deals — and draws nnz samples per epoch; the skip
+    counter equals the oracle's restatement of the sampler under the conveyor's deal key, draw for draw;
+    (2) reg = 0 conserves the column sums of the item table (every step adds +d to the positive's row and -d to the
+    negative's: exact in LDS, so only fp32 rounding moves the sum);
+    (3) training moves every block, stays finite, and learns like the plain single-handle fit of the same data.
+    virtual = 8 with four rings: the layout of an 8-rank node (64 blocks, 16 steps per epoch, four ranges per launch)."""
     import torch
 
     from cornac_amd import synth
-    from cornac_amd.dist import RingShardedBprTrainer
+    from cornac_amd.dist import BinConveyorBprTrainer
+    from oracle import oracle as orc
 
     n_users, n_items, k = 30000, 4001, 64
     users, items = synth.zipf_interactions(n_users, n_items, 1_200_000, 0.7, 4)
@@ -789,18 +793,38 @@ def test_ring_conveyor_single_rank_on_the_device(emulate, rings):
     nnz = len(indices)
     rs = np.random.RandomState(0)
     U = ((rs.uniform(0, 1, (n_users, k)) - 0.5) / k).astype(np.float32)
-    V = ((rs.uniform(0, 1, (n_items, k)) - 0.5) / k).astype(np.float32)
-    B = rs.normal(0, 0.01, n_items).astype(np.float32)
+    V = ((rs.uniform(0, 1, (n_items + 7, k)) - 0.5) / k).astype(np.float32)   # 7 rows beyond the train items: never touched
+    B = rs.normal(0, 0.01, n_items + 7).astype(np.float32)
     dev = torch.device("cuda", 0)
-    ring = RingShardedBprTrainer(indptr, indices, n_users, n_items, k, dev, seed=3, emulate_traffic=emulate, rings=rings)
-    assert ring.nb == 2 and ring.K == rings and ring.nnz == nnz and sum(ring.rows) == n_items and len(ring.rows) == 2 * rings
+    ring = BinConveyorBprTrainer(indptr, indices, n_users, n_items + 7, k, dev, seed=3, emulate_traffic=emulate, rings=rings,
+                                 n_train_items=n_items, virtual_world=virtual)
+    nb = 2 * (virtual or 1)
+    assert ring.nb == nb and ring.K == rings and ring.nnz == nnz and ring.n_bins == ring.bpb * nb * rings
+    assert ring.cap * ring.n_bins >= n_items and ring.cap >= 16
     ring.set_user_factors(U)
     ring.load_items(V, B)
-    ring.run_epoch(0.0, 0.0)
+    for _ in range(3):
+        ring.run_epoch(0.0, 0.0)
     c, s = ring.finish()
     V1, B1 = ring.gather()
-    assert 0 < s < 0.2 * nnz and c + s <= nnz
+    assert ring.redeals == 2 and 0 < s < 0.2 * 3 * nnz and c + s <= 3 * nnz
     assert np.array_equal(V1, V) and np.array_equal(B1, B) and np.array_equal(ring.get_user_factors(), U)
+    tables = orc.ldsbin_tables(indptr, indices, n_items, ring.n_bins, 10 ** 9)      # (no hot items in the conveyor layout)
+    hog_seed = (3 * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
+    want = sum(orc.ldsbin_epoch(hog_seed, e, ring.n_bins, 10 ** 9, indptr, indices, n_items, tables=tables,
+                                deal=(ring.deal_seed, e))[0] for e in range(3))
+    assert s == want, "the conveyor's sampler deviates from its oracle restatement: %d != %d" % (s, want)
+    assert ring.trainer.tr.ldsbin_stats()["lock_timeouts"] == 0
+    # (2) reg = 0: column sums
+    ring.run_epoch(0.05, 0.0)
+    ring.finish()
+    Vc, Bc = ring.gather()
+    assert np.abs(Vc - V).max() > 1e-4
+    drift = np.abs(Vc[:n_items].astype(np.float64).sum(0) - V[:n_items].astype(np.float64).sum(0)).max()
+    assert drift < 2e-3 and abs(float(Bc[:n_items].astype(np.float64).sum() - B[:n_items].astype(np.float64).sum())) < 2e-3, drift
+    # (3) training
+    ring.set_user_factors(U)
+    ring.load_items(V, B)
     for _ in range(5):
         ring.run_epoch(0.05, 0.01)
     ring.finish()
@@ -809,12 +833,12 @@ def test_ring_conveyor_single_rank_on_the_device(emulate, rings):
     acc_ring = c / (nnz - s)
     V2, B2 = ring.gather()
     U2 = ring.get_user_factors()
-    assert ring.steps_trained[: 4 * rings] == [(t % 2, (t % 2) * rings + g) for t in range(4) for g in range(rings)]
+    assert ring.steps_trained[: nb * rings] == [(t, t * rings + g) for t in range(nb) for g in range(rings)]
     ring.close()
-    assert np.isfinite(V2).all() and np.isfinite(U2).all()
-    assert all(np.abs(V2[b:: 2 * rings] - V[b:: 2 * rings]).max() > 1e-3 for b in range(2 * rings)) and np.abs(U2 - U).max() > 1e-3
+    assert np.isfinite(V2).all() and np.isfinite(U2).all() and np.array_equal(V2[n_items:], V[n_items:])
+    assert (np.abs(V2[:n_items] - V[:n_items]).max(1) > 1e-4).mean() > 0.99 and np.abs(U2 - U).max() > 1e-3
     tr = _lib.BprTrainer(indptr, indices, n_users, n_items, n_users, n_items, k)
-    tr.set_factors(U, V, B)
+    tr.set_factors(U, V[:n_items], B[:n_items])
     tr.seed_hogwild(3)
     tr.fit_epochs(5, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
     c, s = tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
@@ -842,10 +866,10 @@ def test_eight_virtual_ranks_at_the_slice_density_ring_conveyor_against_replicas
     THE DEVICE, each its own user slice, next to ONE process that trains all eight slices' users together; the measure is
     the pairwise accuracy on rank 0's probe triplets in the MIDDLE of training, where a stale item side costs most.
 
-      * regime 2, the ring conveyor (RingShardedBprTrainer's schedule: 16 item blocks, rank r trains block (2 r + t) % 16
-        in step t, a handle per (rank, block), here executed step by step on one device — the serial execution the gloo
-        test shows the ranks' parallel run to equal): every item row is in one place, nothing is reconciled.  Gate: within
-        1.5 points of the single process.
+      * regime 2, the ring conveyor (BinConveyorBprTrainer's schedule: 16 blocks = bin ranges of the epoch's deal, rank r
+        trains block (2 r + t) % 16 in step t, re-dealt between the epochs; here executed step by step on one device — the
+        serial execution the gloo test shows the ranks' parallel run to equal): every item row is in one place, nothing is
+        reconciled.  Gate: within 1.5 points of the single process.
       * regime 1, replicas reconciled with ItemTableReplica's "align" algebra once every 1 / 2 / 4 epochs (round 4's
         exchange_schedule returned 4 here on the strength of a CPU toy): every rank moves every item row the same way, the
         rule averages the R aligned deltas, and the shared item side learns at a fraction of the single process's pace —
@@ -853,7 +877,7 @@ def test_eight_virtual_ranks_at_the_slice_density_ring_conveyor_against_replicas
         replicas catch up (gate: within 1.5 points after twice the epochs)."""
     import torch
 
-    from cornac_amd.dist import exchange_schedule, split_csr_by_item_block
+    from cornac_amd.dist import exchange_schedule
 
     R, n_items, k, epochs, lr, reg, C = 8, 48_000, 32, 16, 0.1, 0.01, 60
     n_users, degree = 60_000, 5
@@ -909,32 +933,65 @@ def test_eight_virtual_ranks_at_the_slice_density_ring_conveyor_against_replicas
         return accuracy(Ur, V, B)
 
     def conveyor(n_epochs):
+        """the conveyor's schedule executed step by step on one device (the serial execution the gloo test shows the ranks'
+        parallel run to equal): one handle per virtual rank in conveyor layout over 16 blocks, ONE set of block buffers, the rows
+        re-dealt to the next epoch's slots between the epochs"""
         dev, nb = torch.device("cuda", 0), 2 * R
-        blocks = [(torch.as_tensor(np.ascontiguousarray(V0[b::nb])).to(dev), torch.zeros(len(range(b, n_items, nb)), device=dev)) for b in range(nb)]
+        deg = sum(np.bincount(ix, minlength=n_items) for _, ix in slices)
+        order = np.argsort(-deg, kind="stable").astype(np.int32)
         Us = [torch.as_tensor(U0[r]).to(dev) for r in range(R)]
         torch.cuda.synchronize()
         handles = []
         for r, (ip, ix) in enumerate(slices):
-            row = []
-            for b, (ipb, ixb) in enumerate(split_csr_by_item_block(ip, ix, nb)):
-                t = _lib.BprTrainer(ipb, ixb, n_users, blocks[b][0].shape[0], n_users, blocks[b][0].shape[0], k)
-                t.bind_device(Us[r].data_ptr(), blocks[b][0].data_ptr(), blocks[b][1].data_ptr())
-                t.seed_hogwild(7000 + 100 * r + b)
-                row.append((t, len(ixb)))
-            handles.append(row)
-        for step in range(n_epochs * nb):
-            for r in range(R):
-                t, n = handles[r][(2 * r + step) % nb]
-                t.hogwild_enqueue(n, lr, reg, True, _lib.NEG_UNIFORM, 0)
-                t.sync()           # (the next handle works on the same user table / another handle on this block later)
-        V, B = np.empty_like(V0), np.empty(n_items, np.float32)
-        for b in range(nb):
-            V[b::nb], B[b::nb] = blocks[b][0].cpu().numpy(), blocks[b][1].cpu().numpy()
-        Ur = Us[0].cpu().numpy()
-        for row in handles:
-            for t, _ in row:
-                t.close()
-        return accuracy(Ur, V, B)
+            t = _lib.BprTrainer(ip, ix, n_users, n_items, n_users, n_items, k)
+            t.bind_device(Us[r].data_ptr(), None, None)
+            t.seed_hogwild(7000 + 100 * r)
+            dims = t.conveyor_setup(nb, order, 4242)
+            handles.append(t)
+        n_bins, bpb, cap = dims
+        W = bpb * cap
+        table = torch.zeros((nb, W * (k + 1)), dtype=torch.float32, device=dev)     # the 16 block buffers
+
+        def layout(e):
+            si = torch.empty(n_bins * cap, dtype=torch.int32, device=dev)
+            handles[0].conveyor_layout(e, si.data_ptr(), None)
+            handles[0].sync()
+            return si.long()
+
+        def scatter(V, B, si):
+            ok = si >= 0
+            rows = torch.zeros((nb * W, k), device=dev)
+            bias = torch.zeros(nb * W, device=dev)
+            rows[ok], bias[ok] = V[si[ok]], B[si[ok]]
+            table[:, : W * k] = rows.view(nb, W * k)
+            table[:, W * k:] = bias.view(nb, W)
+
+        def collect(si):
+            ok = si >= 0
+            V, B = torch.zeros((n_items, k), device=dev), torch.zeros(n_items, device=dev)
+            V[si[ok]] = table[:, : W * k].reshape(nb * W, k)[ok]
+            B[si[ok]] = table[:, W * k:].reshape(nb * W)[ok]
+            return V, B
+
+        si = layout(0)
+        scatter(torch.as_tensor(V0).to(dev), torch.zeros(n_items, device=dev), si)
+        torch.cuda.synchronize()
+        for e in range(n_epochs):
+            if e:
+                V, B = collect(si)
+                si = layout(e)
+                scatter(V, B, si)
+                torch.cuda.synchronize()
+            for step in range(nb):
+                for r in range(R):
+                    blk = (2 * r + step) % nb
+                    handles[r].conveyor_enqueue(e, e, [blk], [table[blk].data_ptr()], lr, reg, True, _lib.NEG_UNIFORM, 0)
+                    handles[r].sync()     # (another handle trains this block in the next step)
+        V, B = collect(si)
+        assert sum(t.ldsbin_stats()["lock_timeouts"] for t in handles) == 0
+        for t in handles:
+            t.close()
+        return accuracy(Us[0].cpu().numpy(), V.cpu().numpy(), B.cpu().numpy())
 
     acc_one = one_process(epochs)
     acc_ring = conveyor(epochs)
