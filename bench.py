@@ -669,7 +669,7 @@ def conveyor_one_rank(args, torch, dev, rings, epochs, plain_s=None, virtual_wor
                        "step over %d bin range(s), %.0f MB copied per step on the communication stream, rows re-dealt every epoch"
                        % (virtual_world, ring.nb_total, ring.bpb, ring.K, ring.nb, ring.K, ring.K * ring.bufs[0][0].numel() * 4 / 1e6),
            "blocks": ring.nb_total, "bins": ring.n_bins, "rows_per_bin": ring.cap, "block_threads": st["block_threads"],
-           "launch_ms": ev["launch"][1], "launches": ev["launch"][0], "move_ms": ev["move"][1], "redeal_ms": ev["redeal"][1],
+           "launch_ms": ev["launch"][1], "launches": ev["launch"][0], "move_ms": ev["move"][1], "redeal_ms": ev["redeal"][1], "redeal_ms_min": ev["redeal"][2],
            "redeals": ev["redeal"][0], "triplets_per_s_driver": ring.nnz / driven, "skipped_frac": s / float(ring.nnz * epochs),
            "correct_frac": c / max(ring.nnz * epochs - s, 1), "lock_timeouts": st["lock_timeouts"], "setup_s": t_setup,
            "torch_bytes_allocated": int(mem), "sampling": CONVEYOR_SAMPLING % (ring.cap, ring.bpb)}
@@ -845,7 +845,7 @@ def main_ring(args, _lib, torch, dist, dev, world, rank, k, barrier):
                             "frac_kernel_only": (step_bytes / ring.nb / launch_s / 1e9 / HBM_PEAK_GBS) if launch_s else None,
                             "avg_launch_ms": ev["launch"][1], "launches": ev["launch"][0],
                             "algorithmic_bytes_per_triplet": b_full},
-               "per_step": {"launch_ms": ev["launch"][1], "transfer_ms": ev["move"][1], "redeal_ms_per_epoch": ev["redeal"][1],
+               "per_step": {"launch_ms": ev["launch"][1], "transfer_ms": ev["move"][1], "redeal_ms_per_epoch": ev["redeal"][1], "redeal_ms_min": ev["redeal"][2],
                             "steps_per_epoch": ring.nb, "transfer_MB": ring.K * ring.bufs[0][0].numel() * 4 / 1e6},
                "train_stats": {"correct_frac": correct / max(nnz * args.steps - skipped, 1.0), "skipped_frac": skip,
                                "lock_timeouts": st["lock_timeouts"]},

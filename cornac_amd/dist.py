@@ -1284,13 +1284,13 @@ class BinConveyorBprTrainer:
         return _T()
 
     def timing_summary(self):
-        """{what: (count, mean ms)} of the launches (compute stream), the block transfers (communication stream) and the re-deals
+        """{what: (count, mean ms, min ms)} of the launches (compute stream), the block transfers (communication stream) and the re-deals
         recorded since the last call; synchronises"""
         self._drain()
         out = {}
         for what, evs in self._events.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            out[what] = (len(ms), float(np.mean(ms)) if ms else 0.0)
+            out[what] = (len(ms), float(np.mean(ms)) if ms else 0.0, float(np.min(ms)) if ms else 0.0)
             evs.clear()
         return out
 
@@ -1340,10 +1340,27 @@ class BinConveyorBprTrainer:
                 w.wait()
 
     # ---- the epoch-boundary re-deal ----
+    def _owner_major(self):
+        """the blocks in owner-major order: (om [nb_total] block -> its index in that order, om_inv, owner [nb_total] block ->
+        rank, H = home blocks per rank); a rank's home slots are then the contiguous range [rank H W, (rank + 1) H W)"""
+        if getattr(self, "_om", None) is None:
+            H = len(self.home_blocks(0))
+            om = np.zeros(self.nb_total, np.int64)
+            owner = np.zeros(self.nb_total, np.int64)
+            for r in range(self.world):
+                for h, (_, _, blk) in enumerate(self.home_blocks(r)):
+                    om[blk], owner[blk] = r * H + h, r
+            om_inv = np.argsort(om)
+            self._om = tuple(torch.as_tensor(x, device=self.device) for x in (om, om_inv, owner)) + (H,)
+        return self._om
+
     def _redeal(self, new_layout_epoch):
         """every row from its slot under the deal of self.layout_epoch to its slot under the deal of new_layout_epoch; at an
-        epoch boundary (every rank holds its home blocks).  One all_to_all_single of [row | bias] records."""
-        W, k, S = self.W, self.k, self.n_bins * self.cap
+        epoch boundary (every rank holds its home blocks).  One all_to_all_single of [row | bias] records: the message of rank r
+        for rank s holds r's rows in the order of their OLD slots (owner-major), so the sender places a row by a running count
+        per destination and the receiver finds it by a running count over the source's old slots — prefix sums over the slot
+        tables, no sort; both sides compute them from the two layouts, which every rank has."""
+        W, k, N = self.W, self.k, self.world
         home = self.home_blocks()
         for g in range(self.K):                       # the last step's receives fill home buffers
             for buf in range(len(self.bufs[g])):
@@ -1353,47 +1370,49 @@ class BinConveyorBprTrainer:
             w.wait()
         self._sent = []
         with self._on(self.stream), self._timed("redeal", self.stream):
-            old_slot_item, old_item_slot = self._layout(self.layout_epoch)
-            new_slot_item, new_item_slot = self._layout(new_layout_epoch)
-            owner = torch.as_tensor(self._block_owner(), device=self.device)
-            base = torch.cat([torch.arange(blk * W, (blk + 1) * W, device=self.device) for _, _, blk in home])  # my slots, ascending
-            # sender side: my rows, ordered by (destination rank, destination slot)
-            items = old_slot_item[base].long()
-            have = items >= 0
-            dst_slot = new_item_slot[items[have]].long()
-            dst_rank = owner[dst_slot // W]
-            order = torch.argsort(dst_rank * S + dst_slot)
-            send_counts = torch.bincount(dst_rank, minlength=self.world)
-            rec = torch.empty((len(base), k + 1), dtype=torch.float32, device=self.device)
+            om, om_inv, owner, H = self._owner_major()
+            HW, me = H * W, self.rank
+            old_slot_item, _ = self._layout(self.layout_epoch)
+            _, new_item_slot = self._layout(new_layout_epoch)
+            if getattr(self, "_stage", None) is None:
+                self._stage = [torch.zeros((HW + 1, k + 1), dtype=torch.float32, device=self.device) for _ in range(2 if N > 1 else 1)]
+                self._om_slots = (om_inv[:, None] * W + torch.arange(W, device=self.device)[None, :]).reshape(-1)
+            send, recv = self._stage[0], self._stage[-1]
+            # D[g]: the rank the row at old owner-major position g goes to (-1: an empty slot), T[g]: its new owner-major position
+            items = old_slot_item[self._om_slots].long()
+            valid = items >= 0
+            nu = new_item_slot[items.clamp_(min=0)].long()
+            T = om[nu // W] * W + nu % W
+            D = torch.where(valid, owner[nu // W], torch.full_like(nu, -1))
+            # sender: my rows, destination-major, inside a destination in the order of my old slots
+            D_me = D[me * HW: (me + 1) * HW]
+            onehot = D_me[None, :] == torch.arange(N, device=self.device)[:, None]
+            run = onehot.cumsum(1)
+            send_counts = run[:, -1]
+            send_base = torch.cumsum(send_counts, 0) - send_counts
+            dst = D_me.clamp(min=0)
+            pos = torch.where(D_me >= 0, send_base[dst] + run.gather(0, dst[None, :])[0] - 1, torch.full_like(D_me, HW))
             for h, (g, b, blk) in enumerate(home):
                 v, bb = self._views(g, self.where[g][b])
-                rec[h * W: (h + 1) * W, :k] = v
-                rec[h * W: (h + 1) * W, k] = bb
-            send = rec[have][order].contiguous()
-            # receiver side: my new slots, ordered by (source rank, slot) — the order the senders packed them in
-            items_n = new_slot_item[base].long()
-            want = items_n >= 0
-            my_slot = base[want]
-            src_rank = owner[old_item_slot[items_n[want]].long() // W]
-            order_r = torch.argsort(src_rank * S + my_slot)
-            recv_counts = torch.bincount(src_rank, minlength=self.world)
-            recv = torch.empty((int(want.sum()), k + 1), dtype=torch.float32, device=self.device)
-            if self.world > 1:
-                dist.all_to_all_single(recv, send, [int(c) for c in recv_counts.cpu()], [int(c) for c in send_counts.cpu()],
-                                       group=self.group)
-            else:
-                recv.copy_(send)
-            rec.zero_()
-            # position of a global slot in `rec`: the home block's index x W + the slot's offset inside the block
-            hpos = torch.full((self.nb_total,), -1, dtype=torch.long, device=self.device)
-            for h, (_, _, blk) in enumerate(home):
-                hpos[blk] = h
-            tgt = my_slot[order_r]
-            rec[hpos[tgt // W] * W + tgt % W] = recv
+                send[:, :k].index_copy_(0, pos[h * W: (h + 1) * W], v)
+                send[:, k].index_copy_(0, pos[h * W: (h + 1) * W], bb)
+            # receiver: the rows for me, source-major, inside a source in the order of ITS old slots = a running count over D == me
+            mine = D == me
+            got = torch.cumsum(mine, 0)
+            recv_counts = torch.stack([got[(r + 1) * HW - 1] for r in range(N)])
+            recv_counts = recv_counts - torch.cat([recv_counts.new_zeros(1), recv_counts[:-1]])
+            if N > 1:
+                rc, sc = [int(c) for c in recv_counts.cpu()], [int(c) for c in send_counts.cpu()]
+                dist.all_to_all_single(recv[: sum(rc)], send[: sum(sc)], rc, sc, group=self.group)
+            src_of = torch.full((HW,), HW, dtype=torch.long, device=self.device)        # my new local slot -> row of `recv` (HW: none)
+            at = mine.nonzero().squeeze(1)
+            src_of[T[at] - me * HW] = got[at] - 1
+            recv[HW].zero_()
             for h, (g, b, blk) in enumerate(home):
                 v, bb = self._views(g, self.where[g][b])
-                v.copy_(rec[h * W: (h + 1) * W, :k])
-                bb.copy_(rec[h * W: (h + 1) * W, k])
+                idx = src_of[h * W: (h + 1) * W]
+                torch.index_select(recv[:, :k], 0, idx, out=v)
+                torch.index_select(recv[:, k], 0, idx, out=bb)
         self.layout_epoch = new_layout_epoch
         self.redeals += 1
 
