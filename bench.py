@@ -78,6 +78,27 @@ def scale_slice(rank):
     return nu, ni, indptr, indices
 
 
+def scale_slice_zipf(rank, zipf_a=0.55, users=None):
+    """The same slice with a popularity head: every user's 5 items drawn from Zipf(zipf_a) over a random permutation of the
+    10 M items (SURVEY.md 8d C2's exponent; the most popular item then holds 0.026 % of the interactions — 23 x a passing
+    bin's share), duplicates inside a user dropped.  Returns (n_users, n_items, indptr, indices)."""
+    nu, ni, d = users or SCALE["users_per_gpu"], SCALE["items"], SCALE["degree"]
+    rs = np.random.RandomState(4500 + rank)
+    perm = np.random.RandomState(4499).permutation(ni).astype(np.int32)        # the same popularity on every rank
+    items = np.empty((nu, d), np.int32)
+    e = 1.0 - zipf_a
+    for c0 in range(0, nu, 2_500_000):          # inverse CDF of the continuous power law x^-a on [1, ni + 1): rank = floor(x) - 1
+        c1 = min(nu, c0 + 2_500_000)
+        x = (rs.random_sample((c1 - c0, d)) * ((ni + 1.0) ** e - 1.0) + 1.0) ** (1.0 / e)
+        items[c0:c1] = perm[np.minimum(x.astype(np.int64) - 1, ni - 1)]
+    items.sort(axis=1)
+    keep = np.ones(items.shape, bool)
+    keep[:, 1:] = items[:, 1:] != items[:, :-1]
+    indptr = np.zeros(nu + 1, np.int64)
+    np.cumsum(keep.sum(1), out=indptr[1:])
+    return nu, ni, indptr.astype(np.int32), items[keep]
+
+
 def scale_factors(nu, ni, k, rank):
     """item table from a fixed seed (identical on every rank), user rows from a per-rank seed"""
     r2 = np.random.RandomState(2)
@@ -457,29 +478,38 @@ def cpu_baseline_vbpr(F, u, i, j, params, nu, ni, k, k2, B, budget_s):
                       "%d threads, %.1f s" % (n_steps, B, torch.get_num_threads(), dt)}
 
 
-def leg_bpr_k128_scale(args, _lib):
-    """One GPU's share of configs[4] (100 M users x 10 M items, k = 128, 8 GPUs): users are partitioned, so a rank
-    owns 12.5 M users; the item table (10 M x 128 fp32 = 5.1 GB) is held whole.  5 distinct items per user."""
-    d, k = SCALE["degree"], SCALE["k"]
-    t0 = time.time()
-    nu, ni, indptr, indices = scale_slice(0)
-    t_gen = time.time() - t0
-    nnz = len(indices)
+def _scale_fit(_lib, nu, ni, indptr, indices, k, epochs):
+    """one handle over a configs[4]-sized slice: (c, skipped, seconds, kernel ms, launches, ldsbin stats, setup seconds)"""
     t0 = time.time()
     tr = _lib.BprTrainer(indptr, indices, nu, ni, nu, ni, k)
     U, V, B = scale_factors(nu, ni, k, 0)
     tr.set_factors(U, V, B)
+    del U, V, B
     tr.seed_hogwild(7)
-    tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)  # warm-up: builds ownership tables
+    tr.fit_epochs(1, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)  # warm-up: builds the form's tables
     t_setup = time.time() - t0
     lb = tr.ldsbin_stats()
-    epochs = 2
     tr.kernel_timing(True)
     t0 = time.perf_counter()
     c, sk = tr.fit_epochs(epochs, 0.05, 0.01, True, _lib.NEG_UNIFORM, _lib.MODE_HOGWILD)
     dt = time.perf_counter() - t0
     kms, launches = tr.kernel_timing(False)
+    lb["lock_timeouts"] = tr.ldsbin_stats()["lock_timeouts"]
     tr.close()
+    return c, sk, dt, kms, launches, lb, t_setup
+
+
+def leg_bpr_k128_scale(args, _lib):
+    """One GPU's share of configs[4] (100 M users x 10 M items, k = 128, 8 GPUs): users are partitioned, so a rank
+    owns 12.5 M users; the item table (10 M x 128 fp32 = 5.1 GB) is held whole.  5 distinct items per user.  Timed over 8
+    epochs (round 5: 2).  `zipf_0.55`: the same slice with a Zipf(0.55) popularity head (scale_slice_zipf)."""
+    d, k = SCALE["degree"], SCALE["k"]
+    t0 = time.time()
+    nu, ni, indptr, indices = scale_slice(0)
+    t_gen = time.time() - t0
+    nnz = len(indices)
+    epochs = 8
+    c, sk, dt, kms, launches, lb, t_setup = _scale_fit(_lib, nu, ni, indptr, indices, k, epochs)
     b_full, b_skip = algorithmic_bytes_per_triplet(k, d)
     skip = sk / float(nnz * epochs)
     # an epoch is one launch (LDS-bin form with passing bins — the automatic choice when an epoch draws >= 2 interactions
@@ -526,6 +556,33 @@ def leg_bpr_k128_scale(args, _lib):
                                       "frac_of_probe_ceiling": req / 20.0,
                                       "evidence": "profiles/r05_scale_pmc.csv, profiles/r05_exp_scale_passing.log (ablations: no "
                                                   "updates 19.8 ms, user rows by racy read-modify-write instead of atomics 32.0 vs 33.8)"}
+    if os.environ.get("CORNAC_BENCH_SCALE_ZIPF", "1") != "0":
+        try:
+            t0 = time.time()
+            zu, zi, zip_, zix = scale_slice_zipf(0)
+            zt = time.time() - t0
+            zn = len(zix)
+            zc, zs, zdt, zk, zl, zlb, _ = _scale_fit(_lib, zu, zi, zip_, zix, k, epochs)
+            zskip = zs / float(zn * epochs)
+            zb_full, zb_skip = algorithmic_bytes_per_triplet(k, zn / zu)
+            zbytes = zn * ((1 - zskip) * zb_full + zskip * zb_skip)
+            deg = np.bincount(zix, minlength=zi)
+            out["zipf_0.55"] = {"value": zn * epochs / zdt, "ms_per_step": 1e3 * zdt / epochs, "steps": epochs,
+                                "frac": zbytes * epochs / zdt / 1e9 / HBM_PEAK_GBS,
+                                "frac_kernel_only": zbytes * epochs / (zk / 1e3) / 1e9 / HBM_PEAK_GBS, "launches": zl,
+                                "interactions": zn, "top_item_share": float(deg.max()) / zn,
+                                "bins": zlb["bins"], "rows_per_bin": zlb["rows_per_bin"], "n_hot": zlb["n_hot"],
+                                "hot_interaction_share": zlb["hot_interactions"] / float(zn),
+                                # a hot triplet side updates its item row by k / 16 memory-side atomic requests on top of the
+                                # user row's: the hot rows' share of all atomic requests
+                                "hot_row_atomic_share": zlb["hot_interactions"] / float(zn + zlb["hot_interactions"]),
+                                "lock_timeouts": zlb["lock_timeouts"], "correct_frac": zc / max(zn * epochs - zs, 1),
+                                "skipped_frac": zskip, "generate_s": zt,
+                                "workload": "the same slice, every user's 5 items from Zipf(0.55) over the 10 M items"}
+            del zip_, zix, deg
+        except Exception as e:
+            print("[bench] scale zipf variant failed: %r" % (e,), file=sys.stderr)
+            out["zipf_0.55"] = {"error": repr(e)}
     # this leg's rate differs by up to 25 % between GPU boxes (11.5 GB of randomly accessed tables); the line carries a
     # calibration of the box it ran on — copy, streaming read and random 512-byte gather rates over 6 GiB buffers — and
     # the partition modes rocm-smi reports, so that a slow run can be told from a slow box
@@ -687,8 +744,8 @@ def leg_dist_tax(args, _lib):
     replicated item table bound to the handle, delta passes, all-reduce, overlapped schedule) next to the plain
     fit_epochs call, same data, same tables, same kernel form, at the ML-20M shape and at the configs[4] slice.
     tax = 1 - plain time / driver time.  How often and by which rule the replicas are reconciled: cornac_amd.dist.exchange_schedule
-    (ML-20M shape: 16 exchanges per epoch, "sqrt", from inside one launch per epoch; configs[4] slice: one exchange every
-    4 epochs, "align" — tools/emulate_exchange_interval.py; the timed region holds a whole number of intervals)."""
+    (ML-20M shape: 16 exchanges per epoch, "sqrt", from inside one launch per epoch; configs[4] slice, `scale`: one exchange per
+    epoch, "align" — what regime 1 does there when asked; that shape's own regime is the conveyor, `scale_ring`)."""
     import torch
 
     from cornac_amd.dist import ShardedBprTrainer, exchange_schedule

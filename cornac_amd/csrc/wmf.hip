@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_kernel(const float *__re
         const int64_t m0 = tile * kBM;
         const int64_t rows_here = min((int64_t)kBM, n_users - m0);
         // (a) P = U_t V_b^T
-        gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);  // (columns >= B of V_b^T are zero)
+        if (!(ablate & 1)) gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);  // (columns >= B of V_b^T are zero)
         // (b) G = 2 b P into the scratch tile (zero outside the live rows / columns); loss += b sum P^2
         float sq = 0.f;  // (64 squares of |P| <= a few units per thread and tile: fp32 partial, fp64 across tiles)
         const int nrow = (int)rows_here;
@@ -397,7 +397,11 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
                                                                    const float *__restrict__ vals,
                                                                    const int32_t *__restrict__ ids, float a, float b,
                                                                    float lambda_u, const TfAdam ad,
-                                                                   float *__restrict__ dv_part, double *loss) {
+                                                                   float *__restrict__ dv_part, double *loss, int ablate) {
+#ifndef CORNAC_PROFILE
+    ablate = 0;   // (profile builds: CORNAC_HIP_WMF_ABLATE bit 0 skips the P product, 1 the dV product, 2 the dU product, 3 the Adam
+                  // epilogue, 4 the non-zeros' fix-up — the time each piece costs; results are garbage)
+#endif
     extern __shared__ float lds[];
     float *Gl = lds;                  // [128][128] swizzled; also the P product's staging and the epilogue's stage
     float *sb = lds + kGl;            // [2][kBK][kBN]
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
         const int nrow = (int)min((int64_t)kBM, n_users - m0);
         // (a) P = U_t V_b^T  (staging tiles over the G region; the trailing barrier of gemm_block separates their last
         // read from the G stores below)
-        gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);
+        if (!(ablate & 1)) gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);
         // (b) G = 2 b P (zero outside the live rows / columns); loss += b sum P^2
         float sq = 0.f;
         for_each_acc_local(acc, kMaxBatch, [&](int, int rl, int cl, float pv) {
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
         part += (double)b * (double)sq;
         __syncthreads();
         // (c) the batch's non-zeros whose user is in this tile: G = 2 a (p - r), loss += a (r - p)^2 - b p^2
-        if ((int)threadIdx.x < B) {
+        if ((int)threadIdx.x < B && !(ablate & 16)) {
             const int c = threadIdx.x;
             const float *vrow = Vb + (int64_t)c * ld;
             const int64_t m1 = m0 + nrow;
@@ -471,13 +475,13 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
         }
         __syncthreads();
         // (e) dV += G_t^T U_t  (U before its update): M = batch columns, N = ld, K = the tile's users
-        gemm_lds_a<true, false>(Gl, U + m0 * ld, ld, ld, nrow, sb, accv);
+        if (!(ablate & 2)) gemm_lds_a<true, false>(Gl, U + m0 * ld, ld, ld, nrow, sb, accv);
         // (d) dU = G_t V_b
-        gemm_lds_a<false, true>(Gl, Vb, ld, ld, B, sb, acc);
+        if (!(ablate & 4)) gemm_lds_a<false, true>(Gl, Vb, ld, ld, B, sb, acc);
         // (the trailing barrier of the product: G is dead, its region now stages dU, 64 rows at a time) clipped TF1 Adam
         // on float4s of U, m_U, v_U; loss += lambda_u/2 |U|^2 (pre-update).  (Parking the whole 128-row tile at once and
         // keeping the loads of 2 or 4 row groups in flight was measured slower: 0.82 vs 0.77 ms per step.)
-        {
+        if (!(ablate & 8)) {
             float *stg = Gl;  // [64][128]
             const int wm = (threadIdx.x >> 6) >> 1;
             float usq = 0.f;
@@ -805,7 +809,7 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
                 else
                     wmf_user_step_lds_kernel<<<h->fused_wgs, kWb, kWmfLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p,
                                                                                      h->vU.p, h->indptr.p, h->rows.p, h->vals.p, d_ids,
-                                                                                     a, b, lambda_u, ad, h->dv_part.p, d_loss);
+                                                                                     a, b, lambda_u, ad, h->dv_part.p, d_loss, wmf_ablate);
                 wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, h->fused_wgs, B, ld, h->dV.p);
                 wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
                 wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);

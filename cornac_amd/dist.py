@@ -45,7 +45,14 @@ def exchanges_per_epoch(nnz_per_rank, total_items, updates_per_row=93.5, at_most
     return int(min(max(1, int(x + 0.5)), at_most))
 
 
-def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=64, max_epochs=4):
+def prefers_conveyor(nnz_per_rank, total_items, updates_per_row=93.5):
+    """True for SPARSE item sides — a row collects fewer than ~93.5 updates on a rank in a whole epoch (the configs[4] slice: 12.5)
+    — where replicas reconciled once per epoch lag in mid-training (0.869 against 0.990 for one process, device measurement,
+    profiles/r05_virtual_ranks.log) and the conveyor does not (0.990): fit_bpr_sharded(regime="auto") takes regime 2 there."""
+    return 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row)) < 0.75
+
+
+def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=64, max_epochs=1):
     """(exchanges per epoch, epochs per exchange, rule) of the replicated regime for BPR.
 
     Dense item sides (the ML-20M shape: 1 496 item-row updates per row and epoch on a rank) exchange several times per
@@ -65,9 +72,10 @@ def exchange_schedule(nnz_per_rank, total_items, updates_per_row=93.5, at_most=6
     ranks at the slice's density, profiles/r05_virtual_ranks.log): the replicas reach the single process's quality only at
     convergence (0.9948 vs 0.9964 after 32 epochs); in the MIDDLE of training the averaged, stale item side lags badly
     (16 epochs: 0.869 / 0.708 / 0.618 at one exchange every 1 / 2 / 4 epochs against 0.990 for one process) — every rank
-    moves every row the same way and "align" keeps the mean.  The ring conveyor (BinConveyorBprTrainer, fit_bpr_ring; round 5's form with static item blocks) has
-    no such trade: 0.990 in the same measurement, 3.8 % one-rank tax.  Sparse item sides should take the ring; this
-    schedule remains what regime 1 does when asked."""
+    moves every row the same way and "align" keeps the mean.  The ring conveyor (BinConveyorBprTrainer, fit_bpr_ring) has
+    no such trade: 0.990 in the same measurement.  Sparse item sides should take the ring (prefers_conveyor); since round 6
+    the multi-epoch intervals are off by default (max_epochs = 1: a sparse side asked to run regime 1 exchanges once per
+    epoch, the least bad of the measured schedules) and remain reachable through max_epochs for experiments."""
     x = 2.0 * float(nnz_per_rank) / (float(total_items) * float(updates_per_row))
     if x >= 0.75:
         per_epoch, epochs = int(min(max(1, int(x + 0.5)), at_most)), 1
@@ -1637,9 +1645,9 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     cornac_hip_bpr_set_negative_population; the draw then runs in the fused kernel).  local_popularity=True keeps each
     rank's own interactions as its population (the LDS-bin form's binned draw; the popularity of the rank's users only).
     trainer_factory(table, indptr, indices, n_local, n_items, total_items, k): test hook (host stand-ins on gloo).
-    regime: "replicated" = this regime; "ring" = fit_bpr_ring; "auto" (default) = the ring where exchange_schedule would
-    space the replicas' exchanges over several epochs (sparse item sides — where the replicas lag in mid-training,
-    DESIGN.md 5), the replicas otherwise and whenever the caller fixes the replica protocol (sync_per_epoch, rule,
+    regime: "replicated" = this regime; "ring" = fit_bpr_ring (its sampling contract: that docstring); "auto" (default) = the
+    ring for sparse item sides (prefers_conveyor — where the replicas lag in mid-training), the replicas
+    otherwise and whenever the caller fixes the replica protocol (sync_per_epoch, rule,
     sparse_threshold, trainer_factory).  rings: strided rings of the conveyor (fit_bpr_ring)."""
     from . import _lib
     from .recommender import Recommender
@@ -1658,7 +1666,7 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
     if regime != "replicated":
         X0 = train_set.matrix
         per_rank = int(X0.nnz // max(world, 1)) + 1
-        if regime == "ring" or exchange_schedule(per_rank, train_set.num_items)[1] > 1:
+        if regime == "ring" or prefers_conveyor(per_rank, train_set.num_items):
             return fit_bpr_ring(model, train_set, device=device, group=group,
                                 local_popularity=local_popularity or model._neg_population != _lib.NEG_POPULARITY, rings=rings)
     Recommender.fit(model, train_set)

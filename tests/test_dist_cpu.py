@@ -905,12 +905,14 @@ def test_resident_exchange_of_one_process_keeps_its_own_steps_bit_for_bit():
 
 def test_exchange_schedule_rule():
     """dense item sides: several exchanges per epoch under "sqrt" from 16 on, "align" below; sparse item sides (the
-    configs[4] slice): one exchange every few epochs under "align" (tools/emulate_exchange_interval.py)"""
-    from cornac_amd.dist import exchange_schedule, exchanges_per_epoch
+    configs[4] slice): one exchange per epoch under "align" — and regime "auto" takes the conveyor there"""
+    from cornac_amd.dist import exchange_schedule, exchanges_per_epoch, prefers_conveyor
 
     assert exchange_schedule(20_000_263, 26_744) == (16, 1, "sqrt") and exchanges_per_epoch(20_000_263, 26_744) == 16
     assert exchange_schedule(5_000_000, 26_744) == (4, 1, "align")
-    assert exchange_schedule(62_500_000, 10_000_000) == (1, 4, "align")
+    assert exchange_schedule(62_500_000, 10_000_000) == (1, 1, "align")       # (round 6: no multi-epoch interval by default —
+    assert exchange_schedule(62_500_000, 10_000_000, max_epochs=4) == (1, 4, "align")   # the device measurement overturned it)
+    assert prefers_conveyor(62_500_000, 10_000_000) and not prefers_conveyor(20_000_263 // 8, 26_744)
     assert exchange_schedule(62_500_000, 2_000_000) == (1, 1, "align")        # 62.5 updates per row and epoch: every epoch
     assert exchange_schedule(10_000_000, 10_000_000, max_epochs=8) == (1, 8, "align")
     assert exchange_schedule(4_000_000_000, 26_744)[0] == 64

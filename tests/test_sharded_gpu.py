@@ -871,7 +871,7 @@ def test_eight_virtual_ranks_at_the_slice_density_ring_conveyor_against_replicas
         serial execution the gloo test shows the ranks' parallel run to equal): every item row is in one place, nothing is
         reconciled.  Gate: within 1.5 points of the single process.
       * regime 1, replicas reconciled with ItemTableReplica's "align" algebra once every 1 / 2 / 4 epochs (round 4's
-        exchange_schedule returned 4 here on the strength of a CPU toy): every rank moves every item row the same way, the
+        exchange_schedule returned 4 here on the strength of a CPU toy; since round 6 it returns 1): every rank moves every item row the same way, the
         rule averages the R aligned deltas, and the shared item side learns at a fraction of the single process's pace —
         measured here, printed, and the reason the conveyor is the regime for this shape.  Only at convergence do the
         replicas catch up (gate: within 1.5 points after twice the epochs)."""
