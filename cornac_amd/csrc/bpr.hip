@@ -1714,7 +1714,19 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
 
 // ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
 typedef void (*LdsBinKernel)(const LdsBinArgs);
-static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false, bool passing = false) {
+static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false, bool passing = false, bool conv = false) {
+    if (conv) {  // conveyor launches (passing bins whose rows live in block buffers): the passing regime's shapes
+        if (pop) {
+            if (k <= 64) return bpr_ldsbin_kernel<1, 4, true, false, 1, true>;
+            if (k <= 128) return bpr_ldsbin_kernel<2, 4, true, false, 1, true>;
+            if (k <= 192) return bpr_ldsbin_kernel<3, 2, true, false, 1, true>;
+            return bpr_ldsbin_kernel<4, 1, true, false, 1, true>;
+        }
+        if (k <= 64) return bpr_ldsbin_kernel<1, 4, false, false, 1, true>;
+        if (k <= 128) return bpr_ldsbin_kernel<2, 4, false, false, 1, true>;
+        if (k <= 192) return bpr_ldsbin_kernel<3, 2, false, false, 1, true>;
+        return bpr_ldsbin_kernel<4, 1, false, false, 1, true>;
+    }
     // passing bins (8-wave workgroups, two per CU): 4 triplets in flight per wave at k in 65..128 — measured on the
     // configs[4] slice (profiles/r05_exp_scale_passing.log): 2 in flight 38.1 ms, 3: 35.1, 4: 33.8 per epoch; with the
     // rows of a bin loaded 4 at a time 30.5; requesting the user rows two steps ahead instead of one: no gain (31.0)
@@ -2329,7 +2341,7 @@ int cornac_hip_bpr_conveyor_enqueue(cornac_hip_bpr_t h, uint32_t epoch, uint32_t
         REQUIRE(neg_population == CORNAC_HIP_NEG_UNIFORM || neg_population == CORNAC_HIP_NEG_POPULARITY,
                 "unknown neg_population %d", neg_population);
         const int bpb = h->lb_bins / h->cv_blocks;
-        LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, false, true);
+        LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, false, true, true);
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
         LdsBinArgs a;
         ldsbin_fill_args(h, a, lr, reg, use_bias, neg_population, hogwild_flags);

@@ -141,16 +141,24 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
     for (int64_t s = 0; s < n_steps; ++s) {
         const int buf = (int)(s & 1);
         if (s + 1 < n_steps) load_tile(k_begin + (s + 1) * kBK);
+        // the fragments of k pair t + 1 are requested before the four MFMAs of pair t issue: one wave keeps the matrix
+        // pipe busy on its own (the LDS latency hides behind 256 MFMA cycles instead of stalling every fourth MFMA)
+        float fa[2][2], fb[2][2];
+        auto frag = [&](int t, int slot) {
+            fa[slot][0] = sm.a[buf][2 * t + half][wm * 64 + l31];
+            fa[slot][1] = sm.a[buf][2 * t + half][wm * 64 + 32 + l31];
+            fb[slot][0] = sm.b[buf][2 * t + half][wn * 64 + l31];
+            fb[slot][1] = sm.b[buf][2 * t + half][wn * 64 + 32 + l31];
+        };
+        frag(0, 0);
 #pragma unroll
         for (int t = 0; t < kBK / 2; ++t) {
-            const float a0 = sm.a[buf][2 * t + half][wm * 64 + l31];
-            const float a1 = sm.a[buf][2 * t + half][wm * 64 + 32 + l31];
-            const float b0 = sm.b[buf][2 * t + half][wn * 64 + l31];
-            const float b1 = sm.b[buf][2 * t + half][wn * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int c = t & 1;
+            if (t + 1 < kBK / 2) frag(t + 1, c ^ 1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
         }
         if (s + 1 < n_steps) store_tile(buf ^ 1);  // the other buffer was last read before the previous barrier
         __syncthreads();

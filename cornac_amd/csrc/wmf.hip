@@ -367,23 +367,29 @@ __device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restr
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_steps) load_tile((s + 1) * kBK);
+        // (fragments of k pair t + 1 requested before the MFMAs of pair t issue, as in gemm_block)
+        float fa[2][2], fb[2][2];
+        auto frag = [&](int t, int slot) {
+            const int kk = s * kBK + 2 * t + half;
+            if (K_IS_ROW) {
+                fa[slot][0] = Gl[kk * kMaxBatch + (m_a ^ (kk & 31))];
+                fa[slot][1] = Gl[kk * kMaxBatch + ((m_a + 32) ^ (kk & 31))];
+            } else {
+                fa[slot][0] = Gl[m_a * kMaxBatch + (kk ^ (m_a & 31))];
+                fa[slot][1] = Gl[(m_a + 32) * kMaxBatch + (kk ^ (m_a & 31))];
+            }
+            fb[slot][0] = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + l31];
+            fb[slot][1] = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + 32 + l31];
+        };
+        frag(0, 0);
 #pragma unroll
         for (int t = 0; t < kBK / 2; ++t) {
-            const int kk = s * kBK + 2 * t + half;
-            float a0, a1;
-            if (K_IS_ROW) {
-                a0 = Gl[kk * kMaxBatch + (m_a ^ (kk & 31))];
-                a1 = Gl[kk * kMaxBatch + ((m_a + 32) ^ (kk & 31))];
-            } else {
-                a0 = Gl[m_a * kMaxBatch + (kk ^ (m_a & 31))];
-                a1 = Gl[(m_a + 32) * kMaxBatch + (kk ^ (m_a & 31))];
-            }
-            const float b0 = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + l31];
-            const float b1 = sb[(buf * kBK + 2 * t + half) * kBN + wn * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int c = t & 1;
+            if (t + 1 < kBK / 2) frag(t + 1, c ^ 1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
         }
         if (s + 1 < n_steps) store_tile(buf ^ 1);
         __syncthreads();
