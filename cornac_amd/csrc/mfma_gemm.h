@@ -30,8 +30,12 @@ template <bool A_KC, bool B_NC, bool ZERO = true, bool A_NT = false>
 __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t a_sm, int64_t a_sk,
                                            const float *__restrict__ B, int64_t b_sk, int64_t b_sn, int64_t M,
                                            int64_t N, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
-                                           GemmSmem &sm, f32x16 (&acc)[2][2]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                           GemmSmem &sm, f32x16 (&acc)[2][2], bool skip_loads = false) {
+    // (an opaque copy of the thread index: inside a persistent tile loop the addresses derived from it would otherwise be
+    // hoisted out of the loop as invariants and stay live — dozens of registers — across every other phase of the tile)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
     if (ZERO) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
     __syncthreads();
     for (int64_t s = 0; s < n_steps; ++s) {
         const int buf = (int)(s & 1);
-        if (s + 1 < n_steps) load_tile(k_begin + (s + 1) * kBK);
+        if (s + 1 < n_steps && !skip_loads) load_tile(k_begin + (s + 1) * kBK);   // (skip_loads: profile builds' latency ablation)
         // the fragments of k pair t + 1 are requested before the four MFMAs of pair t issue: one wave keeps the matrix
         // pipe busy on its own (the LDS latency hides behind 256 MFMA cycles instead of stalling every fourth MFMA)
         float fa[2][2], fb[2][2];
@@ -155,6 +159,7 @@ __device__ __forceinline__ void gemm_block(const float *__restrict__ A, int64_t 
         for (int t = 0; t < kBK / 2; ++t) {
             const int c = t & 1;
             if (t + 1 < kBK / 2) frag(t + 1, c ^ 1);
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the reads below the MFMAs to save registers)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);

@@ -321,8 +321,10 @@ __device__ __forceinline__ int gl_index(int row, int col) { return row * kMaxBat
 // contiguous, staged through the double buffer sb[2][kBK][kBN].
 template <bool K_IS_ROW, bool ZERO>
 __device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restrict__ Bp, int64_t b_sk, int N, int k_end,
-                                           float *sb, f32x16 (&acc)[2][2]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                           float *sb, f32x16 (&acc)[2][2], bool skip_loads = false) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (opaque: see gemm_block)
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
     if (ZERO) {
 #pragma unroll
@@ -366,7 +368,7 @@ __device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restr
     const int m_a = wm * 64 + l31;
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < n_steps) load_tile((s + 1) * kBK);
+        if (s + 1 < n_steps && !skip_loads) load_tile((s + 1) * kBK);
         // (fragments of k pair t + 1 requested before the MFMAs of pair t issue, as in gemm_block)
         float fa[2][2], fb[2][2];
         auto frag = [&](int t, int slot) {
@@ -386,6 +388,7 @@ __device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restr
         for (int t = 0; t < kBK / 2; ++t) {
             const int c = t & 1;
             if (t + 1 < kBK / 2) frag(t + 1, c ^ 1);
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the reads below the MFMAs to save registers)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
@@ -396,6 +399,102 @@ __device__ __forceinline__ void gemm_lds_a(const float *Gl, const float *__restr
     }
 }
 
+// ---- full tiles (k = ld = 128, a batch of 128 items, 128 users): the three products with every address a per-thread constant ----
+// The k-step loops above pay 100-200 VALU instructions per 32 MFMAs for 64-bit address arithmetic and range checks, and on this
+// part VALU issue time adds to matrix-pipe time (tools/mfma_probe.hip).  With the extents known the 8 k-steps unroll: operand
+// rows come off a scalar base that advances per step plus one 32-bit per-thread offset, LDS stores and fragment reads take
+// immediate offsets; the swizzled reads of G need 16 per-thread column offsets (`xv4`: ((lane & 31) ^ half ^ 2 j) * 4 bytes).
+//   MODE 0:  P  = U_t VbT    A(m, kk) = U_t[m][kk] staged k-major through `sa` (over the G region), B = VbT rows
+//   MODE 1:  dV += G^T U_t   A(m, kk) = G[kk][m],  B = U_t rows
+//   MODE 2:  dU = G Vb       A(m, kk) = G[m][kk],  B = Vb rows
+template <int MODE, bool ZERO>
+__device__ __forceinline__ void product_full(const float *Gl, float *sa, float *sb, const float *__restrict__ Arows,
+                                             const float *__restrict__ Brows, const int (&xv4)[16], f32x16 (&acc)[2][2],
+                                             bool skip_loads = false) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (opaque: see gemm_block)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    if (ZERO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const uint32_t off_b = (uint32_t)(((tid >> 5) * 128 + (tid & 31) * 4) * 4);   // bytes: row tid / 32 (+ 8 i), 4 floats
+    const uint32_t off_a = (uint32_t)(((tid >> 2) * 128 + (tid & 3) * 4) * 4);    // row tid / 4 (+ 64 i), k (tid & 3) * 4
+    const char *bb = reinterpret_cast<const char *>(Brows), *ab = reinterpret_cast<const char *>(Arows);
+    f32x4 rb[2], ra[2];
+    auto load_tile = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rb[i] = *reinterpret_cast<const f32x4 *>(bb + (size_t)s * (kBK * 512) + (size_t)i * (8 * 512) + off_b);
+            if (MODE == 0) ra[i] = *reinterpret_cast<const f32x4 *>(ab + (size_t)i * (64 * 512) + (size_t)s * (kBK * 4) + off_a);
+        }
+    };
+    float *sb_w = sb + (tid >> 5) * kBN + (tid & 31) * 4;
+    float *sa_w = sa + ((tid & 3) * 4) * kLdT + (tid >> 2);
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4 *>(sb_w + (buf * kBK + 8 * i) * kBN) = rb[i];
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sa_w[(buf * kBK + q) * kLdT + 64 * i] = ra[i][q];
+            }
+        }
+    };
+    const float *sb_r = sb + half * kBN + wn * 64 + l31;
+    const float *sa_r = sa + half * kLdT + wm * 64 + l31;
+    const char *g_r = reinterpret_cast<const char *>(Gl) +
+                      (MODE == 1 ? (half * kMaxBatch + wm * 64) * 4 : (wm * 64 + l31) * kMaxBatch * 4);
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kBM / kBK; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < kBM / kBK && !skip_loads) load_tile(s + 1);   // (skip_loads: profile builds' latency ablation)
+        float fa[2][2], fb[2][2];
+        auto frag = [&](int t, int slot) {
+            if (MODE == 0) {
+                fa[slot][0] = sa_r[(buf * kBK + 2 * t) * kLdT];
+                fa[slot][1] = sa_r[(buf * kBK + 2 * t) * kLdT + 32];
+            } else if (MODE == 1) {   // G[kk][m ^ (kk & 31)], kk = 16 s + 2 t + half
+                const char *q = g_r + (kBK * s + 2 * t) * kMaxBatch * 4 + xv4[8 * (s & 1) + t];
+                fa[slot][0] = *reinterpret_cast<const float *>(q);
+                fa[slot][1] = *reinterpret_cast<const float *>(q + 32 * 4);
+            } else {                  // G[m][kk ^ (m & 31)]
+                const char *q = g_r + (s >> 1) * 32 * 4 + xv4[8 * (s & 1) + t];
+                fa[slot][0] = *reinterpret_cast<const float *>(q);
+                fa[slot][1] = *reinterpret_cast<const float *>(q + 32 * kMaxBatch * 4);
+            }
+            fb[slot][0] = sb_r[(buf * kBK + 2 * t) * kBN];
+            fb[slot][1] = sb_r[(buf * kBK + 2 * t) * kBN + 32];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int t = 0; t < kBK / 2; ++t) {
+            const int c = t & 1;
+            if (t + 1 < kBK / 2) frag(t + 1, c ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < kBM / kBK) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// VAR (bits): 1 / 2 — the Adam epilogue keeps 2 / 4 row groups of U, m_U, v_U in flight per thread; 4 — m_U, v_U and the
+// stores of U bypass the caches' retention (touched once per step: the L2 keeps the U tile the three products re-read);
+// 8 — the second workgroup of a CU starts half a tile late, so that one streams the Adam state while the other multiplies;
+// 16 — without the full-tile product routine (product_full)
+template <int VAR>
 __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *__restrict__ Vb, const float *__restrict__ VbT,
                                                                    int64_t n_users, int B, int k, int ld, float *U, float *mU,
                                                                    float *vU, const int64_t *__restrict__ indptr,
@@ -403,10 +502,21 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
                                                                    const float *__restrict__ vals,
                                                                    const int32_t *__restrict__ ids, float a, float b,
                                                                    float lambda_u, const TfAdam ad,
-                                                                   float *__restrict__ dv_part, double *loss, int ablate) {
+                                                                   float *__restrict__ dv_part, double *loss, int ablate,
+                                                                   int stagger_ticks, int *cu_arrivals) {
 #ifndef CORNAC_PROFILE
     ablate = 0;   // (profile builds: CORNAC_HIP_WMF_ABLATE bit 0 skips the P product, 1 the dV product, 2 the dU product, 3 the Adam
                   // epilogue, 4 the non-zeros' fix-up — the time each piece costs; results are garbage)
+#endif
+#ifdef CORNAC_PROFILE
+    const long long prof_c0 = (long long)clock64(), prof_w0 = (long long)wall_clock64();
+    // phase stamps (100 MHz ticks since the kernel's start) of workgroups 0 and gridDim.x - 1: 6 per tile, 16 tiles at most
+    long long *prof_st = (cu_arrivals && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+                             ? reinterpret_cast<long long *>(cu_arrivals + 1040) + (blockIdx.x == 0 ? 0 : 100) : nullptr;
+    int prof_n = 0;
+#define WMF_STAMP() do { if (prof_st && prof_n < 96) prof_st[prof_n++] = (long long)wall_clock64() - prof_w0; } while (0)
+#else
+#define WMF_STAMP() do { } while (0)
 #endif
     extern __shared__ float lds[];
     float *Gl = lds;                  // [128][128] swizzled; also the P product's staging and the epilogue's stage
@@ -437,12 +547,39 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
         }
         cur = lo;
     }
+    if (VAR & 8) {
+        // the second workgroup to arrive on a CU (a counter per physical CU, zeroed before the launch) waits
+        // `stagger_ticks` of the 100 MHz clock
+        int *late = reinterpret_cast<int *>(sb);
+        if (threadIdx.x == 0) *late = atomicAdd(cu_arrivals + __smid(), 1) & 1;
+        __syncthreads();
+        const bool wait = *late != 0;
+        __syncthreads();
+        if (wait) {
+            if (threadIdx.x == 0) atomicAdd(cu_arrivals + 1024, 1);
+            const uint64_t t0 = wall_clock64();
+            while (wall_clock64() - t0 < (uint64_t)stagger_ticks) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    int xv4[16];   // product_full: byte offsets of the swizzled G columns this lane reads
+    {
+        const int x = (threadIdx.x & 31) ^ ((threadIdx.x >> 5) & 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv4[j] = (x ^ (2 * j)) * 4;
+    }
+    const bool full_shape = !(VAR & 16) && ld == kBN && k == kBN && B == kMaxBatch;
     for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
         const int64_t m0 = tile * kBM;
         const int nrow = (int)min((int64_t)kBM, n_users - m0);
-        // (a) P = U_t V_b^T  (staging tiles over the G region; the trailing barrier of gemm_block separates their last
+        const bool full = full_shape && nrow == kBM;
+        WMF_STAMP();
+        // (a) P = U_t V_b^T  (staging tiles over the G region; the trailing barrier of the product separates their last
         // read from the G stores below)
-        if (!(ablate & 1)) gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc);
+        if (!(ablate & 1)) {
+            if (full) product_full<0, true>(Gl, &sm.a[0][0][0], sb, U + m0 * kBN, VbT, xv4, acc, (ablate & 64) != 0);
+            else gemm_block<true, true>(U, ld, 1, VbT, kMaxBatch, 1, n_users, kMaxBatch, m0, 0, 0, k, sm, acc, (ablate & 64) != 0);
+        }
+        WMF_STAMP();
         // (b) G = 2 b P (zero outside the live rows / columns); loss += b sum P^2
         float sq = 0.f;
         for_each_acc_local(acc, kMaxBatch, [&](int, int rl, int cl, float pv) {
@@ -480,57 +617,98 @@ __global__ __launch_bounds__(kWb, 2) void wmf_user_step_lds_kernel(const float *
             }
         }
         __syncthreads();
+        WMF_STAMP();
         // (e) dV += G_t^T U_t  (U before its update): M = batch columns, N = ld, K = the tile's users
-        if (!(ablate & 2)) gemm_lds_a<true, false>(Gl, U + m0 * ld, ld, ld, nrow, sb, accv);
+        if (!(ablate & 2)) {
+            if (full) product_full<1, false>(Gl, nullptr, sb, nullptr, U + m0 * kBN, xv4, accv, (ablate & 64) != 0);
+            else gemm_lds_a<true, false>(Gl, U + m0 * ld, ld, ld, nrow, sb, accv, (ablate & 64) != 0);
+        }
+        WMF_STAMP();
         // (d) dU = G_t V_b
-        if (!(ablate & 4)) gemm_lds_a<false, true>(Gl, Vb, ld, ld, B, sb, acc);
+        if (!(ablate & 4)) {
+            if (full) product_full<2, true>(Gl, nullptr, sb, nullptr, Vb, xv4, acc, (ablate & 64) != 0);
+            else gemm_lds_a<false, true>(Gl, Vb, ld, ld, B, sb, acc, (ablate & 64) != 0);
+        }
         // (the trailing barrier of the product: G is dead, its region now stages dU, 64 rows at a time) clipped TF1 Adam
         // on float4s of U, m_U, v_U; loss += lambda_u/2 |U|^2 (pre-update).  (Parking the whole 128-row tile at once and
         // keeping the loads of 2 or 4 row groups in flight was measured slower: 0.82 vs 0.77 ms per step.)
+        WMF_STAMP();
         if (!(ablate & 8)) {
-            float *stg = Gl;  // [64][128]
-            const int wm = (threadIdx.x >> 6) >> 1;
+            float *stg = Gl;  // [128][128]: the whole dU tile parked, the accumulators are dead during the sweep
+            constexpr int UQ = (VAR & 2) ? 4 : (VAR & 1) ? 2 : 1;
+            constexpr bool NT = (VAR & 4) != 0;
             float usq = 0.f;
-            for (int h = 0; h < 2; ++h) {
-                if (wm == h) for_each_acc_local(acc, kBN, [&](int off, int, int, float v) { stg[off - h * 64 * kBN] = v; });
-                __syncthreads();
-                const int c4 = (threadIdx.x & 31) * 4;
-                if (c4 < ld) {
+            for_each_acc_local(acc, kBN, [&](int off, int, int, float v) { stg[off] = v; });
+            __syncthreads();
+            int tx = threadIdx.x;
+            asm volatile("" : "+v"(tx));   // (opaque: see gemm_block)
+            const int c4 = (tx & 31) * 4;
+            if (c4 < ld) {
 #pragma unroll 1
-                    for (int q = 0; q < 8; ++q) {
-                        const int row = (threadIdx.x >> 5) + 8 * q;
-                        const int64_t gr = m0 + h * 64 + row;
-                        if (gr < n_users) {
-                            const f32x4 du = *reinterpret_cast<const f32x4 *>(stg + row * kBN + c4);
-                            f32x4 *pu = reinterpret_cast<f32x4 *>(U + gr * ld + c4);
-                            f32x4 *pm = reinterpret_cast<f32x4 *>(mU + gr * ld + c4);
-                            f32x4 *pv = reinterpret_cast<f32x4 *>(vU + gr * ld + c4);
-                            f32x4 u = *pu, m = *pm, v = *pv;
+                for (int q0 = 0; q0 < 16; q0 += UQ) {
+                    f32x4 u[UQ], m[UQ], v[UQ];
+                    int64_t o[UQ];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                usq += u[e] * u[e];
-                                float g = du[e] + lambda_u * u[e];
-                                g = fminf(fmaxf(g, -5.f), 5.f);
-                                m[e] = m[e] + ad.one_minus_beta1 * (g - m[e]);
-                                v[e] = v[e] + ad.one_minus_beta2 * (g * g - v[e]);
-                                u[e] = u[e] - ad.lr_t * m[e] / (sqrtf(v[e]) + ad.eps);
+                    for (int i = 0; i < UQ; ++i) {
+                        const int row = (tx >> 5) + 8 * (q0 + i);
+                        const int64_t gr = m0 + row;
+                        o[i] = gr < n_users ? gr * ld + c4 : -1;
+                        if (o[i] >= 0) {
+                            u[i] = *reinterpret_cast<const f32x4 *>(U + o[i]);
+                            if (NT) {
+                                m[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(mU + o[i]));
+                                v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vU + o[i]));
+                            } else {
+                                m[i] = *reinterpret_cast<const f32x4 *>(mU + o[i]);
+                                v[i] = *reinterpret_cast<const f32x4 *>(vU + o[i]);
                             }
-                            *pm = m;
-                            *pv = v;
-                            *pu = u;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < UQ; ++i) {
+                        if (o[i] < 0) continue;
+                        const int row = (tx >> 5) + 8 * (q0 + i);
+                        const f32x4 du = *reinterpret_cast<const f32x4 *>(stg + row * kBN + c4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            usq += u[i][e] * u[i][e];
+                            float g = du[e] + lambda_u * u[i][e];
+                            g = fminf(fmaxf(g, -5.f), 5.f);
+                            m[i][e] = m[i][e] + ad.one_minus_beta1 * (g - m[i][e]);
+                            v[i][e] = v[i][e] + ad.one_minus_beta2 * (g * g - v[i][e]);
+                            u[i][e] = u[i][e] - ad.lr_t * m[i][e] / (sqrtf(v[i][e]) + ad.eps);
+                        }
+                        if (NT) {
+                            __builtin_nontemporal_store(m[i], reinterpret_cast<f32x4 *>(mU + o[i]));
+                            __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(vU + o[i]));
+                            __builtin_nontemporal_store(u[i], reinterpret_cast<f32x4 *>(U + o[i]));
+                        } else {
+                            *reinterpret_cast<f32x4 *>(mU + o[i]) = m[i];
+                            *reinterpret_cast<f32x4 *>(vU + o[i]) = v[i];
+                            *reinterpret_cast<f32x4 *>(U + o[i]) = u[i];
                         }
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
             part += 0.5 * (double)lambda_u * (double)usq;
         }
+        WMF_STAMP();
     }
+#ifdef CORNAC_PROFILE
+    if (prof_st) prof_st[99] = prof_n;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cu_arrivals) {   // effective shader clock of this launch: cycles / (ticks / 100 MHz)
+        reinterpret_cast<long long *>(cu_arrivals + 1026)[0] = (long long)clock64() - prof_c0;
+        reinterpret_cast<long long *>(cu_arrivals + 1026)[1] = (long long)wall_clock64() - prof_w0;
+    }
+#endif
     float *mine = dv_part + (size_t)blockIdx.x * kMaxBatch * kBN;
     for_each_acc_local(accv, kBN, [&](int off, int, int, float v) { mine[off] = v; });
     const double s = block_sum_f64(part, reinterpret_cast<double *>(sb));
     if (threadIdx.x == 0 && s != 0) atomicAdd(loss, s);
 }
+
+#include "wmf_ws.inc"
 
 // dV[c, f] += sum over a slice of the workgroups' partials (fused path; grid.y slices, dV is zero on entry: the scatter
 // kernel re-zeroes it after every step)
@@ -626,6 +804,9 @@ struct cornac_hip_wmf {
     DevBuf<int32_t> rows, ids;          // ids: all batches of the current call, back to back
     DevBuf<float> vals;
     DevBuf<double> loss;
+    DevBuf<float> ws_dump;                    // wave-specialised kernel: where the updates of rows that do not exist go
+    int ws_wgs = 0;
+    DevBuf<int> cu_arrivals;                  // [1024 physical CU ids + 1]: arrival order of the fused kernel's workgroups
     std::vector<int64_t> h_indptr;
     int64_t step = 0;
     EventTimer timer;
@@ -635,6 +816,24 @@ struct cornac_hip_wmf {
 static void wmf_check(cornac_hip_wmf_t h) {
     REQUIRE(h != nullptr, "WMF handle is NULL");
     HIP_CHECK(hipSetDevice(h->device));
+}
+
+typedef void (*WmfLdsKernel)(const float *, const float *, int64_t, int, int, int, float *, float *, float *, const int64_t *,
+                             const int32_t *, const float *, const int32_t *, float, float, float, const TfAdam, float *, double *,
+                             int, int, int *);
+constexpr int kWmfDefaultVariant = 0;
+// the variant of the fused kernel: kWmfDefaultVariant, or CORNAC_HIP_WMF_VARIANT in profile builds (tools/wmf_ablate.py)
+static WmfLdsKernel pick_wmf_lds_kernel(int var) {
+#ifdef CORNAC_PROFILE
+    switch (var & 31) {
+#define V(i) case i: return wmf_user_step_lds_kernel<i>;
+        V(0) V(1) V(2) V(4) V(5) V(6) V(8) V(9) V(13) V(16) V(21)
+#undef V
+        default: break;
+    }
+#endif
+    (void)var;
+    return wmf_user_step_lds_kernel<kWmfDefaultVariant>;
 }
 
 static int grid_for(int64_t n, int cap = 4096) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kWb - 1) / kWb, cap)); }
@@ -661,6 +860,7 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
         for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV, &h->gV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
         h->Vb.alloc((size_t)kMaxBatch * h->ld);
+        HIP_CHECK(hipMemsetAsync(h->Vb.p, 0, h->Vb.n * 4, h->stream));   // (rows >= the batch size are multiplied by zeros of G)
         h->dV.alloc((size_t)kMaxBatch * h->ld);
         HIP_CHECK(hipMemsetAsync(h->dV.p, 0, h->dV.n * 4, h->stream));
         h->stage.alloc(std::max(nu, ni));
@@ -769,21 +969,34 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
         const int wmf_ablate = prof_env_int("CORNAC_HIP_WMF_ABLATE", 0);
         const bool fused = ld <= kBN && !no_fuse;
         const bool g_scratch = prof_env_set("CORNAC_HIP_WMF_GSCRATCH");  // A/B switch: G in a global scratch tile
+        const int wmf_variant = prof_env_int("CORNAC_HIP_WMF_VARIANT", kWmfDefaultVariant);
+        const int stagger_ticks = prof_env_int("CORNAC_HIP_WMF_STAGGER", 2000);   // 20 us: half of a tile's time
+        const WmfLdsKernel lds_kernel = pick_wmf_lds_kernel(wmf_variant);
+        if (fused && !g_scratch)
+            HIP_CHECK(hipFuncSetAttribute((const void *)lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWmfLdsBytes));
         if (fused && h->fused_wgs == 0) {
             int per_cu = 0;
             if (g_scratch) {
                 HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_kernel, kWb, 0));
             } else {
-                HIP_CHECK(hipFuncSetAttribute((const void *)wmf_user_step_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)kWmfLdsBytes));
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_lds_kernel, kWb, kWmfLdsBytes));
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wmf_user_step_lds_kernel<kWmfDefaultVariant>, kWb, kWmfLdsBytes));
             }
             if (prof_env_set("CORNAC_HIP_WMF_DEBUG")) fprintf(stderr, "[wmf] fused kernel: %d workgroups per CU\n", per_cu);
+            per_cu = std::min(per_cu, prof_env_int("CORNAC_HIP_WMF_WGS_PER_CU", 2));   // (profile builds: single-wave-per-SIMD timing)
             h->fused_wgs = (int)std::min<int64_t>(m_tiles, (int64_t)device_info(h->device).cus * std::max(1, std::min(per_cu, 2)));
             h->g_scratch.alloc((size_t)h->fused_wgs * kBM * kMaxBatch);
             h->dv_part.alloc((size_t)h->fused_wgs * kMaxBatch * kBN);
             h->VbT.alloc((size_t)ld * kMaxBatch);
+            h->cu_arrivals.alloc(1040 + 400);
             HIP_CHECK(hipMemsetAsync(h->VbT.p, 0, h->VbT.n * 4, h->stream));
+        }
+        // ld == 128: one 8-wave workgroup per CU, MFMA waves beside streaming waves (wmf_ws.inc)
+        const bool ws = fused && !g_scratch && ld == kBN && !prof_env_set("CORNAC_HIP_WMF_NO_WS");
+        if (ws && h->ws_wgs == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)wmf_user_step_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kWmfWsLdsBytes));
+            h->ws_wgs = (int)std::min<int64_t>(m_tiles, (int64_t)device_info(h->device).cus);
+            h->ws_dump.alloc((size_t)h->ws_wgs * kWsDumpFloats);
         }
         if (!fused && !h->G.p) h->G.alloc((size_t)nu * kMaxBatch);
         const int64_t n_ids = batch_ptr[n_batches] - batch_ptr[0];
@@ -808,15 +1021,54 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
             ad.eps = 1e-8f;
             wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, fused ? h->VbT.p : nullptr, 0.5f * lambda_v, d_loss);
             if (fused) {
-                if (g_scratch)
+                if (ws)
+                    wmf_user_step_ws_kernel<<<h->ws_wgs, kWsThreads, kWmfWsLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, h->U.p, h->mU.p, h->vU.p,
+                                                                                          h->indptr.p, h->rows.p, h->vals.p, h->nnz, d_ids, a, b,
+                                                                                          lambda_u, ad, h->dv_part.p, h->ws_dump.p, d_loss,
+                                                                                          h->cu_arrivals.p);
+                if (ws && prof_env_set("CORNAC_HIP_WMF_CLOCK") && bi == n_batches - 1) {
+                    static long long st[200];
+                    HIP_CHECK(hipMemcpyAsync(st, h->cu_arrivals.p + 1040, sizeof(st), hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    // per tile: start, P done, G stored, fix-up done, dV done, dU done, parked (us); math wave 0 of workgroup 0
+                    fprintf(stderr, "[wmf-ws] %.3f GHz; stamps of workgroup 0 (us):", st[98] / 10000.0);
+                    for (int i = 0; i < (int)st[99] && i < 98; ++i) fprintf(stderr, "%s%.1f", i % 7 ? " " : " | ", st[i] / 100.0);
+                    fprintf(stderr, "\n");
+                }
+                if (ws) {
+                } else if (g_scratch)
                     wmf_user_step_kernel<<<h->fused_wgs, kWb, 0, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, h->g_scratch.p,
                                                                       h->indptr.p, h->rows.p, h->vals.p, d_ids, a, b, lambda_u, ad,
                                                                       h->dv_part.p, d_loss, wmf_ablate);
-                else
-                    wmf_user_step_lds_kernel<<<h->fused_wgs, kWb, kWmfLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p,
-                                                                                     h->vU.p, h->indptr.p, h->rows.p, h->vals.p, d_ids,
-                                                                                     a, b, lambda_u, ad, h->dv_part.p, d_loss, wmf_ablate);
-                wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, h->fused_wgs, B, ld, h->dV.p);
+                else {
+                    if (wmf_variant & 8) HIP_CHECK(hipMemsetAsync(h->cu_arrivals.p, 0, 1025 * sizeof(int), s));
+                    lds_kernel<<<h->fused_wgs, kWb, kWmfLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, h->indptr.p,
+                                                                       h->rows.p, h->vals.p, d_ids, a, b, lambda_u, ad, h->dv_part.p, d_loss,
+                                                                       wmf_ablate, stagger_ticks, h->cu_arrivals.p);
+                    if (prof_env_set("CORNAC_HIP_WMF_CLOCK") && bi == n_batches - 1 && !ws) {
+                        long long c[2] = {0, 0};
+                        HIP_CHECK(hipMemcpyAsync(c, h->cu_arrivals.p + 1026, sizeof(c), hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipStreamSynchronize(s));
+                        fprintf(stderr, "[wmf] workgroup 0: %lld shader cycles in %.1f us = %.3f GHz\n", c[0], c[1] / 100.0,
+                                c[1] ? c[0] / (c[1] * 10.0) : 0.0);
+                        static long long st[200];
+                        HIP_CHECK(hipMemcpyAsync(st, h->cu_arrivals.p + 1040, sizeof(st), hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipStreamSynchronize(s));
+                        for (int w = 0; w < 2; ++w) {   // per tile: start, P done, G + fix-up done, dV done, dU done, Adam done (us)
+                            fprintf(stderr, "[wmf] stamps of workgroup %s (us):", w ? "last" : "0");
+                            for (int i = 0; i < (int)st[w * 100 + 99] && i < 96; ++i)
+                                fprintf(stderr, "%s%.1f", i % 6 ? " " : " | ", st[w * 100 + i] / 100.0);
+                            fprintf(stderr, "\n");
+                        }
+                    }
+                    if ((wmf_variant & 8) && prof_env_set("CORNAC_HIP_WMF_DEBUG") && bi == 0) {
+                        int late = 0;
+                        HIP_CHECK(hipMemcpyAsync(&late, h->cu_arrivals.p + 1024, sizeof(int), hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipStreamSynchronize(s));
+                        fprintf(stderr, "[wmf] %d of %d workgroups started late\n", late, h->fused_wgs);
+                    }
+                }
+                wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, ws ? h->ws_wgs : h->fused_wgs, B, ld, h->dV.p);
                 wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
                 wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
                 HIP_CHECK(hipGetLastError());

@@ -21,10 +21,13 @@ def _run_both(R, U, V, batches, lu, lv, a, b, lr):
     return o, lo, Ug, Vg, lg
 
 
-@pytest.mark.parametrize("nu,ni,k,bs", [(300, 200, 24, 64), (129, 257, 5, 128), (1000, 90, 200, 37), (64, 3, 33, 2)])
+@pytest.mark.parametrize("nu,ni,k,bs", [(300, 200, 24, 64), (129, 257, 5, 128), (1000, 90, 200, 37), (64, 3, 33, 2),
+                                         (700, 300, 128, 128), (517, 260, 100, 77), (40000, 256, 128, 128)])
 def test_steps_match_oracle(nu, ni, k, bs):
+    """k in 97..128 takes the wave-specialised kernel (wmf_ws.inc): full and ragged user tiles, ragged batches, and at
+    40 000 users several tiles per workgroup (the Adam sweep of a tile runs beside the products of the next one)"""
     rs = np.random.RandomState(nu + k)
-    nnz = min(nu * ni // 3, 6000)
+    nnz = min(nu * ni // 3, max(6000, 4 * nu))
     keys = rs.permutation(nu * ni)[:nnz]
     u, i = keys // ni, keys % ni
     R = sp.csc_matrix((rs.randint(1, 6, nnz).astype(np.float32), (u, i)), shape=(nu, ni))
@@ -38,6 +41,21 @@ def test_steps_match_oracle(nu, ni, k, bs):
     assert np.abs(Ug - o.U).max() <= 1e-4, np.abs(Ug - o.U).max()
     assert np.abs(Vg - o.V).max() <= 1e-4, np.abs(Vg - o.V).max()
     assert np.allclose(lg, lo, rtol=2e-5), np.abs(lg / lo - 1).max()
+
+
+def test_steps_match_oracle_without_the_unobserved_weight():
+    """b = 0: G carries nothing to recover a prediction from, the fix-up recomputes the dot products (both fused kernels)"""
+    for nu, ni, k in [(300, 150, 128), (300, 150, 40)]:
+        rs = np.random.RandomState(k)
+        keys = rs.permutation(nu * ni)[:5000]
+        R = sp.csc_matrix((rs.randint(1, 6, 5000).astype(np.float32), (keys // ni, keys % ni)), shape=(nu, ni))
+        U = rs.normal(0, 0.2, (nu, k)).astype(np.float32)
+        V = rs.normal(0, 0.2, (ni, k)).astype(np.float32)
+        perm = rs.permutation(ni)
+        batches = [perm[s:s + 128] for s in range(0, ni, 128)] * 2
+        o, lo, Ug, Vg, lg = _run_both(R, U, V, batches, 0.02, 0.03, 1.0, 0.0, 0.005)
+        assert np.abs(Ug - o.U).max() <= 1e-4 and np.abs(Vg - o.V).max() <= 1e-4
+        assert np.allclose(lg, lo, rtol=2e-5)
 
 
 def test_fixture_and_model_surface():
