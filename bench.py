@@ -643,8 +643,8 @@ def leg_wmf_netflix(args, _lib):
                                   % (k, n_users, n_items, B, (n_items + B - 1) // B)},
            "roofline": {"bound": "mfma", "achieved": flops * steps / (dev_ms / 1e3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": flops * steps / (dev_ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TF,
-                        "kernel": "wmf_user_step_lds_kernel (+ gather / reduce / scatter / item-side Adam): HIP events around "
-                                  "the whole batch loop", "flops_per_step": flops, "device_ms_per_step": dev_ms / steps,
+                        "kernel": "wmf_user_step_ws_kernel (4 MFMA waves + 4 streaming waves per CU) + gather / reduce / "
+                                  "item-side Adam: HIP events around the whole batch loop", "flops_per_step": flops, "device_ms_per_step": dev_ms / steps,
                         "traffic": leg_traffic("wmf_netflix", n_users=n_users, k=k, batch=B)},
            "train_stats": {"loss_first_last": [float(loss[0]), float(loss[-1])]}, "host_s": {"generate": t_gen},
            "parity": "oracle pinned to the reference's own WMF code run over oracle/tf1_shim (no TensorFlow in the image: its "

@@ -37,12 +37,14 @@ __device__ __forceinline__ double block_sum_f64(double v, double *scratch) {
 // V_b = V[ids]  (contiguous [B x ld]);  also lambda_v/2 * |V_b|^2 into the loss
 __global__ __launch_bounds__(kWb) void wmf_gather_kernel(const float *__restrict__ V, const int32_t *__restrict__ ids,
                                                          int B, int ld, float *__restrict__ Vb,
-                                                         float *__restrict__ VbT, float half_lambda_v, double *loss) {
+                                                         float *__restrict__ VbT, float half_lambda_v, double *loss,
+                                                         uint32_t *__restrict__ slot_tag, uint32_t step) {
     __shared__ double scratch[kWb / 64];
     double part = 0;
     const int64_t n = (int64_t)B * ld;
     for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
         const int c = (int)(e / ld), f = (int)(e % ld);
+        if (f == 0) slot_tag[ids[c]] = (step << 7) | (uint32_t)c;   // this step's batch column of the row (wmf_adam_v_kernel)
         const float v = V[(int64_t)ids[c] * ld + f];
         Vb[e] = v;
         if (VbT) VbT[(int64_t)f * kMaxBatch + c] = v;  // [ld][128]: the n-contiguous B operand of P = U V_b^T
@@ -732,38 +734,43 @@ __global__ __launch_bounds__(kWb) void wmf_reduce_dv_kernel(const float *__restr
     }
 }
 
-// gV rows of the batch: clip(dV + lambda_v V_b) scattered into the dense (otherwise zero) gradient; dV re-zeroed
-__global__ __launch_bounds__(kWb) void wmf_scatter_gv_kernel(float *__restrict__ dV, const float *__restrict__ Vb,
-                                                             const int32_t *__restrict__ ids, int B, int k, int ld,
-                                                             float lambda_v, float *__restrict__ gV) {
-    const int64_t n = (int64_t)B * ld;
-    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
-        const int c = (int)(e / ld), f = (int)(e % ld);
-        float g = 0.f;
-        if (f < k) {
-            g = dV[e] + lambda_v * Vb[e];
-            g = fminf(fmaxf(g, -5.f), 5.f);
-        }
-        dV[e] = 0.f;
-        gV[(int64_t)ids[c] * ld + f] = g;
-    }
-}
-
-// TF1 Adam for an IndexedSlices gradient: m = beta1 m (+ (1-beta1) g on the slice rows), same for v, every row moves
+// TF1 Adam for an IndexedSlices gradient: m = beta1 m (+ (1-beta1) g on the slice rows), same for v, every row moves.
+// The rows of the batch carry this step's tag (set by wmf_gather_kernel): their gradient g = clip(dV + lambda_v V_b) is built
+// here from the reduced dV, which is re-zeroed for the next step's atomics — no dense gradient array, no scatter kernel.
 __global__ __launch_bounds__(kWb) void wmf_adam_v_kernel(float *__restrict__ V, float *__restrict__ mV,
-                                                         float *__restrict__ vV, float *__restrict__ gV, int64_t n,
-                                                         const TfAdam ad) {
-    for (int64_t e = (int64_t)blockIdx.x * kWb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kWb) {
-        const float g = gV[e];
-        float m = mV[e] * ad.beta1, v = vV[e] * ad.beta2;
-        if (g != 0.f) {
-            m = m + ad.one_minus_beta1 * g;
-            v = v + ad.one_minus_beta2 * (g * g);
-            gV[e] = 0.f;
+                                                         float *__restrict__ vV, int64_t n4, int k, int ld,
+                                                         const uint32_t *__restrict__ slot_tag, uint32_t step,
+                                                         float *__restrict__ dV, const float *__restrict__ Vb,
+                                                         float lambda_v, const TfAdam ad) {
+    const int ld4 = ld >> 2;
+    for (int64_t e4 = (int64_t)blockIdx.x * kWb + threadIdx.x; e4 < n4; e4 += (int64_t)gridDim.x * kWb) {
+        const int64_t row = e4 / ld4;
+        const int f = (int)(e4 - row * ld4) * 4;
+        const uint32_t tag = slot_tag[row];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if ((tag >> 7) == step) {
+            const int64_t o = (int64_t)(tag & 127u) * ld + f;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dV + o), vb = *reinterpret_cast<const f32x4 *>(Vb + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (f + q < k) g[q] = fminf(fmaxf(d[q] + lambda_v * vb[q], -5.f), 5.f);
+            *reinterpret_cast<f32x4 *>(dV + o) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        mV[e] = m;
-        vV[e] = v;
-        V[e] = V[e] - ad.lr_t * m / (sqrtf(v) + ad.eps);
+        f32x4 m = *reinterpret_cast<const f32x4 *>(mV + e4 * 4), v = *reinterpret_cast<const f32x4 *>(vV + e4 * 4);
+        f32x4 x = *reinterpret_cast<const f32x4 *>(V + e4 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            m[q] *= ad.beta1;
+            v[q] *= ad.beta2;
+            if (g[q] != 0.f) {
+                m[q] = m[q] + ad.one_minus_beta1 * g[q];
+                v[q] = v[q] + ad.one_minus_beta2 * (g[q] * g[q]);
+            }
+            x[q] = x[q] - ad.lr_t * m[q] / (sqrtf(v[q]) + ad.eps);
+        }
+        *reinterpret_cast<f32x4 *>(mV + e4 * 4) = m;
+        *reinterpret_cast<f32x4 *>(vV + e4 * 4) = v;
+        *reinterpret_cast<f32x4 *>(V + e4 * 4) = x;
     }
 }
 
@@ -796,7 +803,8 @@ struct cornac_hip_wmf {
     int64_t n_users = 0, n_items = 0, nnz = 0;
     int k = 0, ld = 0;
     hipStream_t stream = nullptr;
-    DevBuf<float> U, V, mU, vU, mV, vV, gV;   // [rows x ld], zero padded columns
+    DevBuf<float> U, V, mU, vU, mV, vV;       // [rows x ld], zero padded columns
+    DevBuf<uint32_t> slot_tag;                // [n_items]: (step << 7 | batch column) of the last batch the row was in
     DevBuf<float> G, Vb, dV, stage;           // [n_users x 128], [128 x ld], [128 x ld], host<->device staging
     DevBuf<float> g_scratch, dv_part, VbT;    // fused path: per-workgroup G tile [wgs x 128 x 128], dV partials, V_b^T [ld x 128]
     int fused_wgs = 0;
@@ -858,7 +866,9 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         const size_t nu = (size_t)n_users * h->ld, ni = (size_t)n_items * h->ld;
         for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
-        for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV, &h->gV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
+        for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
+        h->slot_tag.alloc((size_t)n_items);
+        HIP_CHECK(hipMemsetAsync(h->slot_tag.p, 0, (size_t)n_items * 4, h->stream));
         h->Vb.alloc((size_t)kMaxBatch * h->ld);
         HIP_CHECK(hipMemsetAsync(h->Vb.p, 0, h->Vb.n * 4, h->stream));   // (rows >= the batch size are multiplied by zeros of G)
         h->dV.alloc((size_t)kMaxBatch * h->ld);
@@ -916,7 +926,8 @@ int cornac_hip_wmf_set_factors(cornac_hip_wmf_t h, const float *U, const float *
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->stage.upload(V, (size_t)h->n_items * h->k, h->stream);
         wmf_pad_kernel<<<grid_for(h->n_items * h->ld), kWb, 0, h->stream>>>(h->stage.p, h->n_items, h->k, h->ld, h->V.p);
-        for (DevBuf<float> *b : {&h->mU, &h->vU, &h->mV, &h->vV, &h->gV}) HIP_CHECK(hipMemsetAsync(b->p, 0, b->n * 4, h->stream));
+        for (DevBuf<float> *b : {&h->mU, &h->vU, &h->mV, &h->vV}) HIP_CHECK(hipMemsetAsync(b->p, 0, b->n * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(h->slot_tag.p, 0, h->slot_tag.n * 4, h->stream));   // (steps restart at 1: no stale tag may match)
         h->step = 0;
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1019,8 +1030,13 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
             ad.lr_t = (float)((double)learning_rate * std::sqrt(1.0 - std::pow(beta2, (double)h->step)) /
                               (1.0 - std::pow(beta1, (double)h->step)));
             ad.eps = 1e-8f;
-            wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, fused ? h->VbT.p : nullptr, 0.5f * lambda_v, d_loss);
+            wmf_gather_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->V.p, d_ids, B, ld, h->Vb.p, fused ? h->VbT.p : nullptr, 0.5f * lambda_v, d_loss,
+                                                                           h->slot_tag.p, (uint32_t)h->step);
             if (fused) {
+                if (ws && prof_env_set("CORNAC_HIP_WMF_CLOCK")) {
+                    const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+                    HIP_CHECK(hipMemcpyAsync(h->cu_arrivals.p + 1030, init, sizeof(init), hipMemcpyHostToDevice, s));
+                }
                 if (ws)
                     wmf_user_step_ws_kernel<<<h->ws_wgs, kWsThreads, kWmfWsLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, h->U.p, h->mU.p, h->vU.p,
                                                                                           h->indptr.p, h->rows.p, h->vals.p, h->nnz, d_ids, a, b,
@@ -1031,6 +1047,11 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
                     HIP_CHECK(hipMemcpyAsync(st, h->cu_arrivals.p + 1040, sizeof(st), hipMemcpyDeviceToHost, s));
                     HIP_CHECK(hipStreamSynchronize(s));
                     // per tile: start, P done, G stored, fix-up done, dV done, dU done, parked (us); math wave 0 of workgroup 0
+                    unsigned long long mm[4];
+                    HIP_CHECK(hipMemcpyAsync(mm, h->cu_arrivals.p + 1030, sizeof(mm), hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    fprintf(stderr, "[wmf-ws] first start to last end over all workgroups: math waves %.1f us, stream waves %.1f us\n",
+                            (mm[1] - mm[0]) / 100.0, (mm[3] - mm[2]) / 100.0);
                     fprintf(stderr, "[wmf-ws] %.3f GHz; stamps of workgroup 0 (us):", st[98] / 10000.0);
                     for (int i = 0; i < (int)st[99] && i < 98; ++i) fprintf(stderr, "%s%.1f", i % 7 ? " " : " | ", st[i] / 100.0);
                     fprintf(stderr, "\n");
@@ -1069,8 +1090,8 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
                     }
                 }
                 wmf_reduce_dv_kernel<<<dim3(grid_for((int64_t)B * ld, 64), 32), kWb, 0, s>>>(h->dv_part.p, ws ? h->ws_wgs : h->fused_wgs, B, ld, h->dV.p);
-                wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
-                wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
+                wmf_adam_v_kernel<<<grid_for(h->n_items * ld / 4), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->n_items * ld / 4, k, ld, h->slot_tag.p,
+                                                                                (uint32_t)h->step, h->dV.p, h->Vb.p, lambda_v, ad);
                 HIP_CHECK(hipGetLastError());
                 continue;
             }
@@ -1081,8 +1102,8 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
             }
             wmf_grad_v_kernel<<<dim3(n_chunks, n_tiles), kWb, 0, s>>>(h->G.p, h->U.p, nu, B, ld, chunk, h->dV.p);
             wmf_update_u_kernel<<<dim3(m_tiles, n_tiles), kWb, 0, s>>>(h->G.p, h->Vb.p, nu, B, k, ld, h->U.p, h->mU.p, h->vU.p, lambda_u, ad, d_loss);
-            wmf_scatter_gv_kernel<<<grid_for((int64_t)B * ld, 64), kWb, 0, s>>>(h->dV.p, h->Vb.p, d_ids, B, k, ld, lambda_v, h->gV.p);
-            wmf_adam_v_kernel<<<grid_for(h->n_items * ld), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->gV.p, h->n_items * ld, ad);
+            wmf_adam_v_kernel<<<grid_for(h->n_items * ld / 4), kWb, 0, s>>>(h->V.p, h->mV.p, h->vV.p, h->n_items * ld / 4, k, ld, h->slot_tag.p,
+                                                                            (uint32_t)h->step, h->dV.p, h->Vb.p, lambda_v, ad);
             HIP_CHECK(hipGetLastError());
         }
         h->timer.after(s);
