@@ -52,7 +52,7 @@ SYMBOLS = [
     "cornac_hip_wmf_create", "cornac_hip_wmf_destroy", "cornac_hip_wmf_set_factors", "cornac_hip_wmf_get_factors",
     "cornac_hip_wmf_fit_batches", "cornac_hip_wmf_kernel_timing", "cornac_hip_wmf_last_timing",
     "cornac_hip_mf_create", "cornac_hip_mf_destroy", "cornac_hip_mf_set_factors", "cornac_hip_mf_get_factors",
-    "cornac_hip_mf_fit", "cornac_hip_mf_bind_items", "cornac_hip_mf_set_stream", "cornac_hip_mf_epoch_enqueue",
+    "cornac_hip_mf_fit", "cornac_hip_mf_bind_items", "cornac_hip_mf_bind_users", "cornac_hip_mf_set_stream", "cornac_hip_mf_epoch_enqueue",
     "cornac_hip_mf_sync", "cornac_hip_mf_fit_sgd", "cornac_hip_mf_last_timing",
     "cornac_hip_mf_hogwild_form", "cornac_hip_mf_hogwild_stats",
     "cornac_hip_mf_fit_minibatch", "cornac_hip_mf_fit_minibatch_dropout", "cornac_hip_mf_reset_optimizer",
@@ -232,6 +232,7 @@ def lib():
         L.cornac_hip_mf_set_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
         L.cornac_hip_mf_get_factors.argtypes = [_vp, _vp, _vp, _vp, _vp]
         L.cornac_hip_mf_bind_items.argtypes = [_vp, _vp, _vp]
+        L.cornac_hip_mf_bind_users.argtypes = [_vp, _vp, _vp]
         L.cornac_hip_mf_set_stream.argtypes = [_vp, _vp]
         L.cornac_hip_mf_epoch_enqueue.argtypes = [_vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
         L.cornac_hip_mf_sync.argtypes = [_vp, C.POINTER(C.c_double)]
@@ -683,6 +684,11 @@ class MfTrainer:
     def bind_items(self, d_V, d_Bi):
         """train into caller-owned device buffers for the item side (the replicated [V | Bi] table)"""
         check(lib().cornac_hip_mf_bind_items(self.h, d_V, d_Bi))
+
+    def bind_users(self, d_U, d_Bu):
+        """train into caller-owned device buffers for the user side (dist.MfBlockRotationTrainer: the handles of a rank's item
+        blocks share it)"""
+        check(lib().cornac_hip_mf_bind_users(self.h, d_U, d_Bu))
 
     def set_stream(self, hip_stream):
         check(lib().cornac_hip_mf_set_stream(self.h, hip_stream))

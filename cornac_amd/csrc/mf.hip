@@ -1286,9 +1286,21 @@ int cornac_hip_mf_bind_items(cornac_hip_mf_t h, float *dV, float *dBi) {
     return guarded([&] {
         mf_check(h);
         REQUIRE(dV && dBi, "dV and dBi are required");
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        // (the first bind frees the handle's own tables: wait for whatever still reads them; a re-bind from one caller buffer to
+        // another only changes what LATER launches see — the block rotation re-binds before every step without a host wait)
+        if (h->V.owned || h->Bi.owned) HIP_CHECK(hipStreamSynchronize(h->stream));
         h->V.bind(dV, (size_t)h->n_items * h->k);
         h->Bi.bind(dBi, (size_t)h->n_items);
+    });
+}
+
+int cornac_hip_mf_bind_users(cornac_hip_mf_t h, float *dU, float *dBu) {
+    return guarded([&] {
+        mf_check(h);
+        REQUIRE(dU && dBu, "dU and dBu are required");
+        if (h->U.owned || h->Bu.owned) HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->U.bind(dU, (size_t)h->n_users * h->k);
+        h->Bu.bind(dBu, (size_t)h->n_users);
     });
 }
 

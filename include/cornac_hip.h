@@ -414,6 +414,10 @@ int cornac_hip_mf_fit_sgd(int device, const int64_t *rid, const int64_t *cid, co
  * nnz*(part+1)/n_parts) of the stored order, hogwild semantics, NO host synchronisation (n_parts = 1: the whole epoch in
  * the form cornac_hip_mf_fit would pick); sync: wait, and return the sum of squared errors enqueued since the last sync. */
 int cornac_hip_mf_bind_items(cornac_hip_mf_t h, float *dV, float *dBi);
+/* bind_users: train into caller-owned U (n_users x k) and Bu (n_users) — cornac_amd/dist.py MfBlockRotationTrainer: the handles
+ * of a rank's item blocks (each created over the rank's ratings of one block, item ids local to it) share the rank's user side
+ * and are bound, step by step, to whichever buffer holds their block. */
+int cornac_hip_mf_bind_users(cornac_hip_mf_t h, float *dU, float *dBu);
 int cornac_hip_mf_set_stream(cornac_hip_mf_t h, void *hip_stream);
 int cornac_hip_mf_epoch_enqueue(cornac_hip_mf_t h, int part, int n_parts, float lr, float reg, float mu, int use_bias);
 int cornac_hip_mf_sync(cornac_hip_mf_t h, double *sq_err_sum);

@@ -1284,3 +1284,144 @@ def test_global_negative_population_world2():
         assert np.abs(hs / hs.sum() - deg / deg.sum()).max() < 0.01
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
+
+
+# ---- MF block rotation (regime 2 for MF): the ranks' parallel run == the serial execution of the same steps --------------
+class _OracleMfBlockTrainer:
+    """stands in for dist._DeviceMfBlockTrainer with real MF arithmetic: the oracle's sequential fit_sgd loop
+    (backend_cpu.pyx:56-90) over the block's ratings, IN PLACE on the rank's user tables and on the buffer that holds the block"""
+
+    def __init__(self, rid, lid, val, n_users, rows, k, U, Bu):
+        from oracle import oracle as orc
+
+        self.orc = orc
+        self.rid, self.lid = np.ascontiguousarray(rid, np.int64), np.ascontiguousarray(lid, np.int64)
+        self.val = np.ascontiguousarray(val, np.float32)
+        self.U, self.Bu, self.k, self.sq = U.numpy(), Bu.numpy(), k, 0.0
+
+    def enqueue(self, V, Bi, lr, reg, mu, use_bias):
+        loss = np.zeros(1, np.float32)
+        v, bi = V.numpy(), Bi.numpy()
+        assert v.flags.c_contiguous and bi.flags.c_contiguous
+        self.orc.lib().oracle_mf_fit(self.rid.copy(), self.lid.copy(), self.val.copy(), len(self.val), self.U, v, self.Bu, bi, self.k,
+                                     lr, reg, mu, 1, 1, int(use_bias), 0, loss.ctypes.data)
+        self.sq += 2.0 * float(loss[0])
+
+    def sync(self):
+        sq, self.sq = self.sq, 0.0
+        return sq
+
+    def close(self):
+        pass
+
+
+def _mf_rotation_worker(rank, world, port, out, epochs, n_items):
+    from cornac_amd.dist import MfBlockRotationTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k = 5
+        rid, cid, val, n_users, _ = _mf_data(rank, n_users=60, n_items=n_items, per_user=12)
+        order = np.random.RandomState(3).permutation(n_items)
+        rot = MfBlockRotationTrainer(rid, cid, val, n_users, n_items, k, torch.device("cpu"), trainer_factory=_OracleMfBlockTrainer,
+                                     item_order=order)
+        init = np.random.RandomState(7)
+        rot.load_items(init.normal(0, 0.05, (n_items, k)).astype(np.float32), init.normal(0, 0.05, n_items).astype(np.float32))
+        ur = np.random.RandomState(40 + rank)
+        rot.set_user_factors(ur.normal(0, 0.05, (n_users, k)).astype(np.float32), np.zeros(n_users, np.float32))
+        sq = []
+        for _ in range(epochs):
+            rot.run_epoch(0.02, 0.02, 3.2)
+            sq.append(rot.finish())
+        V, Bi = rot.gather()
+        out[rank] = (V, Bi, rot.get_user_factors(), list(rot.steps_trained), sq)
+        rot.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _serial_mf_rotation(world, epochs, n_items):
+    """the same steps, one rank after the other, on ONE copy of the item table (no blocks, no buffers, no transfers)"""
+    from oracle import oracle as orc
+
+    k, nb = 5, 2 * world
+    order = np.random.RandomState(3).permutation(n_items)
+    pos = np.empty(n_items, np.int64)
+    pos[order] = np.arange(n_items)
+    init = np.random.RandomState(7)
+    V, Bi = init.normal(0, 0.05, (n_items, k)).astype(np.float32), init.normal(0, 0.05, n_items).astype(np.float32)
+    data, users, sq = [], [], [[0.0] * epochs for _ in range(world)]
+    for r in range(world):
+        rid, cid, val, n_users, _ = _mf_data(r, n_users=60, n_items=n_items, per_user=12)
+        ur = np.random.RandomState(40 + r)
+        data.append((rid, cid, val))
+        users.append((ur.normal(0, 0.05, (n_users, k)).astype(np.float32), np.zeros(n_users, np.float32)))
+    for e in range(epochs):
+        for t in range(nb):
+            for r in range(world):
+                rid, cid, val = data[r]
+                sel = np.flatnonzero(pos[cid] % nb == (2 * r + t) % nb)
+                if len(sel) == 0:
+                    continue
+                loss = np.zeros(1, np.float32)
+                orc.lib().oracle_mf_fit(rid[sel].copy(), cid[sel].copy(), val[sel].copy(), len(sel), users[r][0], V, users[r][1], Bi, k,
+                                        0.02, 0.02, 3.2, 1, 1, 1, 0, loss.ctypes.data)
+                sq[r][e] += 2.0 * float(loss[0])
+    return V, Bi, users, sq
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 41), (3, 50)])
+def test_mf_block_rotation_equals_its_serial_execution(world, n_items):
+    """MfBlockRotationTrainer over gloo ranks with REAL MF arithmetic (the oracle's fit_sgd loop on every (rank, block) step):
+    rank r trains block (2 r + t) mod 2 N in step t, blocks travel to rank r - 1 — and the result is BIT FOR BIT what one
+    process gets executing the same steps one after the other on one table: every rating applied exactly once per epoch to the
+    one copy of its item row (backend_cpu.pyx:62-88), nothing reconciled.  n_items not a multiple of 2 N: ragged blocks."""
+    out, epochs = mp.Manager().dict(), 3
+    mp.spawn(_mf_rotation_worker, args=(world, _free_port(), out, epochs, n_items), nprocs=world, join=True)
+    V, Bi, users, sq = _serial_mf_rotation(world, epochs, n_items)
+    for r in range(world):
+        Vr, Bir, (Ur, Bur), steps, sq_r = out[r]
+        assert np.array_equal(Vr, V) and np.array_equal(Bir, Bi)            # every rank gathers the same, serial, table
+        assert np.array_equal(Ur, users[r][0]) and np.array_equal(Bur, users[r][1])
+        assert steps == [(t, (2 * r + t) % (2 * world)) for _ in range(epochs) for t in range(2 * world)]
+        assert np.allclose(sq_r, sq[r], rtol=1e-6)
+    assert sq[0][-1] < sq[0][0]                                             # and it learns
+
+
+def _fit_rotation_worker(rank, world, port, out):
+    import cornac_amd as ca
+    from cornac_amd.dist import fit_mf_sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = ca.Dataset.from_uir(_model_data(), seed=3)
+        mf = ca.MF(k=6, max_iter=15, learning_rate=0.02, lambda_reg=0.02, seed=rank, mode="hogwild")
+        fit_mf_sharded(mf, ds, regime="rotation", block_trainer_factory=_OracleMfBlockTrainer)
+        out[rank] = dict(mU=mf.u_factors.copy(), mV=mf.i_factors.copy(), mBu=mf.u_biases.copy(), mBi=mf.i_biases.copy(),
+                         mloss=mf.loss_history.copy(), mu=float(mf.global_mean))
+        with pytest.raises(ValueError):
+            fit_mf_sharded(ca.MF(k=6, seed=1, mode="hogwild"), ds, regime="sideways")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_level_mf_block_rotation_returns_one_complete_model_on_every_rank():
+    """fit_mf_sharded(regime="rotation") on two gloo ranks with real MF arithmetic behind the block handles: both ranks return
+    the same complete model (user rows of both ranges gathered, the item side gathered from the blocks' homes), its loss falls
+    every epoch, and it fits the data better than the mean."""
+    import cornac_amd as ca
+
+    out = mp.Manager().dict()
+    mp.spawn(_fit_rotation_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    for name in ("mU", "mV", "mBu", "mBi"):
+        assert np.array_equal(a[name], b[name]), name
+    assert np.allclose(a["mloss"], b["mloss"]) and a["mloss"][-1] < 0.85 * a["mloss"][0] and np.all(np.diff(a["mloss"]) < 0)
+    ds = ca.Dataset.from_uir(_model_data(), seed=3)
+    rid, cid, val = ds.uir_tuple
+    pred = a["mu"] + a["mBu"][rid] + a["mBi"][cid] + np.einsum("nk,nk->n", a["mU"][rid], a["mV"][cid])
+    assert float(np.sqrt(np.mean((pred - val) ** 2))) < 0.9 * float(np.sqrt(np.mean((a["mu"] - val) ** 2)))
+    for lo, hi in ((0, 20), (ds.num_users - 20, ds.num_users)):
+        assert np.abs(a["mBu"][lo:hi]).max() > 1e-3

@@ -1061,3 +1061,145 @@ def test_negative_population_of_the_whole_matrix_on_a_user_slice():
     tr.set_negative_population(None)
     assert neg_hist()[1::2].sum() == 0
     tr.close()
+
+
+def test_eight_virtual_ranks_mf_block_rotation_and_replicas_against_one_process(capsys):
+    """MF over R = 8 virtual ranks ON THE DEVICE at the Netflix density (~200 ratings per user, thousands per item), every
+    rank its own users, next to ONE process that trains all ratings; the measure is the RMSE on HELD-OUT ratings in the
+    MIDDLE of training, where a stale item side costs most.
+
+      * regime 2, block rotation (MfBlockRotationTrainer's schedule: 16 item blocks, rank r trains block (2 r + t) % 16 in
+        step t; here executed step by step on one device with one cornac_hip_mf handle per (rank, block), all bound to ONE set
+        of block buffers — the serial execution the gloo test shows the ranks' parallel run to equal bit for bit): every rating
+        is applied exactly once per epoch to the one copy of its item row.  Gate: held-out RMSE not more than 0.5 % above one process's.
+      * regime 1, replicas of the item side reconciled with ItemTableReplica's "align" algebra 16 times per epoch
+        (ShardedMfTrainer's count at R = 8): measured and printed — 0.857 where one process has 0.531 after 4 epochs: the shared
+        rows move at a fraction of the pace (the same finding as for BPR's replicas), which is why fit_mf_sharded(regime="auto")
+        takes the rotation."""
+    import torch
+
+    from cornac_amd.dist import _DeviceMfBlockTrainer
+
+    R, nu_r, n_items, k, per_user, mid, lr, reg = 8, 6000, 4800, 64, 200, 4, 0.01, 0.02
+    rs = np.random.RandomState(0)
+    q = rs.normal(0, 1, (n_items, 6)).astype(np.float32)
+    ib = rs.normal(0, 0.4, n_items).astype(np.float32)
+    pop = 1.0 / np.arange(1, n_items + 1) ** 0.45
+    pop /= pop.sum()
+    data = []
+    for r in range(R):
+        rr = np.random.RandomState(100 + r)
+        cid = rr.choice(n_items, (nu_r, per_user), p=pop).astype(np.int64)      # (duplicates within a user are fine for SGD)
+        rid = np.repeat(np.arange(nu_r, dtype=np.int64), per_user)
+        taste = rr.normal(0, 1, (nu_r, 6)).astype(np.float32)
+        val = 3.2 + ib[cid] + 0.45 * np.einsum("uf,unf->un", taste, q[cid]) + rr.normal(0, 0.5, cid.shape)
+        val = np.clip(val, 1, 5).astype(np.float32).reshape(-1)
+        cid = cid.reshape(-1)
+        hold = rr.uniform(size=len(val)) < 0.1
+        data.append((rid[~hold], cid[~hold], val[~hold], rid[hold], cid[hold], val[hold]))
+    mu = float(np.mean(np.concatenate([d[2] for d in data])))
+    init = np.random.RandomState(7)
+    V0 = init.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    U0 = [np.random.RandomState(50 + r).normal(0, 0.01, (nu_r, k)).astype(np.float32) for r in range(R)]
+
+    def rmse(Us, Bus, V, Bi):
+        se, n = 0.0, 0
+        for r in range(R):
+            _, _, _, hr, hc, hv = data[r]
+            pred = mu + Bus[r][hr] + Bi[hc] + np.einsum("nk,nk->n", Us[r][hr], V[hc])
+            se += float(((pred - hv) ** 2).sum())
+            n += len(hv)
+        return float(np.sqrt(se / n))
+
+    def one_process(epochs):
+        rid = np.concatenate([d[0] + r * nu_r for r, d in enumerate(data)])
+        cid, val = np.concatenate([d[1] for d in data]), np.concatenate([d[2] for d in data])
+        tr = _lib.MfTrainer(rid, cid, val, R * nu_r, n_items, k)
+        tr.set_factors(np.concatenate(U0), V0, np.zeros(R * nu_r, np.float32), np.zeros(n_items, np.float32))
+        tr.fit(epochs, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
+        U, V, Bu, Bi = tr.get_factors()
+        tr.close()
+        return rmse([U[r * nu_r:(r + 1) * nu_r] for r in range(R)], [Bu[r * nu_r:(r + 1) * nu_r] for r in range(R)], V, Bi)
+
+    def rotation(epochs):
+        dev, nb = torch.device("cuda", 0), 2 * R
+        pos = np.empty(n_items, np.int64)
+        pos[np.argsort(-np.bincount(np.concatenate([d[1] for d in data]), minlength=n_items), kind="stable")] = np.arange(n_items)
+        blk, row, W = pos % nb, pos // nb, (n_items + nb - 1) // nb
+        stream = torch.cuda.Stream(dev)
+        bufs = [torch.zeros(W * (k + 1), device=dev) for _ in range(nb)]
+        for b in range(nb):
+            items = np.flatnonzero(blk == b)
+            bufs[b][: W * k].view(W, k).index_copy_(0, torch.as_tensor(row[items], device=dev), torch.as_tensor(V0[items]).to(dev))
+        Us = [torch.as_tensor(U0[r]).to(dev) for r in range(R)]
+        Bus = [torch.zeros(nu_r, device=dev) for _ in range(R)]
+        torch.cuda.synchronize()
+        handles = []
+        for r in range(R):
+            rid, cid, val = data[r][:3]
+            hs = []
+            for b in range(nb):
+                sel = np.flatnonzero(blk[cid] == b)
+                hs.append(_DeviceMfBlockTrainer(rid[sel], row[cid[sel]], val[sel], nu_r, W, k, Us[r], Bus[r], stream, 0))
+            handles.append(hs)
+        with torch.cuda.stream(stream):
+            for _ in range(epochs):
+                for t in range(nb):
+                    for r in range(R):
+                        b = (2 * r + t) % nb
+                        handles[r][b].enqueue(bufs[b][: W * k].view(W, k), bufs[b][W * k:], lr, reg, mu, True)
+        for hs in handles:
+            for h in hs:
+                h.sync()
+                h.close()
+        V, Bi = np.zeros((n_items, k), np.float32), np.zeros(n_items, np.float32)
+        for b in range(nb):
+            items = np.flatnonzero(blk == b)
+            flat = bufs[b].cpu().numpy()
+            V[items], Bi[items] = flat[: W * k].reshape(W, k)[row[items]], flat[W * k:][row[items]]
+        return rmse([u.cpu().numpy() for u in Us], [b_.cpu().numpy() for b_ in Bus], V, Bi)
+
+    def replicas(epochs, parts=16):
+        trainers = []
+        for r in range(R):
+            t = _lib.MfTrainer(*data[r][:3], nu_r, n_items, k)
+            t.set_factors(U0[r], V0, np.zeros(nu_r, np.float32), np.zeros(n_items, np.float32))
+            trainers.append(t)
+        V, Bi = V0.copy(), np.zeros(n_items, np.float32)
+        for _ in range(epochs):
+            for p in range(parts):
+                dV, dB = np.zeros_like(V), np.zeros_like(Bi)
+                qV, qB = np.zeros(n_items, np.float64), np.zeros(n_items, np.float64)
+                for t in trainers:
+                    t.set_factors(None, V, None, Bi)
+                    t.epoch_enqueue(p, parts, lr, reg, mu, True)
+                    t.sync()
+                    _, Vr, _, Br = t.get_factors()
+                    dV += Vr - V; dB += Br - Bi
+                    qV += ((Vr - V).astype(np.float64) ** 2).sum(1); qB += (Br - Bi).astype(np.float64) ** 2
+                nV, nB = (dV.astype(np.float64) ** 2).sum(1), dB.astype(np.float64) ** 2   # rule "align" (ItemTableReplica._factors)
+                dV *= np.where(nV > 0, np.minimum(1.0, qV / np.maximum(nV, 1e-300)), 1.0).astype(np.float32)[:, None]
+                dB *= np.where(nB > 0, np.minimum(1.0, qB / np.maximum(nB, 1e-300)), 1.0).astype(np.float32)
+                V, Bi = V + dV, Bi + dB
+        Us, Bus = [], []
+        for t in trainers:
+            U, _, Bu, _ = t.get_factors()
+            Us.append(U); Bus.append(Bu)
+            t.close()
+        return rmse(Us, Bus, V, Bi)
+
+    start = rmse(U0, [np.zeros(nu_r, np.float32)] * R, V0, np.zeros(n_items, np.float32))
+    one, rot, rep = one_process(mid), rotation(mid), replicas(mid)
+    one_late, rot_late = one_process(3 * mid), rotation(3 * mid)
+    with capsys.disabled():
+        print("\n8 virtual MF ranks at the Netflix density (%d ratings, %d per item), held-out RMSE after %d epochs (start %.4f): one "
+              "process %.4f | block rotation over 16 item blocks %.4f | replicas, 'align', 16 exchanges per epoch %.4f | after %d "
+              "epochs: one process %.4f, block rotation %.4f"
+              % (sum(len(d[2]) for d in data), sum(len(d[2]) for d in data) // n_items, mid, start, one, rot, rep, 3 * mid, one_late, rot_late))
+    assert one < 0.9 * start                              # mid-training: the model has learnt, and is still learning
+    assert one_late < one
+    # not worse than one process by more than 0.5 % (measured: ~0.9 % BETTER mid-training — every rating lands on the current
+    # copy of its rows, where one process's atomic kernel works with a few stale ones), nor different in kind
+    assert 0.97 * one <= rot <= 1.005 * one, (rot, one)
+    assert 0.97 * one_late <= rot_late <= 1.005 * one_late, (rot_late, one_late)
+    assert rep < start, (rep, start)     # the replicas learn — at a fraction of the pace (printed above; why fit_mf_sharded rotates)
