@@ -743,6 +743,8 @@ struct cornac_hip_bpr {
     int lb_strata_groups = 16, lb_hot_cost_x16 = 32;  // the deal: stratum width in groups, price of a hot draw
     int lb_n_strata = 1;
     DevBuf<uint32_t> lb_mass, lb_cold, lb_hot_off;
+    DevBuf<int32_t> lb_pre_rec;               // pre-sampled tiles (ldsbin_presample_kernel): [pool][3][64]
+    DevBuf<uint32_t> lb_pre_cnt, lb_pre_base; // [pool] valid triplets per tile; [bins + 1] first record of a bin
     DevBuf<unsigned long long> lb_wg_clock;  // profile build, CORNAC_HIP_LDSBIN_CLOCKS=<file>
     bool lb_deal_valid = false;   // lb_hot_off / lb_cold hold the deal of (lb_deal_seed, lb_deal_epoch)
     uint64_t lb_deal_seed = 0;
@@ -1714,7 +1716,12 @@ static void strata_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
 
 // ---- LDS-resident item bins (bpr_ldsbin.inc) ---------------------------------------------------------------------
 typedef void (*LdsBinKernel)(const LdsBinArgs);
-static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false, bool passing = false, bool conv = false) {
+constexpr int kLdsbinPresampleDefault = 0;
+static LdsBinKernel pick_ldsbin_kernel(int k, bool pop, bool exch = false, bool passing = false, bool conv = false, bool pre = false) {
+    if (pre) {  // resident bins trained from pre-sampled tiles (ldsbin_presample_kernel; opt-in, uniform negatives, k <= 128)
+        if (k <= 64) return bpr_ldsbin_kernel<1, 4, false, false, 1, false, true>;
+        return bpr_ldsbin_kernel<2, 2, false, false, 1, false, true>;
+    }
     if (conv) {  // conveyor launches (passing bins whose rows live in block buffers): the passing regime's shapes
         if (pop) {
             if (k <= 64) return bpr_ldsbin_kernel<1, 4, true, false, 1, true>;
@@ -2008,9 +2015,10 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
     a.n_items = (int32_t)h->n_items; a.n_bins = h->lb_bins; a.n_hot = h->lb_n_hot; a.n_hot_inter = h->lb_n_hot_inter;
     a.bm_words = h->lb_bm_words; a.cap = h->lb_cap; a.n_strata = h->lb_n_strata;
     a.k = h->k; a.use_bias = use_bias; a.lr = lr; a.reg = reg;
-    a.ablate = (flags >> 8) & 0xff;
+    a.ablate = ((flags >> 8) & 0xff) | (prof_env_int("CORNAC_HIP_LDSBIN_X", 0) << 8);
     a.wg_clock = nullptr;
     a.ex = LdsBinExchange{};
+    a.pre_rec = nullptr; a.pre_cnt = nullptr; a.pre_base = nullptr; a.pre_waves = 0;
     a.conv_bpb = 0;
     for (int r = 0; r < kLbMaxRanges; ++r) {
         a.conv_first[r] = 0;
@@ -2018,11 +2026,26 @@ static void ldsbin_fill_args(cornac_hip_bpr_t h, LdsBinArgs &a, float lr, float 
     }
 }
 
+// CORNAC_HIP_LDSBIN_PRESAMPLE=0 / 1 overrides the default (read once)
+static bool ldsbin_presample_enabled() {
+    static const int v = [] {
+        const char *e = getenv("CORNAC_HIP_LDSBIN_PRESAMPLE");
+        return e ? atoi(e) : kLdsbinPresampleDefault;
+    }();
+    return v != 0;
+}
+
 // one launch per epoch (or per chunk of an epoch: the multi-GPU driver's exchange points), one workgroup per bin
 static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, float reg, int use_bias, int neg_population,
                            int flags) {
     ldsbin_build(h);
-    LdsBinKernel kern = pick_ldsbin_kernel(h->k, neg_population == CORNAC_HIP_NEG_POPULARITY, false, h->lb_passing);
+    // resident bins: the draws in a launch of their own (ldsbin_presample_kernel), the bins' workgroups only train
+    const bool pop = neg_population == CORNAC_HIP_NEG_POPULARITY;
+    // (opt-in, CORNAC_HIP_LDSBIN_PRESAMPLE=1: measured at the ML-20M shape, the training launch alone takes 5.77 ms against the
+    // fused launch's 5.86 — the draws were already hidden behind the updates — and the sampling launch adds 1.0 ms;
+    // profiles/r06_headline_ablation.log)
+    const bool pre = !h->lb_passing && !pop && h->k <= 128 && ldsbin_presample_enabled();
+    LdsBinKernel kern = pick_ldsbin_kernel(h->k, pop, false, h->lb_passing, false, pre);
     HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lb_lds_bytes));
     int64_t left = n_samples;
     while (left > 0) {
@@ -2033,6 +2056,23 @@ static void ldsbin_enqueue(cornac_hip_bpr_t h, int64_t n_samples, float lr, floa
         a.n = (uint64_t)n;
         a.nnz = (uint64_t)h->nnz;
         ldsbin_deal(h, a.seed, a.epoch, a.key);
+        if (pre) {
+            const size_t pool = (size_t)n / 32 + 2 * (size_t)h->lb_bins + 8;   // >= the tiles of all bins at either tile width
+            h->lb_pre_rec.ensure(pool * 3 * kWave);
+            h->lb_pre_cnt.ensure(pool);
+            h->lb_pre_base.ensure((size_t)h->lb_bins + 1);
+            a.pre_rec = h->lb_pre_rec.p; a.pre_cnt = h->lb_pre_cnt.p; a.pre_base = h->lb_pre_base.p;
+            a.pre_waves = (uint32_t)(h->lb_block / kWave);
+            LdsTileBaseArgs tb;
+            tb.cold = h->lb_cold.p; tb.hot_off = h->lb_hot_off.p; tb.base = h->lb_pre_base.p;
+            tb.s_begin = a.s_begin; tb.n = a.n; tb.nnz = a.nnz; tb.n_bins = h->lb_bins; tb.n_waves = a.pre_waves;
+            hipLaunchKernelGGL(ldsbin_tilebase_kernel, dim3(1), dim3(kLbBlock), 0, h->stream, tb);
+            // enough sampling workgroups to fill the chip several times over: their memory latencies hide behind each other
+            const int64_t tiles_per_bin = std::max<int64_t>(1, n / 64 / h->lb_bins);
+            const unsigned splits = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_per_bin / 16, 64));
+            const size_t pre_lds = ((size_t)3 * h->lb_cap + 1) * sizeof(uint32_t);
+            hipLaunchKernelGGL((ldsbin_presample_kernel<false>), dim3(h->lb_bins, splits), dim3(kLbPreBlock), pre_lds, h->stream, a);
+        }
 #ifdef CORNAC_PROFILE
         const char *clock_path = getenv("CORNAC_HIP_LDSBIN_CLOCKS");
         if (clock_path) {

@@ -35,6 +35,23 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Sum over the 64 lanes of a wave, every lane gets it — without the LDS crossbar.  __shfl_xor lowers to ds_bpermute_b32 on
+// gfx950: six DEPENDENT LDS round trips per sum (and the LDS is where the LDS-bin kernel's item rows live); here four
+// v_add_f32 with DPP modifiers sum each row of 16 lanes (quad swaps, then the half-row and row mirrors), four v_readlane
+// fetch the row sums and three adds finish.  Measured on the ML-20M headline (profiles/r06_headline_ablation.log): the
+// six-step shuffle sum cost 0.9 ms of a 5.8 ms epoch.  (Different summation order from group_sum: hogwild forms only.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto f2i = [](float x) { return __builtin_bit_cast(int, x); };
+    auto i2f = [](int x) { return __builtin_bit_cast(float, x); };
+    v += i2f(__builtin_amdgcn_update_dpp(0, f2i(v), 0xB1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+    v += i2f(__builtin_amdgcn_update_dpp(0, f2i(v), 0x4E, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+    v += i2f(__builtin_amdgcn_update_dpp(0, f2i(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += i2f(__builtin_amdgcn_update_dpp(0, f2i(v), 0x140, 0xf, 0xf, false));   // row_mirror
+    const float r0 = i2f(__builtin_amdgcn_readlane(f2i(v), 0)), r1 = i2f(__builtin_amdgcn_readlane(f2i(v), 16));
+    const float r2 = i2f(__builtin_amdgcn_readlane(f2i(v), 32)), r3 = i2f(__builtin_amdgcn_readlane(f2i(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // acc = ((acc + p[0]) + p[1]) + ... + p[lim-1] over the lanes of a G-lane group, in lane order (the reference's
 // sequential float sum over factors).  With one group per wave every term is read with v_readlane (constant
 // lane after unrolling); smaller groups need a per-group source lane and go through the cross-lane network.
