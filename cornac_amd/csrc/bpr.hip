@@ -1055,6 +1055,11 @@ static void launch_det_level(cornac_hip_bpr_t h, const int32_t *ou, const int32_
 
 static void bpr_epoch_deterministic(cornac_hip_bpr_t h, double lr, double reg, int use_bias, int neg_population) {
     REQUIRE(h->mt_seeded, "deterministic mode needs cornac_hip_bpr_seed_mt19937 first");
+    // (the sequential engine restates recom_wbpr.pyx:131-139, whose negatives are the items of THIS matrix's interactions; a
+    // caller-supplied population — the multi-GPU driver's global popularity — belongs to the hogwild forms)
+    REQUIRE(!(neg_population == CORNAC_HIP_NEG_POPULARITY && h->neg_pop_n),
+            "a negative population set with cornac_hip_bpr_set_negative_population is not honoured in deterministic mode: "
+            "clear it (n = 0) or fit in hogwild mode");
     const int64_t nnz = h->nnz;
     const uint64_t pos_hi = (uint64_t)nnz - 1;
     const uint64_t neg_hi = neg_population == CORNAC_HIP_NEG_POPULARITY ? (uint64_t)nnz - 1 : (uint64_t)h->n_items - 1;

@@ -601,9 +601,13 @@ class ShardedBprTrainer:
                 dist.all_reduce(err, op=dist.ReduceOp.MAX, group=self.table.group)   # every rank raises together
             if int(err.item()) != 0:
                 self._resident["signals"][-1:].zero_()
-                raise RuntimeError("resident exchange: a communication stream gave up waiting for its epoch launch's "
-                                   "arrivals (%d ms) — that exchange and the later ones of the epoch were left unapplied "
-                                   "on every rank; the item tables of the ranks no longer agree" % self.resident_timeout_ms)
+                # (the flag is per rank and sticky: the rank whose wait gave up withholds the landed flag of that exchange and of
+                # every later one — of later epochs too — until this raise; the other ranks went on applying sums that lack
+                # its contribution.  Fatal either way: the MAX over the ranks makes every rank raise here together.)
+                raise RuntimeError("resident exchange: the communication stream of at least one rank gave up waiting for its "
+                                   "epoch launch's arrivals (%d ms); that rank applied none of the sums from that exchange on, "
+                                   "the others applied sums without its deltas: the item tables of the ranks no longer agree "
+                                   "— restart the fit from the last consistent model" % self.resident_timeout_ms)
         return out
 
 
@@ -1362,30 +1366,37 @@ class BinConveyorBprTrainer:
             self._om = tuple(torch.as_tensor(x, device=self.device) for x in (om, om_inv, owner)) + (H,)
         return self._om
 
-    def _redeal(self, new_layout_epoch):
-        """every row from its slot under the deal of self.layout_epoch to its slot under the deal of new_layout_epoch; at an
-        epoch boundary (every rank holds its home blocks).  One all_to_all_single of [row | bias] records: the message of rank r
-        for rank s holds r's rows in the order of their OLD slots (owner-major), so the sender places a row by a running count
-        per destination and the receiver finds it by a running count over the source's old slots — prefix sums over the slot
-        tables, no sort; both sides compute them from the two layouts, which every rank has."""
-        W, k, N = self.W, self.k, self.world
-        home = self.home_blocks()
-        for g in range(self.K):                       # the last step's receives fill home buffers
-            for buf in range(len(self.bufs[g])):
-                self._await(self.arrived[g][buf])
-                self.arrived[g][buf] = None
-        for w in self._sent:
-            w.wait()
-        self._sent = []
-        with self._on(self.stream), self._timed("redeal", self.stream):
+    def _fetch_layouts(self, old_epoch, new_epoch):
+        """(slot -> item of the old deal, item -> slot of the new one, event): the layout kernels run on the TRAINING stream (the
+        handle's), so they are enqueued in front of the launch the plan is to run beside"""
+        with self._on(self.stream):
+            old_slot_item, _ = self._layout(old_epoch)
+            _, new_item_slot = self._layout(new_epoch)
+            ev = None
+            if self.stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        return old_slot_item, new_item_slot, ev
+
+    def _plan_redeal(self, old_epoch, new_epoch, layouts=None):
+        """the index side of a re-deal — where each of my rows goes in the send buffer, how many go to / come from every rank,
+        which received row lands in which of my new slots: a pure function of the two layouts, which every rank has.  On the
+        device it runs on its own stream, so that the plan of the NEXT boundary is computed beside the current epoch's last
+        launch (step()) and the boundary itself only moves rows."""
+        W, N = self.W, self.world
+        plan_stream = getattr(self, "_plan_stream", None)
+        if plan_stream is None and self.stream is not None:
+            plan_stream = self._plan_stream = torch.cuda.Stream(self.device)
+        old_slot_item, new_item_slot, ev = layouts if layouts is not None else self._fetch_layouts(old_epoch, new_epoch)
+        with self._on(plan_stream):
+            if ev is not None:
+                plan_stream.wait_event(ev)
+                old_slot_item.record_stream(plan_stream)
+                new_item_slot.record_stream(plan_stream)
             om, om_inv, owner, H = self._owner_major()
             HW, me = H * W, self.rank
-            old_slot_item, _ = self._layout(self.layout_epoch)
-            _, new_item_slot = self._layout(new_layout_epoch)
-            if getattr(self, "_stage", None) is None:
-                self._stage = [torch.zeros((HW + 1, k + 1), dtype=torch.float32, device=self.device) for _ in range(2 if N > 1 else 1)]
+            if getattr(self, "_om_slots", None) is None:
                 self._om_slots = (om_inv[:, None] * W + torch.arange(W, device=self.device)[None, :]).reshape(-1)
-            send, recv = self._stage[0], self._stage[-1]
             # D[g]: the rank the row at old owner-major position g goes to (-1: an empty slot), T[g]: its new owner-major position
             items = old_slot_item[self._om_slots].long()
             valid = items >= 0
@@ -1400,21 +1411,60 @@ class BinConveyorBprTrainer:
             send_base = torch.cumsum(send_counts, 0) - send_counts
             dst = D_me.clamp(min=0)
             pos = torch.where(D_me >= 0, send_base[dst] + run.gather(0, dst[None, :])[0] - 1, torch.full_like(D_me, HW))
-            for h, (g, b, blk) in enumerate(home):
-                v, bb = self._views(g, self.where[g][b])
-                send[:, :k].index_copy_(0, pos[h * W: (h + 1) * W], v)
-                send[:, k].index_copy_(0, pos[h * W: (h + 1) * W], bb)
             # receiver: the rows for me, source-major, inside a source in the order of ITS old slots = a running count over D == me
             mine = D == me
             got = torch.cumsum(mine, 0)
             recv_counts = torch.stack([got[(r + 1) * HW - 1] for r in range(N)])
             recv_counts = recv_counts - torch.cat([recv_counts.new_zeros(1), recv_counts[:-1]])
-            if N > 1:
-                rc, sc = [int(c) for c in recv_counts.cpu()], [int(c) for c in send_counts.cpu()]
-                dist.all_to_all_single(recv[: sum(rc)], send[: sum(sc)], rc, sc, group=self.group)
             src_of = torch.full((HW,), HW, dtype=torch.long, device=self.device)        # my new local slot -> row of `recv` (HW: none)
             at = mine.nonzero().squeeze(1)
             src_of[T[at] - me * HW] = got[at] - 1
+            rc = sc = None
+            if N > 1:
+                rc, sc = [int(c) for c in recv_counts.cpu()], [int(c) for c in send_counts.cpu()]
+            done = None
+            if plan_stream is not None:
+                done = torch.cuda.Event()
+                done.record(plan_stream)
+        return {"key": (int(old_epoch), int(new_epoch)), "pos": pos, "src_of": src_of, "rc": rc, "sc": sc, "HW": HW, "done": done}
+
+    def _redeal(self, new_layout_epoch):
+        """every row from its slot under the deal of self.layout_epoch to its slot under the deal of new_layout_epoch; at an
+        epoch boundary (every rank holds its home blocks).  One all_to_all_single of [row | bias] records: the message of rank r
+        for rank s holds r's rows in the order of their OLD slots (owner-major), so the sender places a row by a running count
+        per destination and the receiver finds it by a running count over the source's old slots — prefix sums over the slot
+        tables, no sort; both sides compute them from the two layouts, which every rank has (_plan_redeal, usually already
+        computed beside the previous epoch's last steps)."""
+        W, k, N = self.W, self.k, self.world
+        home = self.home_blocks()
+        for g in range(self.K):                       # the last step's receives fill home buffers
+            for buf in range(len(self.bufs[g])):
+                self._await(self.arrived[g][buf])
+                self.arrived[g][buf] = None
+        for w in self._sent:
+            w.wait()
+        self._sent = []
+        plan = getattr(self, "_plan", None)
+        if plan is None or plan["key"] != (int(self.layout_epoch), int(new_layout_epoch)):
+            plan = self._plan_redeal(self.layout_epoch, new_layout_epoch)
+        self._plan = None
+        with self._on(self.stream), self._timed("redeal", self.stream):
+            if plan["done"] is not None:
+                self.stream.wait_event(plan["done"])
+            HW, pos, src_of = plan["HW"], plan["pos"], plan["src_of"]
+            if self.stream is not None:               # (allocated on the plan's stream, read by this one)
+                pos.record_stream(self.stream)
+                src_of.record_stream(self.stream)
+            if getattr(self, "_stage", None) is None:
+                self._stage = [torch.zeros((HW + 1, k + 1), dtype=torch.float32, device=self.device) for _ in range(2 if N > 1 else 1)]
+            send, recv = self._stage[0], self._stage[-1]
+            for h, (g, b, blk) in enumerate(home):
+                v, bb = self._views(g, self.where[g][b])
+                send[:, :k].index_copy_(0, pos[h * W: (h + 1) * W], v)
+                send[:, k].index_copy_(0, pos[h * W: (h + 1) * W], bb)
+            if N > 1:
+                rc, sc = plan["rc"], plan["sc"]
+                dist.all_to_all_single(recv[: sum(rc)], send[: sum(sc)], rc, sc, group=self.group)
             recv[HW].zero_()
             for h, (g, b, blk) in enumerate(home):
                 v, bb = self._views(g, self.where[g][b])
@@ -1448,6 +1498,11 @@ class BinConveyorBprTrainer:
                 if self.world > 1 or self.emulate_traffic:
                     free = (set(range(len(self.bufs[g]))) - set(self.where[g].values())).pop()
                     moves.append((g, b, buf, free, (b + 2) % self.nb))
+            next_layouts = None
+            if ts == self.nb - 1:   # the next boundary's layouts, in front of this epoch's last launch (see _plan_redeal)
+                want_next = (epoch + 1) - (epoch + 1) % self.redeal_every
+                if want_next != self.layout_epoch:
+                    next_layouts = (want_next, self._fetch_layouts(self.layout_epoch, want_next))
             with self._timed("launch", self.stream):
                 self.trainer.conveyor_enqueue(epoch, self.layout_epoch, blocks, bufs, lr, reg, use_bias, neg_population, flags)
             trained = None
@@ -1500,6 +1555,9 @@ class BinConveyorBprTrainer:
                     self.arrived[g][free] = ev
                     self.where[g][b] = free
         self.t += 1
+        if next_layouts is not None:
+            # the next boundary's plan, beside this epoch's last launch and transfers (the boundary then only moves rows)
+            self._plan = self._plan_redeal(self.layout_epoch, next_layouts[0], layouts=next_layouts[1])
 
     def run_epoch(self, lr, reg, use_bias=True, neg_population=0, flags=0):
         for _ in range(self.nb):
@@ -1907,6 +1965,9 @@ def fit_bpr_sharded(model, train_set, device=None, group=None, sync_per_epoch=No
         regime = "replicated"
     if regime == "auto" and world > 1 and model._neg_population == _lib.NEG_POPULARITY and not local_popularity:
         regime = "replicated"   # WBPR with the GLOBAL popularity: the conveyor only has the rank-local one (fit_bpr_ring)
+    if regime == "ring" and trainer_factory is not None:
+        raise ValueError("trainer_factory is the replicated regime's test hook (its signature differs from the conveyor's): "
+                         "call fit_bpr_ring(..., trainer_factory=...) for the ring")
     if regime != "replicated":
         X0 = train_set.matrix
         per_rank = int(X0.nnz // max(world, 1)) + 1
