@@ -742,12 +742,17 @@ static void mf_build_split(cornac_hip_mf_t h) {
     h->split_of.assign((size_t)ni, -1);
     h->split_ptr_h.assign(1, 0);
     std::vector<int32_t> items;
-    if (n >= (int64_t(1) << 20)) {
+    // form 3 (the step handles of the multi-GPU block rotation: few item rows, 10^4..10^7 ratings per launch): the same
+    // bound — ~16 concurrent stale updates per copy — at any size.  Of a launch's n ratings min(n, ~16 000) are in flight
+    // together, so item i sees cnt_i x min(n, 16 000) / n of them: a copy per 16 (below 16 000 ratings: cnt_i / 16).
+    const bool any_size = h->hog_form == 3;
+    const int64_t per_copy = any_size && n < 16000 ? (n + 15) / 16 : 1000;   // split when cnt_i x per_copy > n
+    if (n >= (int64_t(1) << 20) || any_size) {
         std::vector<int64_t> cnt((size_t)ni, 0);
         for (int64_t s = 0; s < n; ++s) ++cnt[(size_t)h->host_cid[(size_t)s]];
         for (int64_t i = 0; i < ni; ++i)
-            if (cnt[(size_t)i] * 1000 > n) {
-                const int64_t W = std::min<int64_t>(256, (cnt[(size_t)i] * 1000 + n - 1) / n);
+            if (cnt[(size_t)i] * per_copy > n) {
+                const int64_t W = std::min<int64_t>(256, (cnt[(size_t)i] * per_copy + n - 1) / n);
                 h->split_of[(size_t)i] = (int32_t)items.size();
                 items.push_back((int32_t)i);
                 h->split_ptr_h.push_back(h->split_ptr_h.back() + (int32_t)W);
@@ -928,7 +933,7 @@ static std::vector<int32_t> mf_lpt_256(const std::vector<int64_t> &cnt, int *max
 
 static bool mf_uses_blocks(cornac_hip_mf_t h) {
     const DeviceInfo &di = device_info(h->device);
-    if (h->blocks_failed || h->hog_form == 1 || di.cus != 256 || di.xcds != 8 || h->k <= 32 || h->k > 256 || h->n_items < 256)
+    if (h->blocks_failed || h->hog_form == 1 || h->hog_form == 3 || di.cus != 256 || di.xcds != 8 || h->k <= 32 || h->k > 256 || h->n_items < 256)
         return false;
     return h->hog_form == 2 || h->nnz >= (int64_t(1) << 22);
 }
@@ -1436,7 +1441,10 @@ int cornac_hip_mf_kernel_timing(cornac_hip_mf_t h, int enable, double *total_ms,
 int cornac_hip_mf_hogwild_form(cornac_hip_mf_t h, int form) {
     return guarded([&] {
         mf_check(h);
-        REQUIRE(form >= 0 && form <= 2, "form must be 0 (automatic), 1 (fused atomic kernel) or 2 (block rotation)");
+        REQUIRE(form >= 0 && form <= 3, "form must be 0 (automatic), 1 (fused atomic kernel), 2 (block rotation) or 3 (fused "
+                "kernel, popular rows split into copies at any size)");
+        REQUIRE(!h->split_built || (form == 3) == (h->hog_form == 3),
+                "form 3 changes which item rows train through copies: choose it before the handle's first epoch");
         h->hog_form = form;
         if (form == 2) h->blocks_failed = false;
     });

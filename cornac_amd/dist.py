@@ -1620,17 +1620,27 @@ class _DeviceMfBlockTrainer:
     """the ratings of ONE item block of a rank (item ids local to the block) as a cornac_hip_mf handle that trains into the
     rank's shared user tables and into whichever buffer currently holds the block"""
 
+    FORCE_FORM = None     # tools/bench_mf_rotation.py: 1 = the fused atomic kernel, 2 = the handle's own block rotation
+
     def __init__(self, rid, lid, val, n_users, rows, k, U, Bu, stream, device_index):
         from . import _lib
 
         self.t = _lib.MfTrainer(rid, lid, val, n_users, rows, k, device_index)
-        # A block is a few hundred to a few thousand item rows: in the fused atomic kernel every one of them would take
-        # dozens to hundreds of CONCURRENT updates computed from the same stale copy (all of a step's ratings are in flight at
-        # once) and the factorisation diverges — measured: 6 000 users x 300 rows, 67 k ratings per step, loss = inf after one
-        # epoch.  The handle's own (user block x item bin) rotation keeps a row under one LDS lock at a time (mf_blocks.inc):
-        # forced wherever it exists (32 < k <= 256, >= 256 rows).
-        if 32 < k <= 256 and rows >= 256:
-            self.t.hogwild_form(2)
+        # A block is a few hundred to a few thousand item rows and a step a few 10^4..10^7 ratings: in the plain fused atomic
+        # kernel every row would take dozens to hundreds of CONCURRENT updates computed from one stale copy (most of a step's
+        # ratings are in flight at once) and the factorisation diverges — measured: 6 000 users x 300 rows, 67 k ratings per
+        # step, and 60 024 users x 1 111 rows, 0.78 M per step (a node rank's share of the Netflix shape): loss = inf.
+        #   form 3: the fused kernel with such rows trained through copies, one per ~16 updates in flight together, merged
+        #           after the launch (cornac_hip.h) — the step handle's form: 0.71 ms per step of 0.78 M ratings, 5.1 ms per
+        #           step of 6.3 M (profiles/r06_mf_rotation_forms.log; ~0.8 ns per rating);
+        #   form 2: the handle's own (user block x item bin) rotation, every update applied exactly once — 8 launches x 32
+        #           barrier-separated sub-rounds whatever the size, and with ~1 000 rows every row is "hot" (no LDS bin,
+        #           atomics): 4.4 ms and 11.8 ms for the same two steps.  It pays where the plain handle picks it: many rows
+        #           (each a small share of the ratings) and >= 2^24 ratings per step (Netflix whole: 31 ms per 100 M).
+        form = self.FORCE_FORM
+        if form is None:
+            form = 2 if (32 < k <= 256 and rows >= 8192 and len(val) >= (1 << 24)) else 3
+        self.t.hogwild_form(form)
         self.t.bind_users(U.data_ptr(), Bu.data_ptr())
         if stream is not None:
             self.t.set_stream(stream.cuda_stream)
@@ -2115,8 +2125,8 @@ def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=No
     to the one copy of its item row (MfBlockRotationTrainer; equal to one process within 0.5 % of held-out RMSE in
     mid-training, tests/test_sharded_gpu.py); "replicated" — the item side replicated and reconciled (ShardedMfTrainer;
     measured on the device at R = 8 and the Netflix density: held-out RMSE 0.857 where one process has 0.531 after 4 epochs —
-    the shared rows learn at a fraction of the pace); "auto" (default): rotation where the handle's exactly-once form exists
-    (32 < k <= 256 and >= 256 item rows per block), else replicated.
+    the shared rows learn at a fraction of the pace); "auto" (default): rotation from 16 item rows per block on, else
+    replicated.
     trainer_factory(table, rid_local, cid, val, n_local, n_items, k): test hook of the replicated regime (implies it);
     block_trainer_factory: MfBlockRotationTrainer's."""
     from . import _lib
@@ -2149,7 +2159,7 @@ def fit_mf_sharded(model, train_set, device=None, group=None, parts_per_epoch=No
     if regime not in ("auto", "rotation", "replicated"):
         raise ValueError("regime must be 'auto', 'rotation' or 'replicated', not %r" % (regime,))
     if regime == "auto":
-        ok = 32 < model.k <= 256 and model.num_items // (2 * world) >= 256
+        ok = model.num_items // (2 * world) >= 16
         regime = "rotation" if (block_trainer_factory is not None or (trainer_factory is None and ok)) else "replicated"
     if regime == "rotation":
         order = np.argsort(-np.asarray(global_item_degrees(cid_l, model.num_items, device, group)), kind="stable")

@@ -248,3 +248,40 @@ def test_block_rotation_learns_like_the_fused_kernel():
     _, _, Bu2, Bi2 = tr.get_factors()
     tr.close()
     assert not Bu2.any() and not Bi2.any()
+
+
+@pytest.mark.parametrize("shape", [(6_000, 300, 67_000, 64), (20_000, 1_100, 300_000, 128), (2_000, 64, 9_000, 48), (3_000, 200, 30_000, 16)])
+def test_step_form_trains_few_rows_with_every_rating_in_flight(shape):
+    """hogwild form 3 (cornac_hip.h; the per-block step handles of dist.MfBlockRotationTrainer): a handle of few item rows
+    whose ratings are nearly all in flight in ONE launch.  The plain fused kernel (form 1) sums dozens of updates of a row
+    computed from one stale copy and diverges on the first shape (measured, round 6); form 3 trains such rows through copies
+    merged after the launch at ANY size: finite, lr = 0 leaves the tables untouched and counts every rating once, and the
+    training error follows the sequential engine's (backend_cpu.pyx:62-88 on one thread)."""
+    n_users, n_items, nnz, k = shape
+    rid, cid, val = _coo(n_users, n_items, nnz, 11)
+    rs = np.random.RandomState(3)
+    U0 = rs.normal(0, 0.01, (n_users, k)).astype(np.float32)
+    V0 = rs.normal(0, 0.01, (n_items, k)).astype(np.float32)
+    zu, zi = np.zeros(n_users, np.float32), np.zeros(n_items, np.float32)
+    mu, lr, reg = float(val.mean()), 0.01, 0.02
+    tr = _lib.MfTrainer(rid, cid, val, n_users, n_items, k)
+    tr.hogwild_form(3)
+    tr.set_factors(U0, V0, zu, zi)
+    loss0, _ = tr.fit(1, 0.0, 0.0, mu, True, False, _lib.MODE_HOGWILD)
+    assert tr.hogwild_stats()["form_used"] == 1
+    U1, V1, Bu1, Bi1 = tr.get_factors()
+    assert np.array_equal(V1, V0) and np.array_equal(U1, U0) and not Bi1.any() and not Bu1.any()
+    pred = mu + np.einsum("nk,nk->n", U0[rid].astype(np.float64), V0[cid].astype(np.float64))
+    want = 0.5 * float(np.sum((val.astype(np.float64) - pred) ** 2))
+    assert abs(loss0[0] - want) <= 2e-5 * want, (loss0, want)
+    loss_h, _ = tr.fit(6, lr, reg, mu, True, False, _lib.MODE_HOGWILD)
+    got = tr.get_factors()
+    with pytest.raises(_lib.HipError, match="before the handle's first epoch"):
+        tr.hogwild_form(1)
+    tr.set_factors(U0, V0, zu, zi)
+    loss_d, _ = tr.fit(6, lr, reg, mu, True, False, _lib.MODE_DETERMINISTIC)
+    tr.close()
+    assert all(np.isfinite(x).all() for x in got) and np.isfinite(loss_h).all()
+    # (the copies' merge is the "align" rule: between the sum and the mean of their steps — never ahead of the serial run
+    # by more than noise, behind it by at most the damping of correlated copies)
+    assert loss_h[-1] < loss_h[0] and np.all(loss_h[1:] <= 1.25 * loss_d[1:]) and np.all(loss_h[1:] >= 0.9 * loss_d[1:]), (loss_h, loss_d)
