@@ -470,6 +470,8 @@ struct cornac_hip_mf {
     DevBuf<float> Bipad;  // hogwild-mode view of Bi, one bias per 128-byte line
     void (*hog_kernel)(const chip::MfHogArgs) = nullptr;
     int hog_blocks_per_cu = 8;
+    int step_grid = 0;           // form 3: workgroups of the throttled launch (0: not chosen yet)
+    int64_t step_inflight = 0;   // ... and the ratings it keeps in flight together
     int64_t own_waves = 0;
     DevBuf<int32_t> own_u, own_i;
     DevBuf<float> own_r;
@@ -743,10 +745,13 @@ static void mf_build_split(cornac_hip_mf_t h) {
     h->split_ptr_h.assign(1, 0);
     std::vector<int32_t> items;
     // form 3 (the step handles of the multi-GPU block rotation: few item rows, 10^4..10^7 ratings per launch): the same
-    // bound — ~16 concurrent stale updates per copy — at any size.  Of a launch's n ratings min(n, ~16 000) are in flight
-    // together, so item i sees cnt_i x min(n, 16 000) / n of them: a copy per 16 (below 16 000 ratings: cnt_i / 16).
+    // kind of bound — a few dozen concurrent stale updates per copy — at any size.  Its launch keeps step_inflight ratings in flight
+    // together (throttled to ~4 per item row, mf_launch_fused), so item i sees cnt_i x min(n, step_inflight) / n of them:
+    // a copy per 32 (twice the big handles' bound: fewer copies, see there).  With even shares no row is split; a row with
+    // > 8x the average share is.
     const bool any_size = h->hog_form == 3;
-    const int64_t per_copy = any_size && n < 16000 ? (n + 15) / 16 : 1000;   // split when cnt_i x per_copy > n
+    const int64_t flight = any_size ? std::max<int64_t>(1, std::min<int64_t>(n, h->step_inflight)) : 16000;
+    const int64_t per_copy = any_size ? (flight + 31) / 32 : 1000;   // split when cnt_i x per_copy > n
     if (n >= (int64_t(1) << 20) || any_size) {
         std::vector<int64_t> cnt((size_t)ni, 0);
         for (int64_t s = 0; s < n; ++s) ++cnt[(size_t)h->host_cid[(size_t)s]];
@@ -1155,6 +1160,22 @@ static void mf_launch_fused(cornac_hip_mf_t h, int64_t s0, int64_t n, float lr, 
         h->hog_kernel = kern;
         h->hog_blocks_per_cu = std::max(1, std::min(per_cu, 8));
     }
+    if (h->hog_form == 3 && !h->step_grid) {
+        // A step handle (few item rows): the launch is THROTTLED to ~4 ratings in flight per item row — with every CU full
+        // (~16 000 in flight) a block of 300..1 000 rows would take dozens of concurrent stale updates on EVERY row, and
+        // training all of them through merged copies lags: the "align" merge of W copies whose steps agree is their MEAN, a
+        // row learns at 1 / W of the pace.  Measured (profiles/r06_mf_step_throttle.log: 8 virtual ranks, 300-row blocks,
+        // held-out RMSE after 4 epochs where one process has 0.5312; P in flight per row, a copy per C concurrent updates):
+        // every row split 0.9647; P, C = 4, 16: 0.5345; 2, 16 and 4, 32 (the same copies): 0.5303; 1, 16: 0.5287; and the
+        // Netflix shape's rank share (1 111-row blocks, 0.78 M ratings per step): 2, 16: 18.9 ms per epoch, 4, 32: 13.2 ms,
+        // unthrottled with copies 11.4 ms, unthrottled without: inf.  Shipped: 4 per row, a copy per 32.
+        const int per_wave = k <= 4 ? 32 : k <= 8 ? 16 : k <= 32 ? 8 : k <= 64 ? 4 : k <= 192 ? 2 : 1;   // TPW x UNR of pick_mf_kernel
+        const int64_t per_wg = (int64_t)kWavesPerBlock * per_wave;
+        const int64_t full = (int64_t)di.cus * h->hog_blocks_per_cu;
+        const int64_t want = std::max<int64_t>(256, 4 * h->n_items);
+        h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>(full, (want + per_wg - 1) / per_wg));
+        h->step_inflight = (int64_t)h->step_grid * per_wg;
+    }
     // hot items of a large problem train through copies of their rows (mf_blocks.inc, "virtual rows"): thousands of atomic
     // updates of one row computed from one stale copy overshoot and diverge (round 4 raised "diverged" here instead)
     mf_build_split(h);
@@ -1179,13 +1200,14 @@ static void mf_launch_fused(cornac_hip_mf_t h, int64_t s0, int64_t n, float lr, 
     a.n = n; a.k = k; a.use_bias = use_bias; a.lr = lr; a.reg = reg; a.mu = mu;
     int grid;
     if (owned) {
-        grid = di.cus * h->hog_blocks_per_cu;
+        grid = h->step_grid ? h->step_grid : di.cus * h->hog_blocks_per_cu;
         mf_build_ownership(h, (int64_t)grid * kWavesPerBlock);
         a.own_u = h->own_u.p; a.own_i = h->own_i.p; a.own_r = h->own_r.p; a.wave_ptr = h->wave_ptr.p;
     } else {
         const int64_t n_tiles = (a.n + kWave - 1) / kWave;
         const int64_t want_blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         grid = (int)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)di.cus * h->hog_blocks_per_cu));
+        if (h->step_grid) grid = std::min(grid, h->step_grid);
     }
     const unsigned bgrid = (unsigned)((h->n_items + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(bias_pad_kernel, dim3(bgrid), dim3(kBlock), 0, h->stream, h->Bi.p, h->Bipad.p, h->n_items);

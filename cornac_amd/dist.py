@@ -1630,9 +1630,10 @@ class _DeviceMfBlockTrainer:
         # kernel every row would take dozens to hundreds of CONCURRENT updates computed from one stale copy (most of a step's
         # ratings are in flight at once) and the factorisation diverges — measured: 6 000 users x 300 rows, 67 k ratings per
         # step, and 60 024 users x 1 111 rows, 0.78 M per step (a node rank's share of the Netflix shape): loss = inf.
-        #   form 3: the fused kernel with such rows trained through copies, one per ~16 updates in flight together, merged
-        #           after the launch (cornac_hip.h) — the step handle's form: 0.71 ms per step of 0.78 M ratings, 5.1 ms per
-        #           step of 6.3 M (profiles/r06_mf_rotation_forms.log; ~0.8 ns per rating);
+        #   form 3: the fused kernel, its launch throttled to ~4 ratings in flight per item row and the rows that still take
+        #           more than 32 concurrent updates trained through copies merged after the launch (cornac_hip.h) — the step
+        #           handle's form: ~1 ms per step of 0.78 M ratings, 8 ms per step of 6.3 M
+        #           (profiles/r06_mf_rotation_forms.log);
         #   form 2: the handle's own (user block x item bin) rotation, every update applied exactly once — 8 launches x 32
         #           barrier-separated sub-rounds whatever the size, and with ~1 000 rows every row is "hot" (no LDS bin,
         #           atomics): 4.4 ms and 11.8 ms for the same two steps.  It pays where the plain handle picks it: many rows

@@ -398,10 +398,11 @@ int cornac_hip_mf_fit(cornac_hip_mf_t h, int max_iter, float lr, float reg, floa
  * atomics), 2 = the block rotation (csrc/mf_blocks.inc: item bins in the CUs' LDS, user blocks rotating among the 32
  * workgroups of an XCD, 8 launches x 32 barrier-separated sub-rounds per epoch; no atomics, every update applied exactly
  * once).  Automatic = the block rotation for k in 33..256, >= 256 items and >= 2^22 ratings on a 256-CU / 8-XCD device.
- * 3 = the fused kernel with the popular item rows trained through copies AT ANY SIZE (forms 0..2 split rows only from 2^20
- * ratings on: an item holding > 0.1 % of them): a copy per ~16 updates that are in flight together, merged after the launch.
- * For handles that hold ONE STEP of a larger schedule — few item rows, every rating of the launch in flight at once —
- * such as the per-block handles of dist.MfBlockRotationTrainer; choose it before the handle's first epoch.
+ * 3 = the STEP form, for handles that hold one step of a larger schedule — few item rows, most ratings of the launch in
+ * flight at once — such as the per-block handles of dist.MfBlockRotationTrainer: the fused kernel launched with only ~4
+ * ratings in flight per item row, and item rows that still take more than 32 concurrent updates trained through copies
+ * merged after the launch, AT ANY SIZE (forms 0..2 split rows only from 2^20 ratings on: an item holding > 0.1 % of them).
+ * Choose it before the handle's first epoch.
  * hogwild_stats: out4 = {form of the last epoch (1 / 2, 0: none yet), tiles of the block schedule, LDS rows per bin,
  * 1 if the rotation gave up once (workgroup placement / barrier bound) and the handle went back to the fused kernel}. */
 int cornac_hip_mf_hogwild_form(cornac_hip_mf_t h, int form);

@@ -166,7 +166,8 @@ def test_hogwild_trains_through_a_very_popular_item_instead_of_diverging(k, form
     tr.close()
     assert np.isfinite(Vh).all() and np.isfinite(Uh).all() and np.isfinite(loss_h).all()
     assert loss_h[-1] < 0.85 * loss_h[0] and np.allclose(loss_h[1:], loss_d[1:], rtol=0.04), (loss_h, loss_d)
-    assert abs(Bih[hot] - Bid[hot]) < 0.1 + 0.2 * abs(Bid[hot]), (Bih[hot], Bid[hot])
+    # (hogwild spread of the hot item's bias over boxes / runs: |diff| mostly < 0.05, once 0.177 in ~20 runs of round 6)
+    assert abs(Bih[hot] - Bid[hot]) < 0.25 + 0.2 * abs(Bid[hot]), (Bih[hot], Bid[hot])
     # (the factor rows themselves are only defined up to the rotation the trajectory picks: compare what they predict)
     m = cid == hot
     ph = mu + Buh[rid[m]] + Bih[hot] + Uh[rid[m]] @ Vh[hot]
