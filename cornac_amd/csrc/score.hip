@@ -142,6 +142,12 @@ __global__ __launch_bounds__(kBlk) void score_gemm_mfma_kernel(const float *__re
     (void)urow;
 }
 
+// byte offset of a __shared__ object inside the workgroup's LDS allocation
+template <typename T>
+__device__ __forceinline__ uint32_t lds_offset(T *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) T *)p;
+}
+
 // ---- fused scoring GEMM + top-k: the users x items score tile never leaves the registers ------------------
 // One wave owns a 32-user tile (A fragments in registers) and walks a range of 32-item tiles with
 // v_mfma_f32_32x32x2_f32; the 4 waves of a workgroup share each B tile through LDS.
@@ -168,17 +174,18 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     // estimate of their scores, see build_rank_order); the candidates carry the original item ids.
     constexpr int KP = 2 * KT;  // padded row length of the device tables
     __shared__ unsigned long long keys[kBlk / 64][32][CAP];
-    __shared__ int32_t ipos[2][32];
+    __shared__ int32_t ipos[3][32];   // (triple-buffered with wmask: one buffer index for all of a tile's meta words)
     __shared__ int cnt[kBlk / 64][32];
     __shared__ float tau[kBlk / 64][32];
     // the 4 waves of a workgroup walk the same item tiles: the B tile is staged once per workgroup
     // (coalesced 16-byte global loads, double-buffered) instead of gathered 4x through the TA
     __shared__ float btile[2][32][KP + 2];  // row stride == 2 (mod 64): the 64 lanes of a fragment read hit 64 banks
-    __shared__ float ibase[2][32];
+    __shared__ uint32_t meta_dump[1];
     // exclusion bitmap words of the tile being compared: wmask[t % 3][wave][row] has bit c set when the c-th item of
     // tile t is excluded for that row (see excl_bitmap_kernel; 128 four-byte loads per workgroup and tile, L2-served).  Three buffers: tile t's words are read in the
     // survivor path of step t while faster waves already stage tile t+2.
     __shared__ uint32_t wmask[3][kBlk / 64][32];
+    __shared__ float ibase[3][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
     const int64_t n_item_tiles = (n_items + 31) / 32;
@@ -193,41 +200,72 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     int64_t cur_rb = 0;  // row block of the segment being walked (stage_load reads its exclusion words)
     float bcur[KT];
     // staging: 32 items x KP floats = 8*KP float4; thread i moves float4 #i, #i+256, ...
+    // Staging instructions are issue time taken from the matrix pipes (4.62 -> 4.05 ms with staging ablated at the ML-20M
+    // shape), so the loads carry no per-tile address arithmetic: the tile's base is wave-uniform (scalar registers), the
+    // thread's byte offset inside a tile is loop invariant, the tables are padded to whole tiles on the host (zero rows, NaN
+    // item bases: no clamp, no validity test), and the tile's item bases / exclusion words come through ONE per-thread
+    // pointer that advances by the thread's own stride (32 floats for the item-base lanes, one word for the exclusion-word
+    // lanes, 0 for the rest: an unconditional load instead of two exec-mask branches).
     constexpr int STG = (32 * KP / 4 + kBlk - 1) / kBlk;
     v4f32 stg[STG];
-    float stg_ib = 0.f;
-    int32_t stg_id = 0;
-    auto stage_load = [&](int64_t it) {
+    uint32_t voff[STG];
 #pragma unroll
-        for (int q = 0; q < STG; ++q) {
-            const int idx = threadIdx.x + q * kBlk;
-            const int64_t item = min(it * 32 + idx / (KP / 4), n_items - 1);
-            stg[q] = *reinterpret_cast<const v4f32 *>(V + item * KP + 4 * (idx % (KP / 4)));
-        }
+    for (int q = 0; q < STG; ++q) {
+        const int idx = threadIdx.x + q * kBlk;
+        voff[q] = idx < 32 * KP / 4 ? (uint32_t)(((idx / (KP / 4)) * KP + 4 * (idx % (KP / 4))) * 4) : 0u;
+    }
+    uint32_t stg_a = 0;     // item base (lanes 0..31 of wave 0) or exclusion word (threads 32..159) of the staged tile
+    int32_t stg_id = 0;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(item_base);
+    int64_t pa_stride = 0;
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+    const int32_t *pb = perm;
+    auto stage_seek = [&](int64_t it) {   // a segment starts: the meta pointers of tile `it`
         if (threadIdx.x < 32) {
-            const int64_t item = it * 32 + threadIdx.x;
-            stg_ib = item < n_items ? (item_base ? item_base[item] : 0.f) : __builtin_nanf("");
-            stg_id = item < n_items ? (perm ? perm[item] : (int32_t)item) : 0;
+            pa = reinterpret_cast<const uint32_t *>(item_base) + it * 32 + threadIdx.x;
+            pa_stride = 32;
         } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
             const int w = (threadIdx.x - 32) >> 5, rl = (threadIdx.x - 32) & 31;
-            stg_id = (int32_t)excl_bits[((cur_rb * (kBlk / 64) + w) * 32 + rl) * n_item_tiles + it];
+            pa = excl_bits + ((cur_rb * (kBlk / 64) + w) * 32 + rl) * n_item_tiles + it;
+            pa_stride = 1;
+        } else {
+            pa = reinterpret_cast<const uint32_t *>(item_base);
+            pa_stride = 0;
+        }
+        pb = perm + it * 32 + (threadIdx.x & 31);
+    };
+    auto stage_load = [&](int64_t it) {   // tiles are staged in sequence: it = the previous call's + 1
+        const char *vb = reinterpret_cast<const char *>(V) + it * (int64_t)(32 * KP * 4);
+#pragma unroll
+        for (int q = 0; q < STG; ++q) stg[q] = *reinterpret_cast<const v4f32 *>(vb + voff[q]);
+        stg_a = *pa;
+        pa += pa_stride;
+        if (wave0) {   // (a scalar branch)
+            stg_id = *pb;
+            pb += 32;
         }
     };
+    // the meta word's LDS slot: the thread's own (item-base lanes: ibase[.][lane], exclusion-word lanes: wmask[.][w][rl], the
+    // rest: a dump word) + wbuf x the thread's own buffer stride — an unconditional store, like the load
+    uint32_t meta_addr0 = lds_offset(&meta_dump[0]), meta_stride = 0;
+    if (threadIdx.x < 32) {
+        meta_addr0 = lds_offset(&ibase[0][threadIdx.x]);
+        meta_stride = 32 * sizeof(float);
+    } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
+        meta_addr0 = lds_offset(&wmask[0][(threadIdx.x - 32) >> 5][(threadIdx.x - 32) & 31]);
+        meta_stride = (kBlk / 64) * 32 * sizeof(uint32_t);
+    }
     auto stage_store = [&](int buf, int wbuf) {
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
             const int idx = threadIdx.x + q * kBlk;
-            if (idx < 32 * KP / 4) {
+            if ((q + 1) * kBlk <= 32 * KP / 4 || idx < 32 * KP / 4) {   // (compile-time true except in a ragged last group)
                 float *dst = &btile[buf][idx / (KP / 4)][4 * (idx % (KP / 4))];
                 dst[0] = stg[q].x; dst[1] = stg[q].y; dst[2] = stg[q].z; dst[3] = stg[q].w;
             }
         }
-        if (threadIdx.x < 32) {
-            ibase[buf][threadIdx.x] = stg_ib;
-            ipos[buf][threadIdx.x] = stg_id;
-        } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
-            wmask[wbuf][(threadIdx.x - 32) >> 5][(threadIdx.x - 32) & 31] = (uint32_t)stg_id;
-        }
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(meta_addr0 + (uint32_t)wbuf * meta_stride) = stg_a;
+        if (wave0) ipos[wbuf][threadIdx.x & 31] = stg_id;   // (a scalar branch; both halves of the wave hold the same 32 ids)
     };
     // B fragments of one tile: issued in groups of FG so that the loads of group g+1 are in flight while the
     // MFMAs of group g run (the scheduling barriers keep the compiler from sinking every load to its use)
@@ -369,8 +407,10 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
         // compare is kept to one add and one v_cmp (lane mask straight into SGPRs) per accumulator register, and
         // the loop is unrolled by two so that the accumulators ping-pong instead of being copied.
         f32x16 acc_a = zero16, acc_b = zero16;
+        int wb = 0;   // meta buffer (tile index mod 3) of the tile a step compares
         float ib_a = 0.f, ib_b = 0.f;
         int32_t id_a = 0, id_b = 0;
+        stage_seek(t_begin);
         stage_load(t_begin);
         stage_store(0, 0);
         __syncthreads();
@@ -391,8 +431,9 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             if (it + 2 < t_end && !(ablate & 2)) stage_load(it + 2);
             // ---- B fragments + MFMA chain of tile it+1, compare of tile it -----------------------------------
             load_frags(buf_next, 0);
-            ib_nxt = ibase[buf_next][col];
-            id_nxt = ipos[buf_next][col];
+            const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;   // meta buffers of tiles it + 1, it + 2
+            ib_nxt = ibase[wb1][col];
+            id_nxt = ipos[wb1][col];
             const int32_t item = id_cur;
             unsigned long long hm[16];
             float sc[16];
@@ -428,7 +469,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             auto drop_excluded = [&]() __attribute__((always_inline)) {
                 // (requesting this word at the top of the step, behind the MFMA chain, was measured in round 4: 5.50-5.55 ms
                 // against 5.45 ms — no gain, one more live register across the chain)
-                const uint32_t wv = wmask[(int)((unsigned)(it - t_begin) % 3u)][wave][col];
+                const uint32_t wv = wmask[wb][wave][col];
                 unsigned long long left = 0ull;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -479,8 +520,9 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                     }
                 }
             }
-            if (it + 2 < t_end && !(ablate & 8)) stage_store((int)((it + 2 - t_begin) & 1), (int)((unsigned)(it + 2 - t_begin) % 3u));
+            if (it + 2 < t_end && !(ablate & 8)) stage_store((int)((it + 2 - t_begin) & 1), wb2);
             if (!(ablate & 4)) __syncthreads();  // tile it+2 visible; the buffer of tile it+1 is fully read by everybody
+            wb = wb1;
         };
         for (int64_t it = t_begin; it < t_end; it += 2) {
             step(it, acc_a, acc_b, ib_a, ib_b, id_a, id_b);
@@ -1003,9 +1045,15 @@ static void build_rank_order(cornac_hip_scorer_t h, const float *U, const float 
         const float pa = pri[(size_t)a], pb = pri[(size_t)b];
         return (pa > pb) || (pa != pa && pb == pb);  // NaN priorities first: any order is valid, this one is total
     });
-    h->perm.ensure((size_t)ni);
-    h->Vr.ensure((size_t)ni * h->ld);
-    h->ibr.ensure((size_t)ni);
+    // padded to whole tiles of 32 items for the fused kernel's staging (zero rows, NaN bases — a NaN never beats a threshold —
+    // item id 0): its loads need no clamp
+    const int64_t ni_pad = (ni + 31) / 32 * 32;
+    h->perm.ensure((size_t)ni_pad);
+    h->Vr.ensure((size_t)ni_pad * h->ld);
+    h->ibr.ensure((size_t)ni_pad);
+    HIP_CHECK(hipMemsetAsync(h->perm.p, 0, (size_t)ni_pad * sizeof(int32_t), h->stream));
+    HIP_CHECK(hipMemsetAsync(h->Vr.p, 0, (size_t)ni_pad * h->ld * sizeof(float), h->stream));
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->ibr.p, 0x7fc00000u /* NaN */, (size_t)ni_pad, h->stream));
     h->perm.upload(order.data(), (size_t)ni, h->stream);
     std::vector<int32_t> inv_order((size_t)ni);
     for (int64_t p = 0; p < ni; ++p) inv_order[(size_t)order[(size_t)p]] = (int32_t)p;
