@@ -228,6 +228,8 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             const int w = (threadIdx.x - 32) >> 5, rl = (threadIdx.x - 32) & 31;
             pa = excl_bits + ((cur_rb * (kBlk / 64) + w) * 32 + rl) * n_item_tiles + it;
             pa_stride = 1;
+            // (a layout with the workgroup's 128 words of a tile contiguous was emulated — wrong words, right addresses —
+            // and is not faster: 4.73 -> 4.63-4.71 ms with the survivor path off; the lines are L2-resident for 16 tiles)
         } else {
             pa = reinterpret_cast<const uint32_t *>(item_base);
             pa_stride = 0;
@@ -579,7 +581,8 @@ __global__ __launch_bounds__(kBlk) void excl_bitmap_kernel(const int64_t *__rest
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < nt; i += 64) bits[row * n_item_tiles + c0 + i] = bm[i];
+        // (written once, read once by the top-k kernel much later: streamed past the caches)
+        for (int i = lane; i < nt; i += 64) __builtin_nontemporal_store(bm[i], &bits[row * n_item_tiles + c0 + i]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
