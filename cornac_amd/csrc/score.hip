@@ -449,6 +449,8 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
                     else acc_nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcur[t], acc_nxt, 0, 0, 0);
                     if (t < 16) {
                         const int r = t;
+                        // (v_pk_add_f32 on register pairs — 8 packed adds instead of 16 — was measured: 5.900 against 5.903 ms,
+                        // no gain: the packed add takes the issue time of two)
                         sc[r] = UB ? (ib_cur + ubias[r]) + acc_cur[r] : ib_cur + acc_cur[r];
                         hm[r] = __ballot(sc[r] >= thr[r]);
                     }
@@ -546,43 +548,68 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
 
 // Exclusion bitmap of the fused top-k kernel: one word per (row, tile of 32 items in the scorer's RANK ORDER),
 //     bits[row * n_item_tiles + item_tile]  bit c  <=>  the item at position item_tile*32 + c is excluded for that row
-// (row = position in this call's user list, position p = inv_perm[item]).  One WAVE per row gathers the row's exclusion
+// (row = position in this call's user list, position p = inv_perm[item]).  One WAVE per TWO rows gathers each row's exclusion
 // list into a private LDS bitmap (LDS integer atomics: ~2.4 cycles per set bit) in chunks of `chunk_tiles` words and
 // writes it out contiguously.  The lists come either per ROW of this call (indptr[r], by_user = 0) or per USER id from
 // the resident CSR registered with cornac_hip_scorer_set_exclusions (by_user = 1: row r is user users[r] or u0 + r).
 // Rows beyond n_rows (the padding of the last workgroup of the top-k kernel) get all-zero words.
-constexpr int kBitmapChunk = 1024;  // words per wave and pass (4 KB of LDS per wave)
+constexpr int kBitmapChunk = 1024;  // words per row and pass (4 KB of LDS per row)
+constexpr int kBitmapRows = 1;      // rows per wave.  A row is a chain of dependent round trips (indptr -> indices -> inv_perm ->
+                                    // LDS bit); two rows per wave (two chains in flight) were measured: 263 us against 200-212 us
+                                    // for all 138 493 users — the second 4 KB of LDS per wave costs more occupancy than it hides
 __global__ __launch_bounds__(kBlk) void excl_bitmap_kernel(const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices,
                                                           const int32_t *__restrict__ users, int64_t u0, int by_user,
                                                           const int32_t *__restrict__ inv_perm, int64_t n_rows,
                                                           int64_t n_rows_padded, int64_t n_item_tiles,
                                                           uint32_t *__restrict__ bits) {
-    __shared__ uint32_t bm_all[kBlk / 64][kBitmapChunk];
+    constexpr int NR = kBitmapRows;
+    __shared__ uint32_t bm_all[kBlk / 64][NR][kBitmapChunk];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *bm = bm_all[wave];
-    const int64_t row = (int64_t)blockIdx.x * (kBlk / 64) + wave;
-    if (row >= n_rows_padded) return;
-    int64_t lo = 0, hi = 0;
-    if (row < n_rows) {
-        const int64_t key = by_user ? (users ? (int64_t)users[row] : u0 + row) : row;
-        lo = indptr[key];
-        hi = indptr[key + 1];
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlk / 64) + wave) * NR;
+    if (row0 >= n_rows_padded) return;
+    int64_t lo[NR], cnt[NR];
+    int64_t cnt_max = 0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        lo[q] = 0;
+        cnt[q] = 0;
+        const int64_t row = row0 + q;
+        if (row < n_rows) {
+            const int64_t key = by_user ? (users ? (int64_t)users[row] : u0 + row) : row;
+            lo[q] = indptr[key];
+            cnt[q] = indptr[key + 1] - lo[q];
+        }
+        cnt_max = max(cnt_max, cnt[q]);
     }
     for (int64_t c0 = 0; c0 < n_item_tiles; c0 += kBitmapChunk) {
         const int nt = (int)min((int64_t)kBitmapChunk, n_item_tiles - c0);
-        for (int i = lane; i < nt; i += 64) bm[i] = 0u;
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+            for (int i = lane; i < nt; i += 64) bm_all[wave][q][i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int64_t p = lo + lane; p < hi; p += 64) {
-            const int32_t pos = inv_perm[indices[p]];
-            const int t = (pos >> 5) - (int)c0;
-            if (t >= 0 && t < nt) atomicOr(&bm[t], 1u << (pos & 31));
+        for (int64_t p = lane; p < cnt_max; p += 64) {
+            int32_t e[NR], pos[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) e[q] = p < cnt[q] ? indices[lo[q] + p] : 0;   // (item 0: a valid index of inv_perm)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) pos[q] = inv_perm[e[q]];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int t = (pos[q] >> 5) - (int)c0;
+                if (p < cnt[q] && t >= 0 && t < nt) atomicOr(&bm_all[wave][q][t], 1u << (pos[q] & 31));
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // (written once, read once by the top-k kernel much later: streamed past the caches)
-        for (int i = lane; i < nt; i += 64) __builtin_nontemporal_store(bm[i], &bits[row * n_item_tiles + c0 + i]);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            if (row0 + q < n_rows_padded)
+                for (int i = lane; i < nt; i += 64)
+                    __builtin_nontemporal_store(bm_all[wave][q][i], &bits[(row0 + q) * n_item_tiles + c0 + i]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1179,7 +1206,7 @@ static void launch_rank_fused_rows(cornac_hip_scorer_t h, const int32_t *d_users
     if (d_excl_indptr && n_item_tiles <= kMaxBitmapTiles && !no_bitmap) {
         const int64_t rows_padded = wg_rows * 128;  // whole workgroups of the top-k kernel: it reads every wave's words
         h->excl_bits.ensure((size_t)(rows_padded * n_item_tiles));
-        hipLaunchKernelGGL(excl_bitmap_kernel, dim3((unsigned)((rows_padded + kBlk / 64 - 1) / (kBlk / 64))), dim3(kBlk), 0,
+        hipLaunchKernelGGL(excl_bitmap_kernel, dim3((unsigned)((rows_padded + kBitmapRows * (kBlk / 64) - 1) / (kBitmapRows * (kBlk / 64)))), dim3(kBlk), 0,
                            h->stream, d_excl_indptr + (excl_by_user ? 0 : excl_row0), d_excl_indices, d_users, u0,
                            excl_by_user ? 1 : 0, h->inv_perm.p, n, rows_padded, n_item_tiles, h->excl_bits.p);
         d_bits = h->excl_bits.p;
