@@ -865,7 +865,12 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         h->ld = (k + 31) / 32 * 32;
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         const size_t nu = (size_t)n_users * h->ld, ni = (size_t)n_items * h->ld;
-        for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
+        // (U is padded to whole 128-row tiles + one tile, zero filled: the wave-specialised user step reads operand rows of the
+        // ragged last tile and of "the next tile" without clamping; it never writes there)
+        const size_t nu_pad = ((size_t)(n_users + kBM - 1) / kBM + 1) * kBM * h->ld;
+        h->U.alloc(nu_pad);
+        HIP_CHECK(hipMemsetAsync(h->U.p, 0, nu_pad * 4, h->stream));
+        for (DevBuf<float> *b : {&h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
         for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
         h->slot_tag.alloc((size_t)n_items);
         HIP_CHECK(hipMemsetAsync(h->slot_tag.p, 0, (size_t)n_items * 4, h->stream));
@@ -1037,6 +1042,13 @@ int cornac_hip_wmf_fit_batches(cornac_hip_wmf_t h, const int32_t *item_ids, cons
                     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
                     HIP_CHECK(hipMemcpyAsync(h->cu_arrivals.p + 1030, init, sizeof(init), hipMemcpyHostToDevice, s));
                 }
+#ifdef CORNAC_PROFILE
+                if (ws) {   // timing experiments of the stream role (wrong results): wmf_ws.inc WS_ABL
+                    static int abl;
+                    abl = prof_env_int("CORNAC_HIP_WMF_WS_ABLATE", 0);
+                    HIP_CHECK(hipMemcpyAsync(h->cu_arrivals.p + 1038, &abl, sizeof(int), hipMemcpyHostToDevice, s));
+                }
+#endif
                 if (ws)
                     wmf_user_step_ws_kernel<<<h->ws_wgs, kWsThreads, kWmfWsLdsBytes, s>>>(h->Vb.p, h->VbT.p, nu, B, h->U.p, h->mU.p, h->vU.p,
                                                                                           h->indptr.p, h->rows.p, h->vals.p, h->nnz, d_ids, a, b,
