@@ -865,12 +865,11 @@ int cornac_hip_wmf_create(cornac_hip_wmf_t *out, int device, int64_t n_users, in
         h->ld = (k + 31) / 32 * 32;
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         const size_t nu = (size_t)n_users * h->ld, ni = (size_t)n_items * h->ld;
-        // (U is padded to whole 128-row tiles + one tile, zero filled: the wave-specialised user step reads operand rows of the
-        // ragged last tile and of "the next tile" without clamping; it never writes there)
+        // (U, m_U, v_U are padded to whole 128-row tiles + one tile, zero filled: the wave-specialised user step reads operand rows
+        // of the ragged last tile and of "the next tile" without clamping, and its Adam sweep runs over whole tiles — rows that
+        // do not exist hold zeros and stay zero)
         const size_t nu_pad = ((size_t)(n_users + kBM - 1) / kBM + 1) * kBM * h->ld;
-        h->U.alloc(nu_pad);
-        HIP_CHECK(hipMemsetAsync(h->U.p, 0, nu_pad * 4, h->stream));
-        for (DevBuf<float> *b : {&h->mU, &h->vU}) { b->alloc(nu); HIP_CHECK(hipMemsetAsync(b->p, 0, nu * 4, h->stream)); }
+        for (DevBuf<float> *b : {&h->U, &h->mU, &h->vU}) { b->alloc(nu_pad); HIP_CHECK(hipMemsetAsync(b->p, 0, nu_pad * 4, h->stream)); }
         for (DevBuf<float> *b : {&h->V, &h->mV, &h->vV}) { b->alloc(ni); HIP_CHECK(hipMemsetAsync(b->p, 0, ni * 4, h->stream)); }
         h->slot_tag.alloc((size_t)n_items);
         HIP_CHECK(hipMemsetAsync(h->slot_tag.p, 0, (size_t)n_items * 4, h->stream));
