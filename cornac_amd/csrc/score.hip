@@ -224,12 +224,14 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
         if (threadIdx.x < 32) {
             pa = reinterpret_cast<const uint32_t *>(item_base) + it * 32 + threadIdx.x;
             pa_stride = 32;
-        } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64)) {
+        } else if (excl_bits && threadIdx.x < 32 + 32 * (kBlk / 64) && !(ablate & 32)) {
             const int w = (threadIdx.x - 32) >> 5, rl = (threadIdx.x - 32) & 31;
             pa = excl_bits + ((cur_rb * (kBlk / 64) + w) * 32 + rl) * n_item_tiles + it;
             pa_stride = 1;
             // (a layout with the workgroup's 128 words of a tile contiguous was emulated — wrong words, right addresses —
-            // and is not faster: 4.73 -> 4.63-4.71 ms with the survivor path off; the lines are L2-resident for 16 tiles)
+            // and is not faster: 4.73 -> 4.63-4.71 ms with the survivor path off; the lines are L2-resident for 16 tiles.
+            // Ablation bit 32 drops these loads altogether: 4.73 -> 4.60 ms — 128 lanes with 128 different lines per tile cost
+            // 0.13 ms of address processing whatever the layout)
         } else {
             pa = reinterpret_cast<const uint32_t *>(item_base);
             pa_stride = 0;
