@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
     __shared__ float tau[kBlk / 64][32];
     // the 4 waves of a workgroup walk the same item tiles: the B tile is staged once per workgroup
     // (coalesced 16-byte global loads, double-buffered) instead of gathered 4x through the TA
-    __shared__ float btile[2][32][KP + 2];  // row stride == 2 (mod 64): the 64 lanes of a fragment read hit 64 banks
+    __shared__ float btile[2][32][KP + 1];  // row stride == 1 (mod 32): the 32 lanes of a lane group of a fragment read hit 32 banks
     __shared__ uint32_t meta_dump[1];
     // exclusion bitmap words of the tile being compared: wmask[t % 3][wave][row] has bit c set when the c-th item of
     // tile t is excluded for that row (see excl_bitmap_kernel; 128 four-byte loads per workgroup and tile, L2-served).  Three buffers: tile t's words are read in the
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
             const int32_t item = id_cur;
             unsigned long long hm[16];
             float sc[16];
+            // (moving the first four compares in front of the chain, into the wait for the first fragment group: no gain)
 #pragma unroll
             for (int g = 0; g < KT / FG; ++g) {
                 if (g + 1 < KT / FG) load_frags(buf_next, g + 1);
