@@ -432,9 +432,12 @@ __global__ __launch_bounds__(kBlk, ((KT <= 32 || CAP <= 42) ? 2 : 1)) void rank_
         auto step = [&](int64_t it, f32x16 &acc_cur, f32x16 &acc_nxt, float &ib_cur, float &ib_nxt, int32_t &id_cur,
                         int32_t &id_nxt) __attribute__((always_inline)) {
             const int buf_next = (int)((it + 1 - t_begin) & 1);
-            if (it + 2 < t_end && !(ablate & 2)) stage_load(it + 2);
             // ---- B fragments + MFMA chain of tile it+1, compare of tile it -----------------------------------
+            // (the first fragment group is requested before anything else: its LDS round trip is the one nothing hides —
+            // the tile's buffer only became visible at the barrier)
             load_frags(buf_next, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < t_end && !(ablate & 2)) stage_load(it + 2);
             const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;   // meta buffers of tiles it + 1, it + 2
             ib_nxt = ibase[wb1][col];
             id_nxt = ipos[wb1][col];
