@@ -382,3 +382,38 @@ def test_exclusion_bitmap_is_chunked_by_rows_beyond_its_budget():
     ex = excl_idx.reshape(n_users, per)
     assert not (items[:, :, None] == ex[:, None, :]).any()
     assert (np.diff(scores, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("n_items", [32, 64, 33, 31, 12, 1024, 1025])
+@pytest.mark.parametrize("with_excl", [False, True])
+def test_fused_rank_catalogues_around_the_tile_size(oracle, n_items, with_excl):
+    """The fused top-k kernel stages whole 32-item tiles without clamps: its rank-order tables are padded to whole tiles on
+    the host (zero rows, NaN item bases, item id 0).  Catalogues of exactly one / two / many tiles, one item over and under
+    a tile, fewer items than topk + exclusions leave: no padded item may ever be returned, negative scores included (a
+    padded row scores NaN, not 0), the exclusion bitmap's last word is partial."""
+    rs = np.random.RandomState(n_items)
+    nu, k, topk = 200, 64, 10
+    U = rs.normal(0, 0.3, (nu, k)).astype(np.float32)
+    V = rs.normal(0, 0.3, (n_items, k)).astype(np.float32)
+    ib = (rs.normal(0, 0.2, n_items) - 5.0).astype(np.float32)      # every real score is far below a padded row's 0 + 0
+    sc = _lib.Scorer(U, V, ib, None)
+    users = np.arange(nu, dtype=np.int32)
+    tk = min(topk, n_items)
+    if with_excl:
+        rows = [np.sort(rs.choice(n_items, rs.randint(0, max(1, n_items - tk)), replace=False)).astype(np.int32) for _ in users]
+        rows[0] = np.array([n_items - 1], np.int32)                 # the last real item: the bit next to the padding
+        indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        items, scores = sc.rank_topk(users, tk, exclude=(indptr, np.concatenate(rows).astype(np.int32)))
+    else:
+        rows = [np.empty(0, np.int32) for _ in users]
+        items, scores = sc.rank_topk(users, tk)
+    sc.close()
+    full = oracle.score_block(U, V, ib, None, users)
+    for b in range(nu):
+        keep = np.ones(n_items, bool)
+        keep[rows[b]] = False
+        cand = np.flatnonzero(keep)
+        want, _ = oracle.rank(full[b], n_items, n_items, k=-1, item_indices=cand)
+        n_want = min(tk, len(cand))
+        assert np.array_equal(items[b][:n_want], want[:n_want]), (b, items[b], want[:tk])
+        assert np.array_equal(scores[b][:n_want], full[b][want[:n_want]])
