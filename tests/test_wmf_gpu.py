@@ -22,10 +22,14 @@ def _run_both(R, U, V, batches, lu, lv, a, b, lr):
 
 
 @pytest.mark.parametrize("nu,ni,k,bs", [(300, 200, 24, 64), (129, 257, 5, 128), (1000, 90, 200, 37), (64, 3, 33, 2),
-                                         (700, 300, 128, 128), (517, 260, 100, 77), (40000, 256, 128, 128)])
+                                         (700, 300, 128, 128), (517, 260, 100, 77), (40000, 256, 128, 128),
+                                         (128, 140, 128, 128), (129, 140, 120, 100), (5, 130, 128, 128), (33000, 200, 97, 128)])
 def test_steps_match_oracle(nu, ni, k, bs):
     """k in 97..128 takes the wave-specialised kernel (wmf_ws.inc): full and ragged user tiles, ragged batches, and at
-    40 000 users several tiles per workgroup (the Adam sweep of a tile runs beside the products of the next one)"""
+    40 000 users several tiles per workgroup (the Adam sweep of a tile runs beside the products of the next one); exactly one
+    tile, one row over a tile, fewer users than one slice (the tables are padded to whole tiles + one: rows that do not exist
+    must stay out of the result and out of the loss), 33 000 users = 258 tiles on 256 workgroups (two of them sweep a real
+    previous tile, the others only the scratch tile)"""
     rs = np.random.RandomState(nu + k)
     nnz = min(nu * ni // 3, max(6000, 4 * nu))
     keys = rs.permutation(nu * ni)[:nnz]
